@@ -1,0 +1,1163 @@
+// orbx_extractor.hip — stage 1 of the hot path on gfx950: ORBextractor (reference src/ORBextractor.cc).
+//
+// One handle = one (image size, config).  A call processes a batch of independent frames with
+//   k_resize   x (nlevels-1)   E1  ComputePyramid            ORBextractor.cc:1158-1183 (cv::resize INTER_LINEAR, fixed point)
+//   k_fast                     E2  per-cell FAST-9/16 + NMS   ORBextractor.cc:763-855   (cv::FAST semantics per 30-px cell ROI)
+//   k_octree                   E3  DistributeOctTree          ORBextractor.cc:537-761   (+ E4/E8 ordering ranks)
+//   k_describe                 E5-E8 IC_Angle, 7x7 blur (patch-local), rBRIEF, output assembly  :75-145, 1093-1155
+// All integer/fixed-point work is bit-exact w.r.t. the oracle; float expressions are written so that they
+// round exactly as the reference's (compile with -ffp-contract=off and correctly rounded fp32 division).
+//
+// LDS: every kernel carves the dynamic region `orb_smem` only (16-byte aligned base, no static LDS).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbhip.h"
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:72
+#define ORBX_MINB 16          // EDGE_THRESHOLD-3, ORBextractor.cc:769
+#define FAST_QCAP 2048        // corner queue entries (u16) per chunk
+#define FAST_MAXCELLS 32
+
+static __constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+static __constant__ int c_umax[16];
+
+// ============================================================================================================
+// E1  pyramid level:  dst(level l) = cv::resize(src(level l-1), INTER_LINEAR)  — 11-bit fixed point
+// ============================================================================================================
+struct ResizeParams {
+    const uint8_t* src; size_t sFrame; int sStride, sw, sh;
+    uint8_t* dst; size_t dFrame; int dStride, dw, dh;
+    const int* xofs; const short2* alpha;   // per destination column
+    const int* yofs; const short2* beta;    // per destination row
+};
+
+static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dy >= P.dh || dx0 >= P.dw) return;
+    const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
+    int sy0 = P.yofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
+    sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
+    const uint8_t* S0 = S + (size_t)sy0 * P.sStride;
+    const uint8_t* S1 = S + (size_t)sy1 * P.sStride;
+    const short2 b = P.beta[dy];
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = dx0 + k;
+        if (dx < P.dw) {
+            const int sx = P.xofs[dx];
+            const int sx1 = sx + 1 < P.sw ? sx + 1 : P.sw - 1;  // weight is 0 there (fx forced to 0)
+            const short2 a = P.alpha[dx];
+            const int t0 = S0[sx] * a.x + S0[sx1] * a.y;
+            const int t1 = S1[sx] * a.x + S1[sx1] * a.y;
+            const int v = (((b.x * (t0 >> 4)) >> 16) + ((b.y * (t1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * k);
+        }
+    }
+    uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)dy * P.dStride + dx0;
+    if (dx0 + 3 < P.dw) {
+        *(uint32_t*)D = out;  // dStride and dx0 are multiples of 4
+    } else {
+        for (int k = 0; k < 4 && dx0 + k < P.dw; k++) D[k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
+// ============================================================================================================
+// E2  FAST-9/16 + per-cell NMS + per-cell minThFAST retry
+// ============================================================================================================
+struct FastTile { short level, cellRow, cell0, nCells; };
+struct FastLevel {
+    const uint8_t* base; size_t frameStride; int rowStride;
+    int w, h, nCols, nRows, wCell, hCell;
+    size_t candOff;   // offset (u32 units) of this level's candidate slab inside one frame's block
+    int candCap;
+};
+struct FastParams {
+    FastLevel lv[ORBX_MAX_LEVELS];
+    const FastTile* tiles;
+    uint32_t* cand; size_t candFrame;   // [frame][candFrame] u32: x | y<<12 | score<<24, coordinates relative to minBorder
+    int* candCount; int nlevels;        // [frame][nlevels]
+    int iniTh, minTh;
+    int imgBytes;                       // LDS bytes reserved for the image tile (== score-map bytes)
+};
+
+// circular 16-bit mask has a run of >= 9 ones
+static __device__ __forceinline__ bool ring_has9(uint32_t m) {
+    uint32_t M = m | (m << 16);
+    uint32_t r = M & (M >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= M >> 8;
+    return (r & 0xFFFFu) != 0;
+}
+
+#define RING16(F)                                                                                         \
+    F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3)             \
+    F(8, 0, -3) F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+
+// S = max over the sixteen 9-arcs of min(v - x) and of min(x - v): the largest threshold t for which the pixel
+// is still a FAST-9 corner is S-1 (== cv cornerScore<16>), and it is a corner at threshold t iff S > t.
+static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
+    const int v = c[0];
+    int d[16];
+#define LD(k, dx, dy) d[k] = v - (int)c[(dy) * pitch + (dx)];
+    RING16(LD)
+#undef LD
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+    int A = -256, B = 256;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+        A = max(A, lo9);
+        B = min(B, hi9);
+    }
+    return max(A, -B);
+}
+
+static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int tid = threadIdx.x;
+    const FastTile T = P.tiles[blockIdx.x];
+    const int frame = blockIdx.y;
+    const FastLevel& L = P.lv[T.level];
+
+    const int iniY = ORBX_MINB + T.cellRow * L.hCell;
+    const int maxY = min(iniY + L.hCell + 6, L.h - ORBX_MINB);
+    const int iniX = ORBX_MINB + T.cell0 * L.wCell;
+    const int maxX = min(ORBX_MINB + (T.cell0 + T.nCells) * L.wCell + 6, L.w - ORBX_MINB);
+    const int xal = iniX & ~3;
+    const int pitch = ((maxX - xal) + 3) & ~3;
+    const int rows = maxY - iniY;
+    // detection region of the tile, local coordinates (cv::FAST skips a 3-px frame of each ROI; ROIs overlap by 6)
+    const int dx0 = iniX + 3 - xal, dxe = maxX - 3 - xal;
+    const int dy0 = 3, dye = rows - 3;
+    const int detW = dxe - dx0, detH = dye - dy0;
+    if (detW <= 0 || detH <= 0) return;
+
+    uint8_t* img = orb_smem;
+    uint8_t* smap = orb_smem + P.imgBytes;
+    uint16_t* queue = (uint16_t*)(orb_smem + 2 * P.imgBytes);
+    uint32_t* elist = (uint32_t*)queue;               // reused after the scoring phase
+    int* sh = (int*)(orb_smem + 2 * P.imgBytes + FAST_QCAP * 2);  // [0]=queue count [1]=emit count [2]=emit base [8..8+32)=cell counts
+
+    {   // stage the tile (coalesced aligned dword row loads) and clear the score map
+        const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + xal;
+        const int p4 = pitch >> 2;
+        const int n4 = rows * p4;
+        for (int i = tid; i < n4; i += 256) {
+            const int r = i / p4, c = i - r * p4;
+            ((uint32_t*)img)[i] = *(const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
+            ((uint32_t*)smap)[i] = 0;
+        }
+        if (tid < 8 + FAST_MAXCELLS) sh[tid] = 0;
+    }
+    __syncthreads();
+
+    const int t0 = min(P.iniTh, P.minTh);
+    const int npix = detW * detH;
+    const float invW = 1.0f / (float)detW;
+    for (int base = 0; base < npix; base += FAST_QCAP) {
+        // phase A: ring classification -> corner queue
+#pragma unroll 2
+        for (int k = 0; k < FAST_QCAP / 256; k++) {
+            const int p = base + k * 256 + tid;
+            if (p < npix) {
+                int ry = (int)((float)p * invW);
+                int rx = p - ry * detW;
+                if (rx < 0) { ry--; rx += detW; }
+                if (rx >= detW) { ry++; rx -= detW; }
+                const int pos = (dy0 + ry) * pitch + dx0 + rx;
+                const uint8_t* c = img + pos;
+                const int v = c[0];
+                const int lo = v - t0, hi = v + t0;
+                uint32_t md = 0, mb = 0;
+#define CL(k_, dx, dy) { const int x = c[(dy) * pitch + (dx)]; md = (md << 1) | ((uint32_t)(x - lo) >> 31); mb = (mb << 1) | ((uint32_t)(hi - x) >> 31); }
+                RING16(CL)
+#undef CL
+                if (ring_has9(md) || ring_has9(mb)) {
+                    const int slot = atomicAdd(&sh[0], 1);
+                    queue[slot] = (uint16_t)pos;
+                }
+            }
+        }
+        __syncthreads();
+        // phase B: exact score for queued corners
+        const int nq = sh[0];
+        for (int q = tid; q < nq; q += 256) {
+            const int pos = queue[q];
+            const int S = fast_S(img + pos, pitch);
+            smap[pos] = (uint8_t)(S - 1);   // S > t0 >= 0 here
+        }
+        __syncthreads();
+        if (tid == 0) sh[0] = 0;
+        __syncthreads();
+    }
+
+    // NMS: strict maximum over the 8 neighbours inside the same cell's detection region (outside counts as 0).
+    // survive(T) = s >= T && localmax  (threshold-independent localmax, see DESIGN.md "FAST").
+    int* cellCnt = sh + 8;
+    const int wCell = L.wCell;
+    const float invC = 1.0f / (float)wCell;
+    const int iters = (npix + 255) / 256;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int it = 0; it < iters; it++) {
+            const int p = it * 256 + tid;
+            if (p >= npix) continue;
+            int ry = (int)((float)p * invW);
+            int rx = p - ry * detW;
+            if (rx < 0) { ry--; rx += detW; }
+            if (rx >= detW) { ry++; rx -= detW; }
+            const int pos = (dy0 + ry) * pitch + dx0 + rx;
+            const int s = smap[pos];
+            if (s == 0) continue;
+            int cell = (int)((float)rx * invC);
+            if (cell * wCell > rx) cell--;
+            if ((cell + 1) * wCell <= rx) cell++;
+            const int cx = rx - cell * wCell;               // x inside the cell's detection region
+            const int cw = min(wCell, detW - cell * wCell);  // its width
+            const uint8_t* m = smap + pos;
+            const bool hasL = cx > 0, hasR = cx + 1 < cw;
+            bool ok = s > m[-pitch] && s > m[pitch];
+            if (hasL) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
+            if (hasR) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
+            if (!ok) continue;
+            if (pass == 0) {
+                if (s >= P.iniTh) atomicAdd(&cellCnt[cell], 1);
+            } else {
+                const int Tth = cellCnt[cell] > 0 ? P.iniTh : P.minTh;
+                if (s >= Tth) {
+                    // coordinates relative to minBorder, as vToDistributeKeys holds them (ORBextractor.cc:845-850)
+                    const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
+                    const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
+                    const int slot = atomicAdd(&sh[1], 1);
+                    if (slot < FAST_QCAP / 2) {
+                        elist[slot] = packed;
+                    } else {  // LDS list full: straight to global
+                        int* cnt = P.candCount + (size_t)frame * P.nlevels + T.level;
+                        const int g = atomicAdd(cnt, 1);
+                        if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int ne = min(sh[1], FAST_QCAP / 2);
+    if (ne == 0) return;
+    if (tid == 0) sh[2] = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, ne);
+    __syncthreads();
+    const int gbase = sh[2];
+    uint32_t* out = P.cand + (size_t)frame * P.candFrame + L.candOff;
+    for (int i = tid; i < ne; i += 256)
+        if (gbase + i < L.candCap) out[gbase + i] = elist[i];
+}
+
+// ============================================================================================================
+// E3  DistributeOctTree — one workgroup per (frame, level); the serial list algorithm restated as rounds of
+//     data-parallel steps that reproduce the reference's node order, early break and tie-breaks exactly.
+// ============================================================================================================
+struct OctLevel {
+    int W, H;            // maxBorderX-minBorderX, maxBorderY-minBorderY
+    int N;               // mnFeaturesPerLevel[level]
+    int nIni; float hX;  // ORBextractor.cc:541-543
+    int nCols, wCell, hCell;
+    size_t candOff; int candCap;
+    int selOff; int selCap;   // per-frame offsets into sel/selAux (u32 units)
+    float scale;         // mvScaleFactor[level]
+};
+struct OctParams {
+    OctLevel lv[ORBX_MAX_LEVELS];
+    const uint32_t* cand; size_t candFrame;
+    const int* candCount; int nlevels;
+    uint16_t* keyNode;                 // [frame][candFrame] scratch: current node of every key
+    uint32_t* sel; uint32_t* selAux; int selFrame;   // [frame][selFrame]
+    int* selCount; int* lapCount;      // [frame][nlevels]
+    int nodeCap;                       // LDS node capacity C
+    int lap0, lap1;
+};
+
+// In-place exclusive scan of a[0..n) (LDS) by the whole 256-thread block; returns the total.
+static __device__ int block_scan_excl(int* a, int n, int* scratch) {
+    const int tid = threadIdx.x;
+    const int chunk = (n + 255) >> 8;
+    const int s0 = tid * chunk, s1 = min(s0 + chunk, n);
+    int sum = 0;
+    for (int i = s0; i < s1; i++) sum += a[i];
+    scratch[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = tid >= off ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    const int total = scratch[255];
+    int run = scratch[tid] - sum;
+    for (int i = s0; i < s1; i++) { const int t = a[i]; a[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+
+struct ONode { short x0, y0, x1, y1; };
+
+static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const OctLevel& L = P.lv[level];
+    const int C = P.nodeCap;
+    // LDS carve-up (all int-aligned)
+    int* scratch = (int*)orb_smem;                 // 256
+    int* ctl = scratch + 256;                      // 16 control words
+    int* lp = ctl + 16;
+    ONode* rect[2];
+    rect[0] = (ONode*)lp; lp += 2 * C;
+    rect[1] = (ONode*)lp; lp += 2 * C;
+    int* cnt[2]; cnt[0] = lp; lp += C; cnt[1] = lp; lp += C;
+    int* seq[2]; seq[0] = lp; lp += C; seq[1] = lp; lp += C;
+    int* cc = lp; lp += 4 * C;                     // [C][4] child key counts
+    int* nchild = lp; lp += C;                     // [C] #non-empty children of an expandable node | 0x100 if divided
+    int* sb = lp; lp += C;                         // [C] scan buffer (survivor positions)
+    int* elist = lp; lp += C;                      // [C] expandable node indices (list order)
+    int* porder = lp; lp += C;                     // [C] processing order
+    int* pb = lp; lp += C;                         // [C] push base per processed node
+    uint16_t* childPos = (uint16_t*)lp;            // [C][4]
+
+    int nk = P.candCount[(size_t)frame * P.nlevels + level];
+    nk = min(nk, L.candCap);
+    const uint32_t* keys = P.cand + (size_t)frame * P.candFrame + L.candOff;
+    uint16_t* keyNode = P.keyNode + (size_t)frame * P.candFrame + L.candOff;
+    int* selCountOut = P.selCount + (size_t)frame * P.nlevels + level;
+    int* lapCountOut = P.lapCount + (size_t)frame * P.nlevels + level;
+    if (nk == 0) {
+        if (tid == 0) { *selCountOut = 0; *lapCountOut = 0; }
+        return;
+    }
+    const int N = L.N;
+    int cur = 0;
+    // ---- roots (ORBextractor.cc:550-561) and key assignment by kp.pt.x/hX (:564-568)
+    for (int i = tid; i < L.nIni; i += 256) {
+        ONode n;
+        n.x0 = (short)(int)(L.hX * (float)i); n.y0 = 0;
+        n.x1 = (short)(int)(L.hX * (float)(i + 1)); n.y1 = (short)L.H;
+        rect[0][i] = n; cnt[0][i] = 0; seq[0][i] = i;
+    }
+    __syncthreads();
+    for (int k = tid; k < nk; k += 256) {
+        const float x = (float)(keys[k] & 0xFFF);
+        int r = (int)(x / L.hX);
+        r = min(r, L.nIni - 1);
+        keyNode[k] = (uint16_t)r;
+        atomicAdd(&cnt[0][r], 1);
+    }
+    __syncthreads();
+    // drop empty roots (:572-583), keep order
+    for (int i = tid; i < L.nIni; i += 256) sb[i] = cnt[0][i] > 0 ? 1 : 0;
+    __syncthreads();
+    int size = block_scan_excl(sb, L.nIni, scratch);
+    for (int i = tid; i < L.nIni; i += 256)
+        if (cnt[0][i] > 0) { const int np = sb[i]; rect[1][np] = rect[0][i]; cnt[1][np] = cnt[0][i]; seq[1][np] = seq[0][i]; }
+    __syncthreads();
+    for (int k = tid; k < nk; k += 256) keyNode[k] = (uint16_t)sb[keyNode[k]];
+    __syncthreads();
+    cur = 1;
+    int seqCounter = L.nIni;
+    bool sortedMode = false;
+
+    for (;;) {
+        const int prevSize = size;
+        const ONode* R = rect[cur];
+        const int* CN = cnt[cur];
+        // 1. expandable nodes E (count > 1), list order
+        for (int i = tid; i < size; i += 256) { sb[i] = CN[i] > 1 ? 1 : 0; nchild[i] = 0; }
+        __syncthreads();
+        const int nE = block_scan_excl(sb, size, scratch);
+        if (nE == 0) break;  // nothing can be divided: size stays == prevSize (:667)
+        for (int i = tid; i < size; i += 256)
+            if (CN[i] > 1) { elist[sb[i]] = i; cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; }
+        __syncthreads();
+        // 2. child key counts (DivideNode :479-535)
+        for (int k = tid; k < nk; k += 256) {
+            const int nd = keyNode[k];
+            if (CN[nd] > 1) {
+                const ONode n = R[nd];
+                const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                const int x = keys[k] & 0xFFF, y = (keys[k] >> 12) & 0xFFF;
+                const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                atomicAdd(&cc[4 * nd + q], 1);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nE; e += 256) {
+            const int i = elist[e];
+            nchild[i] = (cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0);
+        }
+        __syncthreads();
+        // 3. processing order and cut
+        int nProc = nE;
+        if (!sortedMode) {
+            for (int e = tid; e < nE; e += 256) porder[e] = elist[e];
+            __syncthreads();
+        } else {
+            // descending (size, creation seq): rule R1 replaces the reference's pointer tie-break (:679-683)
+            for (int e = tid; e < nE; e += 256) {
+                const int i = elist[e];
+                const int ci = CN[i], si = seq[cur][i];
+                int rank = 0;
+                for (int f = 0; f < nE; f++) {
+                    const int j = elist[f];
+                    const int cj = CN[j];
+                    rank += (cj > ci) || (cj == ci && seq[cur][j] > si);
+                }
+                porder[rank] = i;
+            }
+            __syncthreads();
+            // early break once lNodes.size() >= N (:728-729): running size after each division
+            for (int e = tid; e < nE; e += 256) pb[e] = nchild[porder[e]] - 1;
+            __syncthreads();
+            block_scan_excl(pb, nE, scratch);  // pb[e] = growth before processing e
+            if (tid == 0) ctl[0] = nE;
+            __syncthreads();
+            for (int e = tid; e < nE; e += 256) {
+                const int after = prevSize + pb[e] + nchild[porder[e]] - 1;
+                if (after >= N) atomicMin(&ctl[0], e + 1);
+            }
+            __syncthreads();
+            nProc = ctl[0];
+            __syncthreads();
+        }
+        // 4. push bases (children are push_front'ed in processing order, n1..n4)
+        for (int i = tid; i < size; i += 256) sb[i] = 1;  // 1 = survives
+        for (int e = tid; e < nProc; e += 256) pb[e] = nchild[porder[e]];
+        __syncthreads();
+        for (int e = tid; e < nProc; e += 256) sb[porder[e]] = 0;
+        __syncthreads();
+        const int totalPushed = block_scan_excl(pb, nProc, scratch);
+        // dflag lives in nchild's sign: remember divided nodes before sb is scanned
+        for (int i = tid; i < size; i += 256) if (sb[i] == 0) nchild[i] |= 0x100;
+        __syncthreads();
+        const int nSurv = block_scan_excl(sb, size, scratch);
+        const int newSize = totalPushed + nSurv;
+        // 5. build the next list: [children, most recently pushed first] ++ [survivors in order]
+        const int nxt = cur ^ 1;
+        if (tid == 0) ctl[1] = 0;
+        __syncthreads();
+        for (int e = tid; e < nProc; e += 256) {
+            const int i = porder[e];
+            const ONode n = R[i];
+            const int hx = (n.x1 - n.x0 + 1) >> 1, hy = (n.y1 - n.y0 + 1) >> 1;
+            int p = pb[e];
+            int nexp = 0;
+            for (int q = 0; q < 4; q++) {
+                const int c = cc[4 * i + q];
+                if (c == 0) { childPos[4 * i + q] = 0xFFFF; continue; }
+                ONode ch;
+                ch.x0 = (q & 1) ? (short)(n.x0 + hx) : n.x0;
+                ch.x1 = (q & 1) ? n.x1 : (short)(n.x0 + hx);
+                ch.y0 = (q & 2) ? (short)(n.y0 + hy) : n.y0;
+                ch.y1 = (q & 2) ? n.y1 : (short)(n.y0 + hy);
+                const int np = totalPushed - 1 - p;
+                if (np < C) { rect[nxt][np] = ch; cnt[nxt][np] = c; seq[nxt][np] = seqCounter + p; }
+                childPos[4 * i + q] = (uint16_t)np;
+                nexp += c > 1;
+                p++;
+            }
+            if (nexp) atomicAdd(&ctl[1], nexp);
+        }
+        for (int i = tid; i < size; i += 256)
+            if (!(nchild[i] & 0x100)) {
+                const int np = totalPushed + sb[i];
+                if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; }
+            }
+        __syncthreads();
+        // 6. move keys
+        for (int k = tid; k < nk; k += 256) {
+            const int nd = keyNode[k];
+            if (nchild[nd] & 0x100) {
+                const ONode n = R[nd];
+                const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                const int x = keys[k] & 0xFFF, y = (keys[k] >> 12) & 0xFFF;
+                const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                keyNode[k] = childPos[4 * nd + q];
+            } else {
+                keyNode[k] = (uint16_t)(totalPushed + sb[nd]);
+            }
+        }
+        const int nToExpand = ctl[1];
+        __syncthreads();
+        cur = nxt;
+        size = min(newSize, C);
+        seqCounter += totalPushed;
+        // 7. termination (:667-671, :731-732)
+        if (newSize >= N || newSize == prevSize) break;
+        if (!sortedMode && newSize + 3 * nToExpand > N) sortedMode = true;
+    }
+
+    // ---- best key per node: max response, first in vToDistributeKeys order on ties (:737-758).
+    // Original order = cell-row-major, then row-major inside the cell's detection region.
+    int* bestS = cc;            // [C]
+    int* bestO = cc + C;        // [C]
+    for (int i = tid; i < size; i += 256) { bestS[i] = -1; bestO[i] = 0x7FFFFFFF; }
+    __syncthreads();
+    for (int k = tid; k < nk; k += 256) atomicMax(&bestS[keyNode[k]], (int)(keys[k] >> 24));
+    __syncthreads();
+    for (int k = tid; k < nk; k += 256) {
+        const uint32_t key = keys[k];
+        const int nd = keyNode[k];
+        if ((int)(key >> 24) == bestS[nd]) {
+            const int x = (int)(key & 0xFFF) - 3, y = (int)((key >> 12) & 0xFFF) - 3;
+            const int cj = x / L.wCell, ci = y / L.hCell;
+            const int ord = (((ci * L.nCols + cj) * 64 + (y - ci * L.hCell)) * 64) + (x - cj * L.wCell);
+            atomicMin(&bestO[nd], ord);
+        }
+    }
+    __syncthreads();
+    uint32_t* sel = P.sel + (size_t)frame * P.selFrame + L.selOff;
+    uint32_t* selAux = P.selAux + (size_t)frame * P.selFrame + L.selOff;
+    for (int k = tid; k < nk; k += 256) {
+        const uint32_t key = keys[k];
+        const int nd = keyNode[k];
+        if ((int)(key >> 24) == bestS[nd]) {
+            const int x = (int)(key & 0xFFF) - 3, y = (int)((key >> 12) & 0xFFF) - 3;
+            const int cj = x / L.wCell, ci = y / L.hCell;
+            const int ord = (((ci * L.nCols + cj) * 64 + (y - ci * L.hCell)) * 64) + (x - cj * L.wCell);
+            if (ord == bestO[nd] && nd < L.selCap) sel[nd] = key;
+        }
+    }
+    __syncthreads();
+    // ---- E8 ordering ranks: lapping keypoints are written from the back (ORBextractor.cc:1137-1152)
+    const int nsel = min(size, L.selCap);
+    for (int i = tid; i < nsel; i += 256) {
+        float xs = (float)((int)(sel[i] & 0xFFF) + ORBX_MINB);
+        if (level != 0) xs = xs * L.scale;
+        sb[i] = (xs >= (float)P.lap0 && xs <= (float)P.lap1) ? 1 : 0;
+        nchild[i] = sb[i];
+    }
+    __syncthreads();
+    const int nLap = block_scan_excl(sb, nsel, scratch);
+    for (int i = tid; i < nsel; i += 256) {
+        const int lap = nchild[i];
+        const int rank = lap ? sb[i] : (i - sb[i]);
+        selAux[i] = (uint32_t)rank | ((uint32_t)lap << 31);
+    }
+    if (tid == 0) { *selCountOut = nsel; *lapCountOut = nLap; }
+}
+
+// ============================================================================================================
+// E5-E8  one wave per keypoint: IC_Angle on the level image, 7x7 sigma=2 integer Gaussian of the 43x43
+//        neighbourhood (only the 37x37 the rBRIEF pattern can reach), 256 rotated comparisons, output write.
+// ============================================================================================================
+struct DescLevel {
+    const uint8_t* base; size_t frameStride; int rowStride;
+    int w, h; int selOff; float scale; float size;   // size = (float)(int)(31*scale)
+};
+struct DescParams {
+    DescLevel lv[ORBX_MAX_LEVELS];
+    const uint32_t* sel; const uint32_t* selAux; int selFrame;
+    const int* selCount; const int* lapCount; int nlevels;
+    orb_keypoint* kps; uint8_t* desc; int cap; int32_t* counts;
+};
+
+static __device__ __forceinline__ int reflect101(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+
+// cv::fastAtan2 (degrees), restated; float ops must not be contracted
+static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float s = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Rule R2: sin/cos as a fixed double polynomial rounded once to float
+static __device__ __forceinline__ void det_sincos(float angle, float* s_out, float* c_out) {
+    const double x = (double)angle;
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double kd = floor(x * TWO_OVER_PI + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double z = r * r;
+    double ps = -1.0 / 355687428096000.0;
+    ps = ps * z + 1.0 / 1307674368000.0;
+    ps = ps * z - 1.0 / 6227020800.0;
+    ps = ps * z + 1.0 / 39916800.0;
+    ps = ps * z - 1.0 / 362880.0;
+    ps = ps * z + 1.0 / 5040.0;
+    ps = ps * z - 1.0 / 120.0;
+    ps = ps * z + 1.0 / 6.0;
+    const double sr = r - r * z * ps;
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * z - 1.0 / 87178291200.0;
+    pc = pc * z + 1.0 / 479001600.0;
+    pc = pc * z - 1.0 / 3628800.0;
+    pc = pc * z + 1.0 / 40320.0;
+    pc = pc * z - 1.0 / 720.0;
+    pc = pc * z + 1.0 / 24.0;
+    pc = pc * z - 0.5;
+    const double cr = 1.0 + z * pc;
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+#define DP 43            // source patch edge (radius 21 = 18 pattern reach + 3 blur taps)
+#define DPP 44           // patch pitch
+#define DB 37            // blurred edge (radius 18)
+#define DBP 40           // blurred pitch
+#define DESC_WAVE_LDS (DP * DPP + DP * DB * 2 + DB * DBP + 2)   // 1892 + 3182 + 1480 (+pad) bytes
+#define DESC_WAVE_STRIDE 6560
+
+static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.y;
+    const int g = blockIdx.x * 4 + wave;
+    uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
+    uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
+    uint8_t* blur = (uint8_t*)(rowp + DP * DB);
+
+    // locate keypoint g of this frame: level, position inside the level's octree list, output slot
+    const int* sc = P.selCount + (size_t)frame * P.nlevels;
+    const int* lc = P.lapCount + (size_t)frame * P.nlevels;
+    int level = -1, pos = 0, nTotal = 0, monoBase = 0, lapBase = 0, monoTotal = 0;
+    {
+        int acc = 0;
+        for (int l = 0; l < P.nlevels; l++) {
+            const int n = sc[l], nl = lc[l];
+            if (level < 0 && g < acc + n) { level = l; pos = g - acc; monoBase = monoTotal; lapBase = nTotal - monoTotal; }
+            acc += n;
+            nTotal += n;
+            monoTotal += n - nl;
+        }
+    }
+    if (g == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
+    const bool valid = level >= 0;
+    const DescLevel& L = P.lv[valid ? level : 0];
+    uint32_t key = 0, aux = 0;
+    if (valid) {
+        key = P.sel[(size_t)frame * P.selFrame + L.selOff + pos];
+        aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
+    }
+    const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
+    if (valid) {
+        const uint8_t* img = L.base + (size_t)frame * L.frameStride;
+        for (int i = lane; i < DP * DP; i += 64) {
+            const int r = i / DP, c = i - r * DP;
+            const int y = reflect101(cy - 21 + r, L.h), x = reflect101(cx - 21 + c, L.w);
+            patch[r * DPP + c] = img[(size_t)y * L.rowStride + x];
+        }
+    }
+    __syncthreads();
+    float angle = 0.f;
+    if (valid) {
+        // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15
+        int m10 = 0, m01 = 0;
+        for (int i = lane; i < 31 * 31; i += 64) {
+            const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
+            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+            if (au <= c_umax[av]) {
+                const int I = patch[(21 + v) * DPP + 21 + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            m10 += __shfl_xor(m10, off);
+            m01 += __shfl_xor(m01, off);
+        }
+        angle = fast_atan2_deg((float)m01, (float)m10);
+        // Gaussian row pass: k = cvRound(256*g) = {18,34,49,55,49,34,18}; sums <= 255*257 fit u16
+        for (int i = lane; i < DP * DB; i += 64) {
+            const int r = i / DB, c = i - r * DB;
+            const uint8_t* p = patch + r * DPP + c;
+            rowp[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        for (int i = lane; i < DB * DB; i += 64) {
+            const int r = i / DB, c = i - r * DB;
+            const uint16_t* p = rowp + r * DB + c;
+            const int acc = 18 * (p[0] + p[6 * DB]) + 34 * (p[DB] + p[5 * DB]) + 49 * (p[2 * DB] + p[4 * DB]) + 55 * p[3 * DB];
+            blur[r * DBP + c] = (uint8_t)min((acc + 32768) >> 16, 255);
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    // rBRIEF (ORBextractor.cc:106-145): lane i evaluates pairs 4i..4i+3
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    det_sincos(angle * factorPI, &b, &a);
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t* pt = c_pattern + (lane * 4 + j) * 4;
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = blur[(18 + r0) * DBP + 18 + q0], t1 = blur[(18 + r1) * DBP + 18 + q1];
+        nib |= (uint32_t)(t0 < t1) << j;
+    }
+    // pack: byte = nibble(even lane) | nibble(odd lane) << 4 ; dword = 4 consecutive bytes
+    uint32_t v = nib | (__shfl_xor(nib, 1) << 4);           // valid on even lanes
+    const uint32_t b1 = __shfl_down(v, 2), b2 = __shfl_down(v, 4), b3 = __shfl_down(v, 6);
+    const uint32_t dw = (v & 255) | ((b1 & 255) << 8) | ((b2 & 255) << 16) | ((b3 & 255) << 24);
+    // output slot (ORBextractor.cc:1141-1152)
+    const int rank = (int)(aux & 0x7FFFFFFF);
+    const int idx = (aux >> 31) ? (nTotal - 1 - (lapBase + rank)) : (monoBase + rank);
+    if (idx < 0 || idx >= P.cap) return;
+    uint32_t* dout = (uint32_t*)(P.desc + ((size_t)frame * P.cap + idx) * 32);
+    if ((lane & 7) == 0) dout[lane >> 3] = dw;
+    if (lane < 7) {
+        float fx = (float)cx, fy = (float)cy;
+        if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+        uint32_t w;
+        switch (lane) {
+            case 0: w = __float_as_uint(fx); break;
+            case 1: w = __float_as_uint(fy); break;
+            case 2: w = __float_as_uint(L.size); break;
+            case 3: w = __float_as_uint(angle); break;
+            case 4: w = __float_as_uint((float)(key >> 24)); break;
+            case 5: w = (uint32_t)level; break;
+            default: w = 0xFFFFFFFFu; break;
+        }
+        ((uint32_t*)(P.kps + (size_t)frame * P.cap + idx))[lane] = w;
+    }
+}
+
+// ============================================================================================================
+// Host side
+// ============================================================================================================
+struct LevelHost {
+    int w, h, stride; size_t planeOff, planeBytes;   // levels >= 1 live in the handle's pyramid slab
+    int maxBX, maxBY, nCols, nRows, wCell, hCell, nIni; float hX;
+    int candCap; size_t candOff; int selCap, selOff;
+    int *d_xofs = nullptr, *d_yofs = nullptr; short2 *d_alpha = nullptr, *d_beta = nullptr;
+};
+
+struct orbx_extractor {
+    orbx_config cfg; int W, H, maxBatch, device;
+    std::vector<float> scale, invScale, sigma2, invSigma2; std::vector<int> nfeat; int umax[16];
+    LevelHost lv[ORBX_MAX_LEVELS];
+    size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
+    int nTiles = 0, fastImgBytes = 0; size_t fastSmem = 0, octSmem = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
+    uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
+    FastTile* d_tiles = nullptr;
+    // single-image staging
+    uint8_t* d_img = nullptr; int imgStride = 0; orb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int32_t* d_counts1 = nullptr;
+    // last call (debug taps / pyramid views)
+    const uint8_t* lastImages = nullptr; size_t lastFrameStride = 0; int lastRowStride = 0, lastBatch = 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed = false;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static inline int cvRoundF(float v) { return (int)lrintf(v); }
+static inline int cvRoundD(double v) { return (int)lrint(v); }
+
+#define HIPCHK(h, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+            return ORB_E_HIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+static int orbx_fail(orbx_extractor* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+static void orbx_free(orbx_extractor* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) {
+        if (h->lv[l].d_xofs) (void)hipFree(h->lv[l].d_xofs);
+        if (h->lv[l].d_yofs) (void)hipFree(h->lv[l].d_yofs);
+        if (h->lv[l].d_alpha) (void)hipFree(h->lv[l].d_alpha);
+        if (h->lv[l].d_beta) (void)hipFree(h->lv[l].d_beta);
+    }
+    void* bufs[] = {h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
+                    h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
+    for (void* p : bufs) if (p) (void)hipFree(p);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int max_batch, int device, orbx_handle* out) {
+    if (!cfg || !out) return orbx_fail(nullptr, ORB_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 || !(cfg->scale_factor > 1.0f) ||
+        width < 1 || height < 1 || width > 4095 + 2 * ORBX_MINB || height > 4095 + 2 * ORBX_MINB || max_batch < 1)
+        return orbx_fail(nullptr, ORB_E_INVALID, "bad configuration");
+    orbx_extractor* h = new orbx_extractor();
+    h->cfg = *cfg; h->W = width; h->H = height; h->maxBatch = max_batch; h->device = device;
+    const int nl = cfg->nlevels;
+    // ---- scale tables, features per level, umax: ORBextractor.cc:408-468 (scaleFactor is a double member)
+    const double sf = (double)cfg->scale_factor;
+    h->scale.resize(nl); h->invScale.resize(nl); h->sigma2.resize(nl); h->invSigma2.resize(nl); h->nfeat.resize(nl);
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) { h->scale[i] = (float)(h->scale[i - 1] * sf); h->sigma2[i] = h->scale[i] * h->scale[i]; }
+    for (int i = 0; i < nl; i++) { h->invScale[i] = 1.0f / h->scale[i]; h->invSigma2[i] = 1.0f / h->sigma2[i]; }
+    {
+        float factor = (float)(1.0f / sf);
+        float nDesired = cfg->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int l = 0; l < nl - 1; l++) { h->nfeat[l] = cvRoundF(nDesired); sum += h->nfeat[l]; nDesired *= factor; }
+        h->nfeat[nl - 1] = std::max(cfg->nfeatures - sum, 0);
+        int v, v0, vmax = (int)std::floor(15 * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(15 * std::sqrt(2.f) / 2);
+        for (v = 0; v <= vmax; ++v) h->umax[v] = cvRoundD(std::sqrt(225.0 - v * v));
+        for (v = 15, v0 = 0; v >= vmin; --v) { while (h->umax[v0] == h->umax[v0 + 1]) ++v0; h->umax[v] = v0; ++v0; }
+    }
+    // ---- per-level geometry: ORBextractor.cc:1162-1163 (sizes), :769-785 (cells), :541-543 (octree roots)
+    std::vector<FastTile> tiles;
+    size_t pyrOff = 0, candOff = 0; int selOff = 0, maxRows = 0, maxPitch = 0, nodeCap = 0, maxKp = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelHost& L = h->lv[l];
+        L.w = cvRoundF((float)width * h->invScale[l]);
+        L.h = cvRoundF((float)height * h->invScale[l]);
+        L.stride = (L.w + 63) & ~63;
+        L.planeBytes = (size_t)L.stride * L.h;
+        L.planeOff = pyrOff;
+        if (l > 0) pyrOff += (L.planeBytes + 255) & ~(size_t)255;
+        L.maxBX = L.w - ORBX_MINB; L.maxBY = L.h - ORBX_MINB;
+        const float fw = (float)(L.maxBX - ORBX_MINB), fh = (float)(L.maxBY - ORBX_MINB);
+        L.nCols = (int)(fw / 30.f); L.nRows = (int)(fh / 30.f);
+        if (L.nCols < 1 || L.nRows < 1) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "image too small for the requested number of pyramid levels"); }
+        L.wCell = (int)std::ceil(fw / L.nCols); L.hCell = (int)std::ceil(fh / L.nRows);
+        L.nIni = (int)std::round(fw / (L.maxBY - ORBX_MINB));
+        if (L.nIni < 1 || L.nCols > 4000) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "unsupported aspect ratio (octree needs width/height >= 0.5)"); }
+        L.hX = fw / L.nIni;
+        // candidate bound: NMS survivors per cell <= ceil(w/2)*ceil(h/2)
+        int cap = 0;
+        const int detWtot = L.w - 2 * ORBX_EDGE, detHtot = L.h - 2 * ORBX_EDGE;
+        for (int i = 0; i < L.nRows; i++) {
+            const int hh = std::min(L.hCell, detHtot - i * L.hCell);
+            if (hh <= 0) continue;
+            for (int j = 0; j < L.nCols; j++) {
+                const int ww = std::min(L.wCell, detWtot - j * L.wCell);
+                if (ww > 0) cap += ((ww + 1) / 2) * ((hh + 1) / 2);
+            }
+        }
+        L.candCap = std::max(cap, 1); L.candOff = candOff; candOff += (size_t)((L.candCap + 3) & ~3);
+        L.selCap = std::max(h->nfeat[l], 4 * L.nIni) + 4; L.selOff = selOff; selOff += L.selCap;
+        nodeCap = std::max(nodeCap, L.selCap); maxKp += L.selCap;
+        if (L.selCap > 60000) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "nfeatures per level too large"); }
+        // FAST tiles: groups of whole cells of one cell row, <= 256 px wide
+        const int cpt = std::max(1, std::min(FAST_MAXCELLS, 256 / L.wCell));
+        const int nT = (L.nCols + cpt - 1) / cpt, per = (L.nCols + nT - 1) / nT;
+        for (int i = 0; i < L.nRows; i++) {
+            const int iniY = ORBX_MINB + i * L.hCell;
+            if (iniY >= L.maxBY - 3) continue;
+            for (int c0 = 0; c0 < L.nCols; c0 += per) {
+                const int n = std::min(per, L.nCols - c0);
+                if (ORBX_MINB + c0 * L.wCell >= L.maxBX - 6) continue;
+                tiles.push_back(FastTile{(short)l, (short)i, (short)c0, (short)n});
+                maxPitch = std::max(maxPitch, ((n * L.wCell + 6 + 3) + 3) & ~3);
+            }
+        }
+        maxRows = std::max(maxRows, L.hCell + 6);
+    }
+    h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
+    h->nTiles = (int)tiles.size();
+    h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
+    h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + (8 + FAST_MAXCELLS) * 4;
+    h->octSmem = (size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8);
+    if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
+
+    if (hipSetDevice(device) != hipSuccess) { orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipSetDevice failed"); }
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::string m = std::string(#call) + ": " + hipGetErrorString(e_); orbx_free(h); return orbx_fail(nullptr, e_ == hipErrorOutOfMemory ? ORB_E_NOMEM : ORB_E_HIP, m); } } while (0)
+    CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) CK(hipEventCreate(&e));
+    const size_t B = (size_t)max_batch;
+    CK(hipMalloc((void**)&h->d_pyr, std::max<size_t>(B * h->pyrFrame, 256)));
+    CK(hipMalloc((void**)&h->d_cand, B * h->candFrame * 4));
+    CK(hipMalloc((void**)&h->d_keyNode, B * h->candFrame * 2));
+    CK(hipMalloc((void**)&h->d_candCount, B * nl * 4));
+    CK(hipMalloc((void**)&h->d_sel, B * h->selFrame * 4));
+    CK(hipMalloc((void**)&h->d_selAux, B * h->selFrame * 4));
+    CK(hipMalloc((void**)&h->d_selCount, B * nl * 4));
+    CK(hipMalloc((void**)&h->d_lapCount, B * nl * 4));
+    CK(hipMalloc((void**)&h->d_tiles, tiles.size() * sizeof(FastTile)));
+    CK(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
+    h->imgStride = (width + 63) & ~63;
+    CK(hipMalloc((void**)&h->d_img, (size_t)h->imgStride * height));
+    CK(hipMalloc((void**)&h->d_kps1, (size_t)maxKp * sizeof(orb_keypoint)));
+    CK(hipMalloc((void**)&h->d_desc1, (size_t)maxKp * 32));
+    CK(hipMalloc((void**)&h->d_counts1, 2 * sizeof(int32_t)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
+    // ---- cv::resize coefficient tables for level l from level l-1 (Appendix B2 of SURVEY.md)
+    for (int l = 1; l < nl; l++) {
+        LevelHost& D = h->lv[l]; const LevelHost& S = h->lv[l - 1];
+        const double scale_x = 1. / ((double)D.w / S.w), scale_y = 1. / ((double)D.h / S.h);
+        std::vector<int> xofs(D.w), yofs(D.h); std::vector<short2> alpha(D.w), beta(D.h);
+        auto sat16 = [](int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); };
+        for (int dx = 0; dx < D.w; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)std::floor(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+            xofs[dx] = sx;
+            alpha[dx].x = sat16(cvRoundF((1.f - fx) * 2048)); alpha[dx].y = sat16(cvRoundF(fx * 2048));
+        }
+        for (int dy = 0; dy < D.h; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)std::floor(fy);
+            fy -= sy;
+            yofs[dy] = sy;
+            beta[dy].x = sat16(cvRoundF((1.f - fy) * 2048)); beta[dy].y = sat16(cvRoundF(fy * 2048));
+        }
+        CK(hipMalloc((void**)&D.d_xofs, D.w * 4)); CK(hipMalloc((void**)&D.d_alpha, D.w * 4));
+        CK(hipMalloc((void**)&D.d_yofs, D.h * 4)); CK(hipMalloc((void**)&D.d_beta, D.h * 4));
+        CK(hipMemcpy(D.d_xofs, xofs.data(), D.w * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(D.d_alpha, alpha.data(), D.w * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(D.d_yofs, yofs.data(), D.h * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(D.d_beta, beta.data(), D.h * 4, hipMemcpyHostToDevice));
+    }
+#undef CK
+    *out = h;
+    return ORB_OK;
+}
+
+extern "C" void orbx_destroy(orbx_handle h) { orbx_free(h); }
+extern "C" const char* orbx_last_error(orbx_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+extern "C" int orbx_max_keypoints(orbx_handle h) { return h ? h->maxKp : ORB_E_INVALID; }
+
+extern "C" int orbx_get_tables(orbx_handle h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl) {
+    if (!h) return ORB_E_INVALID;
+    for (int i = 0; i < h->cfg.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->invScale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->invSigma2[i];
+        if (fpl) fpl[i] = h->nfeat[i];
+    }
+    return ORB_OK;
+}
+
+static void level_view(orbx_extractor* h, int l, const uint8_t*& base, size_t& frameStride, int& rowStride) {
+    if (l == 0) { base = h->lastImages; frameStride = h->lastFrameStride; rowStride = h->lastRowStride; }
+    else { base = h->d_pyr + h->lv[l].planeOff; frameStride = h->pyrFrame; rowStride = h->lv[l].stride; }
+}
+
+extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, int batch, size_t frame_stride, int row_stride,
+                                      int lap0, int lap1, orb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                                      int32_t* d_counts, void* stream_) {
+    if (!h) return ORB_E_INVALID;
+    if (!d_images) return orbx_fail(h, ORB_E_EMPTY_IMAGE, "empty image");
+    if (batch < 1 || batch > h->maxBatch) return orbx_fail(h, ORB_E_INVALID, "batch exceeds max_batch");
+    if (row_stride < h->W || (row_stride & 3) || ((uintptr_t)d_images & 3) || (frame_stride & 3) || !d_kps || !d_desc || !d_counts || cap_per_frame < 1)
+        return orbx_fail(h, ORB_E_INVALID, "bad batch arguments (row stride / base must be 4-byte aligned)");
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int nl = h->cfg.nlevels;
+    h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
+    // E1 pyramid
+    for (int l = 1; l < nl; l++) {
+        ResizeParams R;
+        level_view(h, l - 1, R.src, R.sFrame, R.sStride);
+        R.sw = h->lv[l - 1].w; R.sh = h->lv[l - 1].h;
+        R.dst = h->d_pyr + h->lv[l].planeOff; R.dFrame = h->pyrFrame; R.dStride = h->lv[l].stride;
+        R.dw = h->lv[l].w; R.dh = h->lv[l].h;
+        R.xofs = h->lv[l].d_xofs; R.alpha = h->lv[l].d_alpha; R.yofs = h->lv[l].d_yofs; R.beta = h->lv[l].d_beta;
+        dim3 grid((R.dw + 255) / 256, (R.dh + 3) / 4, batch);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, R);
+    }
+    HIPCHK(h, hipEventRecord(h->ev[1], st));
+    // E2 FAST
+    {
+        FastParams F;
+        memset(&F, 0, sizeof(F));
+        for (int l = 0; l < nl; l++) {
+            FastLevel& fl = F.lv[l]; const LevelHost& L = h->lv[l];
+            level_view(h, l, fl.base, fl.frameStride, fl.rowStride);
+            fl.w = L.w; fl.h = L.h; fl.nCols = L.nCols; fl.nRows = L.nRows; fl.wCell = L.wCell; fl.hCell = L.hCell;
+            fl.candOff = L.candOff; fl.candCap = L.candCap;
+        }
+        F.tiles = h->d_tiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
+        F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
+        F.imgBytes = h->fastImgBytes;
+        hipLaunchKernelGGL(k_fast, dim3(h->nTiles, batch), dim3(256), h->fastSmem, st, F);
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], st));
+    // E3 octree
+    {
+        OctParams O;
+        memset(&O, 0, sizeof(O));
+        for (int l = 0; l < nl; l++) {
+            OctLevel& ol = O.lv[l]; const LevelHost& L = h->lv[l];
+            ol.W = L.maxBX - ORBX_MINB; ol.H = L.maxBY - ORBX_MINB; ol.N = h->nfeat[l]; ol.nIni = L.nIni; ol.hX = L.hX;
+            ol.nCols = L.nCols; ol.wCell = L.wCell; ol.hCell = L.hCell; ol.candOff = L.candOff; ol.candCap = L.candCap;
+            ol.selOff = L.selOff; ol.selCap = L.selCap; ol.scale = h->scale[l];
+        }
+        O.cand = h->d_cand; O.candFrame = h->candFrame; O.candCount = h->d_candCount; O.nlevels = nl; O.keyNode = h->d_keyNode;
+        O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
+        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1;
+        hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(256), h->octSmem, st, O);
+    }
+    HIPCHK(h, hipEventRecord(h->ev[3], st));
+    // E5-E8 orientation + blur + descriptors + assembly
+    {
+        DescParams D;
+        memset(&D, 0, sizeof(D));
+        for (int l = 0; l < nl; l++) {
+            DescLevel& dl = D.lv[l]; const LevelHost& L = h->lv[l];
+            level_view(h, l, dl.base, dl.frameStride, dl.rowStride);
+            dl.w = L.w; dl.h = L.h; dl.selOff = L.selOff; dl.scale = h->scale[l]; dl.size = (float)(int)(31 * h->scale[l]);
+        }
+        D.sel = h->d_sel; D.selAux = h->d_selAux; D.selFrame = h->selFrame; D.selCount = h->d_selCount; D.lapCount = h->d_lapCount;
+        D.nlevels = nl; D.kps = d_kps; D.desc = d_desc; D.cap = cap_per_frame; D.counts = d_counts;
+        hipLaunchKernelGGL(k_describe, dim3((h->maxKp + 3) / 4, batch), dim3(256), 4 * DESC_WAVE_STRIDE, st, D);
+    }
+    HIPCHK(h, hipEventRecord(h->ev[4], st));
+    h->timed = true;
+    HIPCHK(h, hipGetLastError());
+    return ORB_OK;
+}
+
+extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                            orb_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_index) {
+    if (!h) return ORB_E_INVALID;
+    if (n_out) *n_out = 0;
+    if (mono_index) *mono_index = 0;
+    if (!image || width <= 0 || height <= 0) return orbx_fail(h, ORB_E_EMPTY_IMAGE, "empty image");
+    if (width != h->W || height != h->H || stride < width) return orbx_fail(h, ORB_E_INVALID, "image size differs from the handle's");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->imgStride, image, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    int rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1,
+                                    h->maxKp, h->d_counts1, h->stream);
+    if (rc != ORB_OK) return rc;
+    int32_t counts[2];
+    HIPCHK(h, hipMemcpyAsync(counts, h->d_counts1, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_out) *n_out = counts[0];
+    if (mono_index) *mono_index = counts[1];
+    if (counts[0] > cap) return orbx_fail(h, ORB_E_CAPACITY, "output capacity too small");
+    if (counts[0] > 0) {
+        if (!kps || !desc) return orbx_fail(h, ORB_E_INVALID, "null output");
+        HIPCHK(h, hipMemcpyAsync(kps, h->d_kps1, (size_t)counts[0] * sizeof(orb_keypoint), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(desc, h->d_desc1, (size_t)counts[0] * 32, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return ORB_OK;
+}
+
+extern "C" int orbx_pyramid_level(orbx_handle h, int frame, int level, const uint8_t** d_ptr, int* w, int* hgt, int* stride) {
+    if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !h->lastImages) return ORB_E_INVALID;
+    const uint8_t* base; size_t fs; int rs;
+    level_view(h, level, base, fs, rs);
+    if (d_ptr) *d_ptr = base + (size_t)frame * fs;
+    if (w) *w = h->lv[level].w;
+    if (hgt) *hgt = h->lv[level].h;
+    if (stride) *stride = rs;
+    return ORB_OK;
+}
+
+extern "C" int orbx_copy_level(orbx_handle h, int frame, int level, int border, uint8_t* out) {
+    const uint8_t* p; int w, hh, rs;
+    int rc = orbx_pyramid_level(h, frame, level, &p, &w, &hh, &rs);
+    if (rc != ORB_OK || !out || border < 0 || border >= w || border >= hh) return ORB_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<uint8_t> plane((size_t)w * hh);
+    HIPCHK(h, hipMemcpy2DAsync(plane.data(), w, p, rs, w, hh, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (border == 0) { memcpy(out, plane.data(), plane.size()); return ORB_OK; }
+    // copyMakeBorder(BORDER_REFLECT_101), ORBextractor.cc:1173-1179
+    const int ow = w + 2 * border, oh = hh + 2 * border;
+    auto refl = [](int p_, int len) { if (p_ < 0) p_ = -p_; if (p_ >= len) p_ = 2 * (len - 1) - p_; return p_; };
+    for (int y = 0; y < oh; y++)
+        for (int x = 0; x < ow; x++) out[(size_t)y * ow + x] = plane[(size_t)refl(y - border, hh) * w + refl(x - border, w)];
+    return ORB_OK;
+}
+
+extern "C" int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
+    if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int n = 0;
+    HIPCHK(h, hipMemcpy(&n, h->d_candCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    const int m = std::min(std::min(n, cap), h->lv[level].candCap);
+    if (m > 0 && xys) {
+        std::vector<uint32_t> tmp(m);
+        HIPCHK(h, hipMemcpy(tmp.data(), h->d_cand + (size_t)frame * h->candFrame + h->lv[level].candOff, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) { xys[3 * i] = tmp[i] & 0xFFF; xys[3 * i + 1] = (tmp[i] >> 12) & 0xFFF; xys[3 * i + 2] = tmp[i] >> 24; }
+    }
+    return ORB_OK;
+}
+
+extern "C" int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
+    if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int n = 0;
+    HIPCHK(h, hipMemcpy(&n, h->d_selCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    const int m = std::min(n, cap);
+    if (m > 0 && xys) {
+        std::vector<uint32_t> tmp(m);
+        HIPCHK(h, hipMemcpy(tmp.data(), h->d_sel + (size_t)frame * h->selFrame + h->lv[level].selOff, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) { xys[3 * i] = tmp[i] & 0xFFF; xys[3 * i + 1] = (tmp[i] >> 12) & 0xFFF; xys[3 * i + 2] = tmp[i] >> 24; }
+    }
+    return ORB_OK;
+}
+
+extern "C" int orbx_last_timing(orbx_handle h, float* ms5) {
+    if (!h || !ms5 || !h->timed) return ORB_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms5[i], h->ev[i], h->ev[i + 1]));
+    HIPCHK(h, hipEventElapsedTime(&ms5[4], h->ev[0], h->ev[4]));
+    return ORB_OK;
+}

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — hot-path throughput on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] — synthetic 752x480 grayscale batch, ORBextractor, nFeatures=1000,
+8 levels, scale 1.2, FAST 20/7 (EuRoC.yaml values).  Frames are independent units: with N>1 every rank owns
+its own batch (weak scaling, no data-path collective) and `value` = frames all ranks processed / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the oracle = reference algorithm restated, timed on this box's host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+W, H, NFEAT = 752, 480, 1000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured-achievable)
+
+
+def level_sizes(W, H, n=8, sf=1.2):
+    s, out = np.float32(1.0), []
+    for i in range(n):
+        inv = np.float32(1.0) / s
+        out.append((int(np.rint(np.float32(W) * inv)), int(np.rint(np.float32(H) * inv))))
+        s = np.float32(s * np.float64(np.float32(sf)))
+    return out
+
+
+def algorithmic_bytes(W, H, N):
+    """per-frame algorithmic bytes of the whole extract, and of each kernel."""
+    lv = level_sizes(W, H)
+    P = [w * h for w, h in lv]
+    p_ge1 = sum(P[1:])
+    whole = P[0] + 2 * p_ge1 + N * (961 + 512 + 60)
+    per_kernel = {
+        "pyramid": P[0] + sum(P[1:-1]) + p_ge1,      # read levels 0..6 once, write levels 1..7 once
+        "fast": sum(P) + 4 * 10 * N,                   # read every level once + ~10N packed candidates out
+        "octree": 4 * 10 * N * 2 + 8 * N,              # candidates in (twice: assign + select), selection out
+        "describe": N * (43 * 43 + 60),                # 43x43 neighbourhood in, 28 B keypoint + 32 B descriptor out
+    }
+    return whole, per_kernel
+
+
+def make_batch(B, seed0=0, unique=16):
+    from orbhip.synth import synth_image
+    base = [synth_image(seed0 + i, W, H) for i in range(min(unique, B))]
+    frames = []
+    for i in range(B):
+        k = i // len(base)
+        frames.append(np.roll(base[i % len(base)], (7 * k, 13 * k), (0, 1)))
+    return np.stack(frames)
+
+
+def cpu_baseline(frames, budget_s=12.0):
+    """Oracle (reference algorithm restated, g++ -O3) on this host: one extractor per thread, one frame per thread
+    at a time (the reference extracts one image on one thread, Frame.cc:111-114)."""
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 1
+    o1 = O.OrbOracle(NFEAT, 1.2, 8, 20, 7)
+    o1.extract(frames[0], 0, 1000)
+    t0 = time.perf_counter()
+    n1 = 0
+    while n1 < len(frames) and time.perf_counter() - t0 < budget_s / 3:
+        o1.extract(frames[n1], 0, 1000)
+        n1 += 1
+    fps1 = n1 / (time.perf_counter() - t0)
+    per_thread = max(2, int(fps1 * budget_s * 2 / 3))
+    oracles = [O.OrbOracle(NFEAT, 1.2, 8, 20, 7) for _ in range(cores)]
+
+    def work(t):
+        for i in range(per_thread):
+            oracles[t].extract(frames[(t * per_thread + i) % len(frames)], 0, 1000)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    fpsN = cores * per_thread / (time.perf_counter() - t0)
+    return {"value": round(fpsN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d frames of the same synthetic 752x480 batch, oracle (reference algorithm restated, "
+                      "g++ -O3); single thread: %.2f frames/s over %d frames" % (cores, per_thread, fps1, n1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orbhip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B = args.batch
+    frames = make_batch(B, seed0=1000 * rank)
+    d_frames = torch.from_numpy(frames).to(dev)
+    ex = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
+    out = None
+
+    def step():
+        nonlocal out
+        out = ex.extract_batch(d_frames, (0, 1000), out=out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kern = {k: 0.0 for k in ("pyramid", "fast", "octree", "describe", "total")}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-kernel device times (HIP events recorded on the launch stream inside the C ABI) — from one more, untimed step
+    step()
+    torch.cuda.synchronize()
+    for k, v in ex.last_timing().items():
+        kern[k] = v
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    counts = out[2].cpu().numpy()
+
+    if rank == 0:
+        whole, per_kernel = algorithmic_bytes(W, H, NFEAT)
+        dom = max(("pyramid", "fast", "octree", "describe"), key=lambda k: kern[k])
+        ach = per_kernel[dom] * B / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        fps = world * B * args.steps / dt
+        res = {
+            "metric": "frames/sec ORB extract (752x480, 1000 kp)", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 752x480 grayscale batch, ORBextractor only, nFeatures=1000, 8 levels, "
+                                   "bit-exact vs CPU oracle", "frames_per_gpu_per_step": B, "mean_keypoints": float(counts[:, 0].mean()),
+                       "parallelism": "frames sharded, %d rank(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": per_kernel[dom] * B, "kernel_ms": round(kern[dom], 4),
+                         "whole_extract_frac": round(whole * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(frames[:64])
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

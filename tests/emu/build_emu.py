@@ -1,0 +1,31 @@
+"""Builds tests/emu/build/liborbhip_emu.so: the UNMODIFIED product sources (csrc/*.hip) compiled with g++
+against the fiber-based HIP emulator in tests/emu/hip/hip_runtime.h.  TEST INFRASTRUCTURE ONLY: it lets the
+CPU-only test tier check kernel *logic* against the oracle; the product never loads this library."""
+import glob
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+EMU = os.path.join(ROOT, "tests", "emu")
+OUT = os.path.join(EMU, "build", "liborbhip_emu.so")
+SRCS = sorted(glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.hip")))
+
+
+def build(force=False):
+    deps = SRCS + glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.inc")) + \
+        glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.h")) + \
+        [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "orbhip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w",
+           "-I", EMU, "-I", os.path.join(ROOT, "include")]
+    for s in SRCS:
+        cmd += ["-x", "c++", s]
+    cmd += ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,299 @@
+// TEST INFRASTRUCTURE ONLY — a single-threaded, fiber-based emulator of the small slice of the HIP
+// programming model the product kernels use, so that the *unmodified* kernel sources under
+// awesome-orb-slam3-3dvisioncraft-version_amd/csrc/ can be compiled with g++ and their LOGIC checked
+// against the oracle in the CPU-only (`-m "not gpu"`) test tier.  This file shadows <hip/hip_runtime.h>
+// only when tests/emu is put on the include path by tests/emu/build_emu.py.  The product never loads
+// the emulated library; the shipped path is the hipcc-built liborbhip.so and nothing else.
+//
+// Model: one workgroup at a time; every work-item is a ucontext fiber; __syncthreads() and the wave
+// intrinsics (__ballot, __shfl*) are barriers among the fibers of the block / of one 64-lane wave.
+// Fibers are run in ascending or (EMU_REVERSE=1) descending lane order between barriers, which makes
+// most missing-barrier races show up as wrong answers in one of the two orders.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <tuple>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__
+#define __constant__
+#define HIP_EMULATED 1
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct short2 { short x, y; };
+struct int2 { int x, y; };
+struct ushort2 { unsigned short x, y; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct float2 { float x, y; };
+struct double2 { double x, y; };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline int2 make_int2(int a, int b) { return int2{a, b}; }
+static inline short2 make_short2(short a, short b) { return short2{a, b}; }
+
+typedef int hipError_t;
+typedef struct emu_stream_t* hipStream_t;
+typedef struct emu_event_t { double t; }* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+
+namespace emu {
+enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct State {
+    ucontext_t sched;
+    std::vector<ucontext_t> ctx;
+    std::vector<int> st;
+    std::vector<char> stacks;
+    std::function<void()> body;
+    int cur = 0, nthreads = 0;
+    dim3 block;
+    uint64_t wavebuf[16][64];
+};
+inline State& S() { static State s; return s; }
+}  // namespace emu
+
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+alignas(256) inline unsigned char orb_smem[160 * 1024];
+static const int warpSize = 64;
+
+namespace emu {
+inline void set_tid(int t) {
+    State& s = S();
+    threadIdx.x = t % s.block.x;
+    threadIdx.y = (t / s.block.x) % s.block.y;
+    threadIdx.z = t / (s.block.x * s.block.y);
+}
+inline void yield(int why) {
+    State& s = S();
+    s.st[s.cur] = why;
+    swapcontext(&s.ctx[s.cur], &s.sched);
+}
+inline void trampoline() {
+    State& s = S();
+    s.body();
+    s.st[s.cur] = DONE;
+    swapcontext(&s.ctx[s.cur], &s.sched);
+}
+inline void run_block(dim3 block, const std::function<void()>& body) {
+    State& s = S();
+    const int n = (int)(block.x * block.y * block.z);
+    const size_t STK = 128 * 1024;
+    s.block = block;
+    s.nthreads = n;
+    s.body = body;
+    s.ctx.resize(n);
+    s.st.assign(n, RUNNABLE);
+    if (s.stacks.size() < STK * (size_t)n) s.stacks.resize(STK * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        getcontext(&s.ctx[i]);
+        s.ctx[i].uc_stack.ss_sp = s.stacks.data() + STK * (size_t)i;
+        s.ctx[i].uc_stack.ss_size = STK;
+        s.ctx[i].uc_link = &s.sched;
+        makecontext(&s.ctx[i], (void (*)())trampoline, 0);
+    }
+    static const bool reverse = getenv("EMU_REVERSE") && atoi(getenv("EMU_REVERSE"));
+    const int nw = (n + 63) / 64;
+    for (;;) {
+        bool ran = false;
+        for (int k = 0; k < n; k++) {
+            int i = reverse ? n - 1 - k : k;
+            if (s.st[i] != RUNNABLE) continue;
+            s.cur = i;
+            set_tid(i);
+            swapcontext(&s.sched, &s.ctx[i]);
+            ran = true;
+        }
+        bool released = false, alldone = true, allblock = true;
+        for (int w = 0; w < nw; w++) {
+            bool allw = true, any = false;
+            for (int l = w * 64; l < std::min(n, w * 64 + 64); l++) {
+                if (s.st[l] == DONE) continue;
+                any = true;
+                if (s.st[l] != WAIT_WAVE) allw = false;
+            }
+            if (any && allw) {
+                for (int l = w * 64; l < std::min(n, w * 64 + 64); l++)
+                    if (s.st[l] == WAIT_WAVE) s.st[l] = RUNNABLE;
+                released = true;
+            }
+        }
+        for (int i = 0; i < n; i++) {
+            if (s.st[i] != DONE) alldone = false;
+            if (s.st[i] != DONE && s.st[i] != WAIT_BLOCK) allblock = false;
+        }
+        if (alldone) break;
+        if (!released && allblock) {
+            for (int i = 0; i < n; i++)
+                if (s.st[i] == WAIT_BLOCK) s.st[i] = RUNNABLE;
+            released = true;
+        }
+        if (!released && !ran) {
+            fprintf(stderr, "hip_emu: DEADLOCK (divergent barrier) in block (%u,%u,%u)\n", blockIdx.x, blockIdx.y, blockIdx.z);
+            abort();
+        }
+    }
+}
+inline void launch(dim3 grid, dim3 block, size_t smemBytes, const std::function<void()>& body) {
+    if (smemBytes > sizeof(orb_smem)) { fprintf(stderr, "hip_emu: smem %zu too large\n", smemBytes); abort(); }
+    gridDim = grid;
+    blockDim = block;
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                blockIdx = dim3(x, y, z);
+                memset(orb_smem, 0xCD, smemBytes);  // poison: LDS is uninitialised on hardware
+                run_block(block, body);
+            }
+}
+inline int lane() { return S().cur & 63; }
+inline int wave() { return S().cur >> 6; }
+inline uint64_t exchange(uint64_t v, int src) {
+    State& s = S();
+    const int w = wave();
+    s.wavebuf[w][lane()] = v;
+    yield(WAIT_WAVE);
+    uint64_t r = s.wavebuf[w][src & 63];
+    yield(WAIT_WAVE);
+    return r;
+}
+}  // namespace emu
+
+template <typename... KArgs, typename... Args>
+inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smemBytes, hipStream_t, Args... args) {
+    std::tuple<KArgs...> targs(args...);
+    emu::launch(grid, block, smemBytes, [&] { std::apply(kernel, targs); });
+}
+
+// ---- device intrinsics -----------------------------------------------------------------------------------
+inline void __syncthreads() { emu::yield(emu::WAIT_BLOCK); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; *p = std::min(o, v); return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __float2int_rn(float v) { return (int)lrintf(v); }
+inline int __float2int_rz(float v) { return (int)v; }
+inline float __int2float_rn(int v) { return (float)v; }
+inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+inline unsigned long long __ballot(int pred) {
+    emu::State& s = emu::S();
+    const int w = emu::wave();
+    s.wavebuf[w][emu::lane()] = pred ? 1 : 0;
+    emu::yield(emu::WAIT_WAVE);
+    unsigned long long m = 0;
+    const int n = std::min(64, s.nthreads - w * 64);
+    for (int l = 0; l < n; l++)
+        if (s.st[w * 64 + l] != emu::DONE && s.wavebuf[w][l]) m |= 1ull << l;
+    emu::yield(emu::WAIT_WAVE);
+    return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) { return __ballot(!p) == 0; }
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shfl");
+    uint64_t b = 0;
+    memcpy(&b, &v, sizeof(T));
+    const int l = emu::lane();
+    const int base = l & ~(width - 1);
+    b = emu::exchange(b, base + (src & (width - 1)));
+    T r;
+    memcpy(&r, &b, sizeof(T));
+    return r;
+}
+template <class T> inline T __shfl_xor(T v, int m, int width = 64) { return __shfl(v, (emu::lane() ^ m), 64); }
+template <class T> inline T __shfl_down(T v, int d, int width = 64) {
+    int l = emu::lane();
+    return __shfl(v, (l + d < 64 ? l + d : l), 64);
+}
+template <class T> inline T __shfl_up(T v, int d, int width = 64) {
+    int l = emu::lane();
+    return __shfl(v, (l - d >= 0 ? l - d : l), 64);
+}
+inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+    return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
+}
+using std::max;
+using std::min;
+
+// ---- host runtime -------------------------------------------------------------------------------------------
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+    n = (n + 255) & ~(size_t)255;
+    *p = aligned_alloc(256, n ? n : 256);
+    if (*p) memset(*p, 0xAB, n ? n : 256);  // poison: hipMalloc memory is uninitialised
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc((void**)p, n); }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+    return hipSuccess;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hip_emu"; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_t{0}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "hip_emu");
+    strcpy(p->gcnArchName, "emu");
+    p->multiProcessorCount = 1;
+    return hipSuccess;
+}
+#define HIP_SYMBOL(x) x
+template <class T> inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n) { memcpy((void*)&sym, src, n); return hipSuccess; }
+template <class T> inline hipError_t hipFuncSetAttribute(T, int, int) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };

@@ -1,0 +1,142 @@
+"""Stage-1 parity: the HIP extractor vs the oracle.
+
+`backend` = "emu" (product kernels compiled against tests/emu: logic check on CPU, `-m "not gpu"`) or
+"hip" (the real liborbhip.so through the C ABI on an MI355X, `-m gpu`).  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import orbhip
+from orbhip.synth import flat_image, low_contrast_image, synth_image
+
+CASES = [
+    # (name, image factory, nfeatures, lapping, extra ctor args)
+    ("euroc_752x480", lambda: synth_image(0), 1000, (0, 1000), {}),
+    ("lapping_window", lambda: synth_image(3), 1000, (300, 500), {}),
+    ("no_lapping", lambda: synth_image(2), 1000, (0, 0), {}),
+    ("ini_extractor_5x", lambda: synth_image(4), 5000, (0, 1000), {}),
+    ("low_contrast_retries", lambda: low_contrast_image(5), 1000, (0, 1000), {}),
+    ("flat_zero_keypoints", lambda: flat_image(), 1000, (0, 1000), {}),
+    ("tumvi_1280x720", lambda: synth_image(6, 1280, 720), 1500, (0, 0), {}),
+    ("sparse_640x480", lambda: synth_image(7, 640, 480, n_rect=10, n_disc=5), 1000, (100, 200), {}),
+    ("other_config", lambda: synth_image(8, 400, 300), 500, (0, 0), dict(nlevels=4, iniThFAST=30, minThFAST=10, scaleFactor=1.5)),
+    ("tumvi_512", lambda: synth_image(9, 512, 512), 1500, (0, 511), {}),
+]
+EMU_CASES = {"euroc_752x480", "lapping_window", "low_contrast_retries", "flat_zero_keypoints", "other_config", "sparse_640x480"}
+
+
+def _run_case(lib, case, stage_checks=True):
+    name, mk, nf, lap, kw = case
+    img = mk()
+    cfg = dict(scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+    cfg.update(kw)
+    o = O.OrbOracle(nf, cfg["scaleFactor"], cfg["nlevels"], cfg["iniThFAST"], cfg["minThFAST"])
+    mono, k, d = o.extract(img, *lap)
+    e = orbhip.ORBextractor(nf, cfg["scaleFactor"], cfg["nlevels"], cfg["iniThFAST"], cfg["minThFAST"], lib=lib)
+    m2, k2, d2 = e(img, None, lap)
+    if stage_checks:
+        for l in range(cfg["nlevels"]):
+            assert np.array_equal(o.level_image(l), e.pyramid_level(l)), "pyramid level %d" % l
+            ca = set(map(tuple, o.level_candidates(l).tolist()))
+            cb = e.debug_candidates(l)
+            assert len(cb) == len(ca) and set(map(tuple, cb.tolist())) == ca, "FAST candidates level %d" % l
+            ka, _ = o.level_keypoints(l)
+            ka = np.stack([ka["x"] - 16, ka["y"] - 16, ka["response"]], 1).astype(np.int32) if len(ka) else np.zeros((0, 3), np.int32)
+            assert np.array_equal(ka, e.debug_selected(l)), "octree selection/order level %d" % l
+    assert m2 == mono
+    assert len(k2) == len(k)
+    assert np.array_equal(k.view(np.uint8), k2.view(np.uint8)), "keypoints (bitwise)"
+    assert np.array_equal(d, d2), "descriptors"
+    return len(k)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in EMU_CASES], ids=lambda c: c[0])
+def test_emulated_kernels_match_oracle(emu_lib, case):
+    _run_case(emu_lib, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_hip_matches_oracle(hip_lib, case):
+    _run_case(hip_lib, case)
+
+
+def test_empty_image_returns_minus_one(emu_lib):
+    e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=emu_lib)
+    mono, k, d = e(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0 and d.shape == (0, 32)
+
+
+def test_getters_match_oracle(emu_lib):
+    e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=emu_lib)
+    t = O.OrbOracle(1000, 1.2, 8, 20, 7).tables()
+    assert e.GetLevels() == 8 and e.GetScaleFactor() == np.float32(1.2)
+    assert np.array_equal(e.GetScaleFactors(), t["scale"]) and np.array_equal(e.GetInverseScaleFactors(), t["inv_scale"])
+    assert np.array_equal(e.GetScaleSigmaSquares(), t["sigma2"]) and np.array_equal(e.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+    assert np.array_equal(e.features_per_level(), t["nfeat"])
+
+
+def test_too_small_image_is_rejected(emu_lib):
+    e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=emu_lib)
+    with pytest.raises(orbhip.OrbHipError):
+        e(np.zeros((60, 80), np.uint8))  # level 7 would have no FAST cell (reference divides by zero there)
+
+
+def test_bordered_pyramid_matches_reference_layout(emu_lib):
+    img = synth_image(12, 320, 240, n_rect=60, n_disc=30)
+    o = O.OrbOracle(300)
+    o.extract(img, 0, 0)
+    e = orbhip.ORBextractor(300, 1.2, 8, 20, 7, lib=emu_lib)
+    e(img)
+    for l in (0, 3, 7):
+        assert np.array_equal(o.level_bordered(l), e.pyramid_level(l, border=19))
+
+
+@pytest.mark.gpu
+def test_hip_batch_matches_oracle_and_is_deterministic(hip_lib):
+    import torch
+    B = 6
+    imgs = np.stack([synth_image(20 + i) for i in range(B - 2)] + [flat_image(), low_contrast_image(31)])
+    e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=hip_lib)
+    dev = torch.from_numpy(imgs).cuda()
+    outs = []
+    for rep in range(2):
+        kps, desc, counts = e.extract_batch(dev, (0, 1000))
+        torch.cuda.synchronize()
+        outs.append((kps.cpu().numpy().copy(), desc.cpu().numpy().copy(), counts.cpu().numpy().copy()))
+    o = O.OrbOracle(1000)
+    for b in range(B):
+        mono, k, d = o.extract(imgs[b], 0, 1000)
+        n = outs[0][2][b, 0]
+        assert n == len(k) and outs[0][2][b, 1] == mono
+        assert np.array_equal(outs[0][0][b, :n].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1))
+        assert np.array_equal(outs[0][1][b, :n], d)
+        assert np.array_equal(outs[0][0][b, :n].view(np.uint8), outs[1][0][b, :n].view(np.uint8)) and np.array_equal(outs[0][1][b, :n], outs[1][1][b, :n])
+
+
+@pytest.mark.gpu
+def test_hip_full_size_batch_properties(hip_lib):
+    """BASELINE-size batch: size-independent properties (counts, bounds, frame independence under permutation)."""
+    import torch
+    B = 64
+    base = [synth_image(100 + i) for i in range(8)]
+    imgs = np.stack([np.roll(base[i % 8], (3 * (i // 8), 5 * (i // 8)), (0, 1)) for i in range(B)])
+    e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=hip_lib)
+    dev = torch.from_numpy(imgs).cuda()
+    kps, desc, counts = [t.cpu().numpy().copy() for t in e.extract_batch(dev, (0, 0))]
+    perm = np.random.default_rng(0).permutation(B)
+    kps2, desc2, counts2 = [t.cpu().numpy().copy() for t in e.extract_batch(torch.from_numpy(imgs[perm]).cuda(), (0, 0))]
+    assert np.array_equal(counts[perm], counts2)
+    for j, b in enumerate(perm):
+        n = counts[b, 0]
+        assert 990 <= n <= 1032 and counts[b, 1] == n
+        assert np.array_equal(kps[b, :n].view(np.uint8), kps2[j, :n].view(np.uint8)) and np.array_equal(desc[b, :n], desc2[j, :n])
+        k = kps[b, :n]
+        lvl = k[:, 5].view(np.int32)
+        assert (np.diff(lvl) >= 0).all() and lvl.min() >= 0 and lvl.max() <= 7
+        assert (k[:, 0] >= 19).all() and (k[:, 0] <= 752 - 19).all() and (k[:, 1] >= 19).all() and (k[:, 1] <= 480 - 19).all()
+        assert ((k[:, 3] >= 0) & (k[:, 3] < 360)).all()
+    o = O.OrbOracle(1000)
+    for b in (0, 17, 63):
+        mono, k, d = o.extract(imgs[b], 0, 0)
+        assert np.array_equal(kps[b, :len(k)].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) and np.array_equal(desc[b, :len(k)], d)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build the product C-ABI library for gfx950 (cross-compiles without a GPU).
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC="$ROOT/awesome-orb-slam3-3dvisioncraft-version_amd/csrc"
+OUT="$ROOT/awesome-orb-slam3-3dvisioncraft-version_amd/liborbhip.so"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+# -ffp-contract=off + correctly rounded fp32 div/sqrt: float expressions must round exactly as the reference's
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+    -Wall -Wno-unused-function -Wno-unused-result -I"$ROOT/include" "$SRC"/*.hip -o "$OUT" "$@"
+echo "built $OUT"
