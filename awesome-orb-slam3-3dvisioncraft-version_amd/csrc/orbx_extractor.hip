@@ -996,7 +996,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     if (batch < 1 || batch > h->maxBatch) return orbx_fail(h, ORB_E_INVALID, "batch exceeds max_batch");
     if (row_stride < h->W || (row_stride & 3) || ((uintptr_t)d_images & 3) || (frame_stride & 3) || !d_kps || !d_desc || !d_counts || cap_per_frame < 1)
         return orbx_fail(h, ORB_E_INVALID, "bad batch arguments (row stride / base must be 4-byte aligned)");
-    hipStream_t st = stream_ ? (hipStream_t)stream_ : h->stream;
+    hipStream_t st = (hipStream_t)stream_;  // NULL = the HIP default stream (what torch uses unless told otherwise)
     HIPCHK(h, hipSetDevice(h->device));
     const int nl = h->cfg.nlevels;
     h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
@@ -1108,7 +1108,7 @@ extern "C" int orbx_copy_level(orbx_handle h, int frame, int level, int border, 
     int rc = orbx_pyramid_level(h, frame, level, &p, &w, &hh, &rs);
     if (rc != ORB_OK || !out || border < 0 || border >= w || border >= hh) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipDeviceSynchronize());
     std::vector<uint8_t> plane((size_t)w * hh);
     HIPCHK(h, hipMemcpy2DAsync(plane.data(), w, p, rs, w, hh, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1124,7 +1124,7 @@ extern "C" int orbx_copy_level(orbx_handle h, int frame, int level, int border, 
 extern "C" int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipDeviceSynchronize());
     int n = 0;
     HIPCHK(h, hipMemcpy(&n, h->d_candCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
     *n_out = n;
@@ -1140,7 +1140,7 @@ extern "C" int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_
 extern "C" int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipDeviceSynchronize());
     int n = 0;
     HIPCHK(h, hipMemcpy(&n, h->d_selCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
     *n_out = n;

@@ -8,8 +8,8 @@
  * Conventions: plain pointers and sizes only; caller-allocated outputs with explicit capacity; the library
  * owns device buffers per handle; no ownership crosses the ABI; no exceptions cross the ABI; every function
  * returns ORB_OK (0) or a negative ORB_E_* code, with a message retrievable by orb*_last_error().
- * "dev" pointers are HIP device pointers on the handle's device; `stream` is a hipStream_t (NULL = the
- * handle's own stream).  Handles are not re-entrant; distinct handles may be used concurrently
+ * "dev" pointers are HIP device pointers on the handle's device; `stream` is a hipStream_t (NULL = the HIP
+ * default stream; the host-buffer entry points use a private stream of the handle and synchronise it).  Handles are not re-entrant; distinct handles may be used concurrently
  * (reference threading: one ORBextractor per camera, Frame.cc:111-114).
  */
 #ifndef ORBHIP_H

@@ -25,7 +25,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
 #include <list>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -795,6 +797,31 @@ void oro_bordered_level(void* h, int level, uint8_t* out) {  // (w+38) x (h+38) 
     for (int y = 0; y < oh; y++)
         for (int x = 0; x < ow; x++)
             out[(size_t)y * ow + x] = lv.img[(size_t)reflect101(y - B, lv.h) * lv.w + reflect101(x - B, lv.w)];
+}
+
+// cpu_baseline leg of bench.py: `nthreads` workers, one extractor each, one frame per thread at a time (the reference
+// extracts one image on one thread, Frame.cc:111-114); frames are taken round-robin from the B-frame sample.
+// Returns wall seconds for nthreads*frames_per_thread extractions (std::chrono::steady_clock like Frame.cc:109-118).
+double oro_bench_extract_mt(const uint8_t* frames, int B, int W, int H, int nfeatures, float scaleFactor, int nlevels,
+                            int iniTh, int minTh, int lap0, int lap1, int nthreads, int frames_per_thread, long* kp_total) {
+    std::vector<std::thread> th;
+    std::vector<long> kp(nthreads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t] {
+            OrbOracle o(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+            std::vector<KeyPoint> k;
+            std::vector<uint8_t> d;
+            for (int i = 0; i < frames_per_thread; i++) {
+                const uint8_t* f = frames + (size_t)((t * frames_per_thread + i) % B) * W * H;
+                o.extract(f, W, H, W, lap0, lap1, k, d);
+                kp[t] += (long)k.size();
+            }
+        });
+    for (auto& x : th) x.join();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (kp_total) { *kp_total = 0; for (long v : kp) *kp_total += v; }
+    return s;
 }
 
 }  // extern "C"

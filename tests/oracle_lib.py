@@ -46,6 +46,9 @@ def lib():
         _lib.oro_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.oro_cvround.argtypes = [C.c_float]
         _lib.oro_bordered_level.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.oro_bench_extract_mt.restype = C.c_double
+        _lib.oro_bench_extract_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -157,3 +160,12 @@ def sincos(a):
     s, c = C.c_float(), C.c_float()
     lib().oro_sincos(float(a), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def bench_extract_mt(frames, nthreads, frames_per_thread, nfeatures=1000, lap=(0, 1000)):
+    """-> (seconds, total keypoints) for nthreads*frames_per_thread extractions in native threads."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    B, H, W = frames.shape
+    tot = C.c_long(0)
+    s = lib().oro_bench_extract_mt(_p(frames), B, W, H, nfeatures, 1.2, 8, 20, 7, lap[0], lap[1], nthreads, frames_per_thread, C.byref(tot))
+    return s, tot.value
