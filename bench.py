@@ -70,13 +70,19 @@ def cpu_baseline(frames, budget_s=10.0):
     n1 = max(8, int(fps1 * budget_s / 3))
     s1, _ = O.bench_extract_mt(frames, 1, n1)
     fps1 = n1 / s1
-    per_thread = max(4, int(fps1 * budget_s * 2 / 3))
-    sN, kp = O.bench_extract_mt(frames, cores, per_thread)
-    fpsN = cores * per_thread / sN
-    return {"value": round(fpsN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d native threads x %d frames (round-robin over %d frames of the same synthetic 752x480 batch), oracle = "
-                      "reference algorithm restated, g++ -O3; single thread: %.2f frames/s over %d frames; mean %.1f keypoints/frame"
-                      % (cores, per_thread, len(frames), fps1, n1, kp / (cores * per_thread))}
+    # thread-count sweep (allocator / page-fault contention makes "all hardware threads" slower than fewer on big hosts)
+    best = None
+    for nt in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
+        per_thread = max(4, int(fps1 * budget_s / 6))
+        sN, kp = O.bench_extract_mt(frames, nt, per_thread)
+        fpsN = nt * per_thread / sN
+        if best is None or fpsN > best[0]:
+            best = (fpsN, nt, per_thread, kp / (nt * per_thread))
+    fpsN, nt, per_thread, meankp = best
+    return {"value": round(fpsN, 2), "unit": "frames/s", "cores": nt, "kind": "port",
+            "sample": "best of a thread-count sweep on a %d-thread host: %d native threads x %d frames (round-robin over %d frames of "
+                      "the same synthetic 752x480 batch), oracle = reference algorithm restated, g++ -O3; single thread: %.2f frames/s "
+                      "over %d frames; mean %.1f keypoints/frame" % (cores, nt, per_thread, len(frames), fps1, n1, meankp)}
 
 
 def main():
@@ -144,6 +150,13 @@ def main():
         dom = max(("pyramid", "fast", "octree", "describe"), key=lambda k: kern[k])
         ach = per_kernel[dom] * B / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
         fps = world * B * args.steps / dt
+        traffic = None  # HBM bytes per launch of the dominant kernel from the last committed PMC pass (profiles/pmc_latest.json)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if B == 512:  # the PMC pass ran the default batch
+                traffic = pm["kernels"]["k_" + dom]["traffic_corrected"]
+        except Exception:
+            pass
         res = {
             "metric": "frames/sec ORB extract (752x480, 1000 kp)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -152,7 +165,7 @@ def main():
                                    "bit-exact vs CPU oracle", "frames_per_gpu_per_step": B, "mean_keypoints": float(counts[:, 0].mean()),
                        "parallelism": "frames sharded, %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_kernel[dom] * B, "kernel_ms": round(kern[dom], 4),
                          "whole_extract_frac": round(whole * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},

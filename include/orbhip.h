@@ -94,6 +94,97 @@ int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int c
  * ms[0]=pyramid ms[1]=FAST ms[2]=octree ms[3]=orient+blur+rBRIEF ms[4]=total.  Synchronises the stream. */
 int orbx_last_timing(orbx_handle h, float* ms5);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Stage 2 — ORBmatcher  (reference include/ORBmatcher.h:39-94, src/ORBmatcher.cc) + the Frame grid helpers it
+ * depends on (src/Frame.cc:444-478, 755-862).  The reference functions walk pointer graphs (Frame&, KeyFrame*,
+ * MapPoint*); this ABI works on the flattened records the adapters in include/orbslam3_hip/ORBmatcher.h gather,
+ * batched over `batch` independent problems (frames / frame pairs) laid out as fixed-capacity slabs:
+ * problem b uses kps + b*cap_k, desc + b*cap_k*32, queries + b*cap_q, ...   All pointers are device pointers.
+ * ------------------------------------------------------------------------------------------------------- */
+#define ORBM_TH_HIGH 100      /* ORBmatcher.cc:36 */
+#define ORBM_TH_LOW 50        /* ORBmatcher.cc:37 */
+#define ORBM_HISTO_LENGTH 30  /* ORBmatcher.cc:38 */
+#define ORBM_GRID_COLS 64     /* FRAME_GRID_COLS, Frame.h:38 */
+#define ORBM_GRID_ROWS 48     /* FRAME_GRID_ROWS, Frame.h:39 */
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2700-2716) for every (query, train) pair:
+ * out[b][i*nt + j] = Hamming(q[b][i], t[b][j]) as uint16.  nq/nt are the per-problem counts (same for all b). */
+int orbm_hamming(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int batch, uint16_t* d_out, void* stream);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used by Frame::ComputeStereoFishEyeMatches (Frame.cc:1300):
+ * per query the two nearest train descriptors, scanning train indices ascending with strict '<' (equal distances
+ * keep the lower train index first).  d_nq / d_nt: per-problem counts (int32, element stride `count_stride`).
+ * out_idx / out_dist: [batch][cap_q][2]; missing neighbours are idx -1, dist 256. */
+int orbm_knn2(const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t, const int32_t* d_nt, int cap_t,
+              int count_stride, int batch, int32_t* d_out_idx, int32_t* d_out_dist, void* stream);
+
+/* Frame bounds/grid scalars: mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv (Frame.cc:388-399) */
+typedef struct orbm_grid_params {
+    float min_x, min_y, grid_w_inv, grid_h_inv;
+} orbm_grid_params;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:444-478, 852-862) as a CSR grid per frame:
+ * cell = ix*ORBM_GRID_ROWS + iy; grid_start[b][cell..cell+1] delimit indices into grid_idx[b][], which lists keypoint
+ * indices in insertion (ascending) order.  d_nkp: per-frame keypoint counts (element stride count_stride).
+ * grid_start: [batch][64*48+1], grid_idx: [batch][cap_k]. */
+int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
+                    const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream);
+
+/* One projected map point = one query of a windowed search (the per-MapPoint values the reference computes before
+ * calling Frame::GetFeaturesInArea: ORBmatcher.cc:88-103 for the local-map search, :2277-2309 for the motion model). */
+typedef struct orbm_query {
+    float u, v;          /* projection (mTrackProjX/Y, or uv) */
+    float radius;        /* r * mvScaleFactors[level]  (window half-size, also the stereo gate) */
+    float u_right;       /* mTrackProjXR / uv.x - mbf*invzc; only read when ORBM_Q_STEREO is set */
+    float angle;         /* keypoint angle of the source observation (rotation histogram), degrees */
+    int16_t min_level, max_level;   /* GetFeaturesInArea level window (its bCheckLevels rule is applied as is) */
+    uint32_t flags;
+} orbm_query;
+#define ORBM_Q_VALID 1u      /* mbTrackInView && !isBad ... : query takes part */
+#define ORBM_Q_STEREO 2u     /* apply the |u_right - mvuRight[idx]| <= radius gate where mvuRight[idx] > 0 */
+#define ORBM_Q_HAS_OBS 4u    /* pMP->Observations() > 0: once matched, the keypoint is skipped by later queries */
+
+typedef struct orbm_search_params {
+    int32_t mode;              /* ORBM_MODE_LOCAL_MAP or ORBM_MODE_BEST_ONLY */
+    int32_t th_dist;           /* TH_HIGH (100), or ORBdist of the relocalisation variant */
+    float nn_ratio;            /* mfNNratio (LOCAL_MAP only) */
+    int32_t check_orientation; /* mbCheckOrientation: rotation-histogram cull (BEST_ONLY only, as in the reference) */
+    orbm_grid_params grid;
+} orbm_search_params;
+#define ORBM_MODE_LOCAL_MAP 0  /* SearchByProjection(Frame&, vector<MapPoint*>&, th, ...)  ORBmatcher.cc:59-255 (left camera) */
+#define ORBM_MODE_BEST_ONLY 1  /* SearchByProjection(Frame&, const Frame&, th, bMono)      ORBmatcher.cc:2244-2509; and :2520-2652 */
+
+/* Windowed projection search, results identical to the reference's serial loop (queries are resolved in index
+ * order; a keypoint claimed by an earlier query with ORBM_Q_HAS_OBS is skipped by later ones).
+ * Frame side: kps (x,y,octave,angle of mvKeysUn), desc, u_right (mvuRight, may be NULL = mono), occupied0 (may be NULL;
+ * non-zero = mvpMapPoints[idx] already holds an observed point), CSR grid from orbm_grid_build.
+ * Outputs: q_match[b][q] = matched keypoint index or -1; kp_match[b][idx] = index of the query whose map point
+ * mvpMapPoints[idx] holds after the call (-1 = none / culled); nmatches[b] = the reference's return value.
+ * d_work: scratch of orbm_search_workspace_bytes(batch, cap_q) bytes. */
+size_t orbm_search_workspace_bytes(int batch, int cap_q);
+int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
+                              const int32_t* d_nkp, int count_stride, int cap_k,
+                              const int32_t* d_grid_start, const int32_t* d_grid_idx,
+                              const orbm_query* d_queries, const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch,
+                              const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
+                              void* d_work, void* stream);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:323-587, Nleft == -1 branch).
+ * FeatureVector of each side as CSR: node ids ascending (std::map order), node_start[k..k+1] delimit feat_idx[] (the
+ * feature indices of that node in insertion order).  kf_valid[i] != 0 where the KF feature holds a good map point.
+ * Output f_match[b][j] = KF feature index matched to frame feature j or -1 (vpMapPointMatches), nmatches[b]. */
+typedef struct orbm_bow_side {
+    const uint8_t* desc;          /* [batch][cap_f][32] */
+    const float* angle;           /* [batch][cap_f]  keypoint angles */
+    const int32_t* node_id;       /* [batch][cap_nodes] ascending */
+    const int32_t* node_start;    /* [batch][cap_nodes+1] */
+    const int32_t* feat_idx;      /* [batch][cap_f] */
+    const int32_t* n_nodes;       /* [batch] */
+    int32_t cap_f, cap_nodes;
+} orbm_bow_side;
+int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch,
+                       float nn_ratio, int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

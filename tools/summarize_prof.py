@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 (ROCm 7.2 writes rocpd SQLite) outputs that tools/gpu_profile.sh left under
+gpurun_out/prof_<tag>/ into small tracked summaries under profiles/:
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / total / average duration (== `rocprofv3 --kernel-trace --stats`)
+  profiles/<tag>_pmc.csv            FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes), KB per dispatch
+  profiles/pmc_latest.json          HBM bytes per launch per kernel, raw and with the gfx950 FETCH_SIZE x2 correction
+"""
+import json
+import os
+import sqlite3
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+c = sqlite3.connect(os.path.join(src, "stats", "trace_results.db"))
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline  (durations in us)\n")
+    f.write("kernel,calls,total_us,average_us,percentage\n")
+    for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        f.write("%s,%d,%.1f,%.3f,%.2f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
+    f.write("# launch geometry / registers (first dispatch of each kernel)\n")
+    f.write("kernel,grid,workgroup,lds_bytes,vgpr,sgpr\n")
+    for r in c.execute("select name,grid_x,grid_y,grid_z,workgroup_x,lds_size,vgpr_count,sgpr_count from kernels group by name"):
+        f.write("%s,%dx%dx%d,%d,%d,%d,%d\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4], r[5], r[6], r[7]))
+pmc = {}
+with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), same command; values are KB per dispatch as reported\n")
+    f.write("kernel,counter,dispatches,mean_KB_per_dispatch\n")
+    for kind in ("fetch", "write"):
+        d = sqlite3.connect(os.path.join(src, kind, "pmc_results.db"))
+        for name, ctr, n, mean in d.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection group by kernel_name,counter_name"):
+            f.write("%s,%s,%d,%.1f\n" % (name.replace(",", ";"), ctr, n, mean))
+            pmc.setdefault(name.split("(")[0], {})[ctr] = mean * 1024.0
+out = {"tag": tag, "note": "bytes per launch; FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide coalesced reads "
+       "(MI355X_MICROARCH.md §HBM): 'corrected' doubles the read side; other widths are uncalibrated, so raw <= true <= corrected",
+       "kernels": {}}
+for k, v in pmc.items():
+    fr, wr = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+    out["kernels"][k] = {"fetch_raw": fr, "write": wr, "traffic_raw": fr + wr, "traffic_corrected": 2 * fr + wr}
+json.dump(out, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
+print(open(os.path.join(dst, tag + "_pmc.csv")).read())
