@@ -1,4 +1,5 @@
 from ._lib import load, OrbHipError, KP_DTYPE  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
+from .matcher import ORBmatcher, QUERY_DTYPE  # noqa: F401
 
-__all__ = ["load", "OrbHipError", "KP_DTYPE", "ORBextractor"]
+__all__ = ["load", "OrbHipError", "KP_DTYPE", "ORBextractor", "ORBmatcher", "QUERY_DTYPE"]

@@ -1,0 +1,572 @@
+// orbm_matcher.hip — stage 2 of the hot path on gfx950: ORBmatcher (reference src/ORBmatcher.cc) and the Frame grid
+// helpers it depends on (src/Frame.cc:444-478, 755-862), over the flattened records of include/orbhip.h.
+//
+//   k_hamming        M1   ORBmatcher::DescriptorDistance for a Q x T tile            ORBmatcher.cc:2700-2716
+//   k_knn2           M10  BFMatcher(NORM_HAMMING).knnMatch(k=2)                       Frame.cc:1300
+//   k_grid_build     M2   Frame::AssignFeaturesToGrid / PosInGrid -> CSR              Frame.cc:444-478, 852-862
+//   k_sbp_candidates M3   Frame::GetFeaturesInArea + Hamming, one wave per query      Frame.cc:755-850
+//   k_sbp_resolve    M4/M5 serial-order resolution of SearchByProjection (one wave per frame), rotation histogram
+//                                                                                      ORBmatcher.cc:59-255, 2244-2509
+//   k_bow            M6   SearchByBoW(KF,F): one workgroup per pair, one wave per shared vocabulary node  :323-587
+//
+// Results are identical to the reference's serial loops: candidate enumeration order, strict-'<' best/second updates,
+// "skip keypoints claimed earlier in this call" and the rotation-histogram quirks are all reproduced.
+// 256-bit Hamming = 8 x v_bcnt_u32 on two 16-byte loads per descriptor.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/orbhip.h"
+
+#define GRID_CELLS (ORBM_GRID_COLS * ORBM_GRID_ROWS)
+#define SBP_CAPC 64                 // cached candidates per query (more -> the resolver re-enumerates that query inline)
+#define SBP_WORK_PER_Q (SBP_CAPC + 2)  // u32 words of workspace per query: count, bin, list[SBP_CAPC]
+
+struct Desc { uint32_t w[8]; };
+
+static __device__ __forceinline__ Desc load_desc(const uint8_t* p) {
+    Desc d;
+    const uint4 a = *(const uint4*)p, b = *(const uint4*)(p + 16);
+    d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w; d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+    return d;
+}
+static __device__ __forceinline__ int hamming(const Desc& a, const Desc& b) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += __popc(a.w[i] ^ b.w[i]);
+    return s;
+}
+static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ============================================================================================================
+// M1 / M10  brute-force Hamming tiles
+// ============================================================================================================
+// block = 256 train descriptors (one per thread, in registers) x 16 queries staged in LDS (broadcast reads);
+// each of the 16 output rows is written coalesced.
+static __global__ __launch_bounds__(256) void k_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    uint32_t* qs = (uint32_t*)orb_smem;  // [16][8]
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * 16;
+    q += (size_t)b * nq * 32; t += (size_t)b * nt * 32; out += (size_t)b * nq * nt;
+    if (threadIdx.x < 128) {
+        const int qi = i0 + (threadIdx.x >> 3);
+        qs[threadIdx.x] = qi < nq ? ((const uint32_t*)q)[(size_t)qi * 8 + (threadIdx.x & 7)] : 0;
+    }
+    __syncthreads();
+    if (j >= nt) return;
+    const Desc d = load_desc(t + (size_t)j * 32);
+    for (int r = 0; r < 16 && i0 + r < nq; r++) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += __popc(d.w[k] ^ qs[r * 8 + k]);
+        out[(size_t)(i0 + r) * nt + j] = (uint16_t)s;
+    }
+}
+
+// thread = query (descriptor in registers); train descriptors stream through LDS in tiles of 64, scanned in
+// ascending index order with strict '<' so that ties keep the lower train index (cv::BFMatcher semantics).
+static __global__ __launch_bounds__(256) void k_knn2(const uint8_t* q, const int32_t* nqv, int cap_q, const uint8_t* t,
+                                                     const int32_t* ntv, int cap_t, int cstride, int32_t* out_idx, int32_t* out_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    uint32_t* ts = (uint32_t*)orb_smem;  // [64][8]
+    const int b = blockIdx.y;
+    const int nq = min(nqv[(size_t)b * cstride], cap_q), nt = min(ntv[(size_t)b * cstride], cap_t);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    q += (size_t)b * cap_q * 32; t += (size_t)b * cap_t * 32;
+    Desc d;
+    if (i < nq) d = load_desc(q + (size_t)i * 32);
+    else { for (int k = 0; k < 8; k++) d.w[k] = 0; }
+    int d0 = 256, d1 = 256, i0 = -1, i1 = -1;
+    for (int base = 0; base < nt; base += 64) {
+        const int n = min(64, nt - base);
+        __syncthreads();
+        for (int w = threadIdx.x; w < n * 8; w += 256) ts[w] = ((const uint32_t*)t)[(size_t)base * 8 + w];
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += __popc(d.w[k] ^ ts[j * 8 + k]);
+            if (s < d0) { d1 = d0; i1 = i0; d0 = s; i0 = base + j; }
+            else if (s < d1) { d1 = s; i1 = base + j; }
+        }
+    }
+    if (i < cap_q) {
+        int32_t* oi = out_idx + ((size_t)b * cap_q + i) * 2;
+        int32_t* od = out_dist + ((size_t)b * cap_q + i) * 2;
+        const bool ok = i < nq;
+        oi[0] = ok ? i0 : -1; oi[1] = ok ? i1 : -1; od[0] = ok ? d0 : 256; od[1] = ok ? d1 : 256;
+    }
+}
+
+// ============================================================================================================
+// M2  grid build: counting sort into a CSR whose cells list keypoint indices in ascending (= insertion) order
+// ============================================================================================================
+static __device__ __forceinline__ bool pos_in_grid(const orb_keypoint& kp, const orbm_grid_params& g, int& cell) {
+    // Frame::PosInGrid, Frame.cc:852-862 (C round(): half away from zero)
+    const int px = (int)roundf((kp.x - g.min_x) * g.grid_w_inv);
+    const int py = (int)roundf((kp.y - g.min_y) * g.grid_h_inv);
+    if (px < 0 || px >= ORBM_GRID_COLS || py < 0 || py >= ORBM_GRID_ROWS) return false;
+    cell = px * ORBM_GRID_ROWS + py;
+    return true;
+}
+
+static __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* kps, const int32_t* nkp, int cstride, int cap_k,
+                                                          orbm_grid_params g, int32_t* grid_start, int32_t* grid_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* cnt = (int*)orb_smem;            // [GRID_CELLS] counts -> starts
+    int* fill = cnt + GRID_CELLS;         // [GRID_CELLS]
+    int* scratch = fill + GRID_CELLS;     // [256]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nkp[(size_t)b * cstride], cap_k);
+    kps += (size_t)b * cap_k; grid_start += (size_t)b * (GRID_CELLS + 1); grid_idx += (size_t)b * cap_k;
+    for (int c = tid; c < GRID_CELLS; c += 256) { cnt[c] = 0; fill[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int cell;
+        if (pos_in_grid(kps[i], g, cell)) atomicAdd(&cnt[cell], 1);
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counts: 12 per thread
+    {
+        const int per = GRID_CELLS / 256;
+        int sum = 0;
+        for (int k = 0; k < per; k++) sum += cnt[tid * per + k];
+        scratch[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? scratch[tid - off] : 0;
+            __syncthreads();
+            scratch[tid] += v;
+            __syncthreads();
+        }
+        int run = scratch[tid] - sum;
+        for (int k = 0; k < per; k++) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; run += c; }
+        if (tid == 255) grid_start[GRID_CELLS] = run;
+    }
+    __syncthreads();
+    for (int c = tid; c < GRID_CELLS; c += 256) grid_start[c] = cnt[c];
+    for (int i = tid; i < n; i += 256) {
+        int cell;
+        if (pos_in_grid(kps[i], g, cell)) grid_idx[cnt[cell] + atomicAdd(&fill[cell], 1)] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // restore insertion order inside each cell (cells hold a handful of entries)
+    for (int c = tid; c < GRID_CELLS; c += 256) {
+        const int s = cnt[c], m = fill[c];
+        for (int a = 1; a < m; a++) {
+            const int v = grid_idx[s + a];
+            int p = a - 1;
+            while (p >= 0 && grid_idx[s + p] > v) { grid_idx[s + p + 1] = grid_idx[s + p]; p--; }
+            grid_idx[s + p + 1] = v;
+        }
+    }
+}
+
+// ============================================================================================================
+// M3-M5  windowed projection search
+// ============================================================================================================
+struct SbpArgs {
+    const orb_keypoint* kps; const uint8_t* desc; const float* u_right; const uint8_t* occupied0;
+    const int32_t* nkp; int cstride, cap_k;
+    const int32_t* grid_start; const int32_t* grid_idx;
+    const orbm_query* queries; const uint8_t* qdesc; const int32_t* nq; int cap_q;
+    orbm_search_params prm;
+    int32_t* q_match; int32_t* kp_match; int32_t* nmatches;
+    uint32_t* work;
+};
+
+// Wave-level enumeration of Frame::GetFeaturesInArea(u, v, radius, minLevel, maxLevel) in the reference's order
+// (ix outer, iy inner, insertion order inside a cell == CSR order inside one grid column segment), with the
+// candidate filters that do not depend on matches made during the call.  sink(pass, idx, dist, octave) is called
+// wave-uniformly for every 64-entry chunk (lane = entry).
+template <class Sink>
+static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b, const orbm_query& Q, const Desc& qd, int n, Sink&& sink) {
+    const orbm_grid_params& g = A.prm.grid;
+    const float r = Q.radius;
+    // Frame.cc:779-806
+    const int nMinCellX = max(0, (int)floorf((Q.u - g.min_x - r) * g.grid_w_inv));
+    if (nMinCellX >= ORBM_GRID_COLS) return;
+    const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((Q.u - g.min_x + r) * g.grid_w_inv));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = max(0, (int)floorf((Q.v - g.min_y - r) * g.grid_h_inv));
+    if (nMinCellY >= ORBM_GRID_ROWS) return;
+    const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf((Q.v - g.min_y + r) * g.grid_h_inv));
+    if (nMaxCellY < 0) return;
+    const int minLevel = Q.min_level, maxLevel = Q.max_level;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);   // Frame.cc:810
+    const int lane = threadIdx.x & 63;
+    const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
+    const uint8_t* desc = A.desc + (size_t)b * A.cap_k * 32;
+    const float* ur = A.u_right ? A.u_right + (size_t)b * A.cap_k : nullptr;
+    const uint8_t* occ0 = A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
+    const int32_t* gs = A.grid_start + (size_t)b * (GRID_CELLS + 1);
+    const int32_t* gi = A.grid_idx + (size_t)b * A.cap_k;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        if (nMaxCellY < nMinCellY) break;
+        const int s = gs[ix * ORBM_GRID_ROWS + nMinCellY], e = gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
+        for (int base = s; base < e; base += 64) {
+            const int p = base + lane;
+            bool pass = false;
+            int idx = 0, dist = 256, oct = 0;
+            if (p < e) {
+                idx = gi[p];
+                if (idx >= 0 && idx < n) {
+                    const orb_keypoint kp = kps[idx];
+                    oct = kp.octave;
+                    pass = true;
+                    if (bCheckLevels) {
+                        if (oct < minLevel) pass = false;
+                        if (maxLevel >= 0 && oct > maxLevel) pass = false;
+                    }
+                    const float distx = kp.x - Q.u, disty = kp.y - Q.v;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
+                    if (pass && occ0 && occ0[idx]) pass = false;
+                    if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
+                        const float uR = ur[idx];
+                        if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
+                    }
+                    if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
+                }
+            }
+            sink(pass, idx, dist, oct);
+        }
+    }
+}
+
+static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = min(A.nq[b], A.cap_q);
+    if (q >= nq) return;
+    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+    const orbm_query Q = A.queries[(size_t)b * A.cap_q + q];
+    uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
+    int count = 0;
+    if (Q.flags & ORBM_Q_VALID) {
+        const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+        enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < SBP_CAPC) w[2 + pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+            }
+            count += __popcll(m);
+        });
+    }
+    if (lane == 0) { w[0] = (uint32_t)count; w[1] = 0xFFFFFFFFu; }
+}
+
+// One wave per frame walks the queries in index order (ORBmatcher.cc:65 / :2265 loop order) and applies the
+// reference's accept rules against the live occupancy; distances come from k_sbp_candidates.
+static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+    const int nq = min(A.nq[b], A.cap_q);
+    int* hist = (int*)orb_smem;                       // [32]
+    int* ctl = hist + 32;                             // [8]
+    uint8_t* occ = (uint8_t*)(ctl + 8);               // [cap_k] holder has Observations()>0
+    int32_t* q_match = A.q_match + (size_t)b * A.cap_q;
+    int32_t* kp_match = A.kp_match + (size_t)b * A.cap_k;
+    const uint8_t* occ0 = A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
+    for (int i = lane; i < A.cap_k; i += 64) { occ[i] = (i < n && occ0 && occ0[i]) ? 1 : 0; kp_match[i] = -1; }
+    for (int i = lane; i < A.cap_q; i += 64) q_match[i] = -1;
+    if (lane < 32) hist[lane] = 0;
+    __syncthreads();
+    const int mode = A.prm.mode, th = A.prm.th_dist;
+    const float ratio = A.prm.nn_ratio;
+    const bool ori = mode == ORBM_MODE_BEST_ONLY && A.prm.check_orientation;
+    const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
+    int nmatches = 0;
+    for (int q = 0; q < nq; q++) {
+        uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
+        const int count = (int)w[0];
+        if (count == 0) continue;
+        const orbm_query Q = A.queries[(size_t)b * A.cap_q + q];
+        // per-lane two smallest keys; key = dist<<20 | enumeration position  (first minimum wins, strict '<')
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;
+        if (count <= SBP_CAPC) {
+            if (lane < count) {
+                const uint32_t e = w[2 + lane];
+                if (!occ[e & 0xFFFF]) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
+            }
+        } else {  // rare: re-enumerate this query against the live occupancy
+            const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+            int seen = 0;
+            enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+                const unsigned long long m = __ballot(pass);
+                if (pass && !occ[idx]) {
+                    const uint32_t pos = (uint32_t)(seen + __popcll(m & ((1ull << lane) - 1ull)));
+                    const uint32_t key = ((uint32_t)dist << 20) | (pos & 0xFFFFF);
+                    const uint32_t e = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+                    if (key < k1) { k2 = k1; e2 = e1; k1 = key; e1 = e; }
+                    else if (key < k2) { k2 = key; e2 = e; }
+                }
+                seen += __popcll(m);
+            });
+        }
+        const uint32_t m1 = wave_min_u32(k1);
+        if (m1 == 0xFFFFFFFFu) continue;  // every candidate already holds an observed point
+        const bool iBest = k1 == m1;
+        const uint32_t c2 = iBest ? k2 : k1;
+        const uint32_t m2 = wave_min_u32(c2);
+        // broadcast the entries that own m1 / m2
+        const unsigned long long bm1 = __ballot(iBest);
+        const int l1 = __ffsll((long long)bm1) - 1;
+        const uint32_t eb1 = __shfl(e1, l1);
+        const unsigned long long bm2 = __ballot(c2 == m2 && m2 != 0xFFFFFFFFu);
+        uint32_t eb2 = 0;
+        if (bm2) { const int l2 = __ffsll((long long)bm2) - 1; eb2 = __shfl(iBest ? e2 : e1, l2); }
+        const int bestDist = (int)(m1 >> 20), bestIdx = (int)(eb1 & 0xFFFF), bestLevel = (int)((eb1 >> 25) & 0x3F);
+        const int bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
+        const int bestLevel2 = m2 == 0xFFFFFFFFu ? -1 : (int)((eb2 >> 25) & 0x3F);
+        bool accept = false;
+        if (bestDist <= th) {
+            if (mode == ORBM_MODE_LOCAL_MAP) {
+                // ORBmatcher.cc:160-178
+                if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) accept = false;
+                else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
+            } else {
+                accept = true;  // ORBmatcher.cc:2372
+            }
+        }
+        if (accept) {
+            nmatches++;
+            if (lane == 0) {
+                occ[bestIdx] = (Q.flags & ORBM_Q_HAS_OBS) ? 1 : 0;
+                kp_match[bestIdx] = q;
+                q_match[q] = bestIdx;
+                if (ori) {
+                    // ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()
+                    float rot = Q.angle - kps[bestIdx].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                    bin = max(0, min(bin, 31));
+                    hist[bin]++;
+                    w[1] = (uint32_t)bin;
+                }
+            }
+            __syncthreads();  // single-wave block: orders lane 0's LDS writes before the next query's reads
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (ori) {
+        if (lane == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:2654-2695
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            ctl[0] = ind1; ctl[1] = ind2; ctl[2] = ind3; ctl[3] = 0;
+        }
+        __syncthreads();
+        const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
+        for (int q = lane; q < nq; q += 64) {
+            const uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
+            const int bin = (int)w[1];
+            if (q_match[q] >= 0 && bin != ind1 && bin != ind2 && bin != ind3) {
+                kp_match[q_match[q]] = -1;      // CurrentFrame.mvpMapPoints[...] = NULL, :2499
+                atomicAdd(&ctl[3], 1);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        nmatches -= ctl[3];
+    }
+    // a query's match is reported only while its keypoint still holds it
+    for (int q = lane; q < nq; q += 64)
+        if (q_match[q] >= 0 && kp_match[q_match[q]] != q) q_match[q] = -1;
+    if (lane == 0) A.nmatches[b] = nmatches;
+}
+
+// ============================================================================================================
+// M6  SearchByBoW(KeyFrame*, Frame&)
+// ============================================================================================================
+struct BowArgs {
+    orbm_bow_side kf, f;
+    const uint8_t* kf_valid;
+    float nn_ratio; int check_orientation;
+    int32_t* f_match; int32_t* nmatches;
+};
+
+static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* hist = (int*)orb_smem;                    // [32]
+    int* ctl = hist + 32;                          // [8]
+    int* pairF = ctl + 8;                          // [kf.cap_nodes]
+    int8_t* fbin = (int8_t*)(pairF + A.kf.cap_nodes);  // [f.cap_f] rotation bin of an accepted match, -1 otherwise
+    const int nkn = min(A.kf.n_nodes[b], A.kf.cap_nodes), nfn = min(A.f.n_nodes[b], A.f.cap_nodes);
+    const int32_t* kid = A.kf.node_id + (size_t)b * A.kf.cap_nodes;
+    const int32_t* kst = A.kf.node_start + (size_t)b * (A.kf.cap_nodes + 1);
+    const int32_t* kfe = A.kf.feat_idx + (size_t)b * A.kf.cap_f;
+    const int32_t* fid = A.f.node_id + (size_t)b * A.f.cap_nodes;
+    const int32_t* fst = A.f.node_start + (size_t)b * (A.f.cap_nodes + 1);
+    const int32_t* ffe = A.f.feat_idx + (size_t)b * A.f.cap_f;
+    const uint8_t* kdesc = A.kf.desc + (size_t)b * A.kf.cap_f * 32;
+    const uint8_t* fdesc = A.f.desc + (size_t)b * A.f.cap_f * 32;
+    const float* kang = A.kf.angle + (size_t)b * A.kf.cap_f;
+    const float* fang = A.f.angle + (size_t)b * A.f.cap_f;
+    const uint8_t* kvalid = A.kf_valid + (size_t)b * A.kf.cap_f;
+    int32_t* f_match = A.f_match + (size_t)b * A.f.cap_f;
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 8) ctl[tid] = 0;
+    for (int i = tid; i < A.f.cap_f; i += 256) { f_match[i] = -1; fbin[i] = -1; }
+    // the merge walk of the two sorted FeatureVectors (ORBmatcher.cc:343, 553-560) = intersection of the id lists
+    for (int k = tid; k < nkn; k += 256) {
+        const int key = kid[k];
+        int lo = 0, hi = nfn;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (fid[m] < key) lo = m + 1; else hi = m; }
+        pairF[k] = (lo < nfn && fid[lo] == key) ? lo : -1;
+    }
+    __syncthreads();
+    int myMatches = 0;
+    for (int k = wave; k < nkn; k += 4) {
+        const int fn = pairF[k];
+        if (fn < 0) continue;
+        const int fs = fst[fn], fe = fst[fn + 1];
+        for (int iKF = kst[k]; iKF < kst[k + 1]; iKF++) {
+            const int realIdxKF = kfe[iKF];
+            if (!kvalid[realIdxKF]) continue;
+            const Desc dKF = load_desc(kdesc + (size_t)realIdxKF * 32);
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            int idx1 = -1;
+            for (int base = fs; base < fe; base += 64) {
+                const int p = base + lane;
+                if (p < fe) {
+                    const int realIdxF = ffe[p];
+                    if (fbin[realIdxF] == -1 && f_match[realIdxF] < 0) {   // !vpMapPointMatches[realIdxF]
+                        const uint32_t key = ((uint32_t)hamming(dKF, load_desc(fdesc + (size_t)realIdxF * 32)) << 20) | (uint32_t)(p - fs);
+                        if (key < k1) { k2 = k1; k1 = key; idx1 = realIdxF; }
+                        else if (key < k2) { k2 = key; }
+                    }
+                }
+            }
+            const uint32_t m1 = wave_min_u32(k1);
+            if (m1 == 0xFFFFFFFFu) continue;
+            const bool iBest = k1 == m1;
+            const uint32_t m2 = wave_min_u32(iBest ? k2 : k1);
+            const int l1 = __ffsll((long long)__ballot(iBest)) - 1;
+            const int bestIdxF = __shfl(idx1, l1);
+            const int bestDist1 = (int)(m1 >> 20), bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
+            if (bestDist1 <= ORBM_TH_LOW && (float)bestDist1 < A.nn_ratio * (float)bestDist2) {  // :464-470
+                myMatches++;
+                if (lane == 0) {
+                    f_match[bestIdxF] = realIdxKF;
+                    int bin = 30;  // "accepted, orientation unchecked"
+                    if (A.check_orientation) {
+                        float rot = kang[realIdxKF] - fang[bestIdxF];
+                        if (rot < 0.0f) rot += 360.0f;
+                        bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                        bin = max(0, min(bin, 29));
+                        atomicAdd(&hist[bin], 1);
+                    }
+                    fbin[bestIdxF] = (int8_t)bin;
+                }
+                __threadfence_block();
+            }
+        }
+    }
+    if (lane == 0 && myMatches) atomicAdd(&ctl[4], myMatches);
+    __syncthreads();
+    if (A.check_orientation) {
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            ctl[0] = ind1; ctl[1] = ind2; ctl[2] = ind3;
+        }
+        __syncthreads();
+        const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
+        for (int j = tid; j < A.f.cap_f; j += 256) {
+            const int bin = fbin[j];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) { f_match[j] = -1; atomicAdd(&ctl[5], 1); }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) A.nmatches[b] = ctl[4] - ctl[5];
+}
+
+// ============================================================================================================
+// C ABI
+// ============================================================================================================
+static int launch_status() { return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP; }
+
+extern "C" int orbm_hamming(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int batch, uint16_t* d_out, void* stream) {
+    if (!d_q || !d_t || !d_out || nq < 1 || nt < 1 || batch < 1) return ORB_E_INVALID;
+    hipLaunchKernelGGL(k_hamming, dim3((nt + 255) / 256, (nq + 15) / 16, batch), dim3(256), 512, (hipStream_t)stream, d_q, nq, d_t, nt, d_out);
+    return launch_status();
+}
+
+extern "C" int orbm_knn2(const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t, const int32_t* d_nt, int cap_t,
+                         int count_stride, int batch, int32_t* d_out_idx, int32_t* d_out_dist, void* stream) {
+    if (!d_q || !d_t || !d_nq || !d_nt || !d_out_idx || !d_out_dist || cap_q < 1 || cap_t < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
+    hipLaunchKernelGGL(k_knn2, dim3((cap_q + 255) / 256, batch), dim3(256), 64 * 32, (hipStream_t)stream, d_q, d_nq, cap_q, d_t, d_nt, cap_t,
+                       count_stride, d_out_idx, d_out_dist);
+    return launch_status();
+}
+
+extern "C" int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
+                               const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
+    if (!d_kps || !d_nkp || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
+    hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (2 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
+                       *gp, d_grid_start, d_grid_idx);
+    return launch_status();
+}
+
+extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4; }
+
+extern "C" int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
+                                         const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start,
+                                         const int32_t* d_grid_idx, const orbm_query* d_queries, const uint8_t* d_qdesc,
+                                         const int32_t* d_nq, int cap_q, int batch, const orbm_search_params* params,
+                                         int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches, void* d_work, void* stream) {
+    if (!d_kps || !d_desc || !d_nkp || !d_grid_start || !d_grid_idx || !d_queries || !d_qdesc || !d_nq || !params || !d_q_match ||
+        !d_kp_match || !d_nmatches || !d_work || cap_k < 1 || cap_k > 65535 || cap_q < 1 || batch < 1 || count_stride < 1)
+        return ORB_E_INVALID;
+    if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY) return ORB_E_INVALID;
+    const size_t smem = (32 + 8) * 4 + (((size_t)cap_k + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    SbpArgs A;
+    A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = d_occupied0; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;
+    A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
+    A.prm = *params; A.q_match = d_q_match; A.kp_match = d_kp_match; A.nmatches = d_nmatches; A.work = (uint32_t*)d_work;
+    hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
+    return launch_status();
+}
+
+extern "C" int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch, float nn_ratio,
+                                  int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream) {
+    if (!kf || !f || !d_kf_valid || !d_f_match || !d_nmatches || batch < 1 || kf->cap_f < 1 || f->cap_f < 1 || kf->cap_nodes < 1 || f->cap_nodes < 1)
+        return ORB_E_INVALID;
+    const size_t smem = (32 + 8 + (size_t)kf->cap_nodes) * 4 + (((size_t)f->cap_f + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    BowArgs A;
+    A.kf = *kf; A.f = *f; A.kf_valid = d_kf_valid; A.nn_ratio = nn_ratio; A.check_orientation = check_orientation;
+    A.f_match = d_f_match; A.nmatches = d_nmatches;
+    hipLaunchKernelGGL(k_bow, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    return launch_status();
+}

@@ -1,0 +1,146 @@
+"""Host-side mirror of ORB_SLAM3::ORBmatcher (reference include/ORBmatcher.h:39-94) above the C ABI.
+
+The reference methods take Frame&/KeyFrame*/MapPoint* pointer graphs; here they take the flattened records that the
+C++ adapter gathers from those objects (include/orbhip.h "Stage 2"), batched over independent problems.  Arrays may be
+torch CUDA tensors (product path) or numpy arrays (only meaningful with the emulated test build, whose "device" is
+host memory).  Outputs are allocated like the inputs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OrbHipError
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:36-38
+GRID_COLS, GRID_ROWS = 64, 48                 # Frame.h:38-39
+MODE_LOCAL_MAP, MODE_BEST_ONLY = 0, 1
+Q_VALID, Q_STEREO, Q_HAS_OBS = 1, 2, 4
+
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("angle", "<f4"),
+                        ("min_level", "<i2"), ("max_level", "<i2"), ("flags", "<u4")])
+assert QUERY_DTYPE.itemsize == 28
+
+
+class GridParams(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("th_dist", C.c_int32), ("nn_ratio", C.c_float), ("check_orientation", C.c_int32),
+                ("grid", GridParams)]
+
+
+class BowSide(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("angle", C.c_void_p), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
+                ("feat_idx", C.c_void_p), ("n_nodes", C.c_void_p), ("cap_f", C.c_int32), ("cap_nodes", C.c_int32)]
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    assert a.is_contiguous()
+    return C.c_void_p(a.data_ptr())
+
+
+def _like(a, shape, dtype):
+    if isinstance(a, np.ndarray):
+        return np.zeros(shape, dtype)
+    import torch
+    tdt = {np.int32: torch.int32, np.uint16: torch.int16, np.uint8: torch.uint8, np.float32: torch.float32}[dtype]
+    return torch.zeros(shape, dtype=tdt, device=a.device)
+
+
+def _stream(a):
+    if isinstance(a, np.ndarray):
+        return None
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+
+
+def bind(lib):
+    vp, i32, sz, f32 = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+    protos = {
+        "orbm_hamming": (i32, [vp, i32, vp, i32, i32, vp, vp]),
+        "orbm_knn2": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]),
+        "orbm_grid_build": (i32, [vp, vp, i32, i32, i32, C.POINTER(GridParams), vp, vp, vp]),
+        "orbm_search_workspace_bytes": (sz, [i32, i32]),
+        "orbm_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
+                                            vp, vp, vp, vp, vp]),
+        "orbm_search_by_bow": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), i32, f32, i32, vp, vp, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, *, lib=None):   # ORBmatcher.h:39
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+        self._L = bind(lib if lib is not None else _lib.load())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise OrbHipError(rc, "orbm call failed")
+
+    # -- ORBmatcher::DescriptorDistance for all pairs (ORBmatcher.cc:2700-2716): q [B,nq,32], t [B,nt,32] -> [B,nq,nt] uint16
+    def DescriptorDistance(self, q, t):
+        B, nq, _ = q.shape
+        nt = t.shape[1]
+        out = _like(q, (B, nq, nt), np.uint16)
+        self._check(self._L.orbm_hamming(_ptr(q), nq, _ptr(t), nt, B, _ptr(out), _stream(q)))
+        return out
+
+    # -- BFMatcher(NORM_HAMMING).knnMatch(k=2) (Frame.cc:1300): q [B,capq,32], nq [B] int32, t [B,capt,32], nt [B]
+    def knnMatch2(self, q, nq, t, nt):
+        B, capq, _ = q.shape
+        idx = _like(q, (B, capq, 2), np.int32)
+        dist = _like(q, (B, capq, 2), np.int32)
+        self._check(self._L.orbm_knn2(_ptr(q), _ptr(nq), capq, _ptr(t), _ptr(nt), t.shape[1], 1, B, _ptr(idx), _ptr(dist), _stream(q)))
+        return idx, dist
+
+    # -- Frame::AssignFeaturesToGrid (Frame.cc:444-478): kps [B,cap,7] f32 (orb_keypoint), counts int32 (stride in elements)
+    def grid_build(self, kps, counts, grid, count_stride=1):
+        B, cap = kps.shape[0], kps.shape[1]
+        gs = _like(kps, (B, GRID_COLS * GRID_ROWS + 1), np.int32)
+        gi = _like(kps, (B, cap), np.int32)
+        gp = GridParams(*grid)
+        self._check(self._L.orbm_grid_build(_ptr(kps), _ptr(counts), count_stride, cap, B, C.byref(gp), _ptr(gs), _ptr(gi), _stream(kps)))
+        return gs, gi
+
+    # -- SearchByProjection (ORBmatcher.cc:59-255 mode LOCAL_MAP / :2244-2509 mode BEST_ONLY) on flattened records
+    def SearchByProjection(self, kps, desc, counts, grid_start, grid_idx, queries, qdesc, nq, grid, mode, th_dist=TH_HIGH,
+                           u_right=None, occupied0=None, count_stride=1, work=None):
+        B, cap_k = kps.shape[0], kps.shape[1]
+        cap_q = qdesc.shape[1]
+        q_match = _like(kps, (B, cap_q), np.int32)
+        kp_match = _like(kps, (B, cap_k), np.int32)
+        nmatches = _like(kps, (B,), np.int32)
+        if work is None:
+            work = _like(kps, (self._L.orbm_search_workspace_bytes(B, cap_q),), np.uint8)
+        prm = SearchParams(mode, th_dist, self.mfNNratio, int(self.mbCheckOrientation), GridParams(*grid))
+        self._check(self._L.orbm_search_by_projection(_ptr(kps), _ptr(desc), _ptr(u_right), _ptr(occupied0), _ptr(counts), count_stride,
+                                                      cap_k, _ptr(grid_start), _ptr(grid_idx), _ptr(queries), _ptr(qdesc), _ptr(nq),
+                                                      cap_q, B, C.byref(prm), _ptr(q_match), _ptr(kp_match), _ptr(nmatches),
+                                                      _ptr(work), _stream(kps)))
+        return q_match, kp_match, nmatches
+
+    # -- SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:323-587) on FeatureVector CSRs
+    def SearchByBoW(self, kf, kf_valid, f):
+        """kf / f: dict(desc [B,cap,32], angle [B,cap], node_id [B,capn], node_start [B,capn+1], feat_idx [B,cap], n_nodes [B])"""
+        def side(d):
+            return BowSide(_ptr(d["desc"]).value, _ptr(d["angle"]).value, _ptr(d["node_id"]).value, _ptr(d["node_start"]).value,
+                           _ptr(d["feat_idx"]).value, _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1])
+        B = kf["desc"].shape[0]
+        f_match = _like(f["desc"], (B, f["desc"].shape[1]), np.int32)
+        nmatches = _like(f["desc"], (B,), np.int32)
+        a, b = side(kf), side(f)
+        self._check(self._L.orbm_search_by_bow(C.byref(a), _ptr(kf_valid), C.byref(b), B, self.mfNNratio, int(self.mbCheckOrientation),
+                                               _ptr(f_match), _ptr(nmatches), _stream(f["desc"])))
+        return f_match, nmatches

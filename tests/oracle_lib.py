@@ -169,3 +169,58 @@ def bench_extract_mt(frames, nthreads, frames_per_thread, nfeatures=1000, lap=(0
     tot = C.c_long(0)
     s = lib().oro_bench_extract_mt(_p(frames), B, W, H, nfeatures, 1.2, 8, 20, 7, lap[0], lap[1], nthreads, frames_per_thread, C.byref(tot))
     return s, tot.value
+
+
+# ---- stage 2 (oracle/match_oracle.cpp) ------------------------------------------------------------------
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("angle", "<f4"),
+                        ("min_level", "<i2"), ("max_level", "<i2"), ("flags", "<u4")])
+
+
+def hamming(a, b):
+    return lib().omo_hamming(_p(np.ascontiguousarray(a, np.uint8)), _p(np.ascontiguousarray(b, np.uint8)))
+
+
+def grid_build(kps, grid):
+    kps = np.ascontiguousarray(kps)
+    gs = np.zeros(64 * 48 + 1, np.int32)
+    gi = np.zeros(max(len(kps), 1), np.int32)
+    L = lib()
+    L.omo_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.omo_grid_build(_p(kps), len(kps), *[float(g) for g in grid], _p(gs), _p(gi))
+    return gs, gi
+
+
+def search_by_projection(kps, desc, queries, qdesc, grid, mode, th_dist, nnratio, check_ori, u_right=None, occupied0=None):
+    L = lib()
+    L.omo_search_by_projection.restype = C.c_int
+    L.omo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_void_p, C.c_void_p]
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc); queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc)
+    q_match = np.zeros(max(len(queries), 1), np.int32)
+    kp_match = np.zeros(max(len(kps), 1), np.int32)
+    n = L.omo_search_by_projection(_p(kps), _p(desc), _p(u_right) if u_right is not None else None,
+                                   _p(occupied0) if occupied0 is not None else None, len(kps), *[float(g) for g in grid],
+                                   _p(queries), _p(qdesc), len(queries), mode, th_dist, nnratio, int(check_ori), _p(q_match), _p(kp_match))
+    return q_match[:len(queries)], kp_match[:len(kps)], n
+
+
+def search_by_bow(kf, kf_valid, f, nnratio, check_ori):
+    L = lib()
+    L.omo_search_by_bow.restype = C.c_int
+    L.omo_search_by_bow.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    fN = f["desc"].shape[0]
+    f_match = np.zeros(max(fN, 1), np.int32)
+    n = L.omo_search_by_bow(_p(kf["desc"]), _p(kf["angle"]), _p(kf_valid), _p(kf["node_id"]), _p(kf["node_start"]), _p(kf["feat_idx"]),
+                            int(kf["n_nodes"]), _p(f["desc"]), _p(f["angle"]), fN, _p(f["node_id"]), _p(f["node_start"]), _p(f["feat_idx"]),
+                            int(f["n_nodes"]), nnratio, int(check_ori), _p(f_match))
+    return f_match[:fN], n
+
+
+def knn2(q, t):
+    L = lib()
+    L.omo_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    idx = np.zeros((max(len(q), 1), 2), np.int32); dist = np.zeros((max(len(q), 1), 2), np.int32)
+    L.omo_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx[:len(q)], dist[:len(q)]
