@@ -480,6 +480,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
                     fbin[bestIdxF] = (int8_t)bin;
                 }
                 __threadfence_block();
+                __builtin_amdgcn_wave_barrier();  // lane 0's LDS write is program-ordered before the next feature's reads
             }
         }
     }
