@@ -1,0 +1,238 @@
+"""Host-side mirror of the LocalBundleAdjustment linearisation above the C ABI (include/orbhip.h "Stage 3").
+
+`LbaWindow` holds the flattened g2o graph of Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:1957-2193):
+poses (SE3Quat: t, q), points, landmark-major edges and the two CSR views (== BlockSolver::buildStructure).
+`build_system` == BlockSolver::buildSystem (block_solver.hpp:502-560); `compute_errors` == computeActiveErrors.
+Arrays may be torch CUDA tensors (product) or numpy arrays (emulated test build only)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OrbHipError
+from .matcher import _like, _ptr, _stream
+
+EDGE_MONO, EDGE_STEREO, EDGE_BODY = 0, 1, 2
+CAM_PINHOLE, CAM_KB8 = 0, 1
+EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("kind", "<i2"), ("cam", "<i2"), ("obs", "<f4", (3,)), ("inv_sigma2", "<f4")])
+CAM_DTYPE = np.dtype([("model", "<i4"), ("reserved", "<i4"), ("p", "<f8", (8,)), ("bf", "<f8"), ("trl_q", "<f8", (4,)), ("trl_t", "<f8", (3,))])
+assert EDGE_DTYPE.itemsize == 28 and CAM_DTYPE.itemsize == 136
+HUBER_MONO = float(np.float32(np.sqrt(5.991)))     # const float thHuberMono = sqrt(5.991)   Optimizer.cc:2052
+HUBER_STEREO = float(np.float32(np.sqrt(7.815)))   # const float thHuberStereo = sqrt(7.815) Optimizer.cc:2053
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("poses", "pose_hidx", "points", "edges", "lm_start", "pose_start", "pose_edges", "cameras",
+                                          "n_poses", "n_points", "n_edges")] + \
+               [("cap_p", C.c_int32), ("cap_l", C.c_int32), ("cap_e", C.c_int32), ("n_cameras", C.c_int32),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+class LbaSystem(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth", "robust_chi2_sum")]
+
+
+def bind(lib):
+    for name in ("lba_build_system", "lba_compute_errors"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(LbaProblem), C.c_int, C.POINTER(LbaSystem), C.c_void_p]
+    return lib
+
+
+def build_structure(edges, n_poses, n_points):
+    """CSR views of a landmark-major edge array (host side; once per optimize(), like BlockSolver::buildStructure)."""
+    assert (np.diff(edges["point"]) >= 0).all(), "edges must be landmark-major (Optimizer.cc:2060-2190 insertion order)"
+    lm_start = np.zeros(n_points + 1, np.int32)
+    np.add.at(lm_start, edges["point"] + 1, 1)
+    lm_start = np.cumsum(lm_start).astype(np.int32)
+    order = np.argsort(edges["pose"], kind="stable").astype(np.int32)
+    pose_start = np.zeros(n_poses + 1, np.int32)
+    np.add.at(pose_start, edges["pose"] + 1, 1)
+    pose_start = np.cumsum(pose_start).astype(np.int32)
+    return lm_start, pose_start, order
+
+
+class LbaWindows:
+    """A batch of B windows in slab layout, resident wherever `xp` (to-device function) puts them."""
+
+    def __init__(self, windows, cameras, to_dev=lambda a: a, lib=None, huber=(HUBER_MONO, HUBER_STEREO)):
+        self._L = bind(lib if lib is not None else _lib.load())
+        B = len(windows)
+        self.B = B
+        self.cap_p = max(len(w["poses"]) for w in windows)
+        self.cap_l = max(len(w["points"]) for w in windows)
+        self.cap_e = max(len(w["edges"]) for w in windows)
+        h = dict(poses=np.zeros((B, self.cap_p, 7)), pose_hidx=np.full((B, self.cap_p), -1, np.int32), points=np.zeros((B, self.cap_l, 3)),
+                 edges=np.zeros((B, self.cap_e), EDGE_DTYPE), lm_start=np.zeros((B, self.cap_l + 1), np.int32),
+                 pose_start=np.zeros((B, self.cap_p + 1), np.int32), pose_edges=np.zeros((B, self.cap_e), np.int32),
+                 n_poses=np.zeros(B, np.int32), n_points=np.zeros(B, np.int32), n_edges=np.zeros(B, np.int32))
+        for b, w in enumerate(windows):
+            npz, nl, ne = len(w["poses"]), len(w["points"]), len(w["edges"])
+            h["poses"][b, :npz] = w["poses"]; h["pose_hidx"][b, :npz] = w["pose_hidx"]; h["points"][b, :nl] = w["points"]
+            h["edges"][b, :ne] = w["edges"]
+            ls, ps, pe = build_structure(w["edges"], npz, nl)
+            h["lm_start"][b, :nl + 1] = ls; h["lm_start"][b, nl + 1:] = ne
+            h["pose_start"][b, :npz + 1] = ps; h["pose_start"][b, npz + 1:] = ne
+            h["pose_edges"][b, :ne] = pe
+            h["n_poses"][b], h["n_points"][b], h["n_edges"][b] = npz, nl, ne
+        self.host = h
+        self.d = {k: to_dev(v.view(np.uint8).reshape(B, -1) if v.dtype == EDGE_DTYPE else v) for k, v in h.items()}
+        self.d["cameras"] = to_dev(np.ascontiguousarray(cameras).view(np.uint8))
+        self.n_cameras = len(cameras)
+        self.huber = huber
+        like = self.d["poses"]
+        f8 = np.float64
+        self.out = dict(Hpp=_like64(like, (B, self.cap_p, 36)), bp=_like64(like, (B, self.cap_p, 6)), Hll=_like64(like, (B, self.cap_l, 9)),
+                        bl=_like64(like, (B, self.cap_l, 3)), Hpl=_like64(like, (B, self.cap_e, 18)), err=_like64(like, (B, self.cap_e, 3)),
+                        chi2=_like64(like, (B, self.cap_e)), rho=_like64(like, (B, self.cap_e, 2)), depth=_like64(like, (B, self.cap_e)),
+                        robust_chi2_sum=_like64(like, (B,)))
+
+    def _structs(self, outputs):
+        d = self.d
+        P = LbaProblem(*[_ptr(d[k]).value for k in ("poses", "pose_hidx", "points", "edges", "lm_start", "pose_start", "pose_edges",
+                                                    "cameras", "n_poses", "n_points", "n_edges")],
+                       self.cap_p, self.cap_l, self.cap_e, self.n_cameras, self.huber[0], self.huber[1])
+        S = LbaSystem(*[(_ptr(self.out[k]).value if k in outputs else None) for k in
+                        ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth", "robust_chi2_sum")])
+        return P, S
+
+    def build_system(self, outputs=("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth")):
+        P, S = self._structs(outputs)
+        rc = self._L.lba_build_system(C.byref(P), self.B, C.byref(S), _stream(self.d["poses"]))
+        if rc != 0:
+            raise OrbHipError(rc, "lba_build_system failed")
+        return self.out
+
+    def compute_errors(self, outputs=("err", "chi2", "rho", "depth", "robust_chi2_sum")):
+        P, S = self._structs(outputs)
+        rc = self._L.lba_compute_errors(C.byref(P), self.B, C.byref(S), _stream(self.d["poses"]))
+        if rc != 0:
+            raise OrbHipError(rc, "lba_compute_errors failed")
+        return self.out
+
+
+def _like64(a, shape):
+    if isinstance(a, np.ndarray):
+        return np.zeros(shape, np.float64)
+    import torch
+    return torch.zeros(shape, dtype=torch.float64, device=a.device)
+
+
+# ---- synthetic windows: KFs on a circle looking inward, points in a box ------------------
+def rot_to_quat(R):
+    """Eigen Quaterniond(Matrix3d) + SE3Quat::normalizeRotation, as Converter::toSE3Quat -> SE3Quat(R,t) does."""
+    m = R
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    if t > 0:
+        t = np.sqrt(t + 1.0)
+        w = 0.5 * t
+        t = 0.5 / t
+        q = np.array([(m[2, 1] - m[1, 2]) * t, (m[0, 2] - m[2, 0]) * t, (m[1, 0] - m[0, 1]) * t, w])
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+        c = np.zeros(4)
+        c[i] = 0.5 * t
+        t = 0.5 / t
+        c[3] = (m[k, j] - m[j, k]) * t
+        c[j] = (m[j, i] + m[i, j]) * t
+        c[k] = (m[k, i] + m[i, k]) * t
+        q = c
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def synth_window(seed=0, n_kf=100, n_fixed=20, n_pts=20000, max_obs=8, kind="mono", fx=458.654, fy=457.296, cx=367.215, cy=248.375,
+                 W=752, H=480, bf=47.906, outliers=0.05):
+    """-> (window dict, cameras array).  EuRoC pinhole intrinsics (Examples/Monocular/EuRoC.yaml:9-12); kind in
+    {"mono","stereo","kb8","body","mixed"}."""
+    rng = np.random.default_rng(seed)
+    cams = np.zeros(2, CAM_DTYPE)
+    cams[0]["model"] = CAM_PINHOLE
+    cams[0]["p"][:4] = np.float32([fx, fy, cx, cy]); cams[0]["bf"] = np.float32(bf)
+    cams[0]["trl_q"] = [0, 0, 0, 1]
+    cams[1]["model"] = CAM_KB8   # TUM_512.yaml:8-18-like fisheye, also the "right camera" of body edges
+    cams[1]["p"] = np.float32([190.978, 190.973, 254.932, 256.897, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673])
+    Rrl = _rodrigues(np.array([0.002, -0.01, 0.003]))
+    cams[1]["trl_q"] = rot_to_quat(Rrl); cams[1]["trl_t"] = [-0.1, 0.001, 0.0005]
+    poses = np.zeros((n_kf, 7)); Rs = []; ts = []
+    for i in range(n_kf):
+        a = 2 * np.pi * i / n_kf
+        c = np.array([10 * np.cos(a), 10 * np.sin(a), rng.normal(0, 0.2)])
+        z = -c / np.linalg.norm(c); z = z + rng.normal(0, 0.05, 3); z /= np.linalg.norm(z)
+        x = np.cross(np.array([0, 0, 1.0]), z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        Rcw = np.stack([x, y, z]).astype(np.float32).astype(np.float64)   # map poses are float32 (Converter::toSE3Quat widens)
+        t = (-Rcw @ c).astype(np.float32).astype(np.float64)
+        Rs.append(Rcw); ts.append(t)
+        poses[i, :3] = t; poses[i, 3:] = rot_to_quat(Rcw)
+    pts = np.stack([rng.uniform(-5, 5, n_pts), rng.uniform(-5, 5, n_pts), rng.uniform(-2, 2, n_pts)], 1).astype(np.float32).astype(np.float64)
+    scale2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2
+    edges = []
+    kf_order = np.arange(n_kf)
+    for l in range(n_pts):
+        rng.shuffle(kf_order)
+        cnt = 0
+        for i in kf_order:
+            Xc = Rs[i] @ pts[l] + ts[i]
+            if Xc[2] < 0.5:
+                continue
+            use_kb8 = kind in ("kb8", "body") or (kind == "mixed" and i % 3 == 0)
+            if use_kb8:
+                p = cams[1]["p"]; th = np.arctan2(np.hypot(Xc[0], Xc[1]), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
+                r = th + p[4] * th**3 + p[5] * th**5 + p[6] * th**7 + p[7] * th**9
+                u, v = p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3]
+                if not (0 <= u < 512 and 0 <= v < 512 and th < 1.4):
+                    continue
+            else:
+                u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+                if not (0 <= u < W and 0 <= v < H):
+                    continue
+            octave = rng.integers(0, 8)
+            sig = np.sqrt(scale2[octave])
+            du, dv = rng.normal(0, sig, 2)
+            if rng.random() < outliers:
+                du, dv = rng.normal(0, 25, 2)
+            e = np.zeros((), EDGE_DTYPE)
+            e["pose"], e["point"], e["inv_sigma2"] = i, l, np.float32(1.0) / scale2[octave]
+            if use_kb8:
+                e["kind"], e["cam"] = (EDGE_BODY if kind == "body" or (kind == "mixed" and i % 2) else EDGE_MONO), 1
+                if e["kind"] == EDGE_BODY:   # observation in the right camera
+                    Xr = Rrl @ Xc + cams[1]["trl_t"]
+                    th = np.arctan2(np.hypot(Xr[0], Xr[1]), Xr[2]); psi = np.arctan2(Xr[1], Xr[0])
+                    r = th + p[4] * th**3 + p[5] * th**5 + p[6] * th**7 + p[7] * th**9
+                    u, v = p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3]
+                e["obs"] = [u + du, v + dv, 0]
+            elif kind == "stereo" or (kind == "mixed" and l % 2 == 0):
+                e["kind"], e["cam"] = EDGE_STEREO, 0
+                e["obs"] = [u + du, v + dv, u + du - bf / Xc[2] + rng.normal(0, sig)]
+            else:
+                e["kind"], e["cam"] = EDGE_MONO, 0
+                e["obs"] = [u + du, v + dv, 0]
+            edges.append(e)
+            cnt += 1
+            if cnt >= max_obs:
+                break
+    edges = np.array(edges, EDGE_DTYPE)
+    # perturb the estimates so that the linearisation point is not the optimum
+    pts_est = pts + rng.normal(0, 0.02, pts.shape)
+    hidx = np.full(n_kf, -1, np.int32); hidx[n_fixed:] = np.arange(n_kf - n_fixed)
+    for i in range(n_fixed, n_kf):
+        dR = _rodrigues(rng.normal(0, 0.002, 3))
+        poses[i, 3:] = rot_to_quat(dR @ Rs[i]); poses[i, :3] = dR @ ts[i] + rng.normal(0, 0.01, 3)
+    return dict(poses=poses, pose_hidx=hidx, points=pts_est, edges=edges), cams
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)

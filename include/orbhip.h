@@ -185,6 +185,72 @@ typedef struct orbm_bow_side {
 int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch,
                        float nn_ratio, int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Stage 3 — Optimizer::LocalBundleAdjustment's linearisation  (reference src/Optimizer.cc:1957-2344 graph,
+ * src/OptimizableTypes.{h,cpp} edges, Thirdparty/g2o core/block_solver.hpp:502-560 buildSystem,
+ * core/base_binary_edge.hpp:55-120 constructQuadraticForm, core/robust_kernel_impl.cpp:78-91 Huber).
+ * The adapter (include/orbslam3_hip/Optimizer.h) flattens the g2o graph into the SoA below once per optimize()
+ * call (== BlockSolver::buildStructure) and then asks for one linearisation per LM iteration / trial.
+ * `batch` independent windows use fixed-capacity slabs like stage 2; all pointers are device pointers, all
+ * matrices are column-major doubles as in g2o's Eigen::Map blocks.
+ * ------------------------------------------------------------------------------------------------------- */
+#define LBA_EDGE_MONO 0    /* ORB_SLAM3::EdgeSE3ProjectXYZ        OptimizableTypes.h:102-130, .cpp:142-172 */
+#define LBA_EDGE_STEREO 1  /* g2o::EdgeStereoSE3ProjectXYZ        types_six_dof_expmap.h:146-175, .cpp:190-275 */
+#define LBA_EDGE_BODY 2    /* ORB_SLAM3::EdgeSE3ProjectXYZToBody  OptimizableTypes.h:132-159, .cpp:204-225 */
+#define LBA_CAM_PINHOLE 0  /* CameraModels/Pinhole.cpp:43-49, 89-100 */
+#define LBA_CAM_KB8 1      /* CameraModels/KannalaBrandt8.cpp:52-66, 166-196 */
+
+typedef struct lba_camera {
+    int32_t model, reserved;
+    double p[8];        /* mvParameters (float values widened): fx fy cx cy [k1 k2 k3 k4] */
+    double bf;          /* stereo baseline * fx (EdgeStereoSE3ProjectXYZ::bf) */
+    double trl_q[4];    /* mTrl rotation as quaternion x y z w (body edges) */
+    double trl_t[3];    /* mTrl translation */
+} lba_camera;
+
+typedef struct lba_edge {      /* one observation; edges are stored landmark-major (Optimizer.cc:2060-2190 insertion order) */
+    int32_t pose, point;       /* indices into the window's pose / point arrays */
+    int16_t kind, cam;         /* LBA_EDGE_*, index into cameras */
+    float obs[3];              /* kpUn.pt.x, kpUn.pt.y, mvuRight (stereo) — float in the map, widened on use */
+    float inv_sigma2;          /* mvInvLevelSigma2[octave]; information = I * inv_sigma2 */
+} lba_edge;
+
+typedef struct lba_problem {
+    /* vertices */
+    const double* poses;        /* [batch][cap_p][7]  SE3Quat estimate: t(x y z), q(x y z w) */
+    const int32_t* pose_hidx;   /* [batch][cap_p]     Hessian block index of the pose (ascending KF id), -1 = fixed vertex */
+    const double* points;       /* [batch][cap_l][3]  VertexSBAPointXYZ estimates */
+    /* edges + the two CSR views built once per optimize() (BlockSolver::buildStructure, block_solver.hpp:143-295) */
+    const lba_edge* edges;      /* [batch][cap_e] */
+    const int32_t* lm_start;    /* [batch][cap_l+1]   edges of landmark l are [lm_start[l], lm_start[l+1]) */
+    const int32_t* pose_start;  /* [batch][cap_p+1]   CSR over pose_edges */
+    const int32_t* pose_edges;  /* [batch][cap_e]     edge indices of each pose, ascending */
+    const lba_camera* cameras;  /* [n_cameras] shared by the batch */
+    const int32_t* n_poses;     /* [batch] */
+    const int32_t* n_points;    /* [batch] */
+    const int32_t* n_edges;     /* [batch] */
+    int32_t cap_p, cap_l, cap_e, n_cameras;
+    double huber_mono, huber_stereo;   /* thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815); <= 0 disables the kernel */
+} lba_problem;
+
+typedef struct lba_system {     /* outputs; any pointer may be NULL to skip that product */
+    double* Hpp;     /* [batch][cap_p][36]  6x6 block of free pose hidx (rotation first, then translation) */
+    double* bp;      /* [batch][cap_p][6] */
+    double* Hll;     /* [batch][cap_l][9] */
+    double* bl;      /* [batch][cap_l][3] */
+    double* Hpl;     /* [batch][cap_e][18]  logical 6x3 block H(pose, landmark) of each edge with a free pose (else zeros) */
+    double* err;     /* [batch][cap_e][3]   _error = obs - projection */
+    double* chi2;    /* [batch][cap_e]      e^T Omega e */
+    double* rho;     /* [batch][cap_e][2]   Huber rho[0], rho[1] */
+    double* depth;   /* [batch][cap_e]      z of the point in the (projecting) camera frame: isDepthPositive() */
+    double* robust_chi2_sum;  /* [batch]    sum of rho[0] = SparseOptimizer::activeRobustChi2 (sparse_optimizer.cpp:100-114) */
+} lba_system;
+
+/* BlockSolver::buildSystem (block_solver.hpp:502-560): linearizeOplus + constructQuadraticForm over all active edges. */
+int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, void* stream);
+/* SparseOptimizer::computeActiveErrors (sparse_optimizer.cpp:61-75): err / chi2 / rho / depth / robust_chi2_sum only. */
+int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,37 @@ def knn2(q, t):
     idx = np.zeros((max(len(q), 1), 2), np.int32); dist = np.zeros((max(len(q), 1), 2), np.int32)
     L.omo_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
     return idx[:len(q)], dist[:len(q)]
+
+
+# ---- stage 3 (oracle/lba_oracle.cpp) ----------------------------------------------------------------------
+def lba_build_system(window, cameras, huber):
+    L = lib()
+    L.olb_build_system.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+                                   C.c_double] + [C.c_void_p] * 10
+    poses = np.ascontiguousarray(window["poses"], np.float64); hidx = np.ascontiguousarray(window["pose_hidx"], np.int32)
+    pts = np.ascontiguousarray(window["points"], np.float64); edges = np.ascontiguousarray(window["edges"]); cams = np.ascontiguousarray(cameras)
+    npz, nl, ne = len(poses), len(pts), len(edges)
+    nfree = int(hidx.max()) + 1 if (hidx >= 0).any() else 0
+    o = dict(Hpp=np.zeros((max(nfree, 1), 36)), bp=np.zeros((max(nfree, 1), 6)), Hll=np.zeros((nl, 9)), bl=np.zeros((nl, 3)), Hpl=np.zeros((ne, 18)),
+             err=np.zeros((ne, 3)), chi2=np.zeros(ne), rho=np.zeros((ne, 2)), depth=np.zeros(ne), robust_chi2_sum=np.zeros(1))
+    L.olb_build_system(_p(poses), _p(hidx), npz, _p(pts), nl, _p(edges), ne, _p(cams), huber[0], huber[1],
+                       *[_p(o[k]) for k in ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth", "robust_chi2_sum")])
+    o["nfree"] = nfree
+    return o
+
+
+def lba_edge_error(pose7, point3, edge, cam, dpose, dpoint):
+    L = lib()
+    L.olb_edge_error.argtypes = [C.c_void_p] * 7
+    e = np.zeros(3)
+    L.olb_edge_error(_p(np.ascontiguousarray(pose7, np.float64)), _p(np.ascontiguousarray(point3, np.float64)), _p(np.ascontiguousarray(edge)),
+                     _p(np.ascontiguousarray(cam)), _p(np.ascontiguousarray(dpose, np.float64)), _p(np.ascontiguousarray(dpoint, np.float64)), _p(e))
+    return e
+
+
+def quat_from_matrix(R):
+    L = lib()
+    L.olb_quat_from_matrix.argtypes = [C.c_void_p, C.c_void_p]
+    q = np.zeros(4)
+    L.olb_quat_from_matrix(_p(np.ascontiguousarray(R, np.float64)), _p(q))
+    return q
