@@ -149,10 +149,16 @@ def rot_to_quat(R):
     return q / np.linalg.norm(q)
 
 
+def _kb8_project(p, X):
+    th = np.arctan2(np.hypot(X[..., 0], X[..., 1]), X[..., 2]); psi = np.arctan2(X[..., 1], X[..., 0])
+    r = th + p[4] * th**3 + p[5] * th**5 + p[6] * th**7 + p[7] * th**9
+    return p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3], th
+
+
 def synth_window(seed=0, n_kf=100, n_fixed=20, n_pts=20000, max_obs=8, kind="mono", fx=458.654, fy=457.296, cx=367.215, cy=248.375,
                  W=752, H=480, bf=47.906, outliers=0.05):
     """-> (window dict, cameras array).  EuRoC pinhole intrinsics (Examples/Monocular/EuRoC.yaml:9-12); kind in
-    {"mono","stereo","kb8","body","mixed"}."""
+    {"mono","stereo","kb8","body","mixed"}.  Vectorised numpy; deterministic per seed."""
     rng = np.random.default_rng(seed)
     cams = np.zeros(2, CAM_DTYPE)
     cams[0]["model"] = CAM_PINHOLE
@@ -162,65 +168,64 @@ def synth_window(seed=0, n_kf=100, n_fixed=20, n_pts=20000, max_obs=8, kind="mon
     cams[1]["p"] = np.float32([190.978, 190.973, 254.932, 256.897, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673])
     Rrl = _rodrigues(np.array([0.002, -0.01, 0.003]))
     cams[1]["trl_q"] = rot_to_quat(Rrl); cams[1]["trl_t"] = [-0.1, 0.001, 0.0005]
-    poses = np.zeros((n_kf, 7)); Rs = []; ts = []
+    trl_t = np.array(cams[1]["trl_t"])
+    pk = np.array(cams[1]["p"])
+    poses = np.zeros((n_kf, 7)); Rs = np.zeros((n_kf, 3, 3)); ts = np.zeros((n_kf, 3))
     for i in range(n_kf):
         a = 2 * np.pi * i / n_kf
         c = np.array([10 * np.cos(a), 10 * np.sin(a), rng.normal(0, 0.2)])
         z = -c / np.linalg.norm(c); z = z + rng.normal(0, 0.05, 3); z /= np.linalg.norm(z)
         x = np.cross(np.array([0, 0, 1.0]), z); x /= np.linalg.norm(x)
         y = np.cross(z, x)
-        Rcw = np.stack([x, y, z]).astype(np.float32).astype(np.float64)   # map poses are float32 (Converter::toSE3Quat widens)
-        t = (-Rcw @ c).astype(np.float32).astype(np.float64)
-        Rs.append(Rcw); ts.append(t)
-        poses[i, :3] = t; poses[i, 3:] = rot_to_quat(Rcw)
+        Rs[i] = np.stack([x, y, z]).astype(np.float32).astype(np.float64)   # map poses are float32 (Converter::toSE3Quat widens)
+        ts[i] = (-Rs[i] @ c).astype(np.float32).astype(np.float64)
+        poses[i, :3] = ts[i]; poses[i, 3:] = rot_to_quat(Rs[i])
     pts = np.stack([rng.uniform(-5, 5, n_pts), rng.uniform(-5, 5, n_pts), rng.uniform(-2, 2, n_pts)], 1).astype(np.float32).astype(np.float64)
     scale2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2
-    edges = []
-    kf_order = np.arange(n_kf)
-    for l in range(n_pts):
-        rng.shuffle(kf_order)
-        cnt = 0
-        for i in kf_order:
-            Xc = Rs[i] @ pts[l] + ts[i]
-            if Xc[2] < 0.5:
-                continue
-            use_kb8 = kind in ("kb8", "body") or (kind == "mixed" and i % 3 == 0)
-            if use_kb8:
-                p = cams[1]["p"]; th = np.arctan2(np.hypot(Xc[0], Xc[1]), Xc[2]); psi = np.arctan2(Xc[1], Xc[0])
-                r = th + p[4] * th**3 + p[5] * th**5 + p[6] * th**7 + p[7] * th**9
-                u, v = p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3]
-                if not (0 <= u < 512 and 0 <= v < 512 and th < 1.4):
-                    continue
-            else:
-                u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
-                if not (0 <= u < W and 0 <= v < H):
-                    continue
-            octave = rng.integers(0, 8)
-            sig = np.sqrt(scale2[octave])
-            du, dv = rng.normal(0, sig, 2)
-            if rng.random() < outliers:
-                du, dv = rng.normal(0, 25, 2)
-            e = np.zeros((), EDGE_DTYPE)
-            e["pose"], e["point"], e["inv_sigma2"] = i, l, np.float32(1.0) / scale2[octave]
-            if use_kb8:
-                e["kind"], e["cam"] = (EDGE_BODY if kind == "body" or (kind == "mixed" and i % 2) else EDGE_MONO), 1
-                if e["kind"] == EDGE_BODY:   # observation in the right camera
-                    Xr = Rrl @ Xc + cams[1]["trl_t"]
-                    th = np.arctan2(np.hypot(Xr[0], Xr[1]), Xr[2]); psi = np.arctan2(Xr[1], Xr[0])
-                    r = th + p[4] * th**3 + p[5] * th**5 + p[6] * th**7 + p[7] * th**9
-                    u, v = p[0] * r * np.cos(psi) + p[2], p[1] * r * np.sin(psi) + p[3]
-                e["obs"] = [u + du, v + dv, 0]
-            elif kind == "stereo" or (kind == "mixed" and l % 2 == 0):
-                e["kind"], e["cam"] = EDGE_STEREO, 0
-                e["obs"] = [u + du, v + dv, u + du - bf / Xc[2] + rng.normal(0, sig)]
-            else:
-                e["kind"], e["cam"] = EDGE_MONO, 0
-                e["obs"] = [u + du, v + dv, 0]
-            edges.append(e)
-            cnt += 1
-            if cnt >= max_obs:
-                break
-    edges = np.array(edges, EDGE_DTYPE)
+    Xc = np.einsum("kij,lj->kli", Rs, pts) + ts[:, None, :]          # (K, L, 3)
+    kidx = np.arange(n_kf)[:, None]
+    lidx = np.arange(n_pts)[None, :]
+    if kind in ("kb8", "body"):
+        use_kb8 = np.ones((n_kf, n_pts), bool)
+    elif kind == "mixed":
+        use_kb8 = np.broadcast_to(kidx % 3 == 0, (n_kf, n_pts))
+    else:
+        use_kb8 = np.zeros((n_kf, n_pts), bool)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        up, vp = fx * Xc[..., 0] / Xc[..., 2] + cx, fy * Xc[..., 1] / Xc[..., 2] + cy
+    uk, vk, thk = _kb8_project(pk, Xc)
+    vis_p = (up >= 0) & (up < W) & (vp >= 0) & (vp < H)
+    vis_k = (uk >= 0) & (uk < 512) & (vk >= 0) & (vk < 512) & (thk < 1.4)
+    vis = (Xc[..., 2] >= 0.5) & np.where(use_kb8, vis_k, vis_p)
+    key = rng.random((n_kf, n_pts)); key[~vis] = 2.0
+    order = np.argsort(key, axis=0)[:max_obs]                        # (max_obs, L) random visible KFs first
+    sel = np.take_along_axis(key, order, 0) < 1.5
+    pi = order.T[sel.T]                                              # landmark-major edge list
+    li = np.broadcast_to(lidx.T, (n_pts, max_obs))[sel.T] if max_obs else np.zeros(0, int)
+    ne = len(pi)
+    X = Xc[pi, li]
+    kb = use_kb8[pi, li]
+    octave = rng.integers(0, 8, ne)
+    sig = np.sqrt(scale2[octave]).astype(np.float64)
+    noise = rng.normal(0, 1, (ne, 3)) * sig[:, None]
+    out = rng.random(ne) < outliers
+    noise[out, :2] = rng.normal(0, 25, (int(out.sum()), 2))
+    edges = np.zeros(ne, EDGE_DTYPE)
+    edges["pose"], edges["point"] = pi, li
+    edges["inv_sigma2"] = np.float32(1.0) / scale2[octave]
+    body = kb & ((kind == "body") | ((kind == "mixed") & (pi % 2 == 1)))
+    stereo = ~kb & ((kind == "stereo") | ((kind == "mixed") & (li % 2 == 0)))
+    edges["kind"] = np.where(body, EDGE_BODY, np.where(stereo, EDGE_STEREO, EDGE_MONO))
+    edges["cam"] = np.where(kb, 1, 0)
+    u = np.where(kb, uk[pi, li], up[pi, li]); v = np.where(kb, vk[pi, li], vp[pi, li])
+    if body.any():
+        Xr = X[body] @ Rrl.T + trl_t
+        ub, vb, _ = _kb8_project(pk, Xr)
+        u[body], v[body] = ub, vb
+    obs = np.zeros((ne, 3))
+    obs[:, 0], obs[:, 1] = u + noise[:, 0], v + noise[:, 1]
+    obs[stereo, 2] = (u + noise[:, 0] - bf / X[:, 2] + noise[:, 2])[stereo]
+    edges["obs"] = obs.astype(np.float32)
     # perturb the estimates so that the linearisation point is not the optimum
     pts_est = pts + rng.normal(0, 0.02, pts.shape)
     hidx = np.full(n_kf, -1, np.int32); hidx[n_fixed:] = np.arange(n_kf - n_fixed)

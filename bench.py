@@ -50,14 +50,42 @@ def algorithmic_bytes(W, H, N):
     return whole, per_kernel
 
 
+SHIFT = (6, -4)   # frame 2j+1 = frame 2j moved by (dx, dy) px + sensor noise: consecutive views of one scene
+
+
 def make_batch(B, seed0=0, unique=16):
     from orbhip.synth import synth_image
-    base = [synth_image(seed0 + i, W, H) for i in range(min(unique, B))]
+    base = [synth_image(seed0 + i, W, H) for i in range(min(unique, max(1, B // 2)))]
+    rng = np.random.default_rng(seed0 + 12345)
     frames = []
-    for i in range(B):
-        k = i // len(base)
-        frames.append(np.roll(base[i % len(base)], (7 * k, 13 * k), (0, 1)))
-    return np.stack(frames)
+    for j in range((B + 1) // 2):
+        k = j // len(base)
+        a = np.roll(base[j % len(base)], (7 * k, 13 * k), (0, 1))
+        b = np.clip(np.roll(a, (SHIFT[1], SHIFT[0]), (0, 1)).astype(np.int16) + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
+        frames += [a, b]
+    return np.stack(frames[:B])
+
+
+def build_match_queries(kps, counts, scale, cap):
+    """Motion-model queries (ORBmatcher.cc:2265-2331, mono: neither forward nor backward, th=15): every keypoint of the partner
+    frame becomes a projected map point at its position moved by the known inter-frame shift."""
+    from orbhip.matcher import QUERY_DTYPE, Q_VALID, Q_HAS_OBS
+    B = kps.shape[0]
+    q = np.zeros((B, cap), QUERY_DTYPE)
+    src = np.arange(B) ^ 1
+    src[src >= B] = B - 1
+    sgn = np.where(np.arange(B) % 2 == 1, 1.0, -1.0).astype(np.float32)   # odd frames see even frames' points moved by +SHIFT
+    for b in range(B):
+        n = counts[src[b], 0]
+        k = kps[src[b], :n]
+        lvl = k[:, 5].view(np.int32)
+        q["u"][b, :n] = k[:, 0] + sgn[b] * np.float32(SHIFT[0]); q["v"][b, :n] = k[:, 1] + sgn[b] * np.float32(SHIFT[1])
+        q["radius"][b, :n] = np.float32(15.0) * scale[lvl]
+        q["min_level"][b, :n] = lvl - 1; q["max_level"][b, :n] = lvl + 1
+        q["angle"][b, :n] = k[:, 3]
+        q["flags"][b, :n] = Q_VALID | Q_HAS_OBS
+    nq = counts[src, 0].astype(np.int32).copy()
+    return q, nq, src
 
 
 def cpu_baseline(frames, budget_s=10.0):
@@ -92,6 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
+    ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
     args = ap.parse_args()
 
     import torch
@@ -139,11 +169,82 @@ def main():
     torch.cuda.synchronize()
     for k, v in ex.last_timing().items():
         kern[k] = v
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     counts = out[2].cpu().numpy()
+
+    # ---- extra leg 1: extract + match (grid build + motion-model SearchByProjection against the partner frame)
+    extra = {}
+    if not args.headline_only:
+        m = orbhip.ORBmatcher(0.9, True)
+        cap = out[0].shape[1]
+        q, nq, src = build_match_queries(out[0].cpu().numpy(), counts, ex.GetScaleFactors(), cap)
+        d_q = torch.from_numpy(q.view(np.uint8).reshape(B, cap, 28)).to(dev)
+        d_nq = torch.from_numpy(nq).to(dev)
+        d_qdesc = out[1][torch.from_numpy(src).to(dev)].contiguous()      # partner descriptors (prepared once, resident in HBM)
+        grid = (0.0, 0.0, float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H)))
+        work = torch.empty(m._L.orbm_search_workspace_bytes(B, cap), dtype=torch.uint8, device=dev)
+        res = None
+
+        def step_match():
+            nonlocal out, res
+            out = ex.extract_batch(d_frames, (0, 1000), out=out)
+            cnt = out[2].view(-1)
+            gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
+            res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
+        for _ in range(2):
+            step_match()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter()
+        msteps = max(3, args.steps // 4)
+        for i in range(msteps):
+            if i == msteps - 1:
+                out = ex.extract_batch(d_frames, (0, 1000), out=out)
+                ev0.record()
+                cnt = out[2].view(-1)
+                gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
+                res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
+                ev1.record()
+            else:
+                step_match()
+        barrier()
+        dtm = time.perf_counter() - t1
+        nm = res[2].cpu().numpy()
+        extra["extract_match"] = {"frames_per_s": round(B * msteps / dtm, 1), "ms_per_step": round(dtm / msteps * 1e3, 4),
+                                  "match_only_ms": round(ev0.elapsed_time(ev1), 4), "mean_matches_per_frame": float(nm.mean()),
+                                  "queries_per_frame": float(nq.mean()), "search": "SearchByProjection motion model th=15, TH_HIGH, rot. histogram"}
+        # ---- extra leg 2: LocalBundleAdjustment linearisations (C5-size windows: 100 KF / 20k landmarks)
+        from orbhip.lba import LbaWindows, synth_window
+        nwin = args.lba_windows
+        wins, cams = [], None
+        for i in range(min(nwin, 2)):
+            w, cams = synth_window(100 + i + 10 * rank, 100, 20, 20000, 8, "mono")
+            wins.append(w)
+        wins = [wins[i % len(wins)] for i in range(nwin)]
+        Lw = LbaWindows(wins, cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+        outs = ("Hpp", "bp", "Hll", "bl", "Hpl", "chi2")
+        for _ in range(2):
+            Lw.build_system(outs)
+        barrier()
+        lsteps = max(3, args.steps // 2)
+        t2 = time.perf_counter()
+        for _ in range(lsteps):
+            Lw.build_system(outs)
+        barrier()
+        dtl = time.perf_counter() - t2
+        E = float(np.mean([len(w["edges"]) for w in wins]))
+        lba_bytes = E * (28 + 144) + 20000 * (24 + 72 + 24) + 80 * (56 + 288 + 48)    # SURVEY.md §8(d) A_lba with the realised E
+        extra["lba"] = {"linearizations_per_s": round(nwin * lsteps / dtl, 1), "ms_per_step": round(dtl / lsteps * 1e3, 4), "windows_per_step": nwin,
+                        "edges_per_window": E, "algorithmic_GBps": round(lba_bytes * nwin * lsteps / dtl / 1e9, 2),
+                        "hbm_frac": round(lba_bytes * nwin * lsteps / dtl / 1e9 / HBM_PEAK_GBS, 5),
+                        "what": "BlockSolver::buildSystem equivalent (residuals, Huber, Jacobians, Hpp/Hll/Hpl/b) for 100-KF/20k-landmark windows"}
+    if world > 1:
+        t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
+                         dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+        if "extract_match" in extra:
+            extra["extract_match"]["frames_per_s"] = round(world * B / (float(t[1].item()) * 1e-3), 1)
+            extra["lba"]["linearizations_per_s"] = round(world * args.lba_windows / (float(t[2].item()) * 1e-3), 1)
 
     if rank == 0:
         whole, per_kernel = algorithmic_bytes(W, H, NFEAT)
@@ -169,6 +270,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_kernel[dom] * B, "kernel_ms": round(kern[dom], 4),
                          "whole_extract_frac": round(whole * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(frames[:64])
