@@ -251,6 +251,17 @@ int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, 
 /* SparseOptimizer::computeActiveErrors (sparse_optimizer.cpp:61-75): err / chi2 / rho / depth / robust_chi2_sum only. */
 int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Device-memory helpers so that adapters written against this header need no HIP headers.
+ * ------------------------------------------------------------------------------------------------------- */
+int orb_device_count(void);
+int orb_dev_alloc(int device, size_t bytes, void** d_ptr);
+int orb_dev_free(void* d_ptr);
+int orb_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);   /* asynchronous on stream */
+int orb_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);   /* asynchronous on stream */
+int orb_memset(void* d_dst, int value, size_t bytes, void* stream);
+int orb_stream_sync(void* stream);   /* NULL = default stream */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,129 @@
+// orbslam3_hip/ORBextractor.h — header-only adapter with the signature of ORB_SLAM3::ORBextractor
+// (reference include/ORBextractor.h:49-83) forwarding to liborbhip.so (include/orbhip.h, stage 1).
+//
+// Drop-in use inside the reference: compile with -DORBHIP_WITH_OPENCV, include this header instead
+// of "ORBextractor.h" and alias `namespace ORB_SLAM3 { using ORBextractor = orbslam3_hip::ORBextractor; }`.
+// Without OpenCV the POD overload `extract()` offers the same call on plain buffers (used by tests/test_cpp_adapter).
+#ifndef ORBSLAM3_HIP_ORBEXTRACTOR_H
+#define ORBSLAM3_HIP_ORBEXTRACTOR_H
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../orbhip.h"
+#ifdef ORBHIP_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#endif
+
+namespace orbslam3_hip {
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };  // ORBextractor.h:53
+
+    // ORBextractor.h:49-50
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+        : cfg_{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST}, device_(device) {
+        // the scale tables do not depend on the image size: take them from a handle of the reference's default geometry
+        // when that is valid, otherwise they are filled on the first call
+        orbx_handle h = nullptr;
+        if (orbx_create(&cfg_, 752, 480, 1, device_, &h) == ORB_OK) { loadTables(h); orbx_destroy(h); }
+    }
+    ~ORBextractor() { if (h_) orbx_destroy(h_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // POD form of operator() (ORBextractor.cc:1074-1156): returns monoIndex, or -1 for an empty image.
+    int extract(const uint8_t* image, int width, int height, int stride, std::vector<orb_keypoint>& keypoints,
+                std::vector<uint8_t>& descriptors, const std::vector<int>& vLappingArea) {
+        keypoints.clear();
+        descriptors.clear();
+        if (!image || width <= 0 || height <= 0) return -1;  // ORBextractor.cc:1078-1079
+        ensure(width, height);
+        const int cap = orbx_max_keypoints(h_);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0, mono = 0;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        const int rc = orbx_extract(h_, image, width, height, stride, lap0, lap1, keypoints.data(), descriptors.data(), cap, &n, &mono);
+        if (rc == ORB_E_EMPTY_IMAGE) { keypoints.clear(); descriptors.clear(); return -1; }
+        if (rc != ORB_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        return mono;
+    }
+
+#ifdef ORBHIP_WITH_OPENCV
+    // ORBextractor.h:57-59 — identical signature; `_mask` is ignored exactly as in the reference.
+    int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+        if (_image.empty()) return -1;
+        cv::Mat image = _image.getMat();
+        CV_Assert(image.type() == CV_8UC1);  // ORBextractor.cc:1082
+        std::vector<orb_keypoint> k;
+        std::vector<uint8_t> d;
+        const int mono = extract(image.data, image.cols, image.rows, (int)image.step, k, d, vLappingArea);
+        static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint layout");
+        _keypoints.resize(k.size());
+        if (!k.empty()) std::memcpy((void*)_keypoints.data(), k.data(), k.size() * sizeof(orb_keypoint));
+        if (k.empty()) _descriptors.release();
+        else {
+            _descriptors.create((int)k.size(), 32, CV_8U);
+            std::memcpy(_descriptors.getMat().data, d.data(), d.size());
+        }
+        // mvImagePyramid is a public member read by Frame::ComputeStereoMatches (Frame.cc:1052,1071): keep it populated,
+        // each level as the ROI of a bordered parent exactly like ORBextractor.cc:1164-1179
+        mvImagePyramid.resize(cfg_.nlevels);
+        for (int l = 0; l < cfg_.nlevels; l++) {
+            int w = 0, hgt = 0;
+            orbx_pyramid_level(h_, 0, l, nullptr, &w, &hgt, nullptr);
+            cv::Mat temp(hgt + 38, w + 38, CV_8UC1);
+            orbx_copy_level(h_, 0, l, 19, temp.data);
+            mvImagePyramid[l] = temp(cv::Rect(19, 19, w, hgt));
+        }
+        return mono;
+    }
+    std::vector<cv::Mat> mvImagePyramid;  // ORBextractor.h:83
+#endif
+
+    // host copy of pyramid level `level` of the last call; border = 0 or 19 (reference layout)
+    std::vector<uint8_t> pyramidLevel(int level, int border, int& w, int& h) {
+        if (!h_ || orbx_pyramid_level(h_, 0, level, nullptr, &w, &h, nullptr) != ORB_OK) throw std::runtime_error("no pyramid");
+        std::vector<uint8_t> out((size_t)(w + 2 * border) * (h + 2 * border));
+        if (orbx_copy_level(h_, 0, level, border, out.data()) != ORB_OK) throw std::runtime_error(orbx_last_error(h_));
+        return out;
+    }
+
+    // getters ORBextractor.h:61-81 (return by value like the reference)
+    int GetLevels() { return cfg_.nlevels; }
+    float GetScaleFactor() { return cfg_.scale_factor; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+private:
+    void loadTables(orbx_handle h) {
+        const int n = cfg_.nlevels;
+        mvScaleFactor.resize(n); mvInvScaleFactor.resize(n); mvLevelSigma2.resize(n); mvInvLevelSigma2.resize(n);
+        orbx_get_tables(h, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr);
+    }
+    void ensure(int w, int h) {
+        if (h_ && w == w_ && h == hgt_) return;
+        if (h_) { orbx_destroy(h_); h_ = nullptr; }
+        const int rc = orbx_create(&cfg_, w, h, 1, device_, &h_);
+        if (rc != ORB_OK) throw std::runtime_error(std::string("orbx_create: ") + orbx_last_error(nullptr));
+        w_ = w; hgt_ = h;
+        loadTables(h_);
+    }
+    orbx_config cfg_;
+    int device_;
+    orbx_handle h_ = nullptr;
+    int w_ = 0, hgt_ = 0;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+}  // namespace orbslam3_hip
+#endif

@@ -1,0 +1,128 @@
+// orbslam3_hip/Optimizer.h — adapter for the linearisation inside Optimizer::LocalBundleAdjustment
+// (reference include/Optimizer.h:58, src/Optimizer.cc:1811-2523) over liborbhip.so (include/orbhip.h, stage 3).
+//
+// `LbaLinearizer` owns the flattened window (== the g2o graph of Optimizer.cc:1957-2193).  Window selection
+// (:1816-1945), the LM loop and the write-back (:2375-2522) stay in the caller; per iteration it calls buildSystem()
+// (== BlockSolver::buildSystem, block_solver.hpp:502-560) or computeErrors() (== computeActiveErrors).
+#ifndef ORBSLAM3_HIP_OPTIMIZER_H
+#define ORBSLAM3_HIP_OPTIMIZER_H
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+
+#include "../orbhip.h"
+#include "ORBmatcher.h"  // detail::DevBuf
+
+namespace orbslam3_hip {
+
+struct LbaHostSystem {  // column-major doubles, g2o block conventions
+    std::vector<double> Hpp, bp, Hll, bl, Hpl, err, chi2, rho, depth;
+    double robustChi2 = 0;
+};
+
+class LbaLinearizer {
+public:
+    // Converter::toSE3Quat (Converter.cc:34-44): float Tcw (row-major 3x4 or 4x4, `ld` floats per row) -> SE3Quat(R,t) = (t, q)
+    static void poseFromTcw(const float* Tcw, int ld, double out7[7]) {
+        double m[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m[r * 3 + c] = (double)Tcw[r * ld + c];
+        double q[4];  // Eigen Quaterniond(Matrix3d) + SE3Quat::normalizeRotation
+        double t = m[0] + m[4] + m[8];
+        if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t; }
+        else {
+            int i = 0;
+            if (m[4] > m[0]) i = 1;
+            if (m[8] > m[i * 3 + i]) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+            q[i] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t; q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+        }
+        if (q[3] < 0) for (double& v : q) v = -v;
+        const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int r = 0; r < 3; r++) out7[r] = (double)Tcw[r * ld + 3];
+        for (int c = 0; c < 4; c++) out7[3 + c] = q[c] / n;
+    }
+
+    // graph build (Optimizer.cc:1982-2190): vertices first, then edges in insertion order (landmark-major)
+    int addPose(const double pose7[7], bool fixed) {
+        poses_.insert(poses_.end(), pose7, pose7 + 7);
+        hidx_.push_back(fixed ? -1 : nfree_++);
+        return (int)hidx_.size() - 1;
+    }
+    int addPoint(const double xyz[3]) { points_.insert(points_.end(), xyz, xyz + 3); return (int)points_.size() / 3 - 1; }
+    int addCamera(const lba_camera& c) { cams_.push_back(c); return (int)cams_.size() - 1; }
+    void addEdge(int pose, int point, int kind, int cam, float u, float v, float uR, float invSigma2) {
+        if (!edges_.empty() && point < edges_.back().point) throw std::runtime_error("edges must be added landmark-major");
+        lba_edge e{pose, point, (int16_t)kind, (int16_t)cam, {u, v, uR}, invSigma2};
+        edges_.push_back(e);
+        dirty_ = true;
+    }
+    void setPose(int i, const double pose7[7]) { std::copy(pose7, pose7 + 7, poses_.begin() + 7 * i); posesDirty_ = true; }
+    void setPoint(int i, const double xyz[3]) { std::copy(xyz, xyz + 3, points_.begin() + 3 * i); pointsDirty_ = true; }
+    int numFreePoses() const { return nfree_; }
+
+    void buildSystem(LbaHostSystem& out) { run(out, true); }
+    void computeErrors(LbaHostSystem& out) { run(out, false); }
+
+private:
+    void upload() {
+        const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
+        if (dirty_) {  // == BlockSolver::buildStructure: the two CSR views
+            std::vector<int32_t> lm(nl + 1, 0), ps(np + 1, 0), pe(ne);
+            for (const lba_edge& e : edges_) { lm[e.point + 1]++; ps[e.pose + 1]++; }
+            std::partial_sum(lm.begin(), lm.end(), lm.begin());
+            std::partial_sum(ps.begin(), ps.end(), ps.begin());
+            std::vector<int32_t> fill(ps.begin(), ps.end() - 1);
+            for (int i = 0; i < ne; i++) pe[fill[edges_[i].pose]++] = i;
+            dEdges_ = e_.upload(edges_.data(), ne); dLm_ = lm_.upload(lm.data(), nl + 1); dPs_ = ps_.upload(ps.data(), np + 1);
+            dPe_ = pe_.upload(pe.data(), ne); dH_ = h_.upload(hidx_.data(), np); dCams_ = c_.upload(cams_.data(), cams_.size());
+            int32_t cnt[3] = {np, nl, ne};
+            dCnt_ = cnt_.upload(cnt, 3);
+            posesDirty_ = pointsDirty_ = true; dirty_ = false;
+        }
+        if (posesDirty_) { dPoses_ = p_.upload(poses_.data(), poses_.size()); posesDirty_ = false; }
+        if (pointsDirty_) { dPoints_ = x_.upload(points_.data(), points_.size()); pointsDirty_ = false; }
+    }
+    void run(LbaHostSystem& o, bool full) {
+        upload();
+        const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
+        lba_problem P{};
+        P.poses = dPoses_; P.pose_hidx = dH_; P.points = dPoints_; P.edges = dEdges_; P.lm_start = dLm_; P.pose_start = dPs_;
+        P.pose_edges = dPe_; P.cameras = dCams_; P.n_poses = dCnt_; P.n_points = dCnt_ + 1; P.n_edges = dCnt_ + 2;
+        P.cap_p = np; P.cap_l = nl; P.cap_e = ne; P.n_cameras = (int)cams_.size();
+        P.huber_mono = (double)std::sqrt(5.991f);    // const float thHuberMono = sqrt(5.991)   Optimizer.cc:2052
+        P.huber_stereo = (double)std::sqrt(7.815f);  // const float thHuberStereo = sqrt(7.815) Optimizer.cc:2053
+        lba_system S{};
+        const size_t sz[10] = {(size_t)np * 36, (size_t)np * 6, (size_t)nl * 9, (size_t)nl * 3, (size_t)ne * 18, (size_t)ne * 3, (size_t)ne, (size_t)ne * 2, (size_t)ne, 1};
+        double** ptr[10] = {&S.Hpp, &S.bp, &S.Hll, &S.bl, &S.Hpl, &S.err, &S.chi2, &S.rho, &S.depth, &S.robust_chi2_sum};
+        std::vector<double>* host[9] = {&o.Hpp, &o.bp, &o.Hll, &o.bl, &o.Hpl, &o.err, &o.chi2, &o.rho, &o.depth};
+        for (int i = 0; i < 10; i++) {
+            const bool want = full ? i < 9 : i >= 5;
+            *ptr[i] = want ? (double*)out_[i].ensure(sz[i] * 8 + 16) : nullptr;
+        }
+        const int rc = full ? lba_build_system(&P, 1, &S, nullptr) : lba_compute_errors(&P, 1, &S, nullptr);
+        if (rc != ORB_OK) throw std::runtime_error("lba call failed");
+        for (int i = 0; i < 9; i++)
+            if (*ptr[i]) { host[i]->resize(sz[i]); orb_memcpy_d2h(host[i]->data(), *ptr[i], sz[i] * 8, nullptr); }
+        if (S.robust_chi2_sum) orb_memcpy_d2h(&o.robustChi2, S.robust_chi2_sum, 8, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+    }
+    std::vector<double> poses_, points_;
+    std::vector<int32_t> hidx_;
+    std::vector<lba_edge> edges_;
+    std::vector<lba_camera> cams_;
+    int nfree_ = 0;
+    bool dirty_ = true, posesDirty_ = true, pointsDirty_ = true;
+    detail::DevBuf p_, x_, e_, lm_, ps_, pe_, h_, c_, cnt_, out_[10];
+    const double *dPoses_ = nullptr, *dPoints_ = nullptr;
+    const lba_edge* dEdges_ = nullptr;
+    const int32_t *dLm_ = nullptr, *dPs_ = nullptr, *dPe_ = nullptr, *dH_ = nullptr, *dCnt_ = nullptr;
+    const lba_camera* dCams_ = nullptr;
+};
+
+}  // namespace orbslam3_hip
+#endif

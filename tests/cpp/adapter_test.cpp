@@ -1,0 +1,133 @@
+// Exercises the header-only C++ adapters (include/orbslam3_hip/*.h) against the oracle's C API.
+// Built by tests/test_cpp_adapter.py against either the emulated library (CPU tier) or the real liborbhip.so (GPU tier).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "orbslam3_hip/ORBextractor.h"
+#include "orbslam3_hip/ORBmatcher.h"
+#include "orbslam3_hip/Optimizer.h"
+
+extern "C" {
+void* oro_create(int, float, int, int, int);
+void oro_destroy(void*);
+int oro_extract(void*, const uint8_t*, int, int, int, int, int, void*, uint8_t*, int, int*);
+int omo_search_by_projection(const void*, const uint8_t*, const float*, const uint8_t*, int, float, float, float, float, const void*,
+                             const uint8_t*, int, int, int, float, int, int32_t*, int32_t*);
+void olb_build_system(const double*, const int32_t*, int, const double*, int, const void*, int, const void*, double, double, double*,
+                      double*, double*, double*, double*, double*, double*, double*, double*, double*);
+}
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static uint32_t rng_state = 12345u;
+static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+
+static std::vector<uint8_t> make_image(int W, int H, int dx, int dy) {
+    std::vector<uint8_t> img((size_t)W * H, 110);
+    rng_state = 777u;
+    for (int r = 0; r < 220; r++) {
+        const int cx = rnd() % W + dx, cy = rnd() % H + dy, hw = 3 + rnd() % 25, hh = 3 + rnd() % 25, g = 20 + rnd() % 215;
+        for (int y = cy - hh; y <= cy + hh; y++)
+            for (int x = cx - hw; x <= cx + hw; x++)
+                if (x >= 0 && x < W && y >= 0 && y < H) img[(size_t)y * W + x] = (uint8_t)g;
+    }
+    for (size_t i = 0; i < img.size(); i++) img[i] = (uint8_t)std::min(255, std::max(0, (int)img[i] + (int)(rnd() % 5) - 2));
+    return img;
+}
+
+int main() {
+    const int W = 400, H = 300, NF = 400;
+    // ---- stage 1 through the adapter
+    orbslam3_hip::ORBextractor ex(NF, 1.2f, 8, 20, 7);
+    CHECK(ex.GetLevels() == 8 && std::fabs(ex.GetScaleFactors()[3] - 1.728f) < 1e-5f);
+    std::vector<uint8_t> imgA = make_image(W, H, 0, 0), imgB = make_image(W, H, 5, -3);
+    std::vector<orb_keypoint> kA, kB;
+    std::vector<uint8_t> dA, dB;
+    std::vector<int> lap = {0, 1000};
+    const int monoA = ex.extract(imgA.data(), W, H, W, kA, dA, lap);
+    const int monoB = ex.extract(imgB.data(), W, H, W, kB, dB, lap);
+    void* o = oro_create(NF, 1.2f, 8, 20, 7);
+    std::vector<orb_keypoint> ok(NF + 64);
+    std::vector<uint8_t> od((NF + 64) * 32);
+    int n = 0;
+    const int omono = oro_extract(o, imgB.data(), W, H, W, 0, 1000, ok.data(), od.data(), NF + 64, &n);
+    CHECK(omono == monoB && n == (int)kB.size() && n > 150);
+    CHECK(std::memcmp(ok.data(), kB.data(), (size_t)n * sizeof(orb_keypoint)) == 0);
+    CHECK(std::memcmp(od.data(), dB.data(), (size_t)n * 32) == 0);
+    CHECK(ex.extract(nullptr, 0, 0, 0, ok, od, lap) == -1);   // empty image -> -1 (ORBextractor.cc:1078-1079)
+    int pw, ph;
+    CHECK(ex.pyramidLevel(2, 19, pw, ph).size() == (size_t)(pw + 38) * (ph + 38));
+    oro_destroy(o);
+    (void)monoA;
+    // ---- stage 2: motion-model search of A's keypoints in B
+    orbslam3_hip::FrameView F;
+    F.N = (int)kB.size(); F.keysUn = kB.data(); F.descriptors = dB.data();
+    F.grid = orbm_grid_params{0.f, 0.f, 64.f / W, 48.f / H};
+    std::vector<orbm_query> q(kA.size());
+    const std::vector<float> sf = ex.GetScaleFactors();
+    for (size_t i = 0; i < kA.size(); i++) {
+        q[i].u = kA[i].x + 5.f; q[i].v = kA[i].y - 3.f; q[i].radius = 15.f * sf[kA[i].octave]; q[i].u_right = 0; q[i].angle = kA[i].angle;
+        q[i].min_level = (int16_t)(kA[i].octave - 1); q[i].max_level = (int16_t)(kA[i].octave + 1); q[i].flags = ORBM_Q_VALID | ORBM_Q_HAS_OBS;
+    }
+    orbslam3_hip::ORBmatcher m(0.9f, true);
+    std::vector<int> kpMatch, qMatch;
+    const int nm = m.SearchByProjection(F, q, dA, ORBM_MODE_BEST_ONLY, ORBM_TH_HIGH, kpMatch, qMatch);
+    std::vector<int32_t> oq(q.size()), okm(kB.size());
+    const int onm = omo_search_by_projection(kB.data(), dB.data(), nullptr, nullptr, F.N, 0.f, 0.f, 64.f / W, 48.f / H, q.data(), dA.data(),
+                                             (int)q.size(), 1, 100, 0.9f, 1, oq.data(), okm.data());
+    CHECK(nm == onm && nm > 40);
+    CHECK(std::memcmp(okm.data(), kpMatch.data(), okm.size() * 4) == 0 && std::memcmp(oq.data(), qMatch.data(), oq.size() * 4) == 0);
+    CHECK(orbslam3_hip::ORBmatcher::DescriptorDistance(dA.data(), dA.data()) == 0);
+    // ---- stage 3: a toy window (4 KFs, first fixed; 30 points) through LbaLinearizer
+    orbslam3_hip::LbaLinearizer L;
+    lba_camera cam{};
+    cam.model = LBA_CAM_PINHOLE; cam.p[0] = 458.654f; cam.p[1] = 457.296f; cam.p[2] = 367.215f; cam.p[3] = 248.375f; cam.bf = 47.906f; cam.trl_q[3] = 1;
+    L.addCamera(cam);
+    std::vector<double> poses, points;
+    std::vector<int32_t> hidx;
+    for (int k = 0; k < 4; k++) {
+        const float a = 0.05f * k;
+        const float Tcw[12] = {std::cos(a), 0, std::sin(a), 0.1f * k, 0, 1, 0, 0.02f * k, -std::sin(a), 0, std::cos(a), 0.03f * k};
+        double p7[7];
+        orbslam3_hip::LbaLinearizer::poseFromTcw(Tcw, 4, p7);
+        L.addPose(p7, k == 0);
+        poses.insert(poses.end(), p7, p7 + 7);
+        hidx.push_back(k == 0 ? -1 : k - 1);
+    }
+    std::vector<lba_edge> edges;
+    for (int l = 0; l < 30; l++) {
+        const double X[3] = {((int)(rnd() % 400) - 200) / 100.0, ((int)(rnd() % 300) - 150) / 100.0, 4.0 + (rnd() % 300) / 100.0};
+        L.addPoint(X);
+        points.insert(points.end(), X, X + 3);
+        for (int k = 0; k < 4; k++) {
+            if ((l + k) % 5 == 0) continue;
+            const int kind = (l % 3 == 0) ? LBA_EDGE_STEREO : LBA_EDGE_MONO;
+            const float u = 367.f + 80.f * (float)X[0] + (float)(rnd() % 7) - 3.f, v = 248.f + 80.f * (float)X[1] + (float)(rnd() % 7) - 3.f;
+            const float s2 = 1.0f / (1.44f * (1 + k % 3));
+            L.addEdge(k, l, kind, 0, u, v, u - 9.f, s2);
+            edges.push_back(lba_edge{k, l, (int16_t)kind, 0, {u, v, u - 9.f}, s2});
+        }
+    }
+    orbslam3_hip::LbaHostSystem S;
+    L.buildSystem(S);
+    const int ne = (int)edges.size();
+    std::vector<double> Hpp(3 * 36), bp(3 * 6), Hll(30 * 9), bl(30 * 3), Hpl((size_t)ne * 18), err((size_t)ne * 3), chi2(ne), rho((size_t)ne * 2), depth(ne);
+    double rs = 0;
+    olb_build_system(poses.data(), hidx.data(), 4, points.data(), 30, edges.data(), ne, &cam, (double)std::sqrt(5.991f), (double)std::sqrt(7.815f),
+                     Hpp.data(), bp.data(), Hll.data(), bl.data(), Hpl.data(), err.data(), chi2.data(), rho.data(), depth.data(), &rs);
+    auto close = [](const std::vector<double>& a, const double* b, size_t n) {
+        double mx = 1e-300, d = 0;
+        for (size_t i = 0; i < n; i++) { mx = std::max(mx, std::fabs(b[i])); d = std::max(d, std::fabs(a[i] - b[i])); }
+        return d / mx < 1e-10;
+    };
+    CHECK(close(S.Hpp, Hpp.data(), 3 * 36) && close(S.bp, bp.data(), 18) && close(S.Hll, Hll.data(), 270) && close(S.bl, bl.data(), 90));
+    CHECK(close(S.Hpl, Hpl.data(), (size_t)ne * 18) && close(S.chi2, chi2.data(), ne) && close(S.err, err.data(), (size_t)ne * 3));
+    orbslam3_hip::LbaHostSystem S2;
+    L.computeErrors(S2);
+    CHECK(std::fabs(S2.robustChi2 - rs) < 1e-9 * rs);
+    std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges\n", n, nm, ne);
+    return 0;
+}
