@@ -38,34 +38,52 @@ static __constant__ int c_umax[16];
 struct ResizeParams {
     const uint8_t* src; size_t sFrame; int sStride, sw, sh;
     uint8_t* dst; size_t dFrame; int dStride, dw, dh;
-    const int* xofs; const short2* alpha;   // per destination column
-    const int* yofs; const short2* beta;    // per destination row
+    double scale_x, scale_y;   // 1 / ((double)dw / sw), 1 / ((double)dh / sh)  — cv::resize's scale_x / scale_y
 };
+
+// cv::resize coefficient of one destination coordinate, computed in-kernel with the same IEEE
+// double/float operations as OpenCV's table setup (no table loads on the critical path): source index + the two 11-bit weights.
+static __device__ __forceinline__ void resize_coef(int d, double scale, int slen, bool clampIndex, int& s0, int& w0, int& w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (clampIndex) {   // x: OpenCV clamps index and weight (resize.cpp alpha table); y keeps the weight and clips rows later
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si >= slen - 1) { f = 0.f; si = slen - 1; }
+    }
+    s0 = si;
+    w0 = __float2int_rn((1.f - f) * 2048.f);
+    w1 = __float2int_rn(f * 2048.f);
+    w0 = max(-32768, min(32767, w0));
+    w1 = max(-32768, min(32767, w1));
+}
 
 static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dy >= P.dh || dx0 >= P.dw) return;
     const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
-    int sy0 = P.yofs[dy], sy1 = sy0 + 1;
+    int sy0, b0, b1;
+    resize_coef(dy, P.scale_y, P.sh, false, sy0, b0, b1);
+    int sy1 = sy0 + 1;
     sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
     sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
     const uint8_t* S0 = S + (size_t)sy0 * P.sStride;
     const uint8_t* S1 = S + (size_t)sy1 * P.sStride;
-    const short2 b = P.beta[dy];
+    int sx[4], a0[4], a1[4], t0[4], t1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) resize_coef(min(dx0 + k, P.dw - 1), P.scale_x, P.sw, true, sx[k], a0[k], a1[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // all 16 loads are independent of each other
+        const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
+        t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
+        t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
+    }
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = dx0 + k;
-        if (dx < P.dw) {
-            const int sx = P.xofs[dx];
-            const int sx1 = sx + 1 < P.sw ? sx + 1 : P.sw - 1;  // weight is 0 there (fx forced to 0)
-            const short2 a = P.alpha[dx];
-            const int t0 = S0[sx] * a.x + S0[sx1] * a.y;
-            const int t1 = S1[sx] * a.x + S1[sx1] * a.y;
-            const int v = (((b.x * (t0 >> 4)) >> 16) + ((b.y * (t1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 255) << (8 * k);
-        }
+        const int v = (((b0 * (t0[k] >> 4)) >> 16) + ((b1 * (t1[k] >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 255) << (8 * k);
     }
     uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)dy * P.dStride + dx0;
     if (dx0 + 3 < P.dw) {
@@ -132,9 +150,31 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
     return max(A, -B);
 }
 
+// LDS layout of k_fast (dynamic region), sizes fixed per handle:
+//   img[imgBytes] | smap[imgBytes] | q1[FAST_QCAP] u16 | q2[FAST_Q2CAP] u16 | colTab[256] u8 | sh[8 + FAST_MAXCELLS] int
+// q1: pixels that passed the 4-point cardinal pre-test in the current row chunk; q2: every corner (S > min(ini,min)) of the tile.
+// Queue entries are (row << 8 | col) inside the tile's detection region (<= 66 rows x <= 256 cols); q2 bit 15 = local maximum.
+// The emit list reuses q1 (FAST_QCAP/2 u32 entries).
+#ifndef FAST_Q2CAP
+#define FAST_Q2CAP 4096   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
+#endif
+#define FAST_ROWS_PER_CHUNK 8
+
+static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
+    // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
+    const unsigned long long m = __ballot(pass);
+    int base = 0;
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(counter, __popcll(m));
+        base = __shfl(base, leader);
+    }
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const FastTile T = P.tiles[blockIdx.x];
     const int frame = blockIdx.y;
     const FastLevel& L = P.lv[T.level];
@@ -154,111 +194,164 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 
     uint8_t* img = orb_smem;
     uint8_t* smap = orb_smem + P.imgBytes;
-    uint16_t* queue = (uint16_t*)(orb_smem + 2 * P.imgBytes);
-    uint32_t* elist = (uint32_t*)queue;               // reused after the scoring phase
-    int* sh = (int*)(orb_smem + 2 * P.imgBytes + FAST_QCAP * 2);  // [0]=queue count [1]=emit count [2]=emit base [8..8+32)=cell counts
+    uint16_t* q1 = (uint16_t*)(orb_smem + 2 * P.imgBytes);
+    uint32_t* elist = (uint32_t*)q1;                  // reused after the scoring phase
+    uint16_t* q2 = q1 + FAST_QCAP;
+    uint8_t* colTab = (uint8_t*)(q2 + FAST_Q2CAP);    // per detection column: cell | leftEdge<<6 | rightEdge<<7
+    int* sh = (int*)(colTab + 256);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
 
     {   // stage the tile (coalesced aligned dword row loads) and clear the score map
         const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + xal;
         const int p4 = pitch >> 2;
         const int n4 = rows * p4;
+        int r = tid / p4, c = tid - r * p4;
+        const int dr = 256 / p4, dc = 256 - dr * p4;
         for (int i = tid; i < n4; i += 256) {
-            const int r = i / p4, c = i - r * p4;
             ((uint32_t*)img)[i] = *(const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
             ((uint32_t*)smap)[i] = 0;
+            r += dr; c += dc;
+            if (c >= p4) { c -= p4; r++; }
         }
         if (tid < 8 + FAST_MAXCELLS) sh[tid] = 0;
+        if (tid < detW) {
+            const int cell = tid / L.wCell;
+            const int cx = tid - cell * L.wCell, cw = min(L.wCell, detW - cell * L.wCell);
+            colTab[tid] = (uint8_t)(cell | (cx == 0 ? 0x40 : 0) | (cx + 1 >= cw ? 0x80 : 0));
+        }
     }
     __syncthreads();
 
     const int t0 = min(P.iniTh, P.minTh);
-    const int npix = detW * detH;
-    const float invW = 1.0f / (float)detW;
-    for (int base = 0; base < npix; base += FAST_QCAP) {
-        // phase A: ring classification -> corner queue
-#pragma unroll 2
-        for (int k = 0; k < FAST_QCAP / 256; k++) {
-            const int p = base + k * 256 + tid;
-            if (p < npix) {
-                int ry = (int)((float)p * invW);
-                int rx = p - ry * detW;
-                if (rx < 0) { ry--; rx += detW; }
-                if (rx >= detW) { ry++; rx -= detW; }
-                const int pos = (dy0 + ry) * pitch + dx0 + rx;
-                const uint8_t* c = img + pos;
+    const bool colOk = tid < detW;
+    int chunk = 0;
+    for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK, chunk ^= 1) {
+        int* q1cnt = chunk ? &sh[5] : &sh[0];
+        if (tid == 0) sh[chunk ? 0 : 5] = 0;   // the other chunk parity's counter: next used two barriers from now
+        // ---- stage 1: 4-point pre-test.  Any 9-arc of the 16-ring contains >= 2 of the compass points 0,4,8,12, so a
+        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> q1.
+        const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
+        const uint8_t* c = img + (dy0 + r0) * pitch + dx0 + tid;
+        for (int ry = r0; ry < rend; ry++, c += pitch) {
+            bool pass = false;
+            if (colOk) {
                 const int v = c[0];
                 const int lo = v - t0, hi = v + t0;
+                const int a = c[3 * pitch], b = c[3], d = c[-3 * pitch], e = c[-3];
+                const int nd = (a < lo) + (b < lo) + (d < lo) + (e < lo);
+                const int nb = (a > hi) + (b > hi) + (d > hi) + (e > hi);
+                pass = nd >= 2 || nb >= 2;
+            }
+            const int slot = wave_append(pass, q1cnt, lane);
+            if (pass) q1[slot] = (uint16_t)((ry << 8) | tid);
+        }
+        __syncthreads();
+        // ---- stage 2: full ring classification of the survivors (dense lanes) -> q2
+        const int n1 = *q1cnt;
+        for (int i0 = 0; i0 < n1; i0 += 256) {
+            const int i = i0 + tid;
+            bool corner = false;
+            int ent = 0;
+            if (i < n1) {
+                ent = q1[i];
+                const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
+                const int v = cc[0];
+                const int lo = v - t0, hi = v + t0;
                 uint32_t md = 0, mb = 0;
-#define CL(k_, dx, dy) { const int x = c[(dy) * pitch + (dx)]; md = (md << 1) | ((uint32_t)(x - lo) >> 31); mb = (mb << 1) | ((uint32_t)(hi - x) >> 31); }
+#define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; md = __builtin_amdgcn_alignbit(md, (uint32_t)(x - lo), 31); mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(hi - x), 31); }
                 RING16(CL)
 #undef CL
-                if (ring_has9(md) || ring_has9(mb)) {
-                    const int slot = atomicAdd(&sh[0], 1);
-                    queue[slot] = (uint16_t)pos;
+                corner = ring_has9(md) || ring_has9(mb);
+            }
+            const int slot = wave_append(corner, &sh[3], lane);
+            if (corner) { if (slot < FAST_Q2CAP) q2[slot] = (uint16_t)ent; else sh[4] = 1; }
+        }
+        __syncthreads();
+    }
+    const bool overflow = sh[4] != 0;
+    const int n2 = min(sh[3], FAST_Q2CAP);
+    int* cellCnt = sh + 8;
+    if (!overflow) {
+        // ---- stage 3: exact score of every corner (dense)
+        for (int i = tid; i < n2; i += 256) {
+            const int ent = q2[i];
+            const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
+            smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
+        }
+        __syncthreads();
+        // ---- NMS over the corner list: strict maximum over the 8 neighbours inside the same cell's detection region.
+        //      survive(T) = s >= T && localmax (threshold-independent localmax, DESIGN.md "FAST as set algebra").
+        for (int i = tid; i < n2; i += 256) {
+            const int ent = q2[i];
+            const int rx = ent & 255;
+            const uint8_t* m = smap + (dy0 + (ent >> 8)) * pitch + dx0 + rx;
+            const int s = m[0], ct = colTab[rx];
+            bool ok = s > 0 && s > m[-pitch] && s > m[pitch];
+            if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
+            if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
+            if (ok) {
+                q2[i] = (uint16_t)(ent | 0x8000);
+                if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n2; i += 256) {
+            const int ent = q2[i];
+            if (!(ent & 0x8000)) continue;
+            const int rx = ent & 255, ry = (ent >> 8) & 127;
+            const int s = smap[(dy0 + ry) * pitch + dx0 + rx];
+            const int Tth = cellCnt[colTab[rx] & 63] > 0 ? P.iniTh : P.minTh;   // per-cell retry, ORBextractor.cc:825-828
+            if (s >= Tth) {
+                // coordinates relative to minBorder, as vToDistributeKeys holds them (ORBextractor.cc:845-850)
+                const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
+                const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
+                const int slot = atomicAdd(&sh[1], 1);
+                if (slot < FAST_QCAP / 2) elist[slot] = packed;
+                else {
+                    const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, 1);
+                    if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
                 }
             }
         }
         __syncthreads();
-        // phase B: exact score for queued corners
-        const int nq = sh[0];
-        for (int q = tid; q < nq; q += 256) {
-            const int pos = queue[q];
+    } else {
+        // ---- fallback (more than FAST_Q2CAP corners in one tile): score every pixel of the tile in place and scan the
+        //      whole score map.  Same results, no queue bound.
+        const int npix = detW * detH;
+        for (int p = tid; p < npix; p += 256) {
+            const int ry = p / detW, rx = p - ry * detW;
+            const int pos = (dy0 + ry) * pitch + dx0 + rx;
             const int S = fast_S(img + pos, pitch);
-            smap[pos] = (uint8_t)(S - 1);   // S > t0 >= 0 here
+            smap[pos] = (uint8_t)(S > t0 ? S - 1 : 0);
         }
         __syncthreads();
-        if (tid == 0) sh[0] = 0;
-        __syncthreads();
-    }
-
-    // NMS: strict maximum over the 8 neighbours inside the same cell's detection region (outside counts as 0).
-    // survive(T) = s >= T && localmax  (threshold-independent localmax, see DESIGN.md "FAST").
-    int* cellCnt = sh + 8;
-    const int wCell = L.wCell;
-    const float invC = 1.0f / (float)wCell;
-    const int iters = (npix + 255) / 256;
-    for (int pass = 0; pass < 2; pass++) {
-        for (int it = 0; it < iters; it++) {
-            const int p = it * 256 + tid;
-            if (p >= npix) continue;
-            int ry = (int)((float)p * invW);
-            int rx = p - ry * detW;
-            if (rx < 0) { ry--; rx += detW; }
-            if (rx >= detW) { ry++; rx -= detW; }
-            const int pos = (dy0 + ry) * pitch + dx0 + rx;
-            const int s = smap[pos];
-            if (s == 0) continue;
-            int cell = (int)((float)rx * invC);
-            if (cell * wCell > rx) cell--;
-            if ((cell + 1) * wCell <= rx) cell++;
-            const int cx = rx - cell * wCell;               // x inside the cell's detection region
-            const int cw = min(wCell, detW - cell * wCell);  // its width
-            const uint8_t* m = smap + pos;
-            const bool hasL = cx > 0, hasR = cx + 1 < cw;
-            bool ok = s > m[-pitch] && s > m[pitch];
-            if (hasL) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
-            if (hasR) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
-            if (!ok) continue;
-            if (pass == 0) {
-                if (s >= P.iniTh) atomicAdd(&cellCnt[cell], 1);
-            } else {
-                const int Tth = cellCnt[cell] > 0 ? P.iniTh : P.minTh;
-                if (s >= Tth) {
-                    // coordinates relative to minBorder, as vToDistributeKeys holds them (ORBextractor.cc:845-850)
-                    const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
-                    const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
-                    const int slot = atomicAdd(&sh[1], 1);
-                    if (slot < FAST_QCAP / 2) {
-                        elist[slot] = packed;
-                    } else {  // LDS list full: straight to global
-                        int* cnt = P.candCount + (size_t)frame * P.nlevels + T.level;
-                        const int g = atomicAdd(cnt, 1);
-                        if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int p = tid; p < npix; p += 256) {
+                const int ry = p / detW, rx = p - ry * detW;
+                const uint8_t* m = smap + (dy0 + ry) * pitch + dx0 + rx;
+                const int s = m[0], ct = colTab[rx];
+                if (s == 0) continue;
+                bool ok = s > m[-pitch] && s > m[pitch];
+                if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
+                if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
+                if (!ok) continue;
+                if (pass == 0) {
+                    if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
+                } else {
+                    const int Tth = cellCnt[ct & 63] > 0 ? P.iniTh : P.minTh;
+                    if (s >= Tth) {
+                        const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
+                        const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
+                        const int slot = atomicAdd(&sh[1], 1);
+                        if (slot < FAST_QCAP / 2) elist[slot] = packed;
+                        else {
+                            const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, 1);
+                            if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
+                        }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     const int ne = min(sh[1], FAST_QCAP / 2);
     if (ne == 0) return;
@@ -643,11 +736,11 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 }
 
 #define DP 43            // source patch edge (radius 21 = 18 pattern reach + 3 blur taps)
-#define DPP 44           // patch pitch
+#define DPP 52           // patch pitch in bytes (13 dwords: odd -> lane-per-row accesses are bank-conflict free)
 #define DB 37            // blurred edge (radius 18)
+#define DRP 38           // row-pass pitch in u16 (19 dwords, odd)
 #define DBP 40           // blurred pitch
-#define DESC_WAVE_LDS (DP * DPP + DP * DB * 2 + DB * DBP + 2)   // 1892 + 3182 + 1480 (+pad) bytes
-#define DESC_WAVE_STRIDE 6560
+#define DESC_WAVE_STRIDE 6992   // 43*52 + 43*38*2 + 37*40 = 2236 + 3268 + 1480 = 6984 -> 16-byte multiple
 
 static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
@@ -656,7 +749,7 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     const int g = blockIdx.x * 4 + wave;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
-    uint8_t* blur = (uint8_t*)(rowp + DP * DB);
+    uint8_t* blur = (uint8_t*)(rowp + DP * DRP);
 
     // locate keypoint g of this frame: level, position inside the level's octree list, output slot
     const int* sc = P.selCount + (size_t)frame * P.nlevels;
@@ -681,47 +774,78 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
         aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
     }
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
+    int ox = 0;   // column of the patch's first pixel inside the LDS rows
     if (valid) {
         const uint8_t* img = L.base + (size_t)frame * L.frameStride;
-        for (int i = lane; i < DP * DP; i += 64) {
-            const int r = i / DP, c = i - r * DP;
-            const int y = reflect101(cy - 21 + r, L.h), x = reflect101(cx - 21 + c, L.w);
-            patch[r * DPP + c] = img[(size_t)y * L.rowStride + x];
+        const int xs = cx - 21, ys = cy - 21;
+        if (xs >= 0 && ys >= 0 && cy + 21 < L.h && cx + 27 <= L.w) {
+            // interior: 43 rows x 12 aligned dwords (48 B cover the 43 columns at any alignment), coalesced per row
+            const int x0 = xs & ~3;
+            ox = xs - x0;
+            const uint8_t* src = img + (size_t)ys * L.rowStride + x0;
+            for (int i = lane; i < DP * 12; i += 64) {
+                const int r = i / 12, c = i - r * 12;
+                *(uint32_t*)(patch + r * DPP + 4 * c) = *(const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
+            }
+        } else {
+            // the 7x7 blur taps may cross the image border: BORDER_REFLECT_101 at load (GaussianBlur on the un-bordered clone)
+            for (int i = lane; i < DP * DP; i += 64) {
+                const int r = i / DP, c = i - r * DP;
+                const int y = reflect101(ys + r, L.h), x = reflect101(xs + c, L.w);
+                patch[r * DPP + c] = img[(size_t)y * L.rowStride + x];
+            }
         }
     }
     __syncthreads();
     float angle = 0.f;
     if (valid) {
-        // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15
+        // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15; lane = row v
         int m10 = 0, m01 = 0;
-        for (int i = lane; i < 31 * 31; i += 64) {
-            const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
-            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-            if (au <= c_umax[av]) {
-                const int I = patch[(21 + v) * DPP + 21 + u];
+        if (lane < 31) {
+            const int v = lane - 15;
+            const int d = c_umax[v < 0 ? -v : v];
+            const uint8_t* row = patch + (21 + v) * DPP + ox + 21;
+            int rs = 0;
+#pragma unroll
+            for (int u = -15; u <= 15; u++) {
+                const int I = (u >= -d && u <= d) ? (int)row[u] : 0;
                 m10 += u * I;
-                m01 += v * I;
+                rs += I;
             }
+            m01 = v * rs;
         }
         for (int off = 32; off > 0; off >>= 1) {
             m10 += __shfl_xor(m10, off);
             m01 += __shfl_xor(m01, off);
         }
         angle = fast_atan2_deg((float)m01, (float)m10);
-        // Gaussian row pass: k = cvRound(256*g) = {18,34,49,55,49,34,18}; sums <= 255*257 fit u16
-        for (int i = lane; i < DP * DB; i += 64) {
-            const int r = i / DB, c = i - r * DB;
-            const uint8_t* p = patch + r * DPP + c;
-            rowp[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+        // Gaussian row pass, lane = patch row, sliding window in registers: k = cvRound(256*g) = {18,34,49,55,49,34,18};
+        // sums <= 255*257 fit u16
+        if (lane < DP) {
+            const uint8_t* p = patch + lane * DPP + ox;
+            uint32_t px[DP];
+#pragma unroll
+            for (int c = 0; c < DP; c++) px[c] = p[c];
+            uint32_t* o = (uint32_t*)(rowp + lane * DRP);
+#pragma unroll
+            for (int c = 0; c < DB; c += 2) {
+                const uint32_t a = 18 * (px[c] + px[c + 6]) + 34 * (px[c + 1] + px[c + 5]) + 49 * (px[c + 2] + px[c + 4]) + 55 * px[c + 3];
+                uint32_t b = 0;
+                if (c + 1 < DB) b = 18 * (px[c + 1] + px[c + 7]) + 34 * (px[c + 2] + px[c + 6]) + 49 * (px[c + 3] + px[c + 5]) + 55 * px[c + 4];
+                o[c >> 1] = a | (b << 16);
+            }
         }
     }
     __syncthreads();
-    if (valid) {
-        for (int i = lane; i < DB * DB; i += 64) {
-            const int r = i / DB, c = i - r * DB;
-            const uint16_t* p = rowp + r * DB + c;
-            const int acc = 18 * (p[0] + p[6 * DB]) + 34 * (p[DB] + p[5 * DB]) + 49 * (p[2 * DB] + p[4 * DB]) + 55 * p[3 * DB];
-            blur[r * DBP + c] = (uint8_t)min((acc + 32768) >> 16, 255);
+    if (valid && lane < DB) {
+        // column pass, lane = column: out = (sum + 32768) >> 16, saturated
+        uint32_t rp[DP];
+#pragma unroll
+        for (int r = 0; r < DP; r++) rp[r] = rowp[r * DRP + lane];
+#pragma unroll
+        for (int r = 0; r < DB; r++) {
+            const uint32_t acc = 18 * (rp[r] + rp[r + 6]) + 34 * (rp[r + 1] + rp[r + 5]) + 49 * (rp[r + 2] + rp[r + 4]) + 55 * rp[r + 3];
+            blur[r * DBP + lane] = (uint8_t)min((acc + 32768u) >> 16, 255u);
         }
     }
     __syncthreads();
@@ -774,7 +898,6 @@ struct LevelHost {
     int w, h, stride; size_t planeOff, planeBytes;   // levels >= 1 live in the handle's pyramid slab
     int maxBX, maxBY, nCols, nRows, wCell, hCell, nIni; float hX;
     int candCap; size_t candOff; int selCap, selOff;
-    int *d_xofs = nullptr, *d_yofs = nullptr; short2 *d_alpha = nullptr, *d_beta = nullptr;
 };
 
 struct orbx_extractor {
@@ -817,12 +940,6 @@ static int orbx_fail(orbx_extractor* h, int code, const std::string& msg) {
 static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (int l = 0; l < ORBX_MAX_LEVELS; l++) {
-        if (h->lv[l].d_xofs) (void)hipFree(h->lv[l].d_xofs);
-        if (h->lv[l].d_yofs) (void)hipFree(h->lv[l].d_yofs);
-        if (h->lv[l].d_alpha) (void)hipFree(h->lv[l].d_alpha);
-        if (h->lv[l].d_beta) (void)hipFree(h->lv[l].d_beta);
-    }
     void* bufs[] = {h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
                     h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
     for (void* p : bufs) if (p) (void)hipFree(p);
@@ -908,7 +1025,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size();
     h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
-    h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + (8 + FAST_MAXCELLS) * 4;
+    h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + 256 + (8 + FAST_MAXCELLS) * 4;
     h->octSmem = (size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8);
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
 
@@ -933,35 +1050,6 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_desc1, (size_t)maxKp * 32));
     CK(hipMalloc((void**)&h->d_counts1, 2 * sizeof(int32_t)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
-    // ---- cv::resize coefficient tables for level l from level l-1 (Appendix B2 of SURVEY.md)
-    for (int l = 1; l < nl; l++) {
-        LevelHost& D = h->lv[l]; const LevelHost& S = h->lv[l - 1];
-        const double scale_x = 1. / ((double)D.w / S.w), scale_y = 1. / ((double)D.h / S.h);
-        std::vector<int> xofs(D.w), yofs(D.h); std::vector<short2> alpha(D.w), beta(D.h);
-        auto sat16 = [](int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); };
-        for (int dx = 0; dx < D.w; dx++) {
-            float fx = (float)((dx + 0.5) * scale_x - 0.5);
-            int sx = (int)std::floor(fx);
-            fx -= sx;
-            if (sx < 0) { fx = 0; sx = 0; }
-            if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
-            xofs[dx] = sx;
-            alpha[dx].x = sat16(cvRoundF((1.f - fx) * 2048)); alpha[dx].y = sat16(cvRoundF(fx * 2048));
-        }
-        for (int dy = 0; dy < D.h; dy++) {
-            float fy = (float)((dy + 0.5) * scale_y - 0.5);
-            int sy = (int)std::floor(fy);
-            fy -= sy;
-            yofs[dy] = sy;
-            beta[dy].x = sat16(cvRoundF((1.f - fy) * 2048)); beta[dy].y = sat16(cvRoundF(fy * 2048));
-        }
-        CK(hipMalloc((void**)&D.d_xofs, D.w * 4)); CK(hipMalloc((void**)&D.d_alpha, D.w * 4));
-        CK(hipMalloc((void**)&D.d_yofs, D.h * 4)); CK(hipMalloc((void**)&D.d_beta, D.h * 4));
-        CK(hipMemcpy(D.d_xofs, xofs.data(), D.w * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(D.d_alpha, alpha.data(), D.w * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(D.d_yofs, yofs.data(), D.h * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(D.d_beta, beta.data(), D.h * 4, hipMemcpyHostToDevice));
-    }
 #undef CK
     *out = h;
     return ORB_OK;
@@ -1009,7 +1097,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.sw = h->lv[l - 1].w; R.sh = h->lv[l - 1].h;
         R.dst = h->d_pyr + h->lv[l].planeOff; R.dFrame = h->pyrFrame; R.dStride = h->lv[l].stride;
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
-        R.xofs = h->lv[l].d_xofs; R.alpha = h->lv[l].d_alpha; R.yofs = h->lv[l].d_yofs; R.beta = h->lv[l].d_beta;
+        R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
         dim3 grid((R.dw + 255) / 256, (R.dh + 3) / 4, batch);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, R);
     }

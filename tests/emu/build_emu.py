@@ -11,7 +11,13 @@ OUT = os.path.join(EMU, "build", "liborbhip_emu.so")
 SRCS = sorted(glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.hip")))
 
 
-def build(force=False):
+def build(force=False, defines=(), tag=""):
+    global OUT
+    out = OUT if not tag else OUT.replace(".so", "_" + tag + ".so")
+    return _build(out, force, defines)
+
+
+def _build(OUT, force, defines):
     deps = SRCS + glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.inc")) + \
         glob.glob(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc", "*.h")) + \
         [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "orbhip.h")]
@@ -19,7 +25,7 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w",
-           "-I", EMU, "-I", os.path.join(ROOT, "include")]
+           "-I", EMU, "-I", os.path.join(ROOT, "include")] + ["-D" + d for d in defines]
     for s in SRCS:
         cmd += ["-x", "c++", s]
     cmd += ["-o", OUT]

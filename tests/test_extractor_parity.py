@@ -21,8 +21,10 @@ CASES = [
     ("sparse_640x480", lambda: synth_image(7, 640, 480, n_rect=10, n_disc=5), 1000, (100, 200), {}),
     ("other_config", lambda: synth_image(8, 400, 300), 500, (0, 0), dict(nlevels=4, iniThFAST=30, minThFAST=10, scaleFactor=1.5)),
     ("tumvi_512", lambda: synth_image(9, 512, 512), 1500, (0, 511), {}),
+    # white noise: > 4096 FAST corners per tile -> the kernel's whole-tile fallback path; also the densest octree input
+    ("noise_tile_overflow", lambda: np.random.default_rng(77).integers(0, 256, (300, 400), dtype=np.uint8), 1000, (0, 1000), dict(nlevels=4)),
 ]
-EMU_CASES = {"euroc_752x480", "lapping_window", "low_contrast_retries", "flat_zero_keypoints", "other_config", "sparse_640x480"}
+EMU_CASES = {"noise_tile_overflow", "euroc_752x480", "lapping_window", "low_contrast_retries", "flat_zero_keypoints", "other_config", "sparse_640x480"}
 
 
 def _run_case(lib, case, stage_checks=True):
@@ -59,6 +61,17 @@ def test_emulated_kernels_match_oracle(emu_lib, case):
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
 def test_hip_matches_oracle(hip_lib, case):
     _run_case(hip_lib, case)
+
+
+def test_emulated_fast_tile_fallback_path():
+    """FAST_Q2CAP=48 forces the whole-tile fallback of k_fast in almost every tile; results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_Q2CAP=48",), tag="q2cap48")))
+    for case in CASES:
+        if case[0] in ("sparse_640x480", "noise_tile_overflow"):
+            _run_case(lib, case)
 
 
 def test_empty_image_returns_minus_one(emu_lib):
