@@ -267,6 +267,9 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
 
 // One wave per frame walks the queries in index order (ORBmatcher.cc:65 / :2265 loop order) and applies the
 // reference's accept rules against the live occupancy; distances come from k_sbp_candidates.
+// The serial chain touches LDS only: queries are staged 64 at a time (count, HAS_OBS flag and the first SBP_STAGE candidates
+// of each, loaded lane-parallel), and the rotation-histogram bins are computed after the loop (they do not feed back).
+#define SBP_STAGE 8
 static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -274,7 +277,9 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     const int nq = min(A.nq[b], A.cap_q);
     int* hist = (int*)orb_smem;                       // [32]
     int* ctl = hist + 32;                             // [8]
-    uint8_t* occ = (uint8_t*)(ctl + 8);               // [cap_k] holder has Observations()>0
+    uint32_t* sEnt = (uint32_t*)(ctl + 8);            // [64][SBP_STAGE]
+    int* sCnt = (int*)(sEnt + 64 * SBP_STAGE);        // [64] count | hasObs << 30
+    uint8_t* occ = (uint8_t*)(sCnt + 64);             // [cap_k] holder has Observations()>0
     int32_t* q_match = A.q_match + (size_t)b * A.cap_q;
     int32_t* kp_match = A.kp_match + (size_t)b * A.cap_k;
     const uint8_t* occ0 = A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
@@ -286,82 +291,106 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     const float ratio = A.prm.nn_ratio;
     const bool ori = mode == ORBM_MODE_BEST_ONLY && A.prm.check_orientation;
     const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
+    const orbm_query* queries = A.queries + (size_t)b * A.cap_q;
     int nmatches = 0;
-    for (int q = 0; q < nq; q++) {
-        uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
-        const int count = (int)w[0];
-        if (count == 0) continue;
-        const orbm_query Q = A.queries[(size_t)b * A.cap_q + q];
-        // per-lane two smallest keys; key = dist<<20 | enumeration position  (first minimum wins, strict '<')
-        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;
-        if (count <= SBP_CAPC) {
-            if (lane < count) {
-                const uint32_t e = w[2 + lane];
-                if (!occ[e & 0xFFFF]) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        {   // stage this block of queries (lane-parallel loads)
+            const int q = q0 + lane;
+            int c = 0, obs = 0;
+            if (q < nq) {
+                const uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
+                c = (int)w[0];
+                obs = (queries[q].flags & ORBM_Q_HAS_OBS) ? 1 : 0;
+                const int m = min(c, SBP_STAGE);
+                for (int k = 0; k < m; k++) sEnt[lane * SBP_STAGE + k] = w[2 + k];
             }
-        } else {  // rare: re-enumerate this query against the live occupancy
-            const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-            int seen = 0;
-            enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
-                const unsigned long long m = __ballot(pass);
-                if (pass && !occ[idx]) {
-                    const uint32_t pos = (uint32_t)(seen + __popcll(m & ((1ull << lane) - 1ull)));
-                    const uint32_t key = ((uint32_t)dist << 20) | (pos & 0xFFFFF);
-                    const uint32_t e = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
-                    if (key < k1) { k2 = k1; e2 = e1; k1 = key; e1 = e; }
-                    else if (key < k2) { k2 = key; e2 = e; }
+            sCnt[lane] = c | (obs << 30);
+        }
+        __syncthreads();
+        const int qend = min(64, nq - q0);
+        for (int i = 0; i < qend; i++) {
+            const int q = q0 + i;
+            const int cw = sCnt[i];
+            const int count = cw & 0x3FFFFFFF;
+            if (count == 0) continue;
+            // per-lane two smallest keys; key = dist<<20 | enumeration position  (first minimum wins, strict '<')
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;
+            if (count <= SBP_CAPC) {
+                if (lane < count) {
+                    const uint32_t e = count <= SBP_STAGE ? sEnt[i * SBP_STAGE + lane]
+                                                          : A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2 + lane];
+                    if (!occ[e & 0xFFFF]) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
                 }
-                seen += __popcll(m);
-            });
-        }
-        const uint32_t m1 = wave_min_u32(k1);
-        if (m1 == 0xFFFFFFFFu) continue;  // every candidate already holds an observed point
-        const bool iBest = k1 == m1;
-        const uint32_t c2 = iBest ? k2 : k1;
-        const uint32_t m2 = wave_min_u32(c2);
-        // broadcast the entries that own m1 / m2
-        const unsigned long long bm1 = __ballot(iBest);
-        const int l1 = __ffsll((long long)bm1) - 1;
-        const uint32_t eb1 = __shfl(e1, l1);
-        const unsigned long long bm2 = __ballot(c2 == m2 && m2 != 0xFFFFFFFFu);
-        uint32_t eb2 = 0;
-        if (bm2) { const int l2 = __ffsll((long long)bm2) - 1; eb2 = __shfl(iBest ? e2 : e1, l2); }
-        const int bestDist = (int)(m1 >> 20), bestIdx = (int)(eb1 & 0xFFFF), bestLevel = (int)((eb1 >> 25) & 0x3F);
-        const int bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
-        const int bestLevel2 = m2 == 0xFFFFFFFFu ? -1 : (int)((eb2 >> 25) & 0x3F);
-        bool accept = false;
-        if (bestDist <= th) {
-            if (mode == ORBM_MODE_LOCAL_MAP) {
-                // ORBmatcher.cc:160-178
-                if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) accept = false;
-                else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
-            } else {
-                accept = true;  // ORBmatcher.cc:2372
+            } else {  // rare: re-enumerate this query against the live occupancy
+                const orbm_query Q = queries[q];
+                const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+                int seen = 0;
+                enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+                    const unsigned long long m = __ballot(pass);
+                    if (pass && !occ[idx]) {
+                        const uint32_t pos = (uint32_t)(seen + __popcll(m & ((1ull << lane) - 1ull)));
+                        const uint32_t key = ((uint32_t)dist << 20) | (pos & 0xFFFFF);
+                        const uint32_t e = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+                        if (key < k1) { k2 = k1; e2 = e1; k1 = key; e1 = e; }
+                        else if (key < k2) { k2 = key; e2 = e; }
+                    }
+                    seen += __popcll(m);
+                });
             }
-        }
-        if (accept) {
-            nmatches++;
-            if (lane == 0) {
-                occ[bestIdx] = (Q.flags & ORBM_Q_HAS_OBS) ? 1 : 0;
-                kp_match[bestIdx] = q;
-                q_match[q] = bestIdx;
-                if (ori) {
-                    // ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()
-                    float rot = Q.angle - kps[bestIdx].angle;
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
-                    if (bin == ORBM_HISTO_LENGTH) bin = 0;
-                    bin = max(0, min(bin, 31));
-                    hist[bin]++;
-                    w[1] = (uint32_t)bin;
+            const uint32_t m1 = wave_min_u32(k1);
+            if (m1 == 0xFFFFFFFFu) continue;  // every candidate already holds an observed point
+            const bool iBest = k1 == m1;
+            const int l1 = __ffsll((long long)__ballot(iBest)) - 1;
+            const uint32_t eb1 = __shfl(e1, l1);
+            const int bestDist = (int)(m1 >> 20), bestIdx = (int)(eb1 & 0xFFFF);
+            bool accept = false;
+            if (bestDist <= th) {
+                if (mode == ORBM_MODE_LOCAL_MAP) {
+                    const uint32_t c2 = iBest ? k2 : k1;
+                    const uint32_t m2 = wave_min_u32(c2);
+                    const unsigned long long bm2 = __ballot(c2 == m2 && m2 != 0xFFFFFFFFu);
+                    uint32_t eb2 = 0;
+                    if (bm2) { const int l2 = __ffsll((long long)bm2) - 1; eb2 = __shfl(iBest ? e2 : e1, l2); }
+                    const int bestLevel = (int)((eb1 >> 25) & 0x3F);
+                    const int bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
+                    const int bestLevel2 = m2 == 0xFFFFFFFFu ? -1 : (int)((eb2 >> 25) & 0x3F);
+                    // ORBmatcher.cc:160-178
+                    if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) accept = false;
+                    else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
+                } else {
+                    accept = true;  // ORBmatcher.cc:2372
                 }
             }
-            __syncthreads();  // single-wave block: orders lane 0's LDS writes before the next query's reads
+            if (accept) {
+                nmatches++;
+                if (lane == 0) {
+                    occ[bestIdx] = (uint8_t)(cw >> 30);
+                    kp_match[bestIdx] = q;
+                    q_match[q] = bestIdx;
+                }
+                __syncthreads();  // single-wave block: orders lane 0's LDS write before the next query's reads
+            }
         }
+        __syncthreads();  // the staging area is rewritten by the next block
     }
     __threadfence_block();
     __syncthreads();
     if (ori) {
+        // rotation histogram (ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()) of every accepted match
+        for (int q = lane; q < nq; q += 64) {
+            const int idx = q_match[q];
+            if (idx >= 0) {
+                float rot = queries[q].angle - kps[idx].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                bin = max(0, min(bin, 31));
+                atomicAdd(&hist[bin], 1);
+                A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 1] = (uint32_t)bin;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
         if (lane == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:2654-2695
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
             for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
@@ -377,11 +406,12 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
         __syncthreads();
         const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
         for (int q = lane; q < nq; q += 64) {
-            const uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
-            const int bin = (int)w[1];
-            if (q_match[q] >= 0 && bin != ind1 && bin != ind2 && bin != ind3) {
-                kp_match[q_match[q]] = -1;      // CurrentFrame.mvpMapPoints[...] = NULL, :2499
-                atomicAdd(&ctl[3], 1);
+            if (q_match[q] >= 0) {
+                const int bin = (int)A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 1];
+                if (bin != ind1 && bin != ind2 && bin != ind3) {
+                    kp_match[q_match[q]] = -1;      // CurrentFrame.mvpMapPoints[...] = NULL, :2499
+                    atomicAdd(&ctl[3], 1);
+                }
             }
         }
         __threadfence_block();
@@ -548,7 +578,7 @@ extern "C" int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_
         !d_kp_match || !d_nmatches || !d_work || cap_k < 1 || cap_k > 65535 || cap_q < 1 || batch < 1 || count_stride < 1)
         return ORB_E_INVALID;
     if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY) return ORB_E_INVALID;
-    const size_t smem = (32 + 8) * 4 + (((size_t)cap_k + 15) & ~(size_t)15);
+    const size_t smem = (32 + 8 + 64 * 8 + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     SbpArgs A;
     A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = d_occupied0; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;

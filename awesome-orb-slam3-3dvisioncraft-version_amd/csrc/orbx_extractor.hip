@@ -151,14 +151,15 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
 }
 
 // LDS layout of k_fast (dynamic region), sizes fixed per handle:
-//   img[imgBytes] | smap[imgBytes] | q1[FAST_QCAP] u16 | q2[FAST_Q2CAP] u16 | colTab[256] u8 | sh[8 + FAST_MAXCELLS] int
+//   img[imgBytes] | smap[imgBytes] | q1[FAST_QCAP] u16 | q2[FAST_Q2CAP] u16 | colTab[FAST_TW] u8 | sh[8 + FAST_MAXCELLS] int
 // q1: pixels that passed the 4-point cardinal pre-test in the current row chunk; q2: every corner (S > min(ini,min)) of the tile.
 // Queue entries are (row << 8 | col) inside the tile's detection region (<= 66 rows x <= 256 cols); q2 bit 15 = local maximum.
 // The emit list reuses q1 (FAST_QCAP/2 u32 entries).
 #ifndef FAST_Q2CAP
-#define FAST_Q2CAP 4096   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
+#define FAST_Q2CAP 2048   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
 #endif
-#define FAST_ROWS_PER_CHUNK 8
+#define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
+#define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)
 
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
@@ -198,7 +199,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     uint32_t* elist = (uint32_t*)q1;                  // reused after the scoring phase
     uint16_t* q2 = q1 + FAST_QCAP;
     uint8_t* colTab = (uint8_t*)(q2 + FAST_Q2CAP);    // per detection column: cell | leftEdge<<6 | rightEdge<<7
-    int* sh = (int*)(colTab + 256);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
+    int* sh = (int*)(colTab + FAST_TW);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
 
     {   // stage the tile (coalesced aligned dword row loads) and clear the score map
         const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + xal;
@@ -222,7 +223,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __syncthreads();
 
     const int t0 = min(P.iniTh, P.minTh);
-    const bool colOk = tid < detW;
+    const int col = tid & (FAST_TW - 1), rsub = tid / FAST_TW;
+    const bool colOk = col < detW;
     int chunk = 0;
     for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK, chunk ^= 1) {
         int* q1cnt = chunk ? &sh[5] : &sh[0];
@@ -230,8 +232,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         // ---- stage 1: 4-point pre-test.  Any 9-arc of the 16-ring contains >= 2 of the compass points 0,4,8,12, so a
         //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> q1.
         const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
-        const uint8_t* c = img + (dy0 + r0) * pitch + dx0 + tid;
-        for (int ry = r0; ry < rend; ry++, c += pitch) {
+        const uint8_t* c = img + (dy0 + r0 + rsub) * pitch + dx0 + col;
+        for (int ry = r0 + rsub; ry < rend; ry += 256 / FAST_TW, c += (256 / FAST_TW) * pitch) {
             bool pass = false;
             if (colOk) {
                 const int v = c[0];
@@ -242,7 +244,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 pass = nd >= 2 || nb >= 2;
             }
             const int slot = wave_append(pass, q1cnt, lane);
-            if (pass) q1[slot] = (uint16_t)((ry << 8) | tid);
+            if (pass) q1[slot] = (uint16_t)((ry << 8) | col);
         }
         __syncthreads();
         // ---- stage 2: full ring classification of the survivors (dense lanes) -> q2
@@ -740,7 +742,7 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 #define DB 37            // blurred edge (radius 18)
 #define DRP 38           // row-pass pitch in u16 (19 dwords, odd)
 #define DBP 40           // blurred pitch
-#define DESC_WAVE_STRIDE 6992   // 43*52 + 43*38*2 + 37*40 = 2236 + 3268 + 1480 = 6984 -> 16-byte multiple
+#define DESC_WAVE_STRIDE 5504   // 43*52 (patch; reused for the 37x40 blurred tile once the row pass is done) + 43*38*2 (row pass)
 
 static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
@@ -749,7 +751,7 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     const int g = blockIdx.x * 4 + wave;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
-    uint8_t* blur = (uint8_t*)(rowp + DP * DRP);
+    uint8_t* blur = patch;   // the source patch is dead after IC_Angle + the row pass
 
     // locate keypoint g of this frame: level, position inside the level's octree list, output slot
     const int* sc = P.selCount + (size_t)frame * P.nlevels;
@@ -1008,7 +1010,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
         nodeCap = std::max(nodeCap, L.selCap); maxKp += L.selCap;
         if (L.selCap > 60000) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "nfeatures per level too large"); }
         // FAST tiles: groups of whole cells of one cell row, <= 256 px wide
-        const int cpt = std::max(1, std::min(FAST_MAXCELLS, 256 / L.wCell));
+        const int cpt = std::max(1, std::min(FAST_MAXCELLS, FAST_TW / L.wCell));
         const int nT = (L.nCols + cpt - 1) / cpt, per = (L.nCols + nT - 1) / nT;
         for (int i = 0; i < L.nRows; i++) {
             const int iniY = ORBX_MINB + i * L.hCell;
@@ -1025,7 +1027,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size();
     h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
-    h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + 256 + (8 + FAST_MAXCELLS) * 4;
+    h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
     h->octSmem = (size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8);
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
 
