@@ -58,26 +58,63 @@ static __device__ __forceinline__ void resize_coef(int d, double scale, int slen
     w1 = max(-32768, min(32767, w1));
 }
 
+// One workgroup = one 64 x 16 destination tile: the <= 21 x 84 source footprint is staged in LDS with coalesced aligned dword
+// row loads (2 KB), every thread then produces 4 horizontally adjacent pixels (one dword store) from LDS byte reads.
+#define RS_TW 64
+#define RS_TH 16
+#define RS_PITCH 92      // bytes per staged source row (23 dwords, odd): 64*scale + 2 taps + 3 alignment slack for scale <= 1.3
+#define RS_ROWS 24       // staged rows: 16*scale + 2 for scale <= 1.3 (larger scale factors take the direct path)
 static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dy >= P.dh || dx0 >= P.dw) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * RS_TH;
+    const int dx0 = bx0 + tx * 4, dy = by0 + ty;
     const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
+    // source footprint of the tile
+    int sxa, sxb, sya, syb, w0, w1;
+    resize_coef(bx0, P.scale_x, P.sw, true, sxa, w0, w1);
+    resize_coef(min(bx0 + RS_TW - 1, P.dw - 1), P.scale_x, P.sw, true, sxb, w0, w1);
+    resize_coef(by0, P.scale_y, P.sh, false, sya, w0, w1);
+    resize_coef(min(by0 + RS_TH - 1, P.dh - 1), P.scale_y, P.sh, false, syb, w0, w1);
+    const int xal = sxa & ~3;
+    const int xend = min(sxb + 1, P.sw - 1);             // last source column read
+    const int ylo = max(sya, 0), yhi = min(syb + 1, P.sh - 1);
+    const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;
+    const bool staged = ndw * 4 <= RS_PITCH && nrows <= RS_ROWS;   // block-uniform
+    if (staged) {
+        for (int i = threadIdx.x; i < nrows * ndw; i += 256) {
+            const int r = i / ndw, c = i - r * ndw;
+            *(uint32_t*)(orb_smem + r * RS_PITCH + 4 * c) = *(const uint32_t*)(S + (size_t)(ylo + r) * P.sStride + xal + 4 * c);
+        }
+    }
+    __syncthreads();
+    if (dy >= P.dh || dx0 >= P.dw) return;
     int sy0, b0, b1;
     resize_coef(dy, P.scale_y, P.sh, false, sy0, b0, b1);
     int sy1 = sy0 + 1;
     sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
     sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
-    const uint8_t* S0 = S + (size_t)sy0 * P.sStride;
-    const uint8_t* S1 = S + (size_t)sy1 * P.sStride;
     int sx[4], a0[4], a1[4], t0[4], t1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) resize_coef(min(dx0 + k, P.dw - 1), P.scale_x, P.sw, true, sx[k], a0[k], a1[k]);
+    if (staged) {
+        const uint8_t* S0 = orb_smem + (sy0 - ylo) * RS_PITCH - xal;
+        const uint8_t* S1 = orb_smem + (sy1 - ylo) * RS_PITCH - xal;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {   // all 16 loads are independent of each other
-        const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
-        t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
-        t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
+        for (int k = 0; k < 4; k++) {
+            const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
+            t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
+            t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
+        }
+    } else {
+        const uint8_t* S0 = S + (size_t)sy0 * P.sStride;
+        const uint8_t* S1 = S + (size_t)sy1 * P.sStride;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;
+            t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
+            t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
+        }
     }
     uint32_t out = 0;
 #pragma unroll
@@ -801,33 +838,43 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     __syncthreads();
     float angle = 0.f;
     if (valid) {
-        // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15; lane = row v
+        // lane r owns patch row r: 12 aligned dword LDS reads, realigned by the wave-uniform column offset ox, serve both
+        // IC_Angle (rows 6..36) and the Gaussian row pass (all 43 rows) from registers
+        uint32_t px[DP];
         int m10 = 0, m01 = 0;
-        if (lane < 31) {
-            const int v = lane - 15;
-            const int d = c_umax[v < 0 ? -v : v];
-            const uint8_t* row = patch + (21 + v) * DPP + ox + 21;
-            int rs = 0;
+        if (lane < DP) {
+            const uint32_t* rw = (const uint32_t*)(patch + lane * DPP);
+            uint32_t d[12];
 #pragma unroll
-            for (int u = -15; u <= 15; u++) {
-                const int I = (u >= -d && u <= d) ? (int)row[u] : 0;
-                m10 += u * I;
-                rs += I;
+            for (int k = 0; k < 12; k++) d[k] = rw[k];
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const uint32_t e = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ox);   // bytes ox+4k .. ox+4k+3 of the row
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (4 * k + t < DP) px[4 * k + t] = (e >> (8 * t)) & 255u;
             }
-            m01 = v * rs;
+            // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15; row v = lane - 21
+            const int v = lane - 21;
+            if (v >= -15 && v <= 15) {
+                const int dmax = c_umax[v < 0 ? -v : v];
+                int rs = 0;
+#pragma unroll
+                for (int u = -15; u <= 15; u++) {
+                    const int I = (u >= -dmax && u <= dmax) ? (int)px[21 + u] : 0;
+                    m10 += u * I;
+                    rs += I;
+                }
+                m01 = v * rs;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) {
             m10 += __shfl_xor(m10, off);
             m01 += __shfl_xor(m01, off);
         }
         angle = fast_atan2_deg((float)m01, (float)m10);
-        // Gaussian row pass, lane = patch row, sliding window in registers: k = cvRound(256*g) = {18,34,49,55,49,34,18};
-        // sums <= 255*257 fit u16
+        // Gaussian row pass, sliding window in registers: k = cvRound(256*g) = {18,34,49,55,49,34,18}; sums <= 255*257 fit u16
         if (lane < DP) {
-            const uint8_t* p = patch + lane * DPP + ox;
-            uint32_t px[DP];
-#pragma unroll
-            for (int c = 0; c < DP; c++) px[c] = p[c];
             uint32_t* o = (uint32_t*)(rowp + lane * DRP);
 #pragma unroll
             for (int c = 0; c < DB; c += 2) {
@@ -1100,8 +1147,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.dst = h->d_pyr + h->lv[l].planeOff; R.dFrame = h->pyrFrame; R.dStride = h->lv[l].stride;
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
-        dim3 grid((R.dw + 255) / 256, (R.dh + 3) / 4, batch);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, R);
+        dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS, st, R);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     // E2 FAST

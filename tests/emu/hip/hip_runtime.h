@@ -247,6 +247,9 @@ template <class T> inline T __shfl_up(T v, int d, int width = 64) {
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
 }
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
+    return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
+}
 using std::max;
 using std::min;
 
