@@ -66,60 +66,61 @@ static __device__ __forceinline__ void resize_coef(int d, double scale, int slen
 #define RS_ROWS 24       // staged rows: 16*scale + 2 for scale <= 1.3 (larger scale factors take the direct path)
 static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* cxs = (int*)orb_smem;                 // [64] source column of each destination column of the tile
+    int* cxw = cxs + RS_TW;                    // [64] a0 | a1 << 16
+    int* cys = cxw + RS_TW;                    // [16] source row (unclipped)
+    int* cyw = cys + RS_TH;                    // [16] b0 | b1 << 16
+    uint8_t* tile = (uint8_t*)(cyw + RS_TH);   // [RS_ROWS][RS_PITCH]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * RS_TH;
     const int dx0 = bx0 + tx * 4, dy = by0 + ty;
     const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
+    // the tile's 64 + 16 coefficient sets, one per thread (FP64/FP32 setup math is not repeated per pixel)
+    if (threadIdx.x < RS_TW) {
+        int s0, w0, w1;
+        resize_coef(min(bx0 + (int)threadIdx.x, P.dw - 1), P.scale_x, P.sw, true, s0, w0, w1);
+        cxs[threadIdx.x] = s0; cxw[threadIdx.x] = (w0 & 0xFFFF) | (w1 << 16);
+    } else if (threadIdx.x < RS_TW + RS_TH) {
+        const int t = threadIdx.x - RS_TW;
+        int s0, w0, w1;
+        resize_coef(min(by0 + t, P.dh - 1), P.scale_y, P.sh, false, s0, w0, w1);
+        cys[t] = s0; cyw[t] = (w0 & 0xFFFF) | (w1 << 16);
+    }
+    __syncthreads();
     // source footprint of the tile
-    int sxa, sxb, sya, syb, w0, w1;
-    resize_coef(bx0, P.scale_x, P.sw, true, sxa, w0, w1);
-    resize_coef(min(bx0 + RS_TW - 1, P.dw - 1), P.scale_x, P.sw, true, sxb, w0, w1);
-    resize_coef(by0, P.scale_y, P.sh, false, sya, w0, w1);
-    resize_coef(min(by0 + RS_TH - 1, P.dh - 1), P.scale_y, P.sh, false, syb, w0, w1);
-    const int xal = sxa & ~3;
-    const int xend = min(sxb + 1, P.sw - 1);             // last source column read
-    const int ylo = max(sya, 0), yhi = min(syb + 1, P.sh - 1);
+    const int xal = cxs[0] & ~3;
+    const int xend = min(cxs[RS_TW - 1] + 1, P.sw - 1);  // last source column read
+    const int ylo = max(cys[0], 0), yhi = min(cys[RS_TH - 1] + 1, P.sh - 1);
     const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;
     const bool staged = ndw * 4 <= RS_PITCH && nrows <= RS_ROWS;   // block-uniform
     if (staged) {
+        int r = threadIdx.x / ndw, c = threadIdx.x - r * ndw;
+        const int dr = 256 / ndw, dc = 256 - dr * ndw;
         for (int i = threadIdx.x; i < nrows * ndw; i += 256) {
-            const int r = i / ndw, c = i - r * ndw;
-            *(uint32_t*)(orb_smem + r * RS_PITCH + 4 * c) = *(const uint32_t*)(S + (size_t)(ylo + r) * P.sStride + xal + 4 * c);
+            *(uint32_t*)(tile + r * RS_PITCH + 4 * c) = *(const uint32_t*)(S + (size_t)(ylo + r) * P.sStride + xal + 4 * c);
+            r += dr; c += dc;
+            if (c >= ndw) { c -= ndw; r++; }
         }
     }
     __syncthreads();
     if (dy >= P.dh || dx0 >= P.dw) return;
-    int sy0, b0, b1;
-    resize_coef(dy, P.scale_y, P.sh, false, sy0, b0, b1);
+    int sy0 = cys[ty];
+    const int bw = cyw[ty], b0 = (int)(short)(bw & 0xFFFF), b1 = bw >> 16;
     int sy1 = sy0 + 1;
     sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
     sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
-    int sx[4], a0[4], a1[4], t0[4], t1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) resize_coef(min(dx0 + k, P.dw - 1), P.scale_x, P.sw, true, sx[k], a0[k], a1[k]);
-    if (staged) {
-        const uint8_t* S0 = orb_smem + (sy0 - ylo) * RS_PITCH - xal;
-        const uint8_t* S1 = orb_smem + (sy1 - ylo) * RS_PITCH - xal;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
-            t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
-            t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
-        }
-    } else {
-        const uint8_t* S0 = S + (size_t)sy0 * P.sStride;
-        const uint8_t* S1 = S + (size_t)sy1 * P.sStride;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x1 = sx[k] + 1 < P.sw ? sx[k] + 1 : P.sw - 1;
-            t0[k] = S0[sx[k]] * a0[k] + S0[x1] * a1[k];
-            t1[k] = S1[sx[k]] * a0[k] + S1[x1] * a1[k];
-        }
-    }
+    const uint8_t *S0, *S1;
+    if (staged) { S0 = tile + (sy0 - ylo) * RS_PITCH - xal; S1 = tile + (sy1 - ylo) * RS_PITCH - xal; }
+    else { S0 = S + (size_t)sy0 * P.sStride; S1 = S + (size_t)sy1 * P.sStride; }
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int v = (((b0 * (t0[k] >> 4)) >> 16) + ((b1 * (t1[k] >> 4)) >> 16) + 2) >> 2;
+        const int sx = cxs[tx * 4 + k], aw = cxw[tx * 4 + k];
+        const int a0 = (int)(short)(aw & 0xFFFF), a1 = aw >> 16;
+        const int x1 = sx + 1 < P.sw ? sx + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
+        const int t0 = S0[sx] * a0 + S0[x1] * a1;
+        const int t1 = S1[sx] * a0 + S1[x1] * a1;
+        const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)(v & 255) << (8 * k);
     }
     uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)dy * P.dStride + dx0;
@@ -270,18 +271,38 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> q1.
         const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
         const uint8_t* c = img + (dy0 + r0 + rsub) * pitch + dx0 + col;
-        for (int ry = r0 + rsub; ry < rend; ry += 256 / FAST_TW, c += (256 / FAST_TW) * pitch) {
-            bool pass = false;
+        uint32_t mask = 0;   // bit k: row r0 + rsub + k*(256/FAST_TW) of this lane's column passed
+        int kbit = 0;
+        for (int ry = r0 + rsub; ry < rend; ry += 256 / FAST_TW, c += (256 / FAST_TW) * pitch, kbit++) {
             if (colOk) {
                 const int v = c[0];
                 const int lo = v - t0, hi = v + t0;
                 const int a = c[3 * pitch], b = c[3], d = c[-3 * pitch], e = c[-3];
                 const int nd = (a < lo) + (b < lo) + (d < lo) + (e < lo);
                 const int nb = (a > hi) + (b > hi) + (d > hi) + (e > hi);
-                pass = nd >= 2 || nb >= 2;
+                mask |= (uint32_t)(nd >= 2 || nb >= 2) << kbit;
             }
-            const int slot = wave_append(pass, q1cnt, lane);
-            if (pass) q1[slot] = (uint16_t)((ry << 8) | col);
+        }
+        {   // one compaction per chunk: wave-inclusive scan of the per-lane survivor counts, one LDS atomic per wave
+            const int cnt = __popc(mask);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            int base = 0;
+            if (total) {
+                if (lane == 63) base = atomicAdd(q1cnt, total);
+                base = __shfl(base, 63);
+            }
+            int slot = base + incl - cnt;
+            while (mask) {
+                const int k = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                q1[slot++] = (uint16_t)(((r0 + rsub + k * (256 / FAST_TW)) << 8) | col);
+            }
         }
         __syncthreads();
         // ---- stage 2: full ring classification of the survivors (dense lanes) -> q2
@@ -1148,7 +1169,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
         dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS, st, R);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     // E2 FAST
