@@ -109,17 +109,25 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
     int sy1 = sy0 + 1;
     sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
     sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
-    const uint8_t *S0, *S1;
-    if (staged) { S0 = tile + (sy0 - ylo) * RS_PITCH - xal; S1 = tile + (sy1 - ylo) * RS_PITCH - xal; }
-    else { S0 = S + (size_t)sy0 * P.sStride; S1 = S + (size_t)sy1 * P.sStride; }
+    // NB: LDS and global operands are kept in separate code paths and LDS offsets are formed as in-range indices — a mixed
+    // (flat) pointer that is moved below the LDS aperture base faults on gfx950.
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int sx = cxs[tx * 4 + k], aw = cxw[tx * 4 + k];
         const int a0 = (int)(short)(aw & 0xFFFF), a1 = aw >> 16;
         const int x1 = sx + 1 < P.sw ? sx + 1 : P.sw - 1;   // weight is 0 there (fx forced to 0)
-        const int t0 = S0[sx] * a0 + S0[x1] * a1;
-        const int t1 = S1[sx] * a0 + S1[x1] * a1;
+        int p00, p01, p10, p11;
+        if (staged) {
+            const int r0 = (sy0 - ylo) * RS_PITCH, r1 = (sy1 - ylo) * RS_PITCH;
+            p00 = tile[r0 + sx - xal]; p01 = tile[r0 + x1 - xal]; p10 = tile[r1 + sx - xal]; p11 = tile[r1 + x1 - xal];
+        } else {
+            const uint8_t* G0 = S + (size_t)sy0 * P.sStride;
+            const uint8_t* G1 = S + (size_t)sy1 * P.sStride;
+            p00 = G0[sx]; p01 = G0[x1]; p10 = G1[sx]; p11 = G1[x1];
+        }
+        const int t0 = p00 * a0 + p01 * a1;
+        const int t1 = p10 * a0 + p11 * a1;
         const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)(v & 255) << (8 * k);
     }
