@@ -969,6 +969,165 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     }
 }
 
+struct Desc { uint32_t w[8]; };
+static __device__ __forceinline__ Desc load_desc16(const uint8_t* p) {
+    Desc d;
+    const uint4 a = *(const uint4*)p, b = *(const uint4*)(p + 16);
+    d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w; d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+    return d;
+}
+
+// ============================================================================================================
+// M9  Frame::ComputeStereoMatches (Frame.cc:955-1133): rectified stereo association.  Left keypoints are independent:
+//     one wave per left keypoint scans the right keypoints in index order (row band +-2*scale, octave +-1, disparity range),
+//     keeps the first minimum Hamming distance, then refines with the 11x11 L1 patch match over +-5 px on the pyramid
+//     level of the left keypoint (parabola sub-pixel).  A second kernel applies the 1.5*1.4*median SAD cull per frame.
+// ============================================================================================================
+struct StereoParams {
+    DescLevel lvL[ORBX_MAX_LEVELS], lvR[ORBX_MAX_LEVELS];   // pyramid views (base, strides, w, h, scale)
+    float invScale[ORBX_MAX_LEVELS];
+    const orb_keypoint *kpsL, *kpsR; const uint8_t *descL, *descR; const int32_t *cntL, *cntR;
+    int cap; float mb, mbf; float* uRight; float* depth; int32_t* sad; int nRows;
+};
+
+static __device__ __forceinline__ int stereo_pix(const DescLevel& L, int frame, int y, int x) {
+    // mvImagePyramid[level] is the ROI of a BORDER_REFLECT_101 parent: reads a few pixels outside the ROI see the reflection
+    y = reflect101(y, L.h); x = reflect101(x, L.w);
+    return L.base[(size_t)frame * L.frameStride + (size_t)y * L.rowStride + x];
+}
+
+static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frame = blockIdx.y, iL = blockIdx.x * 4 + wave;
+    const int N = min(P.cntL[2 * frame], P.cap), Nr = min(P.cntR[2 * frame], P.cap);
+    if (iL >= P.cap) return;
+    float* uRo = P.uRight + (size_t)frame * P.cap + iL;
+    float* dpo = P.depth + (size_t)frame * P.cap + iL;
+    int32_t* sado = P.sad + (size_t)frame * P.cap + iL;
+    if (iL >= N) { if (lane == 0) { *uRo = -1.0f; *dpo = -1.0f; *sado = -1; } return; }
+    const orb_keypoint kpL = P.kpsL[(size_t)frame * P.cap + iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const float minZ = P.mb, minD = 0.f, maxD = P.mbf / minZ;
+    const float minU = uL - maxD, maxU = uL - minD;
+    float outU = -1.0f, outD = -1.0f; int outS = -1;
+    const int rowL = (int)vL;   // vRowIndices[vL]
+    uint32_t best = 0xFFFFFFFFu;
+    if (!(maxU < 0) && rowL >= 0 && rowL < P.nRows) {
+        const Desc dL = load_desc16(P.descL + ((size_t)frame * P.cap + iL) * 32);
+        for (int base = 0; base < Nr; base += 64) {
+            const int iR = base + lane;
+            if (iR < Nr) {
+                const orb_keypoint kpR = P.kpsR[(size_t)frame * P.cap + iR];
+                const float r = 2.0f * P.lvL[kpR.octave].scale;
+                const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+                if (rowL >= minr && rowL <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) && kpR.x >= minU && kpR.x <= maxU) {
+                    const Desc dR = load_desc16(P.descR + ((size_t)frame * P.cap + iR) * 32);
+                    int dist = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) dist += __popc(dL.w[k] ^ dR.w[k]);
+                    best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);   // first (lowest iR) minimum wins, strict '<'
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+    const int bestDist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);
+    if (bestDist < ORBM_TH_HIGH && bestDist < (ORBM_TH_HIGH + ORBM_TH_LOW) / 2) {
+        const int bestIdxR = (int)(best & 0xFFFF);
+        const float uR0 = P.kpsR[(size_t)frame * P.cap + bestIdxR].x;
+        const float scaleFactor = P.invScale[levelL];
+        const int scaleduL = (int)roundf(kpL.x * scaleFactor), scaledvL = (int)roundf(kpL.y * scaleFactor);
+        const int scaleduR0 = (int)roundf(uR0 * scaleFactor);
+        const DescLevel& PL = P.lvL[levelL];
+        const DescLevel& PR = P.lvR[levelL];
+        const int w = 5, Lw = 5;
+        const float iniu = (float)(scaleduR0 + Lw - w), endu = (float)(scaleduR0 + Lw + w + 1);
+        if (!(iniu < 0 || endu >= (float)PR.w)) {
+            // lanes own patch pixels p = lane and lane + 64 (121 pixels)
+            const int cLv = stereo_pix(PL, frame, scaledvL, scaleduL);
+            int il[2], pa[2], pb[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int p = lane + 64 * t;
+                pa[t] = p / 11; pb[t] = p - pa[t] * 11;
+                il[t] = p < 121 ? stereo_pix(PL, frame, scaledvL - w + pa[t], scaleduL - w + pb[t]) - cLv : 0;
+            }
+            float vDists[11];
+            int bestSad = 2147483647, bestincR = 0;
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++) {
+                const int incR = inc - Lw;
+                const int cRv = stereo_pix(PR, frame, scaledvL, scaleduR0 + incR);
+                int sum = 0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int p = lane + 64 * t;
+                    if (p < 121) {
+                        const int v = stereo_pix(PR, frame, scaledvL - w + pa[t], scaleduR0 + incR - w + pb[t]) - cRv;
+                        const int dd = il[t] - v;
+                        sum += dd < 0 ? -dd : dd;
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                const float dist = (float)sum;
+                if (dist < (float)bestSad) { bestSad = (int)dist; bestincR = incR; }
+                vDists[inc] = dist;
+            }
+            if (!(bestincR == -Lw || bestincR == Lw)) {
+                float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                for (int inc = 1; inc < 10; inc++)
+                    if (inc == Lw + bestincR) { dist1 = vDists[inc - 1]; dist2 = vDists[inc]; dist3 = vDists[inc + 1]; }
+                const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = PL.scale * ((float)scaleduR0 + (float)bestincR + deltaR);
+                    float disparity = uL - bestuR;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }
+                        outD = P.mbf / disparity; outU = bestuR; outS = bestSad;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { *uRo = outU; *dpo = outD; *sado = outS; }
+}
+
+// median SAD cull (Frame.cc:1119-1132): sort (dist, iL); median = element size/2; drop everything with dist >= 1.5*1.4*median
+static __global__ __launch_bounds__(256) void k_stereo_cull(StereoParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* sd = (int*)orb_smem;   // [cap]
+    int* ctl = sd + P.cap;      // [2]
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int N = min(P.cntL[2 * frame], P.cap);
+    const int32_t* sad = P.sad + (size_t)frame * P.cap;
+    if (tid == 0) { ctl[0] = 0; ctl[1] = -1; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < N; i += 256) { const int s = sad[i]; sd[i] = s; mine += s >= 0; }
+    if (mine) atomicAdd(&ctl[0], mine);
+    __syncthreads();
+    const int size = ctl[0];
+    if (size == 0) return;   // (the reference reads vDistIdx[0] unconditionally; nothing to cull here)
+    const int target = size / 2;
+    for (int i = tid; i < N; i += 256) {
+        const int s = sd[i];
+        if (s < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < N; j++) { const int t = sd[j]; rank += (t >= 0) && (t < s || (t == s && j < i)); }
+        if (rank == target) ctl[1] = s;
+    }
+    __syncthreads();
+    const float median = (float)ctl[1];
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = tid; i < N; i += 256) {
+        const int s = sd[i];
+        if (s >= 0 && !((float)s < thDist)) { P.uRight[(size_t)frame * P.cap + i] = -1.0f; P.depth[(size_t)frame * P.cap + i] = -1.0f; }
+    }
+}
+
 // ============================================================================================================
 // Host side
 // ============================================================================================================
@@ -1255,6 +1414,37 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
         HIPCHK(h, hipMemcpyAsync(desc, h->d_desc1, (size_t)counts[0] * 32, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    return ORB_OK;
+}
+
+extern "C" int orbx_stereo_matches(orbx_handle left, orbx_handle right, const orb_keypoint* d_kps_l, const uint8_t* d_desc_l,
+                                   const int32_t* d_counts_l, const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_counts_r,
+                                   int cap_per_frame, int batch, float mb, float mbf, float* d_u_right, float* d_depth, int32_t* d_work,
+                                   void* stream) {
+    if (!left || !right) return ORB_E_INVALID;
+    orbx_extractor* h = left;
+    if (!d_kps_l || !d_desc_l || !d_counts_l || !d_kps_r || !d_desc_r || !d_counts_r || !d_u_right || !d_depth || !d_work || cap_per_frame < 1 ||
+        cap_per_frame > 65535 || batch < 1 || batch > left->lastBatch || batch > right->lastBatch || left->W != right->W || left->H != right->H ||
+        left->cfg.nlevels != right->cfg.nlevels || !left->lastImages || !right->lastImages || !(mb > 0))
+        return orbx_fail(h, ORB_E_INVALID, "bad stereo arguments (both handles must have extracted this batch)");
+    HIPCHK(h, hipSetDevice(h->device));
+    StereoParams S;
+    memset(&S, 0, sizeof(S));
+    for (int l = 0; l < h->cfg.nlevels; l++) {
+        for (int side = 0; side < 2; side++) {
+            orbx_extractor* e = side ? right : left;
+            DescLevel& dl = side ? S.lvR[l] : S.lvL[l];
+            level_view(e, l, dl.base, dl.frameStride, dl.rowStride);
+            dl.w = e->lv[l].w; dl.h = e->lv[l].h; dl.scale = e->scale[l];
+        }
+        S.invScale[l] = h->invScale[l];
+    }
+    S.kpsL = d_kps_l; S.kpsR = d_kps_r; S.descL = d_desc_l; S.descR = d_desc_r; S.cntL = d_counts_l; S.cntR = d_counts_r;
+    S.cap = cap_per_frame; S.mb = mb; S.mbf = mbf; S.uRight = d_u_right; S.depth = d_depth; S.sad = d_work; S.nRows = h->H;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(cap_per_frame + 2) * 4, st, S);
+    HIPCHK(h, hipGetLastError());
     return ORB_OK;
 }
 

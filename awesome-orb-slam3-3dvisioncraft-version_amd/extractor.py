@@ -150,3 +150,36 @@ class ORBextractor:
         out = np.zeros((max(n.value, 1), 3), np.int32)
         self._check(self._L.orbx_debug_selected(self._h, frame, level, ptr(out), n.value, C.byref(n)))
         return out[:n.value]
+
+
+def stereo_matches(left, right, out_left, out_right, mb, mbf, stream=None):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:955-1133) for the batch both extractors just processed.
+    out_left / out_right: the (kps, desc, counts) tuples returned by ORBextractor.extract_batch.  -> (mvuRight, mvDepth) float32 [B, cap]"""
+    import torch
+    kl, dl, cl = out_left
+    kr, dr, cr = out_right
+    B, cap = kl.shape[0], kl.shape[1]
+    ur = torch.empty((B, cap), dtype=torch.float32, device=kl.device)
+    dp = torch.empty((B, cap), dtype=torch.float32, device=kl.device)
+    work = torch.empty((B, cap), dtype=torch.int32, device=kl.device)
+    st = stream if stream is not None else torch.cuda.current_stream(kl.device).cuda_stream
+    rc = left._L.orbx_stereo_matches(left._h, right._h, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(), cr.data_ptr(),
+                                     cap, B, float(mb), float(mbf), ur.data_ptr(), dp.data_ptr(), work.data_ptr(), C.c_void_p(st))
+    left._check(rc)
+    return ur, dp
+
+
+def stereo_matches_host(left, right, kl, dl, kr, dr, mb, mbf):
+    """Single-pair host-array form (numpy in/out); with the emulated test build device memory == host memory."""
+    cap = max(len(kl), len(kr), 1)
+    K = [np.zeros((1, cap, 7), np.float32) for _ in range(2)]
+    D = [np.zeros((1, cap, 32), np.uint8) for _ in range(2)]
+    for i, (k, d) in enumerate(((kl, dl), (kr, dr))):
+        K[i][0, :len(k)] = k.view(np.float32).reshape(-1, 7)
+        D[i][0, :len(k)] = d
+    cnt = [np.array([[len(kl), 0]], np.int32), np.array([[len(kr), 0]], np.int32)]
+    ur = np.zeros((1, cap), np.float32); dp = np.zeros((1, cap), np.float32); work = np.zeros((1, cap), np.int32)
+    rc = left._L.orbx_stereo_matches(left._h, right._h, ptr(K[0]), ptr(D[0]), ptr(cnt[0]), ptr(K[1]), ptr(D[1]), ptr(cnt[1]), cap, 1,
+                                     float(mb), float(mbf), ptr(ur), ptr(dp), ptr(work), None)
+    left._check(rc)
+    return ur[0, :len(kl)], dp[0, :len(kl)]

@@ -82,6 +82,15 @@ int orbx_pyramid_level(orbx_handle h, int frame, int level, const uint8_t** d_pt
 /* Copies level to host; border = 0 (plane) or 19 (reference layout incl. reflected frame), out is tightly packed. */
 int orbx_copy_level(orbx_handle h, int frame, int level, int border, uint8_t* out);
 
+/* Frame::ComputeStereoMatches (Frame.cc:955-1133) for `batch` rectified stereo pairs whose left / right images were just
+ * extracted by `left` / `right` (the 11x11 SAD refinement reads their pyramids — mvImagePyramid of both extractors).
+ * kps / desc / counts are the orbx_extract_batch_dev outputs of the two handles (counts = [batch][2]).
+ * Outputs per left keypoint: u_right (mvuRight, -1 = no match) and depth (mvDepth, -1); d_work: cap_per_frame int32 per frame. */
+int orbx_stereo_matches(orbx_handle left, orbx_handle right, const orb_keypoint* d_kps_l, const uint8_t* d_desc_l,
+                        const int32_t* d_counts_l, const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_counts_r,
+                        int cap_per_frame, int batch, float mb, float mbf, float* d_u_right, float* d_depth, int32_t* d_work,
+                        void* stream);
+
 /* Stage-level taps for parity tests (valid after an extract call; host outputs):
  * FAST candidates of (frame, level) = vToDistributeKeys (ORBextractor.cc:776,845-850) as (x,y,score) int triples
  * in arbitrary order (the set is what the octree consumes); returns count via n_out. */

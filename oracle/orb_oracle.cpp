@@ -824,4 +824,112 @@ double oro_bench_extract_mt(const uint8_t* frames, int B, int W, int H, int nfea
     return s;
 }
 
+// ---- Frame::ComputeStereoMatches (reference src/Frame.cc:955-1133) over two extractor states (left/right pyramids of the
+// last oro_extract calls).  Follows the reference line by line; ORBmatcher::DescriptorDistance is restated inline.
+static int descDist(const uint8_t* a, const uint8_t* b) {
+    int d = 0;
+    for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+void oro_stereo_matches(void* hL, void* hR, const void* kpsL_, const uint8_t* descL, int N, const void* kpsR_, const uint8_t* descR,
+                        int Nr, float mb, float mbf, float* mvuRight, float* mvDepth) {
+    OrbOracle* L = (OrbOracle*)hL;
+    OrbOracle* R = (OrbOracle*)hR;
+    const KeyPoint* mvKeys = (const KeyPoint*)kpsL_;
+    const KeyPoint* mvKeysRight = (const KeyPoint*)kpsR_;
+    const std::vector<float>& mvScaleFactors = L->mvScaleFactor;
+    const std::vector<float>& mvInvScaleFactors = L->mvInvScaleFactor;
+    for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+    const int thOrbDist = (100 + 50) / 2;
+    const int nRows = L->L[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const KeyPoint& kp = mvKeysRight[iR];
+        const float& kpY = kp.y;
+        const float r = 2.0f * mvScaleFactors[mvKeysRight[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // (the reference indexes unchecked; keypoints keep a 19-px margin)
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const KeyPoint& kpL = mvKeys[iL];
+        const int& levelL = kpL.octave;
+        const float& vL = kpL.y;
+        const float& uL = kpL.x;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KeyPoint& kpR = mvKeysRight[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float& uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = descDist(dL, descR + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = mvKeysRight[bestIdxR].x;
+            const float scaleFactor = mvInvScaleFactors[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5;
+            const OrbOracle::Level& PL = L->L[kpL.octave];
+            const OrbOracle::Level& PR = R->L[kpL.octave];
+            auto pix = [](const OrbOracle::Level& P, int y, int x) -> int { return P.img[(size_t)reflect101(y, P.h) * P.w + reflect101(x, P.w)]; };
+            short IL[11][11];
+            const int cL = pix(PL, (int)scaledvL, (int)scaleduL);
+            for (int a = 0; a < 11; a++)
+                for (int b = 0; b < 11; b++) IL[a][b] = (short)(pix(PL, (int)scaledvL - w + a, (int)scaleduL - w + b) - cL);
+            int bestDist2 = 2147483647, bestincR = 0;
+            const int Lw = 5;
+            std::vector<float> vDists(2 * Lw + 1);
+            const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+            if (iniu < 0 || endu >= PR.w) continue;
+            for (int incR = -Lw; incR <= +Lw; incR++) {
+                const int cR = pix(PR, (int)scaledvL, (int)scaleduR0 + incR);
+                double sum = 0;
+                for (int a = 0; a < 11; a++)
+                    for (int b = 0; b < 11; b++) {
+                        const short v = (short)(pix(PR, (int)scaledvL - w + a, (int)scaleduR0 + incR - w + b) - cR);
+                        sum += std::abs((int)IL[a][b] - (int)v);
+                    }
+                float dist = (float)sum;
+                if (dist < bestDist2) { bestDist2 = (int)dist; bestincR = incR; }
+                vDists[Lw + incR] = dist;
+            }
+            if (bestincR == -Lw || bestincR == Lw) continue;
+            const float dist1 = vDists[Lw + bestincR - 1], dist2 = vDists[Lw + bestincR], dist3 = vDists[Lw + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDist2, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return;   // (the reference reads vDistIdx[0] unconditionally)
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1;
+        mvDepth[vDistIdx[i].second] = -1;
+    }
+}
+
 }  // extern "C"

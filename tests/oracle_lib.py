@@ -258,3 +258,14 @@ def quat_from_matrix(R):
     q = np.zeros(4)
     L.olb_quat_from_matrix(_p(np.ascontiguousarray(R, np.float64)), _p(q))
     return q
+
+
+def stereo_matches(oL, oR, kl, dl, kr, dr, mb, mbf):
+    """Frame::ComputeStereoMatches restated (oracle/orb_oracle.cpp); oL / oR: OrbOracle objects that just extracted the pair."""
+    L = lib()
+    L.oro_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                     C.c_void_p, C.c_void_p]
+    kl = np.ascontiguousarray(kl); kr = np.ascontiguousarray(kr); dl = np.ascontiguousarray(dl); dr = np.ascontiguousarray(dr)
+    ur = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
+    L.oro_stereo_matches(oL.h, oR.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), mb, mbf, _p(ur), _p(dp))
+    return ur[:len(kl)], dp[:len(kl)]
