@@ -36,8 +36,9 @@ def _check(lib, backend, seed):
         ur, dp = stereo_matches_host(eL, eR, kl, dl, kr, dr, mb, BF)
     else:
         import torch
-        outL = eL.extract_batch(torch.from_numpy(left[None]).cuda(), (0, 0))
-        outR = eR.extract_batch(torch.from_numpy(right[None]).cuda(), (0, 0))
+        dLimg, dRimg = torch.from_numpy(left[None]).cuda(), torch.from_numpy(right[None]).cuda()   # level 0 of each pyramid aliases
+        outL = eL.extract_batch(dLimg, (0, 0))                                                        # the caller's image batch:
+        outR = eR.extract_batch(dRimg, (0, 0))                                                        # keep it alive
         u, d = stereo_matches(eL, eR, outL, outR, mb, BF)
         ur, dp = u.cpu().numpy()[0, :len(kl)], d.cpu().numpy()[0, :len(kl)]
     assert np.array_equal(ur.view(np.uint32), our.view(np.uint32)), "mvuRight (bitwise)"
