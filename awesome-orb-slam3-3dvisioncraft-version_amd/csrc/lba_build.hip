@@ -133,6 +133,12 @@ static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const S
         }
     } else {
         L.D = 2;
+        if (WITH_JAC) {
+#pragma unroll
+            for (int i = 6; i < 9; i++) L.A[i] = 0.0;
+#pragma unroll
+            for (int i = 12; i < 18; i++) L.B[i] = 0.0;
+        }
         double proj[2], xl[3], xp[3], Rm[9];
         se3_map(T, X, xl);
         Quat ql = {cam.trl_q[0], cam.trl_q[1], cam.trl_q[2], cam.trl_q[3]};
@@ -191,7 +197,8 @@ static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const S
     }
     const double s = (double)E.inv_sigma2;
     double chi2 = 0;
-    for (int i = 0; i < L.D; i++) chi2 += L.e[i] * s * L.e[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) chi2 += L.e[i] * s * L.e[i];   // e[2] == 0 for 2-D edges
     L.chi2 = chi2;
     const double delta = E.kind == LBA_EDGE_STEREO ? huberStereo : huberMono;
     L.rho0 = chi2; L.rho1 = 1.;
@@ -237,16 +244,16 @@ static __global__ __launch_bounds__(128) void k_lba_landmarks(LbaArgs A) {
         // constructQuadraticForm, robust branch (base_binary_edge.hpp:91-113): omega_r = -Omega e rho1; wOmega = rho1 Omega
         const double s = (double)E.inv_sigma2, w = L.rho1 * s;
         double om[3];
-        for (int i = 0; i < 3; i++) om[i] = i < L.D ? -s * L.e[i] * L.rho1 : 0.0;
+        for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             double acc = 0;
-            for (int r = 0; r < L.D; r++) acc += L.A[r * 3 + c] * om[r];
+            for (int r = 0; r < 3; r++) acc += L.A[r * 3 + c] * om[r];
             bl[c] += acc;
 #pragma unroll
             for (int c2 = 0; c2 < 3; c2++) {
                 double h = 0;
-                for (int r = 0; r < L.D; r++) h += L.A[r * 3 + c] * w * L.A[r * 3 + c2];
+                for (int r = 0; r < 3; r++) h += L.A[r * 3 + c] * w * L.A[r * 3 + c2];
                 H[c2 * 3 + c] += h;
             }
         }
@@ -259,7 +266,7 @@ static __global__ __launch_bounds__(128) void k_lba_landmarks(LbaArgs A) {
                 for (int c = 0; c < 6; c++) {
                     double h = 0;
                     if (freePose)
-                        for (int r = 0; r < L.D; r++) h += L.B[r * 6 + c] * w * L.A[r * 3 + c2];
+                        for (int r = 0; r < 3; r++) h += L.B[r * 6 + c] * w * L.A[r * 3 + c2];
                     hp[c2 * 6 + c] = h;   // logical 6x3 block (pose, landmark), column-major (_hessianTransposed)
                 }
         }
@@ -292,20 +299,20 @@ static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
         edge_linearize<true>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
         const double s = (double)E.inv_sigma2, w = L.rho1 * s;
         double om[3];
-        for (int i = 0; i < 3; i++) om[i] = i < L.D ? -s * L.e[i] * L.rho1 : 0.0;
+        for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
         int t = 0;
 #pragma unroll
         for (int c2 = 0; c2 < 6; c2++)
 #pragma unroll
             for (int c = 0; c <= c2; c++) {
                 double hh = 0;
-                for (int r = 0; r < L.D; r++) hh += L.B[r * 6 + c] * w * L.B[r * 6 + c2];
+                for (int r = 0; r < 3; r++) hh += L.B[r * 6 + c] * w * L.B[r * 6 + c2];
                 acc[t++] += hh;
             }
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             double a = 0;
-            for (int r = 0; r < L.D; r++) a += L.B[r * 6 + c] * om[r];
+            for (int r = 0; r < 3; r++) a += L.B[r * 6 + c] * om[r];
             acc[21 + c] += a;
         }
     }
