@@ -161,7 +161,11 @@ typedef struct orbm_search_params {
     orbm_grid_params grid;
 } orbm_search_params;
 #define ORBM_MODE_LOCAL_MAP 0  /* SearchByProjection(Frame&, vector<MapPoint*>&, th, ...)  ORBmatcher.cc:59-255 (left camera) */
-#define ORBM_MODE_BEST_ONLY 1  /* SearchByProjection(Frame&, const Frame&, th, bMono)      ORBmatcher.cc:2244-2509; and :2520-2652 */
+#define ORBM_MODE_BEST_ONLY 1  /* SearchByProjection(Frame&, const Frame&, th, bMono)      ORBmatcher.cc:2244-2509;
+                                * SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) :2520-2652 with th_dist = ORBdist,
+                                *   occupied0 = (mvpMapPoints[i] != NULL), every query ORBM_Q_HAS_OBS;
+                                * SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) :593-824 with
+                                *   check_orientation = 0, th_dist = floor(TH_LOW*ratioHamming), levels [L-1, L] */
 
 /* Windowed projection search, results identical to the reference's serial loop (queries are resolved in index
  * order; a keypoint claimed by an earlier query with ORBM_Q_HAS_OBS is skipped by later ones).
