@@ -205,7 +205,7 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
 #define FAST_Q2CAP 2048   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
 #endif
 #define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
-#define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)
+#define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)   // 16 rows: each of the 4 waves owns 8 rows x 64 columns = FAST_QCAP/4 pixels
 
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
@@ -269,14 +269,18 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __syncthreads();
 
     const int t0 = min(P.iniTh, P.minTh);
+    // Stages 1-3 are wave-private: wave w owns columns (w&1)*64.. of the rows with parity (w>>1), compacts its own survivors
+    // and corners into its own slices of q1 / q2 and scores them itself -> no workgroup barrier and no LDS atomic until NMS.
+    const int wave = tid >> 6;
     const int col = tid & (FAST_TW - 1), rsub = tid / FAST_TW;
     const bool colOk = col < detW;
-    int chunk = 0;
-    for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK, chunk ^= 1) {
-        int* q1cnt = chunk ? &sh[5] : &sh[0];
-        if (tid == 0) sh[chunk ? 0 : 5] = 0;   // the other chunk parity's counter: next used two barriers from now
+    uint16_t* q1w = q1 + wave * (FAST_QCAP / 4);        // 512 entries: 8 rows x 64 columns per chunk, exact bound
+    uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);
+    int n2w = 0;                                        // corners of this wave (wave-uniform)
+    bool ovf = false;
+    for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK) {
         // ---- stage 1: 4-point pre-test.  Any 9-arc of the 16-ring contains >= 2 of the compass points 0,4,8,12, so a
-        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> q1.
+        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> this wave's q1 slice.
         const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
         const uint8_t* c = img + (dy0 + r0 + rsub) * pitch + dx0 + col;
         uint32_t mask = 0;   // bit k: row r0 + rsub + k*(256/FAST_TW) of this lane's column passed
@@ -291,36 +295,32 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 mask |= (uint32_t)(nd >= 2 || nb >= 2) << kbit;
             }
         }
-        {   // one compaction per chunk: wave-inclusive scan of the per-lane survivor counts, one LDS atomic per wave
-            const int cnt = __popc(mask);
-            int incl = cnt;
+        const int cnt = __popc(mask);
+        int incl = cnt;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            const int total = __shfl(incl, 63);
-            int base = 0;
-            if (total) {
-                if (lane == 63) base = atomicAdd(q1cnt, total);
-                base = __shfl(base, 63);
-            }
-            int slot = base + incl - cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int n1 = __shfl(incl, 63);
+        {
+            int slot = incl - cnt;
             while (mask) {
                 const int k = __ffs((int)mask) - 1;
                 mask &= mask - 1;
-                q1[slot++] = (uint16_t)(((r0 + rsub + k * (256 / FAST_TW)) << 8) | col);
+                q1w[slot++] = (uint16_t)(((r0 + rsub + k * (256 / FAST_TW)) << 8) | col);
             }
         }
-        __syncthreads();
-        // ---- stage 2: full ring classification of the survivors (dense lanes) -> q2
-        const int n1 = *q1cnt;
-        for (int i0 = 0; i0 < n1; i0 += 256) {
-            const int i = i0 + tid;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- stage 2: full ring classification of the survivors (dense lanes) -> this wave's q2 slice
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
             bool corner = false;
             int ent = 0;
             if (i < n1) {
-                ent = q1[i];
+                ent = q1w[i];
                 const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
                 const int v = cc[0];
                 const int lo = v - t0, hi = v + t0;
@@ -330,26 +330,32 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 #undef CL
                 corner = ring_has9(md) || ring_has9(mb);
             }
-            const int slot = wave_append(corner, &sh[3], lane);
-            if (corner) { if (slot < FAST_Q2CAP) q2[slot] = (uint16_t)ent; else sh[4] = 1; }
+            const unsigned long long m = __ballot(corner);
+            const int slot = n2w + __popcll(m & ((1ull << lane) - 1ull));
+            if (corner) { if (slot < FAST_Q2CAP / 4) q2w[slot] = (uint16_t)ent; else ovf = true; }
+            n2w += __popcll(m);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // q1w is rewritten by the next chunk
     }
+    if (ovf) sh[4] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    n2w = min(n2w, FAST_Q2CAP / 4);
+    // ---- stage 3: exact score of this wave's corners (dense)
+    for (int i = lane; i < n2w; i += 64) {
+        const int ent = q2w[i];
+        const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
+        smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
+    }
+    __syncthreads();
     const bool overflow = sh[4] != 0;
-    const int n2 = min(sh[3], FAST_Q2CAP);
     int* cellCnt = sh + 8;
     if (!overflow) {
-        // ---- stage 3: exact score of every corner (dense)
-        for (int i = tid; i < n2; i += 256) {
-            const int ent = q2[i];
-            const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-            smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
-        }
-        __syncthreads();
-        // ---- NMS over the corner list: strict maximum over the 8 neighbours inside the same cell's detection region.
+        // ---- NMS over the corner lists: strict maximum over the 8 neighbours inside the same cell's detection region.
         //      survive(T) = s >= T && localmax (threshold-independent localmax, DESIGN.md "FAST as set algebra").
-        for (int i = tid; i < n2; i += 256) {
-            const int ent = q2[i];
+        for (int i = lane; i < n2w; i += 64) {
+            const int ent = q2w[i];
             const int rx = ent & 255;
             const uint8_t* m = smap + (dy0 + (ent >> 8)) * pitch + dx0 + rx;
             const int s = m[0], ct = colTab[rx];
@@ -357,13 +363,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
             if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
             if (ok) {
-                q2[i] = (uint16_t)(ent | 0x8000);
+                q2w[i] = (uint16_t)(ent | 0x8000);
                 if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
             }
         }
         __syncthreads();
-        for (int i = tid; i < n2; i += 256) {
-            const int ent = q2[i];
+        for (int i = lane; i < n2w; i += 64) {
+            const int ent = q2w[i];
             if (!(ent & 0x8000)) continue;
             const int rx = ent & 255, ry = (ent >> 8) & 127;
             const int s = smap[(dy0 + ry) * pitch + dx0 + rx];

@@ -185,6 +185,7 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
 // ---- device intrinsics -----------------------------------------------------------------------------------
 inline void __syncthreads() { emu::yield(emu::WAIT_BLOCK); }
 inline void __builtin_amdgcn_wave_barrier() { emu::yield(emu::WAIT_WAVE); }  // lanes are not lock-step here
+inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
