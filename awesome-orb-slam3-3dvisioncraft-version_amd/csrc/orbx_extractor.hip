@@ -315,38 +315,25 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- stage 2: full ring classification of the survivors (dense lanes) -> this wave's q2 slice
-        //      Wavefront voting: one v_cmp per ring pixel and polarity gives a 64-lane ballot in SGPRs; "9 contiguous of 16"
-        //      is then evaluated for all 64 lanes at once with 64-bit scalar AND/OR (doubling: runs of 2, 4, 8, then 9), so the
-        //      vector ALU only does the loads and the 32 compares.
         for (int i0 = 0; i0 < n1; i0 += 64) {
             const int i = i0 + lane;
-            const bool act = i < n1;
-            const int ent = act ? (int)q1w[i] : 0;
-            const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-            const int v = cc[0];
-            const int lo = v - t0, hi = v + t0;
-            int x[16];
-#define LD(k_, dx, dy) x[k_] = cc[(dy) * pitch + (dx)];
-            RING16(LD)
-#undef LD
-            unsigned long long cm = 0;
-#pragma unroll
-            for (int pol = 0; pol < 2; pol++) {
-                unsigned long long D[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) D[k] = __ballot(act && (pol ? x[k] > hi : x[k] < lo));
-                unsigned long long P2[16], P4[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) P2[k] = D[k] & D[(k + 1) & 15];
-#pragma unroll
-                for (int k = 0; k < 16; k++) P4[k] = P2[k] & P2[(k + 2) & 15];
-#pragma unroll
-                for (int k = 0; k < 16; k++) cm |= P4[k] & P4[(k + 4) & 15] & D[(k + 8) & 15];
+            bool corner = false;
+            int ent = 0;
+            if (i < n1) {
+                ent = q1w[i];
+                const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
+                const int v = cc[0];
+                const int lo = v - t0, hi = v + t0;
+                uint32_t md = 0, mb = 0;
+#define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; md = __builtin_amdgcn_alignbit(md, (uint32_t)(x - lo), 31); mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(hi - x), 31); }
+                RING16(CL)
+#undef CL
+                corner = ring_has9(md) || ring_has9(mb);
             }
-            const bool corner = (cm >> lane) & 1ull;
-            const int slot = n2w + __popcll(cm & ((1ull << lane) - 1ull));
+            const unsigned long long m = __ballot(corner);
+            const int slot = n2w + __popcll(m & ((1ull << lane) - 1ull));
             if (corner) { if (slot < FAST_Q2CAP / 4) q2w[slot] = (uint16_t)ent; else ovf = true; }
-            n2w += __popcll(cm);
+            n2w += __popcll(m);
         }
         __builtin_amdgcn_wave_barrier();   // q1w is rewritten by the next chunk
     }
