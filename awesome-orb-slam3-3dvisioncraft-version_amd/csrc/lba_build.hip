@@ -15,6 +15,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 #include "../../include/orbhip.h"
 
@@ -391,4 +393,543 @@ extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_
     if (out->robust_chi2_sum && hipMemsetAsync(out->robust_chi2_sum, 0, (size_t)batch * 8, st) != hipSuccess) return ORB_E_HIP;
     hipLaunchKernelGGL(k_lba_errors, dim3((prob->cap_e + 255) / 256, batch), dim3(256), 256 * 8, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+// ============================================================================================================
+// Levenberg-Marquardt on the GPU (one SparseOptimizer::optimize(iterations) call per window, batched).
+// The LM control state lives in device memory per window; the host only launches the fixed kernel sequence of a trial and
+// polls one "any window needs another trial" word, exactly where g2o polls terminate().
+//   k_lm_maxdiag     computeLambdaInit                       optimization_algorithm_levenberg.cpp:171-186
+//   k_lm_begin       per-iteration bookkeeping               :85-105
+//   k_lm_dinv        (Hll + lambda I)^-1, Dinv*b_l           block_solver.hpp:381-397 (+ setLambda :564-589)
+//   k_lm_bd          B_i * Dinv per edge                     :404
+//   k_lm_schur_row   one workgroup per free pose = one 6 x 6n block row of Hschur and of the coefficient vector; thread = column
+//                    block, fixed edge order -> deterministic, no f64 atomics          :398-432
+//   k_lm_chol        dense in-place Cholesky + two triangular solves, one workgroup per window   (linear_solver_eigen.h:94-123)
+//   k_lm_backsub     x_l = Dinv (b_l - Hpl^T x_p), X += x_l, scale partials            block_solver.hpp:461-481, levenberg.cpp:188-195
+//   k_lm_update_pose T <- exp(x_p) * T                       types_six_dof_expmap.h:73-76, se3quat.h:223-256
+//   k_lm_decide      rho test, lambda update, push/pop       optimization_algorithm_levenberg.cpp:126-149
+//   k_lm_restore     pop (restore the backup state of rejected windows)
+//   k_lm_end         "Raul" stop rule                        :151-165
+// ============================================================================================================
+struct LmState {
+    double lambda, ni, currentChi, iniChi, tempChi, rho, scale, maxDiag;
+    int32_t qmax, nBad, iter, active, needTrial, ok, trials, accepted;
+};
+struct LmArgs {
+    lba_problem P; lba_system S;
+    double* poses; double* points;          // == P.poses / P.points (mutable)
+    double* posesBak; double* pointsBak;
+    double* Dinv; double* db; double* BD;   // [cap_l][9], [cap_l][3], [cap_e][18]
+    double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
+    double* part;                           // [batch][nPart] partial sums (chi2 / scale)
+    LmState* st; int* flag; int nPart, np6;
+};
+
+static __global__ void k_lm_init(LmArgs A, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    LmState s;
+    s.lambda = -1; s.ni = 2; s.currentChi = 0; s.iniChi = 0; s.tempChi = 0; s.rho = 0; s.scale = 0; s.maxDiag = 0;
+    s.qmax = 0; s.nBad = 0; s.iter = 0; s.active = 1; s.needTrial = 0; s.ok = 1; s.trials = 0; s.accepted = 0;
+    A.st[b] = s;
+}
+
+// deterministic second stage of the chi2 / scale reductions: one thread per window sums the block partials in order
+static __global__ void k_lm_sum_partials(LmArgs A, int batch, int n, int what, int extra) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double s = 0;
+    for (int i = 0; i < n; i++) s += A.part[(size_t)b * A.nPart + i];
+    if (extra >= 0) s += A.part[(size_t)b * A.nPart + extra];
+    if (what == 0) A.st[b].tempChi = s; else A.st[b].scale = s;
+}
+
+// computeActiveErrors + per-block partial sums of rho[0] (blocks of 256 edges)
+static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double* red = (double*)orb_smem;
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, ei = blockIdx.x * 256 + threadIdx.x;
+    const int ne = min(P.n_edges[b], P.cap_e);
+    double r0 = 0;
+    if (ei < ne && A.st[b].active) {
+        const lba_edge E = P.edges[(size_t)b * P.cap_e + ei];
+        const SE3 T = load_pose(A.poses + ((size_t)b * P.cap_p + E.pose) * 7);
+        const double* Xp = A.points + ((size_t)b * P.cap_l + E.point) * 3;
+        const double X[3] = {Xp[0], Xp[1], Xp[2]};
+        Lin L;
+        edge_linearize<false>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+        r0 = L.rho0;
+    }
+    red[threadIdx.x] = r0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.part[(size_t)b * A.nPart + blockIdx.x] = red[0];
+}
+
+static __global__ __launch_bounds__(256) void k_lm_maxdiag(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double* red = (double*)orb_smem;
+    const lba_problem& P = A.P;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int np = min(P.n_poses[b], P.cap_p), nl = min(P.n_points[b], P.cap_l);
+    double m = 0;
+    for (int i = tid; i < np * 6; i += 256) m = fmax(m, fabs(A.S.Hpp[((size_t)b * P.cap_p + i / 6) * 36 + (i % 6) * 7]));   // fixed blocks are zero
+    for (int i = tid; i < nl * 3; i += 256) m = fmax(m, fabs(A.S.Hll[((size_t)b * P.cap_l + i / 3) * 9 + (i % 3) * 4]));
+    red[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) A.st[b].maxDiag = red[0];
+}
+
+static __global__ void k_lm_begin(LmArgs A, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    LmState& s = A.st[b];
+    if (!s.active) { s.needTrial = 0; return; }
+    s.currentChi = s.tempChi;      // activeRobustChi2 of the state the system was built at
+    s.iniChi = s.currentChi;
+    if (s.iter == 0) { s.lambda = 1e-50 * s.maxDiag; s.ni = 2; s.nBad = 0; }
+    s.rho = 0; s.qmax = 0; s.needTrial = 1;
+}
+
+static __device__ __forceinline__ bool inv3_sym(const double* D, double* o) {   // column-major 3x3, cofactor inverse
+    const double a = D[0], b = D[3], c = D[6], d = D[1], e = D[4], f = D[7], g = D[2], h = D[5], i = D[8];
+    const double Ac = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+    const double det = a * Ac + b * Bc + c * Cc;
+    const double id = 1.0 / det;
+    o[0] = Ac * id; o[3] = -(b * i - c * h) * id; o[6] = (b * f - c * e) * id;
+    o[1] = Bc * id; o[4] = (a * i - c * g) * id; o[7] = -(a * f - c * d) * id;
+    o[2] = Cc * id; o[5] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+    return det != 0.0 && det == det && fabs(det) < 1.7e308;
+}
+
+static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    if (!A.st[b].needTrial) return;
+    const int nl = min(P.n_points[b], P.cap_l);
+    if (l >= nl) return;
+    const double lam = A.st[b].lambda;
+    const double* H = A.S.Hll + ((size_t)b * P.cap_l + l) * 9;
+    double D[9], o[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) D[k] = H[k] + ((k % 4 == 0) ? lam : 0.0);
+    if (!inv3_sym(D, o)) A.st[b].ok = 0;
+    double* out = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[k] = o[k];
+    const double* bl = A.S.bl + ((size_t)b * P.cap_l + l) * 3;
+    double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
+#pragma unroll
+    for (int r = 0; r < 3; r++) db[r] = o[r] * bl[0] + o[3 + r] * bl[1] + o[6 + r] * bl[2];
+}
+
+static __global__ __launch_bounds__(256) void k_lm_bd(LmArgs A) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (!A.st[b].needTrial) return;
+    const int ne = min(P.n_edges[b], P.cap_e);
+    if (e >= ne) return;
+    const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
+    const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e) * 18;
+    const double* Di = A.Dinv + ((size_t)b * P.cap_l + E.point) * 9;
+    double* o = A.BD + ((size_t)b * P.cap_e + e) * 18;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 6; r++) o[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
+}
+
+// One workgroup per pose i1.  Thread t < n_poses owns the 6x6 block Hschur(h1, hidx[t]); it walks pose i1's edges in order,
+// looks for an edge of pose t on the same landmark (<= ~8 candidates, broadcast reads) and accumulates in registers.
+static __global__ __launch_bounds__(128) void k_lm_schur_row(LmArgs A) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, i1 = blockIdx.x, t = threadIdx.x;
+    if (!A.st[b].needTrial) return;
+    const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
+    if (i1 >= np) return;
+    const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
+    const int h1 = hidx[i1];
+    if (h1 < 0) return;
+    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
+    const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
+    const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+    const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
+    const double lam = A.st[b].lambda;
+    const int np6 = A.np6;
+    double* Hs = A.Hs + (size_t)b * np6 * np6;
+    for (int i2 = t; i2 < np; i2 += 128) {
+        const int h2 = hidx[i2];
+        if (h2 < 0) continue;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[k] = 0;
+        if (i2 == i1) {   // _Hpp->add(_Hschur) + setLambda
+            const double* H = A.S.Hpp + ((size_t)b * P.cap_p + h1) * 36;
+#pragma unroll
+            for (int k = 0; k < 36; k++) acc[k] = H[k] + ((k % 7 == 0) ? lam : 0.0);
+        }
+        for (int k = s0; k < s1; k++) {
+            const int e1 = pe[k];
+            const int l = edges[e1].point;
+            const int m0 = lms[l], m1 = min(lms[l + 1], ne);
+            for (int m = m0; m < m1; m++) {   // every edge of pose i2 on this landmark contributes (mono + body twins)
+                if (edges[m].pose != i2) continue;
+                const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
+                const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + m) * 18;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = acc[c * 6 + r];
+    }
+    if (t < 6) {   // _bschur row: b_p - sum_e B_i * (Dinv b_l), fixed edge order
+        double c = 0;
+        for (int k = s0; k < s1; k++) {
+            const int e1 = pe[k];
+            const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
+            const double* db = A.db + ((size_t)b * P.cap_l + edges[e1].point) * 3;
+            c += Bi[t] * db[0] + Bi[6 + t] * db[1] + Bi[12 + t] * db[2];
+        }
+        A.xp[(size_t)b * np6 + h1 * 6 + t] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + t] - c;
+    }
+}
+
+// dense Cholesky (lower, column-major, in place) + forward / backward substitution; one workgroup per window.
+// Right-looking: wave w takes trailing columns k+1+w, k+5+w, ...; its lanes run down the rows of the column (coalesced).
+static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t* nfreeArr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!A.st[b].needTrial) return;
+    const int n = nfreeArr[b] * 6, ld = A.np6;
+    double* col = (double*)orb_smem;                                   // [max(ld,256)] current column / reduction scratch
+    int* bad = (int*)(col + (ld > 256 ? ld : 256));
+    double* S = A.Hs + (size_t)b * ld * ld;
+    double* x = A.xp + (size_t)b * ld;
+    if (tid == 0) *bad = 0;
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        const double dkk = S[(size_t)k * ld + k];
+        if (!(dkk > 0) || !(dkk < 1.7e308)) { if (tid == 0) *bad = 1; break; }   // uniform: every thread reads the same dkk
+        const double sq = sqrt(dkk);
+        __syncthreads();   // every thread has read the pivot before thread 0 overwrites it with its square root
+        for (int i = k + tid; i < n; i += 256) { const double v = (i == k) ? sq : S[(size_t)k * ld + i] / sq; col[i] = v; S[(size_t)k * ld + i] = v; }
+        __syncthreads();
+        for (int j = k + 1 + wave; j < n; j += 4) {
+            const double ljk = col[j];
+            double* Sj = S + (size_t)j * ld;
+            for (int i = j + lane; i < n; i += 64) Sj[i] -= col[i] * ljk;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    __syncthreads();
+    if (*bad) { if (tid == 0) A.st[b].ok = 0; return; }
+    // L y = b (forward, column-oriented), then L^T x = y (backward, row-oriented dot products)
+    for (int k = 0; k < n; k++) {
+        if (tid == 0) x[k] = x[k] / S[(size_t)k * ld + k];
+        __threadfence_block();
+        __syncthreads();
+        const double xk = x[k];
+        for (int i = k + 1 + tid; i < n; i += 256) x[i] -= S[(size_t)k * ld + i] * xk;
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double sum = 0;
+        for (int i = k + 1 + tid; i < n; i += 256) sum += S[(size_t)k * ld + i] * x[i];
+        col[tid] = sum;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) { if (tid < off) col[tid] += col[tid + off]; __syncthreads(); }
+        if (tid == 0) x[k] = (x[k] - col[0]) / S[(size_t)k * ld + k];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nPose) { if (A.st[i / capP7].needTrial) A.posesBak[i] = A.poses[i]; }
+    else if (i < nPose + nPoint) { const size_t j = i - nPose; if (A.st[j / capL3].needTrial) A.pointsBak[j] = A.points[j]; }
+}
+
+static __global__ __launch_bounds__(256) void k_lm_backsub(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double* red = (double*)orb_smem;
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    const LmState st = A.st[b];
+    double sc = 0;
+    if (st.needTrial && st.ok) {
+        const int nl = min(P.n_points[b], P.cap_l), ne = min(P.n_edges[b], P.cap_e);
+        if (l < nl) {
+            const double* bl = A.S.bl + ((size_t)b * P.cap_l + l) * 3;
+            double cl[3] = {bl[0], bl[1], bl[2]};
+            const int m0 = P.lm_start[(size_t)b * (P.cap_l + 1) + l], m1 = min(P.lm_start[(size_t)b * (P.cap_l + 1) + l + 1], ne);
+            for (int m = m0; m < m1; m++) {
+                const int h = P.pose_hidx[(size_t)b * P.cap_p + P.edges[(size_t)b * P.cap_e + m].pose];
+                if (h < 0) continue;
+                const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + m) * 18;
+                const double* xp = A.xp + (size_t)b * A.np6 + h * 6;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int r = 0; r < 6; r++) cl[c] -= Bi[c * 6 + r] * xp[r];
+            }
+            const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
+            double* X = A.points + ((size_t)b * P.cap_l + l) * 3;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double xl = Di[r] * cl[0] + Di[3 + r] * cl[1] + Di[6 + r] * cl[2];
+                sc += xl * (st.lambda * xl + bl[r]);      // computeScale, landmark part
+                X[r] += xl;                               // VertexSBAPointXYZ::oplusImpl
+            }
+        }
+    }
+    red[threadIdx.x] = sc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) A.part[(size_t)b * A.nPart + blockIdx.x] = red[0];
+}
+
+static __device__ __forceinline__ Quat quat_from_R(const double m[9]) {   // Eigen Quaterniond(Matrix3d), row-major in
+    Quat q;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t; t = 0.5 / t;
+        q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        double c[3];
+        c[i] = 0.5 * t; t = 0.5 / t;
+        q.w = (m[k * 3 + j] - m[j * 3 + k]) * t; c[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; c[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+        q.x = c[0]; q.y = c[1]; q.z = c[2];
+    }
+    return q;
+}
+
+// pose update + the pose part of computeScale (one thread per pose; the partial goes to slot nPart-1 via a block of its own)
+static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double* red = (double*)orb_smem;
+    const lba_problem& P = A.P;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const LmState st = A.st[b];
+    double sc = 0;
+    if (st.needTrial && st.ok) {
+        const int np = min(P.n_poses[b], P.cap_p);
+        for (int i = tid; i < np; i += 256) {
+            const int h = P.pose_hidx[(size_t)b * P.cap_p + i];
+            if (h < 0) continue;
+            const double* u = A.xp + (size_t)b * A.np6 + h * 6;
+            const double* bp = A.S.bp + ((size_t)b * P.cap_p + h) * 6;
+            for (int r = 0; r < 6; r++) sc += u[r] * (st.lambda * u[r] + bp[r]);
+            // SE3Quat::exp(update) (se3quat.h:223-256)
+            const double om0 = u[0], om1 = u[1], om2 = u[2];
+            const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+            const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+            double O2[9], Rm[9], V[9];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+            for (int k = 0; k < 9; k++) {
+                const double I = (k % 4 == 0) ? 1.0 : 0.0;
+                if (theta < 0.00001) { Rm[k] = I + O[k] + O2[k]; V[k] = Rm[k]; }
+                else {
+                    Rm[k] = I + sin(theta) / theta * O[k] + (1 - cos(theta)) / (theta * theta) * O2[k];
+                    V[k] = I + (1 - cos(theta)) / (theta * theta) * O[k] + (theta - sin(theta)) / (theta * theta * theta) * O2[k];
+                }
+            }
+            SE3 D;
+            D.r = quat_from_R(Rm);
+            quat_normalize(D.r);
+            for (int r = 0; r < 3; r++) D.t[r] = V[r * 3] * u[3] + V[r * 3 + 1] * u[4] + V[r * 3 + 2] * u[5];
+            double* p = A.poses + ((size_t)b * P.cap_p + i) * 7;
+            const SE3 Tn = se3_mul(D, load_pose(p));
+            p[0] = Tn.t[0]; p[1] = Tn.t[1]; p[2] = Tn.t[2]; p[3] = Tn.r.x; p[4] = Tn.r.y; p[5] = Tn.r.z; p[6] = Tn.r.w;
+        }
+    }
+    red[tid] = sc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+    if (tid == 0) A.part[(size_t)b * A.nPart + A.nPart - 1] = red[0];
+}
+
+static __global__ void k_lm_decide(LmArgs A, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    LmState& s = A.st[b];
+    if (!s.needTrial) return;
+    double tempChi = s.tempChi;
+    if (!s.ok) tempChi = 1.7976931348623157e308;
+    double rho = s.currentChi - tempChi;
+    double scale = s.ok ? s.scale : 0.0;
+    scale += 1e-3;
+    rho /= scale;
+    s.accepted = 0;
+    if (rho > 0 && tempChi < 1.7976931348623157e308 && tempChi == tempChi) {   // good step
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        const double scaleFactor = fmax(1. / 3., alpha);
+        s.lambda *= scaleFactor; s.ni = 2; s.currentChi = tempChi; s.accepted = 1;
+    } else {
+        s.lambda *= s.ni; s.ni *= 2;
+    }
+    s.rho = rho; s.qmax++; s.trials++; s.ok = 1;
+    s.needTrial = (rho < 0 && s.qmax < 100) ? 1 : 0;
+    if (s.needTrial) atomicAdd(A.flag, 1);
+}
+
+// pop: windows whose last trial was rejected get their state back (also those that will retry)
+static __global__ void k_lm_restore(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nPose) { const LmState& s = A.st[i / capP7]; if (s.active && s.qmax > 0 && !s.accepted) A.poses[i] = A.posesBak[i]; }
+    else if (i < nPose + nPoint) { const size_t j = i - nPose; const LmState& s = A.st[j / capL3]; if (s.active && s.qmax > 0 && !s.accepted) A.points[j] = A.pointsBak[j]; }
+}
+
+static __global__ void k_lm_end(LmArgs A, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    LmState& s = A.st[b];
+    if (!s.active) return;
+    s.iter++;
+    if (s.qmax == 100 || s.rho == 0) { s.active = 0; return; }      // Terminate
+    if ((s.iniChi - s.currentChi) * 1e3 < s.iniChi) s.nBad++; else s.nBad = 0;
+    if (s.nBad >= 3) s.active = 0;
+}
+
+static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
+    if (!p || batch < 1) return 0;
+    const size_t B = (size_t)batch, np6 = (size_t)p->cap_p * 6;
+    const size_t nPart = (size_t)std::max((p->cap_e + 255) / 256, (p->cap_l + 255) / 256) + 1;
+    size_t s = 0;
+    s += lm_align(B * p->cap_p * 36 * 8) + lm_align(B * p->cap_p * 6 * 8);            // Hpp, bp
+    s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Hll, bl
+    s += lm_align(B * p->cap_e * 18 * 8) * 2;                                         // Hpl, BD
+    s += lm_align(B * p->cap_p * 7 * 8) + lm_align(B * p->cap_l * 3 * 8);            // backups
+    s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
+    s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
+    s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
+    return s;
+}
+
+extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                            const volatile int* abort_flag, void* stream) {
+    lba_system dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    int rc = lba_check(prob, batch, &dummy);
+    if (rc != ORB_OK || !d_workspace || iterations < 0) return ORB_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const lba_problem& P = *prob;
+    const size_t B = (size_t)batch, np6 = (size_t)P.cap_p * 6;
+    const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + 255) / 256) + 1;
+    char* w = (char*)d_workspace;
+    auto take = [&](size_t bytes) { char* p = w; w += lm_align(bytes); return p; };
+    LmArgs A;
+    memset(&A, 0, sizeof(A));
+    A.P = P;
+    A.S.Hpp = (double*)take(B * P.cap_p * 36 * 8); A.S.bp = (double*)take(B * P.cap_p * 6 * 8);
+    A.S.Hll = (double*)take(B * P.cap_l * 9 * 8); A.S.bl = (double*)take(B * P.cap_l * 3 * 8);
+    A.S.Hpl = (double*)take(B * P.cap_e * 18 * 8); A.BD = (double*)take(B * P.cap_e * 18 * 8);
+    A.posesBak = (double*)take(B * P.cap_p * 7 * 8); A.pointsBak = (double*)take(B * P.cap_l * 3 * 8);
+    A.Dinv = (double*)take(B * P.cap_l * 9 * 8); A.db = (double*)take(B * P.cap_l * 3 * 8);
+    A.Hs = (double*)take(B * np6 * np6 * 8); A.xp = (double*)take(B * np6 * 8); A.xl = (double*)take(B * P.cap_l * 3 * 8);
+    A.part = (double*)take(B * nPart * 8); A.st = (LmState*)take(B * sizeof(LmState));
+    int32_t* nfree = (int32_t*)take(B * 4);
+    A.flag = (int*)take(4);
+    A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
+
+    // number of free poses per window (Hessian size) from pose_hidx
+    {
+        std::vector<int32_t> hid(B * P.cap_p), npz(B), nf(B);
+        if (hipMemcpyAsync(hid.data(), P.pose_hidx, hid.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipMemcpyAsync(npz.data(), P.n_poses, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+        for (size_t b = 0; b < B; b++) {
+            int m = 0;
+            for (int i = 0; i < std::min(npz[b], P.cap_p); i++) m = std::max(m, hid[b * P.cap_p + i] + 1);
+            nf[b] = m;
+        }
+        if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+    }
+    const int gB = (batch + 63) / 64;
+    const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
+    const int gCopy = (int)((nPose + nPoint + 255) / 256);
+    const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch);
+    hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
+    int aborted = 0;
+    for (int it = 0; it < iterations && !aborted; it++) {
+        // computeActiveErrors + activeRobustChi2, buildSystem
+        hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+        hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        {
+            LbaArgs L;
+            L.P = P; L.S = A.S;
+            if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
+            if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
+            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + 127) / 128, batch), dim3(128), 0, st, L);
+            hipLaunchKernelGGL(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
+        }
+        if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
+        hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
+        for (int trial = 0; trial < 100; trial++) {
+            if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
+            hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
+            hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
+            hipLaunchKernelGGL(k_lm_bd, gE, dim3(256), 0, st, A);
+            hipLaunchKernelGGL(k_lm_schur_row, dim3(P.cap_p, batch), dim3(128), 0, st, A);
+            hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), std::max<size_t>(np6, 256) * 8 + 16, st, A, (const int32_t*)nfree);
+            hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
+            hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);
+            hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+            hipLaunchKernelGGL(k_lm_decide, dim3(gB), dim3(64), 0, st, A, batch);
+            hipLaunchKernelGGL(k_lm_restore, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);       // pop
+            int more = 0;
+            if (hipMemcpyAsync(&more, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+            if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+            if (abort_flag && *abort_flag) { aborted = 1; break; }
+            if (!more) break;
+        }
+        hipLaunchKernelGGL(k_lm_end, dim3(gB), dim3(64), 0, st, A, batch);
+    }
+    // final activeRobustChi2 + stats
+    {
+        // evaluate every window (also the terminated ones) at its final state
+        std::vector<LmState> hs(B);
+        if (hipMemcpyAsync(hs.data(), A.st, B * sizeof(LmState), hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+        std::vector<LmState> on = hs;
+        for (auto& s : on) s.active = 1;
+        if (hipMemcpyAsync(A.st, on.data(), B * sizeof(LmState), hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
+        hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+        hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        std::vector<LmState> fin(B);
+        if (hipMemcpyAsync(fin.data(), A.st, B * sizeof(LmState), hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+        if (h_stats)
+            for (size_t b = 0; b < B; b++) { h_stats[4 * b] = hs[b].iter; h_stats[4 * b + 1] = fin[b].tempChi; h_stats[4 * b + 2] = hs[b].lambda; h_stats[4 * b + 3] = hs[b].trials; }
+    }
+    if (hipGetLastError() != hipSuccess) return ORB_E_HIP;
+    return aborted ? ORB_E_ABORTED : ORB_OK;
 }

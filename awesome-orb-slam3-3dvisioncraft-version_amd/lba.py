@@ -37,6 +37,10 @@ def bind(lib):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(LbaProblem), C.c_int, C.POINTER(LbaSystem), C.c_void_p]
+    lib.lba_lm_workspace_bytes.restype = C.c_size_t
+    lib.lba_lm_workspace_bytes.argtypes = [C.POINTER(LbaProblem), C.c_int]
+    lib.lba_optimize.restype = C.c_int
+    lib.lba_optimize.argtypes = [C.POINTER(LbaProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -103,6 +107,20 @@ class LbaWindows:
         if rc != 0:
             raise OrbHipError(rc, "lba_build_system failed")
         return self.out
+
+    def optimize(self, iterations):
+        """optimizer.optimize(iterations) (Optimizer.cc:2205 / :2290): LM with Schur complement on the device; poses / points in self.d are
+        updated in place.  -> stats [B,4] = iterations run, final robust chi2, final lambda, lambda trials."""
+        P, _ = self._structs(())
+        if getattr(self, "_lm_ws", None) is None:
+            n = self._L.lba_lm_workspace_bytes(C.byref(P), self.B)
+            self._lm_ws = _like(self.d["poses"], (n,), np.uint8)
+        stats = np.zeros((self.B, 4), np.float64)
+        rc = self._L.lba_optimize(C.byref(P), self.B, int(iterations), _ptr(self._lm_ws), stats.ctypes.data_as(C.c_void_p), None,
+                                  _stream(self.d["poses"]))
+        if rc != 0:
+            raise OrbHipError(rc, "lba_optimize failed")
+        return stats
 
     def compute_errors(self, outputs=("err", "chi2", "rho", "depth", "robust_chi2_sum")):
         P, S = self._structs(outputs)

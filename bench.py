@@ -237,6 +237,20 @@ def main():
                         "edges_per_window": E, "algorithmic_GBps": round(lba_bytes * nwin * lsteps / dtl / 1e9, 2),
                         "hbm_frac": round(lba_bytes * nwin * lsteps / dtl / 1e9 / HBM_PEAK_GBS, 5),
                         "what": "BlockSolver::buildSystem equivalent (residuals, Huber, Jacobians, Hpp/Hll/Hpl/b) for 100-KF/20k-landmark windows"}
+        # full LM iterations: optimizer.optimize(5) per window = linearise + Schur + Cholesky + update + rho test, GPU resident
+        p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
+        Lw.optimize(5)
+        barrier()
+        osteps = 2
+        t3 = time.perf_counter()
+        for _ in range(osteps):
+            Lw.d["poses"].copy_(p0); Lw.d["points"].copy_(x0)
+            stats = Lw.optimize(5)
+        barrier()
+        dto = time.perf_counter() - t3
+        extra["lba"]["lm_iterations_per_s"] = round(float(stats[:, 0].sum()) * osteps / dto, 1)
+        extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
+        extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)

@@ -264,6 +264,18 @@ int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, 
 /* SparseOptimizer::computeActiveErrors (sparse_optimizer.cpp:61-75): err / chi2 / rho / depth / robust_chi2_sum only. */
 int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream);
 
+/* SURVEY.md N4 — the rest of one SparseOptimizer::optimize(iterations) call on the LBA graph, GPU resident:
+ * OptimizationAlgorithmLevenberg::solve (g2o/core/optimization_algorithm_levenberg.cpp:61-168: _tau = 1e-50, <= 100 lambda
+ * trials, rho test, the "nBad" stop), BlockSolver::setLambda / Schur complement / back-substitution
+ * (block_solver.hpp:564-589, 381-481) and the vertex updates (exp(dx)*T, X += dx).  The reduced camera system is solved
+ * with a dense Cholesky per window (g2o: Eigen SimplicialLDLT — same solution of the SPD system).
+ * prob->poses and prob->points are UPDATED IN PLACE (they must be writable device memory).  h_stats: [batch][4] host doubles =
+ * {iterations run, final activeRobustChi2, final lambda, total lambda trials}.  abort_flag (may be NULL) is polled between
+ * trials like pbStopFlag (Optimizer.cc:2197-2199, sparse_optimizer.cpp:376) -> ORB_E_ABORTED.  Synchronous on `stream`. */
+size_t lba_lm_workspace_bytes(const lba_problem* prob, int batch);
+int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                 const volatile int* abort_flag, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device-memory helpers so that adapters written against this header need no HIP headers.
  * ------------------------------------------------------------------------------------------------------- */

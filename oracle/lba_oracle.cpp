@@ -331,3 +331,182 @@ void olb_edge_error(const double* pose7, const double* point3, const void* edge_
 }
 
 }  // extern "C"
+
+// ---- one SparseOptimizer::optimize(iterations) call on the LBA graph, restated densely -------------------------------
+//   OptimizationAlgorithmLevenberg::solve            g2o/core/optimization_algorithm_levenberg.cpp:61-168 (_tau=1e-50, 100 trials, "nBad" stop)
+//   BlockSolver::setLambda / solve (Schur) / restoreDiagonal   g2o/core/block_solver.hpp:564-589, 354-486
+//   LinearSolverEigen (SimplicialLDLT)                g2o/solvers/linear_solver_eigen.h:94-123  -> dense Cholesky here (same solution of the SPD system)
+//   VertexSE3Expmap::oplusImpl / VertexSBAPointXYZ::oplusImpl  types_six_dof_expmap.h:73-76, types_sba.h:49-53
+//   SparseOptimizer::optimize / push / pop / activeRobustChi2   sparse_optimizer.cpp:354-410, 100-114
+namespace {
+SE3 se3exp(const double* upd) {  // se3quat.h:223-256
+    const double* om = upd; const double* up = upd + 3;
+    const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9], Rm[9], V[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += O[r * 3 + k] * O[k * 3 + c]; O2[r * 3 + c] = a; }
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        if (theta < 0.00001) { Rm[i] = I + O[i] + O2[i]; V[i] = Rm[i]; }
+        else {
+            Rm[i] = I + std::sin(theta) / theta * O[i] + (1 - std::cos(theta)) / (theta * theta) * O2[i];
+            V[i] = I + (1 - std::cos(theta)) / (theta * theta) * O[i] + (theta - std::sin(theta)) / (std::pow(theta, 3)) * O2[i];
+        }
+    }
+    SE3 D;
+    D.r = quatFromMatrix(Rm);
+    normalizeRotation(D.r);
+    for (int r = 0; r < 3; r++) D.t[r] = V[r * 3] * up[0] + V[r * 3 + 1] * up[1] + V[r * 3 + 2] * up[2];
+    return D;
+}
+bool inv3(const double* D, double* out) {  // column-major 3x3 (symmetric): cofactor inverse (Eigen fixed-size inverse)
+    const double a = D[0], b = D[3], c = D[6], d = D[1], e = D[4], f = D[7], g = D[2], h = D[5], i = D[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double id = 1.0 / det;
+    out[0] = A * id; out[3] = -(b * i - c * h) * id; out[6] = (b * f - c * e) * id;
+    out[1] = B * id; out[4] = (a * i - c * g) * id; out[7] = -(a * f - c * d) * id;
+    out[2] = C * id; out[5] = -(a * h - b * g) * id; out[8] = (a * e - b * d) * id;
+    return std::isfinite(det) && det != 0.0;
+}
+bool cholSolve(std::vector<double>& S, int n, std::vector<double>& rhs) {  // in-place dense Cholesky (lower), column-major
+    for (int k = 0; k < n; k++) {
+        double dkk = S[(size_t)k * n + k];
+        if (!(dkk > 0) || !std::isfinite(dkk)) return false;
+        dkk = std::sqrt(dkk);
+        S[(size_t)k * n + k] = dkk;
+        for (int i = k + 1; i < n; i++) S[(size_t)k * n + i] /= dkk;
+        for (int j = k + 1; j < n; j++) {
+            const double ljk = S[(size_t)k * n + j];
+            for (int i = j; i < n; i++) S[(size_t)j * n + i] -= S[(size_t)k * n + i] * ljk;
+        }
+    }
+    for (int i = 0; i < n; i++) { double v = rhs[i]; for (int k = 0; k < i; k++) v -= S[(size_t)k * n + i] * rhs[k]; rhs[i] = v / S[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double v = rhs[i]; for (int k = i + 1; k < n; k++) v -= S[(size_t)i * n + k] * rhs[k]; rhs[i] = v / S[(size_t)i * n + i]; }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+void olb_build_system(const double*, const int32_t*, int, const double*, int, const void*, int, const void*, double, double, double*,
+                      double*, double*, double*, double*, double*, double*, double*, double*, double*);
+
+// poses / points are updated in place.  stats[0]=iterations run, [1]=final robust chi2, [2]=final lambda, [3]=total LM trials.
+void olb_optimize(double* poses, const int32_t* pose_hidx, int n_poses, double* points, int n_points, const void* edges_, int n_edges,
+                  const void* cams_, double huberMono, double huberStereo, int iterations, double* stats) {
+    const Edge* edges = (const Edge*)edges_;
+    int nf = 0;
+    for (int i = 0; i < n_poses; i++) if (pose_hidx[i] >= 0) nf = std::max(nf, pose_hidx[i] + 1);
+    std::vector<int> poseOfH(nf, -1);
+    for (int i = 0; i < n_poses; i++) if (pose_hidx[i] >= 0) poseOfH[pose_hidx[i]] = i;
+    const int np6 = nf * 6;
+    std::vector<double> Hpp((size_t)nf * 36), bp(np6), Hll((size_t)n_points * 9), bl((size_t)n_points * 3), Hpl((size_t)n_edges * 18),
+        chi2(n_edges), rho((size_t)n_edges * 2);
+    std::vector<int> lmStart(n_points + 1, 0);
+    for (int e = 0; e < n_edges; e++) lmStart[edges[e].point + 1]++;
+    for (int l = 0; l < n_points; l++) lmStart[l + 1] += lmStart[l];
+    auto robustChi = [&]() { double r = 0; olb_build_system(poses, pose_hidx, n_poses, points, n_points, edges_, n_edges, cams_, huberMono, huberStereo,
+                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &r); return r; };
+    double lambda = -1, ni = 2;
+    int nBad = 0, it = 0, trialsTotal = 0;
+    double currentChi = 0;
+    for (it = 0; it < iterations; it++) {
+        currentChi = robustChi();                       // computeActiveErrors + activeRobustChi2
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        olb_build_system(poses, pose_hidx, n_poses, points, n_points, edges_, n_edges, cams_, huberMono, huberStereo, Hpp.data(), bp.data(),
+                         Hll.data(), bl.data(), Hpl.data(), nullptr, chi2.data(), rho.data(), nullptr, nullptr);
+        if (it == 0) {                                  // computeLambdaInit
+            double maxDiagonal = 0;
+            for (int h = 0; h < nf; h++) for (int j = 0; j < 6; j++) maxDiagonal = std::max(std::fabs(Hpp[(size_t)h * 36 + j * 7]), maxDiagonal);
+            for (int l = 0; l < n_points; l++) for (int j = 0; j < 3; j++) maxDiagonal = std::max(std::fabs(Hll[(size_t)l * 9 + j * 4]), maxDiagonal);
+            lambda = 1e-50 * maxDiagonal; ni = 2; nBad = 0;
+        }
+        double rhoLM = 0;
+        int qmax = 0;
+        std::vector<double> posesBak, pointsBak;
+        do {
+            posesBak.assign(poses, poses + (size_t)n_poses * 7);       // _optimizer->push()
+            pointsBak.assign(points, points + (size_t)n_points * 3);
+            // setLambda + Schur complement (block_solver.hpp:381-432)
+            std::vector<double> S((size_t)np6 * np6, 0.0), coeff(np6, 0.0), Dinv((size_t)n_points * 9), db((size_t)n_points * 3);
+            for (int h = 0; h < nf; h++)
+                for (int c = 0; c < 6; c++) for (int r = 0; r < 6; r++) S[(size_t)(h * 6 + c) * np6 + h * 6 + r] = Hpp[(size_t)h * 36 + c * 6 + r] + (r == c ? lambda : 0.0);
+            bool ok2 = true;
+            for (int l = 0; l < n_points; l++) {
+                double D[9];
+                for (int k = 0; k < 9; k++) D[k] = Hll[(size_t)l * 9 + k] + ((k % 4 == 0) ? lambda : 0.0);
+                if (!inv3(D, &Dinv[(size_t)l * 9])) ok2 = false;
+                for (int r = 0; r < 3; r++) db[(size_t)l * 3 + r] = Dinv[(size_t)l * 9 + r] * bl[(size_t)l * 3] + Dinv[(size_t)l * 9 + 3 + r] * bl[(size_t)l * 3 + 1] + Dinv[(size_t)l * 9 + 6 + r] * bl[(size_t)l * 3 + 2];
+                for (int e1 = lmStart[l]; e1 < lmStart[l + 1]; e1++) {
+                    const int h1 = pose_hidx[edges[e1].pose];
+                    if (h1 < 0) continue;
+                    const double* Bi = &Hpl[(size_t)e1 * 18];       // 6x3 column-major
+                    double BD[18];
+                    for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) BD[c * 6 + r] = Bi[r] * Dinv[(size_t)l * 9 + c * 3] + Bi[6 + r] * Dinv[(size_t)l * 9 + c * 3 + 1] + Bi[12 + r] * Dinv[(size_t)l * 9 + c * 3 + 2];
+                    for (int r = 0; r < 6; r++) coeff[h1 * 6 + r] += Bi[r] * db[(size_t)l * 3] + Bi[6 + r] * db[(size_t)l * 3 + 1] + Bi[12 + r] * db[(size_t)l * 3 + 2];
+                    for (int e2 = lmStart[l]; e2 < lmStart[l + 1]; e2++) {
+                        const int h2 = pose_hidx[edges[e2].pose];
+                        if (h2 < 0) continue;
+                        const double* Bj = &Hpl[(size_t)e2 * 18];
+                        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++)
+                            S[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] -= BD[r] * Bj[c] + BD[6 + r] * Bj[6 + c] + BD[12 + r] * Bj[12 + c];
+                    }
+                }
+            }
+            std::vector<double> xp(np6);
+            for (int i = 0; i < np6; i++) xp[i] = bp[i] - coeff[i];       // _bschur
+            std::vector<double> Sc = S;
+            if (ok2) ok2 = cholSolve(Sc, np6, xp);
+            // back-substitution (block_solver.hpp:461-481): xl = Dinv * (bl - Hpl^T xp)
+            std::vector<double> xl((size_t)n_points * 3, 0.0);
+            if (ok2)
+                for (int l = 0; l < n_points; l++) {
+                    double cl[3] = {bl[(size_t)l * 3], bl[(size_t)l * 3 + 1], bl[(size_t)l * 3 + 2]};
+                    for (int e1 = lmStart[l]; e1 < lmStart[l + 1]; e1++) {
+                        const int h1 = pose_hidx[edges[e1].pose];
+                        if (h1 < 0) continue;
+                        const double* Bi = &Hpl[(size_t)e1 * 18];
+                        for (int c = 0; c < 3; c++) for (int r = 0; r < 6; r++) cl[c] -= Bi[c * 6 + r] * xp[h1 * 6 + r];
+                    }
+                    for (int r = 0; r < 3; r++) xl[(size_t)l * 3 + r] = Dinv[(size_t)l * 9 + r] * cl[0] + Dinv[(size_t)l * 9 + 3 + r] * cl[1] + Dinv[(size_t)l * 9 + 6 + r] * cl[2];
+                }
+            // _optimizer->update(x): pose <- exp(dx) * pose ; point += dx
+            if (ok2) {
+                for (int h = 0; h < nf; h++) {
+                    double* p = poses + (size_t)poseOfH[h] * 7;
+                    SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.r = Quat{p[3], p[4], p[5], p[6]};
+                    const SE3 Tn = se3mul(se3exp(&xp[h * 6]), T);
+                    p[0] = Tn.t[0]; p[1] = Tn.t[1]; p[2] = Tn.t[2]; p[3] = Tn.r.x; p[4] = Tn.r.y; p[5] = Tn.r.z; p[6] = Tn.r.w;
+                }
+                for (size_t k = 0; k < (size_t)n_points * 3; k++) points[k] += xl[k];
+            }
+            tempChi = robustChi();
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            rhoLM = currentChi - tempChi;
+            double scale = 0;                              // computeScale: x^T (lambda x + b)
+            if (ok2) {
+                for (int i = 0; i < np6; i++) scale += xp[i] * (lambda * xp[i] + bp[i]);
+                for (size_t k = 0; k < (size_t)n_points * 3; k++) scale += xl[k] * (lambda * xl[k] + bl[k]);
+            }
+            scale += 1e-3;
+            rhoLM /= scale;
+            if (rhoLM > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rhoLM - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                const double scaleFactor = std::max(1. / 3., alpha);
+                lambda *= scaleFactor; ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                memcpy(poses, posesBak.data(), posesBak.size() * 8);    // pop
+                memcpy(points, pointsBak.data(), pointsBak.size() * 8);
+            }
+            qmax++; trialsTotal++;
+        } while (rhoLM < 0 && qmax < 100);
+        if (qmax == 100 || rhoLM == 0) { it++; break; }                 // Terminate (the iteration still counts in cjIterations)
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) { it++; break; }
+    }
+    if (stats) { stats[0] = it; stats[1] = robustChi(); stats[2] = lambda; stats[3] = trialsTotal; }
+}
+}  // extern "C"

@@ -269,3 +269,15 @@ def stereo_matches(oL, oR, kl, dl, kr, dr, mb, mbf):
     ur = np.zeros(max(len(kl), 1), np.float32); dp = np.zeros(max(len(kl), 1), np.float32)
     L.oro_stereo_matches(oL.h, oR.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), mb, mbf, _p(ur), _p(dp))
     return ur[:len(kl)], dp[:len(kl)]
+
+
+def lba_optimize(window, cameras, huber, iterations):
+    """SparseOptimizer::optimize(iterations) restated (oracle/lba_oracle.cpp olb_optimize) -> (poses, points, stats[4])"""
+    L = lib()
+    L.olb_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double,
+                               C.c_int, C.c_void_p]
+    poses = np.ascontiguousarray(window["poses"], np.float64).copy(); pts = np.ascontiguousarray(window["points"], np.float64).copy()
+    hidx = np.ascontiguousarray(window["pose_hidx"], np.int32); edges = np.ascontiguousarray(window["edges"]); cams = np.ascontiguousarray(cameras)
+    stats = np.zeros(4)
+    L.olb_optimize(_p(poses), _p(hidx), len(poses), _p(pts), len(pts), _p(edges), len(edges), _p(cams), huber[0], huber[1], iterations, _p(stats))
+    return poses, pts, stats

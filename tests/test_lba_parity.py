@@ -127,3 +127,35 @@ def test_hip_lba_c5_size_window(hip_lib):
         n = len(o[k]) if k not in ("Hpp", "bp") else o["nfree"]
         assert np.array_equal(a[k], b[k]), "run-to-run determinism of " + k
         assert rel(a[k][0, :n], o[k][:n]) < 1e-10, k
+
+
+# ---- the LM loop (Schur complement + Cholesky + rho test) ------------------------------------------------------------
+def check_optimize(lib, backend, kinds, iterations):
+    ws, cams = [], None
+    for i, kind in enumerate(kinds):
+        w, cams = window(kind, seed=10 + i, n_kf=10 + i, n_pts=200 + 31 * i)
+        ws.append(w)
+    L = LbaWindows(ws, cams, to_dev(backend), lib=lib, huber=HUBER)
+    stats = L.optimize(iterations)
+    poses, points = to_host(L.d["poses"]), to_host(L.d["points"])
+    for b, w in enumerate(ws):
+        op, ox, ost = O.lba_optimize(w, cams, HUBER, iterations)
+        npz, nl = len(w["poses"]), len(w["points"])
+        assert stats[b, 0] == ost[0] and stats[b, 3] == ost[3], (stats[b], ost)          # same iterations / lambda trials
+        assert abs(stats[b, 1] - ost[1]) < 1e-6 * ost[1]
+        # north_star bar: 1e-4 on BA poses; double arithmetic in both, different summation orders
+        assert np.abs(poses[b, :npz] - op).max() < 1e-7, np.abs(poses[b, :npz] - op).max()
+        assert np.abs(points[b, :nl] - ox).max() < 1e-6
+        assert ost[1] < 0.9 * O.lba_build_system(w, cams, HUBER)["robust_chi2_sum"][0]                                # it really optimised
+        assert np.abs(poses[b, :npz][w["pose_hidx"] < 0] - w["poses"][w["pose_hidx"] < 0]).max() == 0    # fixed KFs untouched
+
+
+@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono",), 10)], ids=["mono+stereo_5it", "mono_10it"])
+def test_emu_lba_optimize_matches_oracle(emu_lib, kinds, its):
+    check_optimize(emu_lib, "emu", kinds, its)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono", "mono", "stereo"), 10)], ids=["mono+stereo_5it", "3win_10it"])
+def test_hip_lba_optimize_matches_oracle(hip_lib, kinds, its):
+    check_optimize(hip_lib, "hip", kinds, its)
