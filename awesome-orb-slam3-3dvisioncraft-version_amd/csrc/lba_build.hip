@@ -548,9 +548,18 @@ static __global__ __launch_bounds__(256) void k_lm_bd(LmArgs A) {
         for (int r = 0; r < 6; r++) o[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
 }
 
-// One workgroup per pose i1.  Thread t < n_poses owns the 6x6 block Hschur(h1, hidx[t]); it walks pose i1's edges in order,
-// looks for an edge of pose t on the same landmark (<= ~8 candidates, broadcast reads) and accumulates in registers.
+// One workgroup per pose i1.  Thread t < n_poses owns the 6x6 block Hschur(h1, hidx[t]).  The co-observation structure of pose
+// i1 (for each of its edges: the landmark's edge range and the poses on it) is staged once into LDS in chunks, so the scan a
+// thread does to find "does pose t also see this landmark" touches LDS only; blocks are accumulated in registers in edge order
+// -> deterministic, no f64 atomics.
+#define SCH_CHUNK 256     // edges of pose i1 staged per round
+#define SCH_MAXOBS 16     // landmark edges cached per staged edge (longer tracks fall back to global reads)
 static __global__ __launch_bounds__(128) void k_lm_schur_row(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* sE1 = (int*)orb_smem;                       // [SCH_CHUNK] edge index e1
+    int* sM0 = sE1 + SCH_CHUNK;                      // [SCH_CHUNK] first edge of its landmark
+    int* sCnt = sM0 + SCH_CHUNK;                     // [SCH_CHUNK] number of edges of its landmark
+    short* sPose = (short*)(sCnt + SCH_CHUNK);       // [SCH_CHUNK][SCH_MAXOBS] poses of those edges
     const lba_problem& P = A.P;
     const int b = blockIdx.y, i1 = blockIdx.x, t = threadIdx.x;
     if (!A.st[b].needTrial) return;
@@ -566,72 +575,118 @@ static __global__ __launch_bounds__(128) void k_lm_schur_row(LmArgs A) {
     const double lam = A.st[b].lambda;
     const int np6 = A.np6;
     double* Hs = A.Hs + (size_t)b * np6 * np6;
-    for (int i2 = t; i2 < np; i2 += 128) {
-        const int h2 = hidx[i2];
-        if (h2 < 0) continue;
-        double acc[36];
+    // this thread's column blocks: i2 = t, t+128, ... (<= 2 for cap_p <= 256)
+    double acc[2][36];
+    int myI2[2], myH2[2];
 #pragma unroll
-        for (int k = 0; k < 36; k++) acc[k] = 0;
-        if (i2 == i1) {   // _Hpp->add(_Hschur) + setLambda
+    for (int u = 0; u < 2; u++) {
+        myI2[u] = t + 128 * u;
+        myH2[u] = myI2[u] < np ? hidx[myI2[u]] : -1;
+#pragma unroll
+        for (int k = 0; k < 36; k++) acc[u][k] = 0;
+        if (myH2[u] >= 0 && myI2[u] == i1) {   // _Hpp->add(_Hschur) + setLambda
             const double* H = A.S.Hpp + ((size_t)b * P.cap_p + h1) * 36;
 #pragma unroll
-            for (int k = 0; k < 36; k++) acc[k] = H[k] + ((k % 7 == 0) ? lam : 0.0);
+            for (int k = 0; k < 36; k++) acc[u][k] = H[k] + ((k % 7 == 0) ? lam : 0.0);
         }
-        for (int k = s0; k < s1; k++) {
-            const int e1 = pe[k];
+    }
+    double coef = 0;   // threads 0..5: row t of sum_e B_i (Dinv b_l)
+    for (int c0 = s0; c0 < s1; c0 += SCH_CHUNK) {
+        const int cn = min(SCH_CHUNK, s1 - c0);
+        __syncthreads();
+        for (int k = t; k < cn; k += 128) {
+            const int e1 = pe[c0 + k];
             const int l = edges[e1].point;
             const int m0 = lms[l], m1 = min(lms[l + 1], ne);
-            for (int m = m0; m < m1; m++) {   // every edge of pose i2 on this landmark contributes (mono + body twins)
-                if (edges[m].pose != i2) continue;
-                const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
-                const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + m) * 18;
+            sE1[k] = e1; sM0[k] = m0; sCnt[k] = m1 - m0;
+            for (int m = m0; m < m1 && m - m0 < SCH_MAXOBS; m++) sPose[k * SCH_MAXOBS + (m - m0)] = (short)edges[m].pose;
+        }
+        __syncthreads();
+        for (int k = 0; k < cn; k++) {
+            const int e1 = sE1[k], m0 = sM0[k], cnt = sCnt[k];
+            for (int q = 0; q < cnt; q++) {
+                const int pq = q < SCH_MAXOBS ? (int)sPose[k * SCH_MAXOBS + q] : edges[m0 + q].pose;
 #pragma unroll
-                for (int c = 0; c < 6; c++)
+                for (int u = 0; u < 2; u++) {
+                    if (myH2[u] >= 0 && pq == myI2[u]) {   // every edge of pose i2 on this landmark contributes (mono + body twins)
+                        const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
+                        const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + m0 + q) * 18;
 #pragma unroll
-                    for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
+                        for (int c = 0; c < 6; c++)
+#pragma unroll
+                            for (int r = 0; r < 6; r++) acc[u][c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
+                    }
+                }
+            }
+            if (t < 6) {   // _bschur row, fixed edge order
+                const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
+                const double* db = A.db + ((size_t)b * P.cap_l + edges[e1].point) * 3;
+                coef += Bi[t] * db[0] + Bi[6 + t] * db[1] + Bi[12 + t] * db[2];
             }
         }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (myH2[u] < 0) continue;
 #pragma unroll
         for (int c = 0; c < 6; c++)
 #pragma unroll
-            for (int r = 0; r < 6; r++) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = acc[c * 6 + r];
+            for (int r = 0; r < 6; r++) Hs[(size_t)(myH2[u] * 6 + c) * np6 + h1 * 6 + r] = acc[u][c * 6 + r];
     }
-    if (t < 6) {   // _bschur row: b_p - sum_e B_i * (Dinv b_l), fixed edge order
-        double c = 0;
-        for (int k = s0; k < s1; k++) {
-            const int e1 = pe[k];
-            const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
-            const double* db = A.db + ((size_t)b * P.cap_l + edges[e1].point) * 3;
-            c += Bi[t] * db[0] + Bi[6 + t] * db[1] + Bi[12 + t] * db[2];
-        }
-        A.xp[(size_t)b * np6 + h1 * 6 + t] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + t] - c;
-    }
+    if (t < 6) A.xp[(size_t)b * np6 + h1 * 6 + t] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + t] - coef;
 }
 
 // dense Cholesky (lower, column-major, in place) + forward / backward substitution; one workgroup per window.
-// Right-looking: wave w takes trailing columns k+1+w, k+5+w, ...; its lanes run down the rows of the column (coalesced).
+// Blocked right-looking: a panel of CH_NB columns is factored in LDS, then the trailing triangle gets ONE rank-CH_NB update
+// (both operands from the LDS panel, one global read-modify-write per element per panel instead of per column).
+#define CH_NB 16
+#define CH_LD (CH_NB + 1)    // padded panel row (17 doubles = 34 dwords: conflict-free 8-byte reads down a column)
 static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t* nfreeArr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!A.st[b].needTrial) return;
     const int n = nfreeArr[b] * 6, ld = A.np6;
-    double* col = (double*)orb_smem;                                   // [max(ld,256)] current column / reduction scratch
-    int* bad = (int*)(col + (ld > 256 ? ld : 256));
+    double* pan = (double*)orb_smem;                    // [ld][CH_LD] panel rows kb.. (row r of the panel = matrix row kb + r)
+    double* red = pan + (size_t)ld * CH_LD;             // [256] reduction scratch
+    int* bad = (int*)(red + 256);
     double* S = A.Hs + (size_t)b * ld * ld;
     double* x = A.xp + (size_t)b * ld;
     if (tid == 0) *bad = 0;
     __syncthreads();
-    for (int k = 0; k < n; k++) {
-        const double dkk = S[(size_t)k * ld + k];
-        if (!(dkk > 0) || !(dkk < 1.7e308)) { if (tid == 0) *bad = 1; break; }   // uniform: every thread reads the same dkk
-        const double sq = sqrt(dkk);
-        __syncthreads();   // every thread has read the pivot before thread 0 overwrites it with its square root
-        for (int i = k + tid; i < n; i += 256) { const double v = (i == k) ? sq : S[(size_t)k * ld + i] / sq; col[i] = v; S[(size_t)k * ld + i] = v; }
+    for (int kb = 0; kb < n; kb += CH_NB) {
+        const int nb = min(CH_NB, n - kb), m = n - kb;   // panel: m rows x nb columns
+        for (int c = wave; c < nb; c += 4)
+            for (int r = lane; r < m; r += 64) pan[r * CH_LD + c] = S[(size_t)(kb + c) * ld + kb + r];
         __syncthreads();
-        for (int j = k + 1 + wave; j < n; j += 4) {
-            const double ljk = col[j];
-            double* Sj = S + (size_t)j * ld;
-            for (int i = j + lane; i < n; i += 64) Sj[i] -= col[i] * ljk;
+        for (int c = 0; c < nb; c++) {
+            const double dkk = pan[c * CH_LD + c];
+            if (!(dkk > 0) || !(dkk < 1.7e308)) { if (tid == 0) *bad = 1; break; }   // uniform
+            const double sq = sqrt(dkk);
+            __syncthreads();                              // pivot read by everyone before it is overwritten
+            for (int r = c + tid; r < m; r += 256) pan[r * CH_LD + c] = (r == c) ? sq : pan[r * CH_LD + c] / sq;
+            __syncthreads();
+            for (int c2 = c + 1 + wave; c2 < nb; c2 += 4) {
+                const double l2 = pan[c2 * CH_LD + c];
+                for (int r = c2 + lane; r < m; r += 64) pan[r * CH_LD + c2] -= pan[r * CH_LD + c] * l2;
+            }
+            __syncthreads();
+        }
+        if (*bad) break;
+        for (int c = wave; c < nb; c += 4)
+            for (int r = c + lane; r < m; r += 64) S[(size_t)(kb + c) * ld + kb + r] = pan[r * CH_LD + c];
+        // trailing update: S(i, j) -= sum_c L(i, kb+c) L(j, kb+c)  for j >= kb+nb, i >= j
+        for (int j = nb + wave; j < m; j += 4) {
+            double lj[CH_NB];
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) lj[c] = c < nb ? pan[j * CH_LD + c] : 0.0;
+            double* Sj = S + (size_t)(kb + j) * ld + kb;
+            for (int r = j + lane; r < m; r += 64) {
+                const double* pr = pan + r * CH_LD;
+                double acc = 0;
+#pragma unroll
+                for (int c = 0; c < CH_NB; c++) acc += pr[c] * lj[c];   // columns >= nb of the panel rows are never read with lj != 0
+                Sj[r] -= acc;
+            }
         }
         __threadfence_block();
         __syncthreads();
@@ -651,10 +706,10 @@ static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t*
     for (int k = n - 1; k >= 0; k--) {
         double sum = 0;
         for (int i = k + 1 + tid; i < n; i += 256) sum += S[(size_t)k * ld + i] * x[i];
-        col[tid] = sum;
+        red[tid] = sum;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) { if (tid < off) col[tid] += col[tid + off]; __syncthreads(); }
-        if (tid == 0) x[k] = (x[k] - col[0]) / S[(size_t)k * ld + k];
+        for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+        if (tid == 0) x[k] = (x[k] - red[0]) / S[(size_t)k * ld + k];
         __threadfence_block();
         __syncthreads();
     }
@@ -836,7 +891,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     lba_system dummy;
     memset(&dummy, 0, sizeof(dummy));
     int rc = lba_check(prob, batch, &dummy);
-    if (rc != ORB_OK || !d_workspace || iterations < 0) return ORB_E_INVALID;
+    if (rc != ORB_OK || !d_workspace || iterations < 0 || prob->cap_p > 180) return ORB_E_INVALID;   // LDS panel: 6*cap_p rows x 17 doubles <= 160 KiB
     hipStream_t st = (hipStream_t)stream;
     const lba_problem& P = *prob;
     const size_t B = (size_t)batch, np6 = (size_t)P.cap_p * 6;
@@ -871,6 +926,10 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
         if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
     }
+    const size_t cholSmem = (np6 * CH_LD + 256) * 8 + 16;
+    if (cholSmem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
+        return ORB_E_HIP;
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
@@ -896,8 +955,8 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
             hipLaunchKernelGGL(k_lm_bd, gE, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_row, dim3(P.cap_p, batch), dim3(128), 0, st, A);
-            hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), std::max<size_t>(np6, 256) * 8 + 16, st, A, (const int32_t*)nfree);
+            hipLaunchKernelGGL(k_lm_schur_row, dim3(P.cap_p, batch), dim3(128), SCH_CHUNK * (12 + 2 * SCH_MAXOBS), st, A);
+            hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);
