@@ -403,8 +403,8 @@ extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_
 //   k_lm_begin       per-iteration bookkeeping               :85-105
 //   k_lm_dinv        (Hll + lambda I)^-1, Dinv*b_l           block_solver.hpp:381-397 (+ setLambda :564-589)
 //   k_lm_bd          B_i * Dinv per edge                     :404
-//   k_lm_schur_row   one workgroup per free pose = one 6 x 6n block row of Hschur and of the coefficient vector; thread = column
-//                    block, fixed edge order -> deterministic, no f64 atomics          :398-432
+//   k_lm_obs / k_lm_schur_blocks   landmark x pose observation table; one wave per lower-triangle 6x6 block of Hschur
+//                    (+ the coefficient rows on the diagonal), fixed butterfly -> deterministic, no f64 atomics   :398-432
 //   k_lm_chol        dense in-place Cholesky + two triangular solves, one workgroup per window   (linear_solver_eigen.h:94-123)
 //   k_lm_backsub     x_l = Dinv (b_l - Hpl^T x_p), X += x_l, scale partials            block_solver.hpp:461-481, levenberg.cpp:188-195
 //   k_lm_update_pose T <- exp(x_p) * T                       types_six_dof_expmap.h:73-76, se3quat.h:223-256
@@ -548,92 +548,87 @@ static __global__ __launch_bounds__(256) void k_lm_bd(LmArgs A) {
         for (int r = 0; r < 6; r++) o[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
 }
 
-// One workgroup per pose i1.  Thread t < n_poses owns the 6x6 block Hschur(h1, hidx[t]).  The co-observation structure of pose
-// i1 (for each of its edges: the landmark's edge range and the poses on it) is staged once into LDS in chunks, so the scan a
-// thread does to find "does pose t also see this landmark" touches LDS only; blocks are accumulated in registers in edge order
-// -> deterministic, no f64 atomics.
-#define SCH_CHUNK 256     // edges of pose i1 staged per round
-#define SCH_MAXOBS 16     // landmark edges cached per staged edge (longer tracks fall back to global reads)
-static __global__ __launch_bounds__(128) void k_lm_schur_row(LmArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    int* sE1 = (int*)orb_smem;                       // [SCH_CHUNK] edge index e1
-    int* sM0 = sE1 + SCH_CHUNK;                      // [SCH_CHUNK] first edge of its landmark
-    int* sCnt = sM0 + SCH_CHUNK;                     // [SCH_CHUNK] number of edges of its landmark
-    short* sPose = (short*)(sCnt + SCH_CHUNK);       // [SCH_CHUNK][SCH_MAXOBS] poses of those edges
+// obs[l][pose] = first edge of pose `pose` on landmark l (or INT_MAX): the co-observation lookup of the Schur complement
+static __global__ __launch_bounds__(256) void k_lm_obs(LmArgs A, int* obs) {
     const lba_problem& P = A.P;
-    const int b = blockIdx.y, i1 = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    const int ne = min(P.n_edges[b], P.cap_e);
+    if (e >= ne) return;
+    const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
+    atomicMin(&obs[((size_t)b * P.cap_l + E.point) * P.cap_p + E.pose], e);
+}
+
+// One wave per lower-triangle block Hschur(h1, h2), h1 >= h2: lanes stride over the edges of pose i1, look the landmark up in the
+// observation table of pose i2 and accumulate  -B_i Dinv B_j^T  in registers; a fixed butterfly adds the 64 partials ->
+// deterministic, no f64 atomics, every block written exactly once (block_solver.hpp:398-432).  The diagonal wave also produces
+// the _bschur rows  b_p - sum_e B_i (Dinv b_l).
+static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const int* obs) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
     if (!A.st[b].needTrial) return;
+    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
-    if (i1 >= np) return;
+    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
+    if (i1 >= np || i2 >= np) return;
     const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
-    const int h1 = hidx[i1];
-    if (h1 < 0) return;
+    const int h1 = hidx[i1], h2 = hidx[i2];
+    if (h1 < 0 || h2 < 0 || h1 < h2) return;
     const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
     const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
     const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
     const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
-    const double lam = A.st[b].lambda;
+    const int* ob = obs + (size_t)b * P.cap_l * P.cap_p;
+    const bool diag = i1 == i2;
+    double acc[36], coef[6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) coef[k] = 0;
+    for (int k = s0 + lane; k < s1; k += 64) {
+        const int e1 = pe[k];
+        const int l = edges[e1].point;
+        int e2 = ob[(size_t)l * P.cap_p + i2];
+        if (e2 >= ne) continue;                               // pose i2 does not observe this landmark
+        const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
+        const int m1 = min(lms[l + 1], ne);
+        for (; e2 < m1 && edges[e2].pose == i2; e2++) {       // the edges of one pose on a landmark are adjacent (mono + body twin)
+            const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + e2) * 18;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
+        }
+        if (diag) {
+            const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
+            const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
+#pragma unroll
+            for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
     const int np6 = A.np6;
     double* Hs = A.Hs + (size_t)b * np6 * np6;
-    // this thread's column blocks: i2 = t, t+128, ... (<= 2 for cap_p <= 256)
-    double acc[2][36];
-    int myI2[2], myH2[2];
+    if (diag) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        myI2[u] = t + 128 * u;
-        myH2[u] = myI2[u] < np ? hidx[myI2[u]] : -1;
+        for (int k = 0; k < 6; k++)
+            for (int off = 32; off > 0; off >>= 1) coef[k] += __shfl_xor(coef[k], off);
+        if (lane < 6) {
+            double c = 0;
 #pragma unroll
-        for (int k = 0; k < 36; k++) acc[u][k] = 0;
-        if (myH2[u] >= 0 && myI2[u] == i1) {   // _Hpp->add(_Hschur) + setLambda
-            const double* H = A.S.Hpp + ((size_t)b * P.cap_p + h1) * 36;
-#pragma unroll
-            for (int k = 0; k < 36; k++) acc[u][k] = H[k] + ((k % 7 == 0) ? lam : 0.0);
+            for (int k = 0; k < 6; k++) if (lane == k) c = coef[k];
+            A.xp[(size_t)b * np6 + h1 * 6 + lane] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + lane] - c;
         }
     }
-    double coef = 0;   // threads 0..5: row t of sum_e B_i (Dinv b_l)
-    for (int c0 = s0; c0 < s1; c0 += SCH_CHUNK) {
-        const int cn = min(SCH_CHUNK, s1 - c0);
-        __syncthreads();
-        for (int k = t; k < cn; k += 128) {
-            const int e1 = pe[c0 + k];
-            const int l = edges[e1].point;
-            const int m0 = lms[l], m1 = min(lms[l + 1], ne);
-            sE1[k] = e1; sM0[k] = m0; sCnt[k] = m1 - m0;
-            for (int m = m0; m < m1 && m - m0 < SCH_MAXOBS; m++) sPose[k * SCH_MAXOBS + (m - m0)] = (short)edges[m].pose;
-        }
-        __syncthreads();
-        for (int k = 0; k < cn; k++) {
-            const int e1 = sE1[k], m0 = sM0[k], cnt = sCnt[k];
-            for (int q = 0; q < cnt; q++) {
-                const int pq = q < SCH_MAXOBS ? (int)sPose[k * SCH_MAXOBS + q] : edges[m0 + q].pose;
+    if (lane < 36) {
+        double v = 0;
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    if (myH2[u] >= 0 && pq == myI2[u]) {   // every edge of pose i2 on this landmark contributes (mono + body twins)
-                        const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
-                        const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + m0 + q) * 18;
-#pragma unroll
-                        for (int c = 0; c < 6; c++)
-#pragma unroll
-                            for (int r = 0; r < 6; r++) acc[u][c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
-                    }
-                }
-            }
-            if (t < 6) {   // _bschur row, fixed edge order
-                const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
-                const double* db = A.db + ((size_t)b * P.cap_l + edges[e1].point) * 3;
-                coef += Bi[t] * db[0] + Bi[6 + t] * db[1] + Bi[12 + t] * db[2];
-            }
-        }
+        for (int k = 0; k < 36; k++) if (lane == k) v = acc[k];
+        if (diag) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + lane] + ((lane % 7 == 0) ? A.st[b].lambda : 0.0);   // _Hpp->add(_Hschur) + setLambda
+        const int c = lane / 6, r = lane - c * 6;
+        Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
     }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        if (myH2[u] < 0) continue;
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-#pragma unroll
-            for (int r = 0; r < 6; r++) Hs[(size_t)(myH2[u] * 6 + c) * np6 + h1 * 6 + r] = acc[u][c * 6 + r];
-    }
-    if (t < 6) A.xp[(size_t)b * np6 + h1 * 6 + t] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + t] - coef;
 }
 
 // dense Cholesky (lower, column-major, in place) + forward / backward substitution; one workgroup per window.
@@ -883,6 +878,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
+    s += lm_align(B * p->cap_l * p->cap_p * 4);                                       // observation table
     return s;
 }
 
@@ -910,6 +906,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     A.part = (double*)take(B * nPart * 8); A.st = (LmState*)take(B * sizeof(LmState));
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
+    int* obs = (int*)take(B * P.cap_l * P.cap_p * 4);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     // number of free poses per window (Hessian size) from pose_hidx
@@ -935,6 +932,8 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
     const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch);
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
+    if (hipMemsetAsync(obs, 0x7F, B * P.cap_l * P.cap_p * 4, st) != hipSuccess) return ORB_E_HIP;   // 0x7F7F7F7F > any edge index
+    hipLaunchKernelGGL(k_lm_obs, gE, dim3(256), 0, st, A, obs);
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
         // computeActiveErrors + activeRobustChi2, buildSystem
@@ -955,7 +954,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
             hipLaunchKernelGGL(k_lm_bd, gE, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_row, dim3(P.cap_p, batch), dim3(128), SCH_CHUNK * (12 + 2 * SCH_MAXOBS), st, A);
+            hipLaunchKernelGGL(k_lm_schur_blocks, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A, (const int*)obs);
             hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
