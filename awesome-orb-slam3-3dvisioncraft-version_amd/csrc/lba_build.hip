@@ -402,7 +402,6 @@ extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_
 //   k_lm_maxdiag     computeLambdaInit                       optimization_algorithm_levenberg.cpp:171-186
 //   k_lm_begin       per-iteration bookkeeping               :85-105
 //   k_lm_dinv        (Hll + lambda I)^-1, Dinv*b_l           block_solver.hpp:381-397 (+ setLambda :564-589)
-//   k_lm_bd          B_i * Dinv per edge                     :404
 //   k_lm_obs / k_lm_schur_blocks   landmark x pose observation table; one wave per lower-triangle 6x6 block of Hschur
 //                    (+ the coefficient rows on the diagonal), fixed butterfly -> deterministic, no f64 atomics   :398-432
 //   k_lm_chol        dense in-place Cholesky + two triangular solves, one workgroup per window   (linear_solver_eigen.h:94-123)
@@ -420,7 +419,7 @@ struct LmArgs {
     lba_problem P; lba_system S;
     double* poses; double* points;          // == P.poses / P.points (mutable)
     double* posesBak; double* pointsBak;
-    double* Dinv; double* db; double* BD;   // [cap_l][9], [cap_l][3], [cap_e][18]
+    double* Dinv; double* db;               // [cap_l][9], [cap_l][3]
     double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
@@ -435,14 +434,15 @@ static __global__ void k_lm_init(LmArgs A, int batch) {
     A.st[b] = s;
 }
 
-// deterministic second stage of the chi2 / scale reductions: one thread per window sums the block partials in order
-static __global__ void k_lm_sum_partials(LmArgs A, int batch, int n, int what, int extra) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+// deterministic second stage of the chi2 / scale reductions: one wave per window, lanes stride over the block partials,
+// fixed butterfly
+static __global__ __launch_bounds__(64) void k_lm_sum_partials(LmArgs A, int batch, int n, int what, int extra) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     double s = 0;
-    for (int i = 0; i < n; i++) s += A.part[(size_t)b * A.nPart + i];
-    if (extra >= 0) s += A.part[(size_t)b * A.nPart + extra];
-    if (what == 0) A.st[b].tempChi = s; else A.st[b].scale = s;
+    for (int i = lane; i < n; i += 64) s += A.part[(size_t)b * A.nPart + i];
+    if (lane == 0 && extra >= 0) s += A.part[(size_t)b * A.nPart + extra];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) { if (what == 0) A.st[b].tempChi = s; else A.st[b].scale = s; }
 }
 
 // computeActiveErrors + per-block partial sums of rho[0] (blocks of 256 edges)
@@ -532,22 +532,6 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
     for (int r = 0; r < 3; r++) db[r] = o[r] * bl[0] + o[3 + r] * bl[1] + o[6 + r] * bl[2];
 }
 
-static __global__ __launch_bounds__(256) void k_lm_bd(LmArgs A) {
-    const lba_problem& P = A.P;
-    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
-    if (!A.st[b].needTrial) return;
-    const int ne = min(P.n_edges[b], P.cap_e);
-    if (e >= ne) return;
-    const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
-    const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e) * 18;
-    const double* Di = A.Dinv + ((size_t)b * P.cap_l + E.point) * 9;
-    double* o = A.BD + ((size_t)b * P.cap_e + e) * 18;
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int r = 0; r < 6; r++) o[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
-}
-
 // obs[l][pose] = first edge of pose `pose` on landmark l (or INT_MAX): the co-observation lookup of the Schur complement
 static __global__ __launch_bounds__(256) void k_lm_obs(LmArgs A, int* obs) {
     const lba_problem& P = A.P;
@@ -589,7 +573,14 @@ static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const 
         const int l = edges[e1].point;
         int e2 = ob[(size_t)l * P.cap_p + i2];
         if (e2 >= ne) continue;                               // pose i2 does not observe this landmark
-        const double* BDi = A.BD + ((size_t)b * P.cap_e + e1) * 18;
+        // B_i * Dinv (block_solver.hpp:404), 6x3 column-major, recomputed here instead of stored per edge
+        const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
+        const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
+        double BDi[18];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) BDi[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
         const int m1 = min(lms[l + 1], ne);
         for (; e2 < m1 && edges[e2].pose == i2; e2++) {       // the edges of one pose on a landmark are adjacent (mono + body twin)
             const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + e2) * 18;
@@ -599,7 +590,6 @@ static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const 
                 for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
         }
         if (diag) {
-            const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
             const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
 #pragma unroll
             for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
@@ -873,7 +863,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     size_t s = 0;
     s += lm_align(B * p->cap_p * 36 * 8) + lm_align(B * p->cap_p * 6 * 8);            // Hpp, bp
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Hll, bl
-    s += lm_align(B * p->cap_e * 18 * 8) * 2;                                         // Hpl, BD
+    s += lm_align(B * p->cap_e * 18 * 8);                                             // Hpl
     s += lm_align(B * p->cap_p * 7 * 8) + lm_align(B * p->cap_l * 3 * 8);            // backups
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
@@ -899,7 +889,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     A.P = P;
     A.S.Hpp = (double*)take(B * P.cap_p * 36 * 8); A.S.bp = (double*)take(B * P.cap_p * 6 * 8);
     A.S.Hll = (double*)take(B * P.cap_l * 9 * 8); A.S.bl = (double*)take(B * P.cap_l * 3 * 8);
-    A.S.Hpl = (double*)take(B * P.cap_e * 18 * 8); A.BD = (double*)take(B * P.cap_e * 18 * 8);
+    A.S.Hpl = (double*)take(B * P.cap_e * 18 * 8);
     A.posesBak = (double*)take(B * P.cap_p * 7 * 8); A.pointsBak = (double*)take(B * P.cap_l * 3 * 8);
     A.Dinv = (double*)take(B * P.cap_l * 9 * 8); A.db = (double*)take(B * P.cap_l * 3 * 8);
     A.Hs = (double*)take(B * np6 * np6 * 8); A.xp = (double*)take(B * np6 * 8); A.xl = (double*)take(B * P.cap_l * 3 * 8);
@@ -938,7 +928,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     for (int it = 0; it < iterations && !aborted; it++) {
         // computeActiveErrors + activeRobustChi2, buildSystem
         hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-        hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
         {
             LbaArgs L;
             L.P = P; L.S = A.S;
@@ -953,14 +943,13 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_bd, gE, dim3(256), 0, st, A);
             hipLaunchKernelGGL(k_lm_schur_blocks, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A, (const int*)obs);
             hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);
             hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
             hipLaunchKernelGGL(k_lm_decide, dim3(gB), dim3(64), 0, st, A, batch);
             hipLaunchKernelGGL(k_lm_restore, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);       // pop
             int more = 0;
@@ -981,7 +970,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
         for (auto& s : on) s.active = 1;
         if (hipMemcpyAsync(A.st, on.data(), B * sizeof(LmState), hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
         hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-        hipLaunchKernelGGL(k_lm_sum_partials, dim3(gB), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
         std::vector<LmState> fin(B);
         if (hipMemcpyAsync(fin.data(), A.st, B * sizeof(LmState), hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;

@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
+    ap.add_argument("--lm-windows", type=int, default=64, help="LBA windows per GPU per step in the full-LM leg")
     args = ap.parse_args()
 
     import torch
@@ -238,6 +239,8 @@ def main():
                         "hbm_frac": round(lba_bytes * nwin * lsteps / dtl / 1e9 / HBM_PEAK_GBS, 5),
                         "what": "BlockSolver::buildSystem equivalent (residuals, Huber, Jacobians, Hpp/Hll/Hpl/b) for 100-KF/20k-landmark windows"}
         # full LM iterations: optimizer.optimize(5) per window = linearise + Schur + Cholesky + update + rho test, GPU resident
+        if args.lm_windows != nwin:   # the LM leg batches more windows: its dense Cholesky is one workgroup per window
+            Lw = LbaWindows([wins[i % len(wins)] for i in range(args.lm_windows)], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
         p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
         Lw.optimize(5)
         barrier()
@@ -251,6 +254,7 @@ def main():
         extra["lba"]["lm_iterations_per_s"] = round(float(stats[:, 0].sum()) * osteps / dto, 1)
         extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
         extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
+        extra["lba"]["lm_windows_per_step"] = args.lm_windows
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)
