@@ -255,6 +255,12 @@ def main():
         extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
         extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
         extra["lba"]["lm_windows_per_step"] = args.lm_windows
+        if world == 1 and not args.no_cpu_baseline:   # the oracle's LM (reference algorithm restated, dense Schur/Cholesky) on one host core
+            import oracle_lib as O
+            from orbhip.lba import HUBER_MONO, HUBER_STEREO
+            tc = time.perf_counter()
+            _, _, ost = O.lba_optimize(wins[0], cams, (HUBER_MONO, HUBER_STEREO), 2)
+            extra["lba"]["cpu_port_lm_iterations_per_s_1core"] = round(float(ost[0]) / (time.perf_counter() - tc), 2)
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)

@@ -68,6 +68,27 @@ public:
     void buildSystem(LbaHostSystem& out) { run(out, true); }
     void computeErrors(LbaHostSystem& out) { run(out, false); }
 
+    // optimizer.optimize(iterations) (Optimizer.cc:2205 / :2290): Levenberg-Marquardt with Schur complement on the device.
+    // Poses / points held by this object are updated (read them back with pose(i) / point(i)); returns the iterations run.
+    // pbStopFlag is polled between lambda trials like g2o's terminate().
+    int optimize(int iterations, const volatile int* pbStopFlag = nullptr, double* finalChi2 = nullptr) {
+        upload();
+        const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
+        lba_problem P{};
+        fillProblem(P, np, nl, ne);
+        void* ws = lm_ws_.ensure(lba_lm_workspace_bytes(&P, 1));
+        double stats[4] = {0, 0, 0, 0};
+        const int rc = lba_optimize(&P, 1, iterations, ws, stats, pbStopFlag, nullptr);
+        if (rc != ORB_OK && rc != ORB_E_ABORTED) throw std::runtime_error("lba_optimize failed");
+        orb_memcpy_d2h(poses_.data(), dPoses_, poses_.size() * 8, nullptr);
+        orb_memcpy_d2h(points_.data(), dPoints_, points_.size() * 8, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        if (finalChi2) *finalChi2 = stats[1];
+        return (int)stats[0];
+    }
+    const double* pose(int i) const { return &poses_[7 * i]; }     // t(x y z), q(x y z w) — SE3Quat estimate
+    const double* point(int i) const { return &points_[3 * i]; }
+
 private:
     void upload() {
         const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
@@ -87,15 +108,18 @@ private:
         if (posesDirty_) { dPoses_ = p_.upload(poses_.data(), poses_.size()); posesDirty_ = false; }
         if (pointsDirty_) { dPoints_ = x_.upload(points_.data(), points_.size()); pointsDirty_ = false; }
     }
-    void run(LbaHostSystem& o, bool full) {
-        upload();
-        const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
-        lba_problem P{};
+    void fillProblem(lba_problem& P, int np, int nl, int ne) {
         P.poses = dPoses_; P.pose_hidx = dH_; P.points = dPoints_; P.edges = dEdges_; P.lm_start = dLm_; P.pose_start = dPs_;
         P.pose_edges = dPe_; P.cameras = dCams_; P.n_poses = dCnt_; P.n_points = dCnt_ + 1; P.n_edges = dCnt_ + 2;
         P.cap_p = np; P.cap_l = nl; P.cap_e = ne; P.n_cameras = (int)cams_.size();
         P.huber_mono = (double)std::sqrt(5.991f);    // const float thHuberMono = sqrt(5.991)   Optimizer.cc:2052
         P.huber_stereo = (double)std::sqrt(7.815f);  // const float thHuberStereo = sqrt(7.815) Optimizer.cc:2053
+    }
+    void run(LbaHostSystem& o, bool full) {
+        upload();
+        const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
+        lba_problem P{};
+        fillProblem(P, np, nl, ne);
         lba_system S{};
         const size_t sz[10] = {(size_t)np * 36, (size_t)np * 6, (size_t)nl * 9, (size_t)nl * 3, (size_t)ne * 18, (size_t)ne * 3, (size_t)ne, (size_t)ne * 2, (size_t)ne, 1};
         double** ptr[10] = {&S.Hpp, &S.bp, &S.Hll, &S.bl, &S.Hpl, &S.err, &S.chi2, &S.rho, &S.depth, &S.robust_chi2_sum};
@@ -117,7 +141,7 @@ private:
     std::vector<lba_camera> cams_;
     int nfree_ = 0;
     bool dirty_ = true, posesDirty_ = true, pointsDirty_ = true;
-    detail::DevBuf p_, x_, e_, lm_, ps_, pe_, h_, c_, cnt_, out_[10];
+    detail::DevBuf p_, x_, e_, lm_, ps_, pe_, h_, c_, cnt_, out_[10], lm_ws_;
     const double *dPoses_ = nullptr, *dPoints_ = nullptr;
     const lba_edge* dEdges_ = nullptr;
     const int32_t *dLm_ = nullptr, *dPs_ = nullptr, *dPe_ = nullptr, *dH_ = nullptr, *dCnt_ = nullptr;

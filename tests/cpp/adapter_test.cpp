@@ -18,6 +18,7 @@ int omo_search_by_projection(const void*, const uint8_t*, const float*, const ui
                              const uint8_t*, int, int, int, float, int, int32_t*, int32_t*);
 void olb_build_system(const double*, const int32_t*, int, const double*, int, const void*, int, const void*, double, double, double*,
                       double*, double*, double*, double*, double*, double*, double*, double*, double*);
+void olb_optimize(double*, const int32_t*, int, double*, int, const void*, int, const void*, double, double, int, double*);
 }
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
@@ -128,6 +129,14 @@ int main() {
     orbslam3_hip::LbaHostSystem S2;
     L.computeErrors(S2);
     CHECK(std::fabs(S2.robustChi2 - rs) < 1e-9 * rs);
-    std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges\n", n, nm, ne);
+    // optimizer.optimize(5) through the adapter vs the oracle's LM
+    std::vector<double> op = poses, ox = points;
+    double ostats[4];
+    olb_optimize(op.data(), hidx.data(), 4, ox.data(), 30, edges.data(), ne, &cam, (double)std::sqrt(5.991f), (double)std::sqrt(7.815f), 5, ostats);
+    double chiFinal = 0;
+    const int its = L.optimize(5, nullptr, &chiFinal);
+    CHECK(its == (int)ostats[0] && std::fabs(chiFinal - ostats[1]) < 1e-6 * ostats[1] && ostats[1] < 0.99 * rs);
+    for (int k = 0; k < 4; k++) for (int c = 0; c < 7; c++) CHECK(std::fabs(L.pose(k)[c] - op[k * 7 + c]) < 1e-7);
+    std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;
 }
