@@ -980,3 +980,310 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     if (hipGetLastError() != hipSuccess) return ORB_E_HIP;
     return aborted ? ORB_E_ABORTED : ORB_OK;
 }
+
+// ============================================================================================================
+// Optimizer::PoseOptimization (reference src/Optimizer.cc:907-1273) — motion-only BA, one workgroup per frame,
+// the whole 4-round x 10-iteration Levenberg-Marquardt schedule inside ONE launch (no host round trips): every thread keeps
+// the same LM scalars, block reductions (fixed order) give H (6x6), b and chi2, each thread solves the 6x6 system redundantly.
+// ============================================================================================================
+struct PLin { int D; double e[3], J[18], chi2; };   // J: 3 x 6 row-major, third row zero for 2-D edges
+
+template <bool WITH_JAC>
+static __device__ __forceinline__ void pose_linearize(const pose_edge& E, const SE3& T, const lba_camera& cam, PLin& L) {
+    const double Xw[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
+    L.e[2] = 0;
+    if (E.kind == LBA_EDGE_STEREO) {   // g2o::EdgeStereoSE3ProjectXYZOnlyPose, types_six_dof_expmap.cpp:339-346, 375-404
+        L.D = 3;
+        double xt[3];
+        se3_map(T, Xw, xt);
+        const double fx = cam.p[0], fy = cam.p[1], cx = cam.p[2], cy = cam.p[3], bf = cam.bf;
+        const float invzf = 1.0f / xt[2];   // float invz, double bf member
+        double proj[3];
+        proj[0] = xt[0] * invzf * fx + cx; proj[1] = xt[1] * invzf * fy + cy; proj[2] = proj[0] - bf * invzf;
+        L.e[0] = (double)E.obs[0] - proj[0]; L.e[1] = (double)E.obs[1] - proj[1]; L.e[2] = (double)E.obs[2] - proj[2];
+        if (WITH_JAC) {
+            const double x = xt[0], y = xt[1], invz = 1.0 / xt[2], invz_2 = invz * invz;
+            double* J = L.J;
+            J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+            J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+            J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+        }
+    } else {   // EdgeSE3ProjectXYZOnlyPose / ...ToBody, OptimizableTypes.h:47-51,75-79, .cpp:50-65,93-109
+        L.D = 2;
+        double xl[3], xp[3], proj[2];
+        se3_map(T, Xw, xl);
+        Quat ql = {cam.trl_q[0], cam.trl_q[1], cam.trl_q[2], cam.trl_q[3]};
+        if (E.kind == LBA_EDGE_MONO) {
+            xp[0] = xl[0]; xp[1] = xl[1]; xp[2] = xl[2];
+            cam_project(cam, xp, proj);
+        } else {
+            SE3 Trl;
+            Trl.r = ql; Trl.t[0] = cam.trl_t[0]; Trl.t[1] = cam.trl_t[1]; Trl.t[2] = cam.trl_t[2];
+            double xe[3];
+            se3_map(se3_mul(Trl, T), Xw, xe);
+            cam_project(cam, xe, proj);
+            se3_map(Trl, xl, xp);
+        }
+        L.e[0] = (double)E.obs[0] - proj[0]; L.e[1] = (double)E.obs[1] - proj[1];
+        if (WITH_JAC) {
+            double Jp[6], M[6];
+            cam_project_jac(cam, xp, Jp);
+#pragma unroll
+            for (int i = 0; i < 6; i++) Jp[i] = -Jp[i];
+            if (E.kind == LBA_EDGE_MONO) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) M[i] = Jp[i];
+            } else {
+                double Rl[9];
+                quat_to_R(ql, Rl);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) M[r * 3 + c] = Jp[r * 3] * Rl[c] + Jp[r * 3 + 1] * Rl[3 + c] + Jp[r * 3 + 2] * Rl[6 + c];
+            }
+            const double x = xl[0], y = xl[1], z = xl[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const double m0 = M[r * 3], m1 = M[r * 3 + 1], m2 = M[r * 3 + 2];
+                L.J[r * 6 + 0] = m0 * 0 + m1 * (-z) + m2 * y;
+                L.J[r * 6 + 1] = m0 * z + m1 * 0 + m2 * (-x);
+                L.J[r * 6 + 2] = m0 * (-y) + m1 * x + m2 * 0;
+                L.J[r * 6 + 3] = m0 * 1 + m1 * 0 + m2 * 0;
+                L.J[r * 6 + 4] = m0 * 0 + m1 * 1 + m2 * 0;
+                L.J[r * 6 + 5] = m0 * 0 + m1 * 0 + m2 * 1;
+            }
+#pragma unroll
+            for (int i = 12; i < 18; i++) L.J[i] = 0.0;
+        }
+    }
+    const double s = (double)E.inv_sigma2;
+    L.chi2 = L.e[0] * s * L.e[0] + L.e[1] * s * L.e[1] + L.e[2] * s * L.e[2];
+}
+
+static __device__ __forceinline__ SE3 se3_exp(const double* u) {   // SE3Quat::exp, se3quat.h:223-256
+    const double om0 = u[0], om1 = u[1], om2 = u[2];
+    const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+    const double O[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+    double O2[9], Rm[9], V[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const double I = (k % 4 == 0) ? 1.0 : 0.0;
+        if (theta < 0.00001) { Rm[k] = I + O[k] + O2[k]; V[k] = Rm[k]; }
+        else {
+            Rm[k] = I + sin(theta) / theta * O[k] + (1 - cos(theta)) / (theta * theta) * O2[k];
+            V[k] = I + (1 - cos(theta)) / (theta * theta) * O[k] + (theta - sin(theta)) / (theta * theta * theta) * O2[k];
+        }
+    }
+    SE3 D;
+    D.r = quat_from_R(Rm);
+    quat_normalize(D.r);
+#pragma unroll
+    for (int r = 0; r < 3; r++) D.t[r] = V[r * 3] * u[3] + V[r * 3 + 1] * u[4] + V[r * 3 + 2] * u[5];
+    return D;
+}
+
+// 6x6 SPD solve (column-major, lower Cholesky) in registers; returns false when the matrix is not positive definite
+static __device__ __forceinline__ bool chol6(double* S, double* x) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        double dkk = S[k * 6 + k];
+        if (!(dkk > 0) || !(dkk < 1.7e308)) return false;
+        dkk = sqrt(dkk);
+        S[k * 6 + k] = dkk;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) S[k * 6 + i] /= dkk;
+#pragma unroll
+        for (int j = k + 1; j < 6; j++)
+#pragma unroll
+            for (int i = j; i < 6; i++) S[j * 6 + i] -= S[k * 6 + i] * S[k * 6 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= S[k * 6 + i] * x[k]; x[i] = v / S[i * 6 + i]; }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < 6; k++) v -= S[i * 6 + k] * x[k]; x[i] = v / S[i * 6 + i]; }
+    return true;
+}
+
+struct PoseOptArgs {
+    const double* posesIn; const pose_edge* edges; const int32_t* nEdges; int capE;
+    const lba_camera* cams; double* posesOut; uint8_t* outlier; int32_t* nGood;
+};
+
+// block-wide sum of NV doubles per thread, result broadcast to every thread (fixed order: butterfly inside a wave, waves 0..3)
+template <int NV>
+static __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) scratch[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = ((scratch[k] + scratch[NV + k]) + scratch[2 * NV + k]) + scratch[3 * NV + k];
+}
+
+static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ne = min(A.nEdges[b], A.capE);
+    double* scratch = (double*)orb_smem;                  // [4 * 28]
+    double* chiLast = scratch + 4 * 28;                   // [capE]
+    uint8_t* level = (uint8_t*)(chiLast + A.capE);        // [capE]
+    uint8_t* outl = level + A.capE;                       // [capE]
+    const pose_edge* edges = A.edges + (size_t)b * A.capE;
+    const SE3 T0 = load_pose(A.posesIn + (size_t)b * 7);
+    for (int e = tid; e < ne; e += 256) { chiLast[e] = 0; level[e] = 0; outl[e] = 0; }
+    __syncthreads();
+    const double deltaMono = (double)sqrtf(5.991f), deltaStereo = (double)sqrtf(7.815f);
+    SE3 T = T0;
+    int nBad = 0;
+    bool robust = true;
+    if (ne >= 3) {
+        for (int it = 0; it < 4; it++) {
+            T = T0;
+            double na[1] = {0};
+            for (int e = tid; e < ne; e += 256) na[0] += level[e] == 0 ? 1.0 : 0.0;
+            block_sum<1>(na, scratch);
+            auto evalErrors = [&](const SE3& Tc) {   // computeActiveErrors + activeRobustChi2
+                double s[1] = {0};
+                for (int e = tid; e < ne; e += 256) {
+                    if (level[e] != 0) continue;
+                    const pose_edge E = edges[e];
+                    PLin L;
+                    pose_linearize<false>(E, Tc, A.cams[E.cam], L);
+                    chiLast[e] = L.chi2;
+                    double r0 = L.chi2;
+                    if (robust) { const double d = E.kind == LBA_EDGE_STEREO ? deltaStereo : deltaMono, dsq = d * d; if (!(L.chi2 <= dsq)) r0 = 2 * sqrt(L.chi2) * d - dsq; }
+                    s[0] += r0;
+                }
+                block_sum<1>(s, scratch);
+                return s[0];
+            };
+            if (na[0] > 0) {
+                double lambda = -1, ni = 2;
+                int nBadLM = 0;
+                for (int iter = 0; iter < 10; iter++) {
+                    double currentChi = evalErrors(T), tempChi = currentChi;
+                    const double iniChi = currentChi;
+                    double acc[27];   // 21 lower-triangle entries of H (column-major order c2 <= c) + 6 of b
+#pragma unroll
+                    for (int k = 0; k < 27; k++) acc[k] = 0;
+                    for (int e = tid; e < ne; e += 256) {
+                        if (level[e] != 0) continue;
+                        const pose_edge E = edges[e];
+                        PLin L;
+                        pose_linearize<true>(E, T, A.cams[E.cam], L);
+                        double rho1 = 1.0;
+                        if (robust) { const double d = E.kind == LBA_EDGE_STEREO ? deltaStereo : deltaMono; if (!(L.chi2 <= d * d)) rho1 = d / sqrt(L.chi2); }
+                        const double s = (double)E.inv_sigma2;
+                        int t = 0;
+#pragma unroll
+                        for (int c2 = 0; c2 < 6; c2++)
+#pragma unroll
+                            for (int c = c2; c < 6; c++) {
+                                double h = 0;
+#pragma unroll
+                                for (int r = 0; r < 3; r++) h += L.J[r * 6 + c] * (rho1 * s) * L.J[r * 6 + c2];
+                                acc[t++] += h;
+                            }
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            double a = 0;
+#pragma unroll
+                            for (int r = 0; r < 3; r++) a += L.J[r * 6 + c] * s * L.e[r];
+                            acc[21 + c] -= rho1 * a;
+                        }
+                    }
+                    block_sum<27>(acc, scratch);
+                    double H[36], bvec[6];
+                    {
+                        int t = 0;
+#pragma unroll
+                        for (int c2 = 0; c2 < 6; c2++)
+#pragma unroll
+                            for (int c = c2; c < 6; c++) { H[c2 * 6 + c] = acc[t]; H[c * 6 + c2] = acc[t]; t++; }
+#pragma unroll
+                        for (int c = 0; c < 6; c++) bvec[c] = acc[21 + c];
+                    }
+                    if (iter == 0) {
+                        double md = 0;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) md = fmax(md, fabs(H[j * 7]));
+                        lambda = 1e-50 * md; ni = 2; nBadLM = 0;
+                    }
+                    double rho = 0;
+                    int qmax = 0;
+                    do {
+                        const SE3 Tbak = T;
+                        double S[36], x[6];
+#pragma unroll
+                        for (int k = 0; k < 36; k++) S[k] = H[k] + ((k % 7 == 0) ? lambda : 0.0);
+#pragma unroll
+                        for (int k = 0; k < 6; k++) x[k] = bvec[k];
+                        const bool ok2 = chol6(S, x);
+                        if (ok2) T = se3_mul(se3_exp(x), T);
+                        tempChi = evalErrors(T);
+                        if (!ok2) tempChi = 1.7976931348623157e308;
+                        rho = currentChi - tempChi;
+                        double scale = 0;
+                        if (ok2) {
+#pragma unroll
+                            for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + bvec[j]);
+                        }
+                        scale += 1e-3;
+                        rho /= scale;
+                        if (rho > 0 && tempChi < 1.7976931348623157e308 && tempChi == tempChi) {
+                            double alpha = 1. - pow((2 * rho - 1), 3);
+                            alpha = fmin(alpha, 2. / 3.);
+                            lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                        } else { lambda *= ni; ni *= 2; T = Tbak; }
+                        qmax++;
+                    } while (rho < 0 && qmax < 100);
+                    if (qmax == 100 || rho == 0) break;
+                    if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                    if (nBadLM >= 3) break;
+                }
+            }
+            // classification (Optimizer.cc:1142-1246)
+            double nb[1] = {0};
+            const float th2 = 5.991f, th3 = 7.815f;
+            for (int e = tid; e < ne; e += 256) {
+                const pose_edge E = edges[e];
+                if (outl[e]) { PLin L; pose_linearize<false>(E, T, A.cams[E.cam], L); chiLast[e] = L.chi2; }
+                const float chi2 = (float)chiLast[e];
+                if (chi2 > (E.kind == LBA_EDGE_STEREO ? th3 : th2)) { outl[e] = 1; level[e] = 1; nb[0] += 1.0; }
+                else { outl[e] = 0; level[e] = 0; }
+            }
+            block_sum<1>(nb, scratch);
+            nBad = (int)nb[0];
+            if (it == 2) robust = false;
+            if (ne < 10) break;
+        }
+    }
+    for (int e = tid; e < A.capE; e += 256) A.outlier[(size_t)b * A.capE + e] = e < ne ? outl[e] : 0;
+    if (tid == 0) {
+        double* o = A.posesOut + (size_t)b * 7;
+        o[0] = T.t[0]; o[1] = T.t[1]; o[2] = T.t[2]; o[3] = T.r.x; o[4] = T.r.y; o[5] = T.r.z; o[6] = T.r.w;
+        A.nGood[b] = ne >= 3 ? ne - nBad : 0;
+    }
+}
+
+extern "C" int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                             const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                             void* stream) {
+    if (!d_poses_in || !d_edges || !d_n_edges || !d_cameras || !d_poses_out || !d_outlier || !d_n_good || cap_e < 1 || batch < 1 || n_cameras < 1)
+        return ORB_E_INVALID;
+    const size_t smem = (size_t)4 * 28 * 8 + (size_t)cap_e * 8 + 2 * (((size_t)cap_e + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    PoseOptArgs A{d_poses_in, d_edges, d_n_edges, cap_e, d_cameras, d_poses_out, d_outlier, d_n_good};
+    hipLaunchKernelGGL(k_pose_opt, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}

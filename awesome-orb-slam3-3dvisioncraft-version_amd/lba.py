@@ -259,3 +259,103 @@ def _rodrigues(w):
     if th < 1e-12:
         return np.eye(3) + K
     return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+# ---- Optimizer::PoseOptimization (Optimizer.cc:907-1273) ---------------------------------------------------------
+POSE_EDGE_DTYPE = np.dtype([("xw", "<f4", (3,)), ("obs", "<f4", (3,)), ("inv_sigma2", "<f4"), ("kind", "<i2"), ("cam", "<i2")])
+assert POSE_EDGE_DTYPE.itemsize == 32
+
+
+def bind_pose(lib):
+    lib.pose_optimize.restype = C.c_int
+    lib.pose_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    return lib
+
+
+def pose_optimization(poses, edges, n_edges, cameras, lib=None):
+    """Batched Optimizer::PoseOptimization: poses [B,7] f64 (t, q of Tcw), edges [B,cap_e] POSE_EDGE_DTYPE viewed as u8 [B,cap_e*32],
+    n_edges [B] i32, cameras u8 view of CAM_DTYPE[n].  All arrays device tensors (or numpy in the emulated build).
+    -> (poses_out [B,7], outlier [B,cap_e] u8, n_good [B] i32) — n_good == the reference's return value nInitialCorrespondences-nBad."""
+    L = bind_pose(lib if lib is not None else _lib.load())
+    B = poses.shape[0]
+    cap_e = edges.shape[1] // POSE_EDGE_DTYPE.itemsize if edges.dtype != POSE_EDGE_DTYPE else edges.shape[1]
+    out = _like64(poses, (B, 7))
+    outlier = _like(poses, (B, cap_e), np.uint8)
+    n_good = _like(poses, (B,), np.int32)
+    n_cam = cameras.shape[0] // CAM_DTYPE.itemsize if cameras.dtype != CAM_DTYPE else cameras.shape[0]
+    rc = L.pose_optimize(_ptr(poses), _ptr(edges), _ptr(n_edges), cap_e, B, _ptr(cameras), n_cam, _ptr(out), _ptr(outlier), _ptr(n_good),
+                         _stream(poses))
+    if rc != 0:
+        raise OrbHipError(rc, "pose_optimize failed")
+    return out, outlier, n_good
+
+
+def synth_pose_frames(seed=0, batch=4, n_pts=300, kind="mono", outlier_frac=0.1, pose_noise=(0.02, 0.05), fx=458.654, fy=457.296, cx=367.215,
+                      cy=248.375, bf=47.9, width=752, height=480):
+    """Synthetic tracking frames: map points in front of a camera, observations with octave-dependent sigma, gross outliers, and an
+    initial pose perturbed off the truth.  kind: mono | stereo (mix of mono and stereo edges, RGB-D/stereo) | body (fisheye rig, KB8)."""
+    rng = np.random.default_rng(seed)
+    cams = np.zeros(2, CAM_DTYPE)
+    if kind == "body":
+        for c in cams:
+            c["model"] = CAM_KB8; c["p"][:8] = [190.978, 190.973, 254.93, 256.9, 0.0034, 0.0007, -0.0020, 0.0002]
+        cams[1]["trl_q"] = rot_to_quat(_rodrigues(np.array([0.0, 0.02, 0.0]))); cams[1]["trl_t"] = [-0.1, 0.001, 0.0005]
+        cams[0]["trl_q"] = [0, 0, 0, 1]
+        width = height = 512
+    else:
+        for c in cams:
+            c["model"] = CAM_PINHOLE; c["p"][:4] = [fx, fy, cx, cy]; c["bf"] = bf; c["trl_q"] = [0, 0, 0, 1]
+    poses0 = np.zeros((batch, 7)); edges = np.zeros((batch, n_pts), POSE_EDGE_DTYPE); n_edges = np.zeros(batch, np.int32)
+    sig2 = 1.2 ** (2 * np.arange(8))
+    for b in range(batch):
+        R = _rodrigues(rng.normal(0, 0.3, 3)); t = rng.normal(0, 1.0, 3)
+        n = n_pts if b % 4 != 3 else max(3, n_pts // (b + 2))
+        if kind == "body":
+            u = rng.uniform(60, width - 60, n); v = rng.uniform(60, height - 60, n); z = rng.uniform(1.0, 12.0, n)
+            p = cams[0]["p"]; mx, my = (u - p[2]) / p[0], (v - p[3]) / p[1]
+            th = np.hypot(mx, my); s = np.where(th > 1e-9, np.tan(np.minimum(th, 1.3)) / np.maximum(th, 1e-9), 1.0)
+            Xc = np.stack([mx * s * z, my * s * z, z], 1)
+        else:
+            u = rng.uniform(20, width - 20, n); v = rng.uniform(20, height - 20, n); z = rng.uniform(0.8, 15.0, n)
+            Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+        Xw = (Xc - t) @ R   # R^T (Xc - t)
+        e = edges[b]
+        e["xw"][:n] = Xw.astype(np.float32)
+        Xw32 = e["xw"][:n].astype(np.float64)
+        Xc = Xw32 @ R.T + t
+        octave = rng.integers(0, 8, n)
+        e["inv_sigma2"][:n] = (1.0 / sig2[octave]).astype(np.float32)
+        noise = rng.normal(0, 1, (n, 2)) * np.sqrt(sig2[octave])[:, None] * 0.7
+        if kind == "body":
+            right = rng.random(n) < 0.4
+            e["kind"][:n] = np.where(right, EDGE_BODY, EDGE_MONO); e["cam"][:n] = np.where(right, 1, 0)
+            Rrl = _quat_to_rot(cams[1]["trl_q"]); trl = cams[1]["trl_t"]
+            Xe = np.where(right[:, None], Xc @ Rrl.T + trl, Xc)
+            p = cams[0]["p"]
+            r = np.hypot(Xe[:, 0], Xe[:, 1]); th = np.arctan2(r, Xe[:, 2])
+            thd = th * (1 + p[4] * th**2 + p[5] * th**4 + p[6] * th**6 + p[7] * th**8)
+            sc = np.where(r > 1e-12, thd / np.maximum(r, 1e-12), 1.0)
+            uv = np.stack([p[0] * sc * Xe[:, 0] + p[2], p[1] * sc * Xe[:, 1] + p[3]], 1)
+            e["obs"][:n, :2] = (uv + noise).astype(np.float32)
+        else:
+            uv = np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy], 1)
+            e["obs"][:n, :2] = (uv + noise).astype(np.float32)
+            if kind == "stereo":
+                st = rng.random(n) < 0.6
+                e["kind"][:n] = np.where(st, EDGE_STEREO, EDGE_MONO)
+                ur = uv[:, 0] - bf / Xc[:, 2] + noise[:, 0] * 0.5
+                e["obs"][:n, 2] = np.where(st, ur, 0).astype(np.float32)
+        bad = rng.random(n) < outlier_frac
+        e["obs"][:n, :2] += (bad[:, None] * rng.normal(0, 40, (n, 2))).astype(np.float32)
+        Rn = _rodrigues(rng.normal(0, pose_noise[0], 3)) @ R; tn = t + rng.normal(0, pose_noise[1], 3)
+        poses0[b, :3] = tn; poses0[b, 3:] = rot_to_quat(Rn)
+        n_edges[b] = n
+    return dict(poses=poses0, edges=edges, n_edges=n_edges, cameras=cams)
+
+
+def _quat_to_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])

@@ -172,8 +172,18 @@ def main():
         kern[k] = v
     counts = out[2].cpu().numpy()
 
-    # ---- extra leg 1: extract + match (grid build + motion-model SearchByProjection against the partner frame)
+    # ---- extra leg 0: the single-image host-buffer entry point (ORBextractor::operator() drop-in): PCIe + sync inclusive
     extra = {}
+    if not args.headline_only:
+        ex1 = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+        ex1(frames[0], None, (0, 1000))
+        th = time.perf_counter()
+        nh = 100
+        for i in range(nh):
+            ex1(frames[i % B], None, (0, 1000))
+        extra["host_api"] = {"frames_per_s": round(nh / (time.perf_counter() - th), 1),
+                             "what": "orbx_extract: one 752x480 host image per call, H2D 361 kB + 4 kernels + D2H 60 kB, synchronous (never `value`)"}
+    # ---- extra leg 1: extract + match (grid build + motion-model SearchByProjection against the partner frame)
     if not args.headline_only:
         m = orbhip.ORBmatcher(0.9, True)
         cap = out[0].shape[1]
@@ -261,6 +271,30 @@ def main():
             tc = time.perf_counter()
             _, _, ost = O.lba_optimize(wins[0], cams, (HUBER_MONO, HUBER_STEREO), 2)
             extra["lba"]["cpu_port_lm_iterations_per_s_1core"] = round(float(ost[0]) / (time.perf_counter() - tc), 2)
+        # ---- extra leg 3: Optimizer::PoseOptimization, one workgroup per frame, 4 x optimize(10) in a single launch
+        from orbhip.lba import pose_optimization, synth_pose_frames
+        pf = synth_pose_frames(seed=40 + rank, batch=64, n_pts=400, kind="stereo")
+        PB = 2048
+        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * (PB // 64)))).to(dev)
+        pP, pE, pN = rep(pf["poses"]), rep(pf["edges"].view(np.uint8).reshape(64, -1)), rep(pf["n_edges"])
+        pC = torch.from_numpy(np.ascontiguousarray(pf["cameras"]).view(np.uint8)).to(dev)
+        pose_optimization(pP, pE, pN, pC)
+        barrier()
+        psteps = 3
+        t4 = time.perf_counter()
+        for _ in range(psteps):
+            po = pose_optimization(pP, pE, pN, pC)
+        barrier()
+        dtp = time.perf_counter() - t4
+        extra["pose_optimization"] = {"frames_per_s": round(PB * psteps / dtp, 1), "ms_per_batch": round(dtp / psteps * 1e3, 3), "frames_per_batch": PB,
+                                      "edges_per_frame": float(pf["n_edges"].mean()), "mean_inliers": float(po[2].float().mean().item()),
+                                      "what": "Optimizer::PoseOptimization (4 rounds x LM optimize(10), outlier re-classification) per frame"}
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib as O
+            tc = time.perf_counter()
+            for b in range(16):
+                O.pose_optimize(pf["poses"][b], pf["edges"][b, :pf["n_edges"][b]], pf["cameras"])
+            extra["pose_optimization"]["cpu_port_frames_per_s_1core"] = round(16 / (time.perf_counter() - tc), 1)
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)

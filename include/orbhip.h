@@ -276,6 +276,23 @@ size_t lba_lm_workspace_bytes(const lba_problem* prob, int batch);
 int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
                  const volatile int* abort_flag, void* stream);
 
+/* SURVEY.md N3 — Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:907-1273): the motion-only BA that follows
+ * every matcher call in Tracking (Tracking.cc:2210,2395,2468).  One pose vertex, unary reprojection edges
+ * (EdgeSE3ProjectXYZOnlyPose OptimizableTypes.h:37-63/.cpp:50-65, EdgeSE3ProjectXYZOnlyPoseToBody :65-91/.cpp:93-109,
+ * g2o::EdgeStereoSE3ProjectXYZOnlyPose types_six_dof_expmap.cpp:339-404), 4 rounds x optimize(10) of g2o's Levenberg-Marquardt
+ * with the dense 6x6 solver, chi2 inlier/outlier re-classification between rounds (5.991 / 7.815), Huber kernel dropped for the
+ * last round, pose reset to the initial estimate at the start of every round.  One workgroup per frame runs the whole thing
+ * in a single launch.  Outputs: the optimised pose, mvbOutlier per edge, and the return value nInitialCorrespondences - nBad. */
+typedef struct pose_edge {
+    float xw[3];        /* pMP->GetWorldPos() (float in the map) */
+    float obs[3];       /* kpUn.pt.x, kpUn.pt.y, mvuRight */
+    float inv_sigma2;   /* mvInvLevelSigma2[octave] */
+    int16_t kind, cam;  /* LBA_EDGE_MONO / LBA_EDGE_STEREO / LBA_EDGE_BODY, camera index */
+} pose_edge;
+int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                  const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device-memory helpers so that adapters written against this header need no HIP headers.
  * ------------------------------------------------------------------------------------------------------- */

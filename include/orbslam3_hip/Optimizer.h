@@ -148,5 +148,52 @@ private:
     const lba_camera* dCams_ = nullptr;
 };
 
+// Optimizer::PoseOptimization(Frame* pFrame) (reference include/Optimizer.h:53, src/Optimizer.cc:907-1273) over pose_optimize().
+// The caller walks pFrame->mvpMapPoints exactly like Optimizer.cc:966-1127 and adds one observation per map point; optimize()
+// returns nInitialCorrespondences - nBad and leaves the pose (-> pFrame->SetPose) and the mvbOutlier flags (in insertion order).
+class PoseOptimizer {
+public:
+    int addCamera(const lba_camera& c) { cams_.push_back(c); return (int)cams_.size() - 1; }
+    void clear() { edges_.clear(); }
+    // monocular observation (Optimizer.cc:979-1011, or :1059-1089 for the left fisheye camera)
+    void addMono(const float Xw[3], float u, float v, float invSigma2, int cam = 0) { add(Xw, u, v, 0.f, invSigma2, LBA_EDGE_MONO, cam); }
+    // stereo observation (Optimizer.cc:1013-1049)
+    void addStereo(const float Xw[3], float u, float v, float uR, float invSigma2, int cam = 0) { add(Xw, u, v, uR, invSigma2, LBA_EDGE_STEREO, cam); }
+    // right fisheye camera observation through mTrl (Optimizer.cc:1091-1122)
+    void addBody(const float Xw[3], float u, float v, float invSigma2, int cam) { add(Xw, u, v, 0.f, invSigma2, LBA_EDGE_BODY, cam); }
+    int size() const { return (int)edges_.size(); }
+
+    // pose7 (t, q of Tcw as SE3Quat; LbaLinearizer::poseFromTcw converts) is updated in place
+    int optimize(double pose7[7], std::vector<bool>& mvbOutlier) {
+        const int ne = (int)edges_.size();
+        mvbOutlier.assign(ne, false);
+        if (ne == 0 || cams_.empty()) return 0;
+        const pose_edge* dE = e_.upload(edges_.data(), ne);
+        const lba_camera* dC = c_.upload(cams_.data(), cams_.size());
+        const double* dP = p_.upload(pose7, 7);
+        const int32_t* dN = n_.upload(&ne, 1);
+        double* dO = (double*)o_.ensure(7 * 8 + 16);
+        uint8_t* dOut = (uint8_t*)f_.ensure((size_t)ne + 16);
+        int32_t* dG = (int32_t*)g_.ensure(16);
+        if (pose_optimize(dP, dE, dN, ne, 1, dC, (int)cams_.size(), dO, dOut, dG, nullptr) != ORB_OK) throw std::runtime_error("pose_optimize");
+        std::vector<uint8_t> fl(ne);
+        int32_t good = 0;
+        orb_memcpy_d2h(pose7, dO, 56, nullptr);
+        orb_memcpy_d2h(fl.data(), dOut, ne, nullptr);
+        orb_memcpy_d2h(&good, dG, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        for (int i = 0; i < ne; i++) mvbOutlier[i] = fl[i] != 0;
+        return good;
+    }
+
+private:
+    void add(const float Xw[3], float u, float v, float uR, float s2, int kind, int cam) {
+        edges_.push_back(pose_edge{{Xw[0], Xw[1], Xw[2]}, {u, v, uR}, s2, (int16_t)kind, (int16_t)cam});
+    }
+    std::vector<pose_edge> edges_;
+    std::vector<lba_camera> cams_;
+    detail::DevBuf e_, c_, p_, n_, o_, f_, g_;
+};
+
 }  // namespace orbslam3_hip
 #endif

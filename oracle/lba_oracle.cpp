@@ -510,3 +510,167 @@ void olb_optimize(double* poses, const int32_t* pose_hidx, int n_poses, double* 
     if (stats) { stats[0] = it; stats[1] = robustChi(); stats[2] = lambda; stats[3] = trialsTotal; }
 }
 }  // extern "C"
+
+// ---- Optimizer::PoseOptimization (reference src/Optimizer.cc:907-1273) -------------------------------------------------
+//   edges: EdgeSE3ProjectXYZOnlyPose (OptimizableTypes.h:47-51, .cpp:50-65), EdgeSE3ProjectXYZOnlyPoseToBody (.h:75-79, .cpp:93-109),
+//          g2o::EdgeStereoSE3ProjectXYZOnlyPose (types_six_dof_expmap.cpp:339-346, 375-404)
+//   BaseUnaryEdge::constructQuadraticForm  g2o/core/base_unary_edge.hpp:43-70 ;  LM as in olb_optimize with LinearSolverDense (6x6)
+namespace {
+struct PEdge { float xw[3]; float obs[3]; float inv_sigma2; int16_t kind, cam; };   // == pose_edge
+struct PLin { int D; double e[3], J[18], chi2; };   // J: D x 6 row-major
+
+void poseLinearize(const PEdge& E, const SE3& T, const Camera& cam, bool withJac, PLin& L) {
+    memset(&L, 0, sizeof(L));
+    const double Xw[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
+    if (E.kind == 1) {
+        L.D = 3;
+        double xt[3];
+        se3map(T, Xw, xt);
+        const double fx = cam.p[0], fy = cam.p[1], cx = cam.p[2], cy = cam.p[3], bf = cam.bf;
+        const float invzf = 1.0f / xt[2];                 // cam_project: float invz, double bf member
+        double proj[3];
+        proj[0] = xt[0] * invzf * fx + cx; proj[1] = xt[1] * invzf * fy + cy; proj[2] = proj[0] - bf * invzf;
+        for (int i = 0; i < 3; i++) L.e[i] = (double)E.obs[i] - proj[i];
+        if (withJac) {
+            const double x = xt[0], y = xt[1], invz = 1.0 / xt[2], invz_2 = invz * invz;
+            double* J = L.J;
+            J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+            J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+            J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+        }
+    } else {
+        L.D = 2;
+        double xl[3], xp[3], proj[2], M[6];
+        se3map(T, Xw, xl);
+        if (E.kind == 0) {
+            memcpy(xp, xl, sizeof(xp));
+            camProject(cam, xp, proj);
+        } else {
+            SE3 Trl;
+            Trl.r = Quat{cam.trl_q[0], cam.trl_q[1], cam.trl_q[2], cam.trl_q[3]};
+            memcpy(Trl.t, cam.trl_t, sizeof(Trl.t));
+            double xe[3];
+            se3map(se3mul(Trl, T), Xw, xe);
+            camProject(cam, xe, proj);
+            se3map(Trl, xl, xp);
+        }
+        L.e[0] = (double)E.obs[0] - proj[0]; L.e[1] = (double)E.obs[1] - proj[1];
+        if (withJac) {
+            double Jp[6];
+            camProjectJac(cam, xp, Jp);
+            for (int i = 0; i < 6; i++) Jp[i] = -Jp[i];
+            if (E.kind == 0) memcpy(M, Jp, sizeof(M));
+            else {
+                double Rl[9];
+                toRotationMatrix(Quat{cam.trl_q[0], cam.trl_q[1], cam.trl_q[2], cam.trl_q[3]}, Rl);
+                for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) M[r * 3 + c] = Jp[r * 3] * Rl[c] + Jp[r * 3 + 1] * Rl[3 + c] + Jp[r * 3 + 2] * Rl[6 + c];
+            }
+            const double x = xl[0], y = xl[1], z = xl[2];
+            const double S[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+            for (int r = 0; r < 2; r++) for (int c = 0; c < 6; c++) L.J[r * 6 + c] = M[r * 3] * S[c] + M[r * 3 + 1] * S[6 + c] + M[r * 3 + 2] * S[12 + c];
+        }
+    }
+    const double s = (double)E.inv_sigma2;
+    for (int i = 0; i < L.D; i++) L.chi2 += L.e[i] * s * L.e[i];
+}
+}  // namespace
+
+extern "C" {
+// One frame.  pose7 in/out; outlier[n_edges] out; returns nInitialCorrespondences - nBad (0 if fewer than 3 edges).
+int opo_pose_optimize(const double* pose_in, const void* edges_, int n_edges, const void* cams_, double* pose_out, uint8_t* outlier) {
+    const PEdge* edges = (const PEdge*)edges_;
+    const Camera* cams = (const Camera*)cams_;
+    const double deltaMono = (double)std::sqrt(5.991f), deltaStereo = (double)std::sqrt(7.815f);   // const float deltaMono = sqrt(5.991)
+    const float chi2Mono[4] = {5.991f, 5.991f, 5.991f, 5.991f}, chi2Stereo[4] = {7.815f, 7.815f, 7.815f, 7.815f};
+    for (int i = 0; i < 7; i++) pose_out[i] = pose_in[i];
+    for (int e = 0; e < n_edges; e++) outlier[e] = 0;
+    if (n_edges < 3) return 0;
+    auto loadT = [](const double* p) { SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.r = Quat{p[3], p[4], p[5], p[6]}; return T; };
+    std::vector<int> level(n_edges, 0);
+    std::vector<double> chiLast(n_edges, 0.0);   // chi2 of the edge's _error at its last computeError()
+    bool robust = true;
+    int nBad = 0;
+    SE3 T = loadT(pose_in);
+    for (int it = 0; it < 4; it++) {
+        T = loadT(pose_in);                                   // vSE3->setEstimate(Converter::toSE3Quat(pFrame->mTcw))
+        // ---- optimizer.initializeOptimization(0); optimizer.optimize(10)
+        int nActive = 0;
+        for (int e = 0; e < n_edges; e++) nActive += level[e] == 0;
+        auto evalErrors = [&](const SE3& Tc) {                // computeActiveErrors + activeRobustChi2
+            double sum = 0;
+            for (int e = 0; e < n_edges; e++) {
+                if (level[e] != 0) continue;
+                PLin L;
+                poseLinearize(edges[e], Tc, cams[edges[e].cam], false, L);
+                chiLast[e] = L.chi2;
+                double r0 = L.chi2;
+                if (robust) { const double d = edges[e].kind == 1 ? deltaStereo : deltaMono, dsq = d * d; if (!(L.chi2 <= dsq)) r0 = 2 * std::sqrt(L.chi2) * d - dsq; }
+                sum += r0;
+            }
+            return sum;
+        };
+        if (nActive > 0) {
+            double lambda = -1, ni = 2;
+            int nBadLM = 0;
+            for (int iter = 0; iter < 10; iter++) {
+                double currentChi = evalErrors(T), tempChi = currentChi;
+                const double iniChi = currentChi;
+                double H[36] = {0}, bvec[6] = {0};
+                for (int e = 0; e < n_edges; e++) {
+                    if (level[e] != 0) continue;
+                    PLin L;
+                    poseLinearize(edges[e], T, cams[edges[e].cam], true, L);
+                    double rho1 = 1.0;
+                    if (robust) { const double d = edges[e].kind == 1 ? deltaStereo : deltaMono; if (!(L.chi2 <= d * d)) rho1 = d / std::sqrt(L.chi2); }
+                    const double s = (double)edges[e].inv_sigma2;
+                    for (int c = 0; c < 6; c++) {
+                        double a = 0;
+                        for (int r = 0; r < L.D; r++) a += L.J[r * 6 + c] * s * L.e[r];
+                        bvec[c] -= rho1 * a;
+                        for (int c2 = 0; c2 < 6; c2++) { double h = 0; for (int r = 0; r < L.D; r++) h += L.J[r * 6 + c] * (rho1 * s) * L.J[r * 6 + c2]; H[c2 * 6 + c] += h; }
+                    }
+                }
+                if (iter == 0) { double md = 0; for (int j = 0; j < 6; j++) md = std::max(md, std::fabs(H[j * 7])); lambda = 1e-50 * md; ni = 2; nBadLM = 0; }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    const SE3 Tbak = T;
+                    std::vector<double> S(H, H + 36), x(bvec, bvec + 6);
+                    for (int j = 0; j < 6; j++) S[j * 7] += lambda;
+                    const bool ok2 = cholSolve(S, 6, x);
+                    if (ok2) T = se3mul(se3exp(x.data()), T);
+                    tempChi = evalErrors(T);
+                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+                    if (ok2) for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + bvec[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && std::isfinite(tempChi)) {
+                        double alpha = 1. - std::pow((2 * rho - 1), 3);
+                        alpha = std::min(alpha, 2. / 3.);
+                        lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                    } else { lambda *= ni; ni *= 2; T = Tbak; }
+                    qmax++;
+                } while (rho < 0 && qmax < 100);
+                if (qmax == 100 || rho == 0) break;
+                if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                if (nBadLM >= 3) break;
+            }
+        }
+        // ---- classification (Optimizer.cc:1142-1246): outliers are re-evaluated at the final pose, inliers keep their last error
+        nBad = 0;
+        for (int e = 0; e < n_edges; e++) {
+            if (outlier[e]) { PLin L; poseLinearize(edges[e], T, cams[edges[e].cam], false, L); chiLast[e] = L.chi2; }
+            const float chi2 = (float)chiLast[e];
+            const float th = edges[e].kind == 1 ? chi2Stereo[it] : chi2Mono[it];
+            if (chi2 > th) { outlier[e] = 1; level[e] = 1; nBad++; }
+            else { outlier[e] = 0; level[e] = 0; }
+        }
+        if (it == 2) robust = false;
+        if (n_edges < 10) break;
+    }
+    pose_out[0] = T.t[0]; pose_out[1] = T.t[1]; pose_out[2] = T.t[2]; pose_out[3] = T.r.x; pose_out[4] = T.r.y; pose_out[5] = T.r.z; pose_out[6] = T.r.w;
+    return n_edges - nBad;
+}
+}  // extern "C"

@@ -19,6 +19,7 @@ int omo_search_by_projection(const void*, const uint8_t*, const float*, const ui
 void olb_build_system(const double*, const int32_t*, int, const double*, int, const void*, int, const void*, double, double, double*,
                       double*, double*, double*, double*, double*, double*, double*, double*, double*);
 void olb_optimize(double*, const int32_t*, int, double*, int, const void*, int, const void*, double, double, int, double*);
+int opo_pose_optimize(const double*, const void*, int, const void*, double*, uint8_t*);
 }
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
@@ -137,6 +138,29 @@ int main() {
     const int its = L.optimize(5, nullptr, &chiFinal);
     CHECK(its == (int)ostats[0] && std::fabs(chiFinal - ostats[1]) < 1e-6 * ostats[1] && ostats[1] < 0.99 * rs);
     for (int k = 0; k < 4; k++) for (int c = 0; c < 7; c++) CHECK(std::fabs(L.pose(k)[c] - op[k * 7 + c]) < 1e-7);
+    // ---- N3: Optimizer::PoseOptimization through PoseOptimizer vs the oracle
+    orbslam3_hip::PoseOptimizer PO;
+    PO.addCamera(cam);
+    std::vector<pose_edge> pe;
+    for (int l = 0; l < 120; l++) {
+        const float X[3] = {((int)(rnd() % 400) - 200) / 100.0f, ((int)(rnd() % 300) - 150) / 100.0f, 4.0f + (rnd() % 300) / 100.0f};
+        float u = 367.215f + 458.654f * X[0] / X[2] + ((int)(rnd() % 200) - 100) / 100.0f, v = 248.375f + 457.296f * X[1] / X[2] + ((int)(rnd() % 200) - 100) / 100.0f;
+        if (l % 11 == 0) { u += 35.f; v -= 20.f; }
+        const float s2 = 1.0f / (1.44f * (1 + l % 3)), uR = u - 47.906f / X[2];
+        if (l % 2) PO.addStereo(X, u, v, uR, s2); else PO.addMono(X, u, v, s2);
+        pe.push_back(pose_edge{{X[0], X[1], X[2]}, {u, v, l % 2 ? uR : 0.f}, s2, (int16_t)(l % 2 ? LBA_EDGE_STEREO : LBA_EDGE_MONO), 0});
+    }
+    const float Tcw0[12] = {std::cos(0.01f), 0, std::sin(0.01f), 0.03f, 0, 1, 0, -0.02f, -std::sin(0.01f), 0, std::cos(0.01f), 0.04f};
+    double pp[7], opp[7];
+    orbslam3_hip::LbaLinearizer::poseFromTcw(Tcw0, 4, pp);
+    std::vector<uint8_t> oout(pe.size());
+    const int ogood = opo_pose_optimize(pp, pe.data(), (int)pe.size(), &cam, opp, oout.data());
+    std::vector<bool> outl;
+    const int good = PO.optimize(pp, outl);
+    CHECK(good == ogood && good > 100 && good < 120);
+    for (size_t i = 0; i < pe.size(); i++) CHECK(outl[i] == (oout[i] != 0));
+    for (int c = 0; c < 7; c++) CHECK(std::fabs(pp[c] - opp[c]) < 1e-7);
+    CHECK(std::fabs(pp[0]) < 0.01 && std::fabs(pp[1]) < 0.01 && std::fabs(pp[2]) < 0.02);   // pulled back to identity
     std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;
 }

@@ -281,3 +281,14 @@ def lba_optimize(window, cameras, huber, iterations):
     stats = np.zeros(4)
     L.olb_optimize(_p(poses), _p(hidx), len(poses), _p(pts), len(pts), _p(edges), len(edges), _p(cams), huber[0], huber[1], iterations, _p(stats))
     return poses, pts, stats
+
+
+def pose_optimize(pose, edges, cameras):
+    """Optimizer::PoseOptimization restated (oracle/lba_oracle.cpp opo_pose_optimize) -> (pose_out[7], outlier[n] u8, n_good)"""
+    L = lib()
+    L.opo_pose_optimize.restype = C.c_int
+    L.opo_pose_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pose = np.ascontiguousarray(pose, np.float64); edges = np.ascontiguousarray(edges); cams = np.ascontiguousarray(cameras)
+    out = np.zeros(7); outl = np.zeros(max(len(edges), 1), np.uint8)
+    n = L.opo_pose_optimize(_p(pose), _p(edges), len(edges), _p(cams), _p(out), _p(outl))
+    return out, outl[:len(edges)], n
