@@ -14,6 +14,7 @@
 // 256-bit Hamming = 8 x v_bcnt_u32 on two 16-byte loads per descriptor.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -182,6 +183,9 @@ struct SbpArgs {
     orbm_search_params prm;
     int32_t* q_match; int32_t* kp_match; int32_t* nmatches;
     uint32_t* work;
+    int chi2_gate;              // Fuse: reprojection gate of ORBmatcher.cc:1791-1815
+    float inv_sigma2[16];
+    int32_t* q_dist;
 };
 
 // Wave-level enumeration of Frame::GetFeaturesInArea(u, v, radius, minLevel, maxLevel) in the reference's order
@@ -234,6 +238,18 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
                         const float uR = ur[idx];
                         if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
                     }
+                    if (pass && A.chi2_gate) {   // ORBmatcher.cc:1791-1815 (float e2 * float sigma, compared as double)
+                        const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                        const float s2 = A.inv_sigma2[oct & 15];
+                        if (ur && ur[idx] >= 0) {
+                            const float er = Q.u_right - ur[idx];
+                            const float e2 = ex * ex + ey * ey + er * er;
+                            if ((double)(e2 * s2) > 7.8) pass = false;
+                        } else {
+                            const float e2 = ex * ex + ey * ey;
+                            if ((double)(e2 * s2) > 5.99) pass = false;
+                        }
+                    }
                     if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
                 }
             }
@@ -265,6 +281,44 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
     if (lane == 0) { w[0] = (uint32_t)count; w[1] = 0xFFFFFFFFu; }
 }
 
+// M12 Fuse (search half): queries are independent -> one wave per query, first minimum of (dist, enumeration position).
+static __global__ __launch_bounds__(256) void k_fuse(SbpArgs A) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= A.cap_q) return;
+    const int nq = min(A.nq[b], A.cap_q);
+    int bestIdx = -1, bestDist = 256;
+    if (q < nq) {
+        const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+        const orbm_query Q = A.queries[(size_t)b * A.cap_q + q];
+        if (Q.flags & ORBM_Q_VALID) {
+            const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+            uint32_t k1 = 0xFFFFFFFFu;
+            int i1 = -1, seen = 0;
+            enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+                const unsigned long long m = __ballot(pass);
+                if (pass) {
+                    const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)((seen + __popcll(m & ((1ull << lane) - 1ull))) & 0xFFFFF);
+                    if (key < k1) { k1 = key; i1 = idx; }
+                }
+                seen += __popcll(m);
+            });
+            const uint32_t m1 = wave_min_u32(k1);
+            if (m1 != 0xFFFFFFFFu) {
+                const int l1 = __ffsll((long long)__ballot(k1 == m1)) - 1;
+                bestIdx = __shfl(i1, l1);
+                bestDist = (int)(m1 >> 20);
+            }
+        }
+    }
+    if (lane == 0) {
+        const bool ok = bestIdx >= 0 && bestDist <= A.prm.th_dist;
+        A.q_match[(size_t)b * A.cap_q + q] = ok ? bestIdx : -1;
+        A.q_dist[(size_t)b * A.cap_q + q] = bestDist;
+        if (ok) atomicAdd(&A.nmatches[b], 1);
+    }
+}
+
 // One wave per frame walks the queries in index order (ORBmatcher.cc:65 / :2265 loop order) and applies the
 // reference's accept rules against the live occupancy; distances come from k_sbp_candidates.
 // The serial chain touches LDS only: queries are staged 64 at a time (count, HAS_OBS flag and the first SBP_STAGE candidates
@@ -280,10 +334,14 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     uint32_t* sEnt = (uint32_t*)(ctl + 8);            // [64][SBP_STAGE]
     int* sCnt = (int*)(sEnt + 64 * SBP_STAGE);        // [64] count | hasObs << 30
     uint8_t* occ = (uint8_t*)(sCnt + 64);             // [cap_k] holder has Observations()>0
+    const bool initMode = A.prm.mode == ORBM_MODE_INIT;
+    uint16_t* mdist = (uint16_t*)(occ + ((A.cap_k + 15) & ~15));   // [cap_k] vMatchedDistance (INIT only; 0xFFFF = INT_MAX)
+    uint16_t* holder = mdist + A.cap_k;                            // [cap_k] vnMatches21      (INIT only; 0xFFFF = -1)
     int32_t* q_match = A.q_match + (size_t)b * A.cap_q;
     int32_t* kp_match = A.kp_match + (size_t)b * A.cap_k;
     const uint8_t* occ0 = A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
     for (int i = lane; i < A.cap_k; i += 64) { occ[i] = (i < n && occ0 && occ0[i]) ? 1 : 0; kp_match[i] = -1; }
+    if (initMode) for (int i = lane; i < A.cap_k; i += 64) { mdist[i] = 0xFFFFu; holder[i] = 0xFFFFu; }
     for (int i = lane; i < A.cap_q; i += 64) q_match[i] = -1;
     if (lane < 32) hist[lane] = 0;
     __syncthreads();
@@ -319,7 +377,8 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 if (lane < count) {
                     const uint32_t e = count <= SBP_STAGE ? sEnt[i * SBP_STAGE + lane]
                                                           : A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2 + lane];
-                    if (!occ[e & 0xFFFF]) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
+                    const bool blocked = initMode ? (uint32_t)mdist[e & 0xFFFF] <= ((e >> 16) & 0x1FF) : occ[e & 0xFFFF] != 0;
+                    if (!blocked) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
                 }
             } else {  // rare: re-enumerate this query against the live occupancy
                 const orbm_query Q = queries[q];
@@ -327,7 +386,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 int seen = 0;
                 enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
                     const unsigned long long m = __ballot(pass);
-                    if (pass && !occ[idx]) {
+                    if (pass && !(initMode ? (int)mdist[idx] <= dist : occ[idx] != 0)) {
                         const uint32_t pos = (uint32_t)(seen + __popcll(m & ((1ull << lane) - 1ull)));
                         const uint32_t key = ((uint32_t)dist << 20) | (pos & 0xFFFFF);
                         const uint32_t e = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
@@ -357,11 +416,37 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     // ORBmatcher.cc:160-178
                     if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) accept = false;
                     else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
+                } else if (initMode) {   // ORBmatcher.cc:914-918: bestDist < (float)bestDist2*mfNNratio, bestDist2 = INT_MAX when alone
+                    const uint32_t m2 = wave_min_u32(iBest ? k2 : k1);
+                    const float bestDist2 = m2 == 0xFFFFFFFFu ? (float)INT_MAX : (float)(int)(m2 >> 20);
+                    accept = (float)bestDist < bestDist2 * ratio;
                 } else {
                     accept = true;  // ORBmatcher.cc:2372
                 }
             }
-            if (accept) {
+            if (accept && initMode) {
+                const int prev = holder[bestIdx];   // vnMatches21[bestIdx2] (:920-924): the displaced F1 keypoint loses its match
+                if (prev != 0xFFFF) nmatches--;
+                nmatches++;
+                __syncthreads();
+                if (lane == 0) {
+                    if (prev != 0xFFFF) q_match[prev] = -1;
+                    q_match[q] = bestIdx;
+                    holder[bestIdx] = (uint16_t)q;
+                    mdist[bestIdx] = (uint16_t)bestDist;
+                    int bin = 30;
+                    if (A.prm.check_orientation) {   // :933-943, factor = HISTO_LENGTH/360.0f
+                        float rot = queries[q].angle - kps[bestIdx].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        bin = (int)roundf(rot * (ORBM_HISTO_LENGTH / 360.0f));
+                        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                        bin = max(0, min(bin, 29));
+                        hist[bin]++;
+                    }
+                    A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 1] = (uint32_t)bin;
+                }
+                __syncthreads();
+            } else if (accept) {
                 nmatches++;
                 if (lane == 0) {
                     occ[bestIdx] = (uint8_t)(cw >> 30);
@@ -375,6 +460,36 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     }
     __threadfence_block();
     __syncthreads();
+    if (initMode) {
+        for (int i = lane; i < n; i += 64) kp_match[i] = holder[i] == 0xFFFF ? -1 : (int)holder[i];
+        if (A.prm.check_orientation) {   // :949-973: every i1 accepted at some point sits in its bin, even if displaced later
+            if (lane == 0) {
+                int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+                for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+                    const int s = hist[i];
+                    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                    else if (s > max3) { max3 = s; ind3 = i; }
+                }
+                if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+                else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+                ctl[0] = ind1; ctl[1] = ind2; ctl[2] = ind3; ctl[3] = 0;
+            }
+            __syncthreads();
+            const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
+            for (int q = lane; q < nq; q += 64) {
+                if (q_match[q] >= 0) {
+                    const int bin = (int)A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 1];
+                    if (bin != ind1 && bin != ind2 && bin != ind3) { q_match[q] = -1; atomicAdd(&ctl[3], 1); }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            nmatches -= ctl[3];
+        }
+        if (lane == 0) A.nmatches[b] = nmatches;
+        return;
+    }
     if (ori) {
         // rotation histogram (ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()) of every accepted match
         for (int q = lane; q < nq; q += 64) {
@@ -541,6 +656,146 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
 }
 
 // ============================================================================================================
+// M12  SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)   ORBmatcher.cc:1138-1428 (pinhole, one camera)
+// ============================================================================================================
+// The reference never sets vbMatched2, so every KF1 feature is independent: its match is the gate-passing candidate of the shared
+// vocabulary node with the smallest distance <= TH_LOW, the LAST one among equals (the `dist>bestDist -> continue` update rule).
+// One workgroup per key-frame pair, one wave per shared node, lanes over the node's KF2 features.
+struct TriArgs {
+    orbm_tri_side k1, k2;
+    const orbm_tri_pair* pairs;
+    int only_stereo, coarse, check_orientation;
+    int32_t* match12; int32_t* nmatches;
+};
+
+static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* hist = (int*)orb_smem;                    // [32]
+    int* ctl = hist + 32;                          // [8]
+    int* pair2 = ctl + 8;                          // [k1.cap_nodes]
+    int8_t* bin1 = (int8_t*)(pair2 + A.k1.cap_nodes);  // [k1.cap_f] rotation bin of a matched KF1 feature, -1 otherwise
+    const int nn1 = min(A.k1.n_nodes[b], A.k1.cap_nodes), nn2 = min(A.k2.n_nodes[b], A.k2.cap_nodes);
+    const int32_t* id1 = A.k1.node_id + (size_t)b * A.k1.cap_nodes;
+    const int32_t* st1 = A.k1.node_start + (size_t)b * (A.k1.cap_nodes + 1);
+    const int32_t* fe1 = A.k1.feat_idx + (size_t)b * A.k1.cap_f;
+    const int32_t* id2 = A.k2.node_id + (size_t)b * A.k2.cap_nodes;
+    const int32_t* st2 = A.k2.node_start + (size_t)b * (A.k2.cap_nodes + 1);
+    const int32_t* fe2 = A.k2.feat_idx + (size_t)b * A.k2.cap_f;
+    const orb_keypoint* kp1s = A.k1.kps + (size_t)b * A.k1.cap_f;
+    const orb_keypoint* kp2s = A.k2.kps + (size_t)b * A.k2.cap_f;
+    const uint8_t* d1s = A.k1.desc + (size_t)b * A.k1.cap_f * 32;
+    const uint8_t* d2s = A.k2.desc + (size_t)b * A.k2.cap_f * 32;
+    const float* ur1 = A.k1.u_right ? A.k1.u_right + (size_t)b * A.k1.cap_f : nullptr;
+    const float* ur2 = A.k2.u_right ? A.k2.u_right + (size_t)b * A.k2.cap_f : nullptr;
+    const uint8_t* mp1 = A.k1.has_mp + (size_t)b * A.k1.cap_f;
+    const uint8_t* mp2 = A.k2.has_mp + (size_t)b * A.k2.cap_f;
+    const orbm_tri_pair& P = A.pairs[b];
+    int32_t* match12 = A.match12 + (size_t)b * A.k1.cap_f;
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 8) ctl[tid] = 0;
+    for (int i = tid; i < A.k1.cap_f; i += 256) { match12[i] = -1; bin1[i] = -1; }
+    for (int k = tid; k < nn1; k += 256) {   // merge walk of the two sorted FeatureVectors = intersection of the id lists
+        const int key = id1[k];
+        int lo = 0, hi = nn2;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (id2[m] < key) lo = m + 1; else hi = m; }
+        pair2[k] = (lo < nn2 && id2[lo] == key) ? lo : -1;
+    }
+    __syncthreads();
+    float F[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) F[i] = P.F12[i];
+    int myMatches = 0;
+    for (int k = wave; k < nn1; k += 4) {
+        const int n2 = pair2[k];
+        if (n2 < 0) continue;
+        const int s2 = st2[n2], e2 = st2[n2 + 1];
+        for (int i1 = st1[k]; i1 < st1[k + 1]; i1++) {
+            const int idx1 = fe1[i1];
+            if (mp1[idx1]) continue;
+            const bool bStereo1 = ur1 && ur1[idx1] >= 0;
+            if (A.only_stereo && !bStereo1) continue;
+            const orb_keypoint kp1 = kp1s[idx1];
+            const Desc d1 = load_desc(d1s + (size_t)idx1 * 32);
+            // Pinhole.cpp:162-165 epipolar line of kp1 in image 2
+            const float la = kp1.x * F[0] + kp1.y * F[3] + F[6];
+            const float lb = kp1.x * F[1] + kp1.y * F[4] + F[7];
+            const float lc = kp1.x * F[2] + kp1.y * F[5] + F[8];
+            const float den = la * la + lb * lb;
+            uint32_t k1 = 0xFFFFFFFFu;
+            int best2 = -1;
+            for (int base = s2; base < e2; base += 64) {
+                const int p = base + lane;
+                if (p >= e2) continue;
+                const int idx2 = fe2[p];
+                if (mp2[idx2]) continue;
+                const bool bStereo2 = ur2 && ur2[idx2] >= 0;
+                if (A.only_stereo && !bStereo2) continue;
+                const int dist = hamming(d1, load_desc(d2s + (size_t)idx2 * 32));
+                if (dist > ORBM_TH_LOW) continue;
+                const orb_keypoint kp2 = kp2s[idx2];
+                if (!bStereo1 && !bStereo2) {   // :1269-1277 too close to the epipole
+                    const float distex = P.ep[0] - kp2.x, distey = P.ep[1] - kp2.y;
+                    if (distex * distex + distey * distey < 100 * P.scale_factors_2[kp2.octave & 15]) continue;
+                }
+                bool ok = A.coarse != 0;
+                if (!ok && den != 0) {
+                    const float num = la * kp2.x + lb * kp2.y + lc;
+                    const float dsqr = num * num / den;
+                    ok = (double)dsqr < 3.84 * (double)P.level_sigma2_2[kp2.octave & 15];
+                }
+                if (!ok) continue;
+                const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(0xFFFFF - ((p - s2) & 0xFFFFF));
+                if (key < k1) { k1 = key; best2 = idx2; }
+            }
+            const uint32_t m1 = wave_min_u32(k1);
+            if (m1 == 0xFFFFFFFFu) continue;
+            const int l1 = __ffsll((long long)__ballot(k1 == m1)) - 1;
+            const int bestIdx2 = __shfl(best2, l1);
+            myMatches++;
+            if (lane == 0) {
+                match12[idx1] = bestIdx2;
+                int bin = 30;
+                if (A.check_orientation) {   // :1344-1353, factor = 1/HISTO_LENGTH quirk
+                    float rot = kp1.angle - kp2s[bestIdx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                    if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                    bin = max(0, min(bin, 29));
+                    atomicAdd(&hist[bin], 1);
+                }
+                bin1[idx1] = (int8_t)bin;
+            }
+        }
+    }
+    if (lane == 0 && myMatches) atomicAdd(&ctl[4], myMatches);
+    __threadfence_block();
+    __syncthreads();
+    if (A.check_orientation) {
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            ctl[0] = ind1; ctl[1] = ind2; ctl[2] = ind3;
+        }
+        __syncthreads();
+        const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
+        for (int j = tid; j < A.k1.cap_f; j += 256) {
+            const int bin = bin1[j];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) { match12[j] = -1; atomicAdd(&ctl[5], 1); }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) A.nmatches[b] = ctl[4] - ctl[5];
+}
+
+// ============================================================================================================
 // C ABI
 // ============================================================================================================
 static int launch_status() { return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP; }
@@ -577,13 +832,16 @@ extern "C" int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_
     if (!d_kps || !d_desc || !d_nkp || !d_grid_start || !d_grid_idx || !d_queries || !d_qdesc || !d_nq || !params || !d_q_match ||
         !d_kp_match || !d_nmatches || !d_work || cap_k < 1 || cap_k > 65535 || cap_q < 1 || batch < 1 || count_stride < 1)
         return ORB_E_INVALID;
-    if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY) return ORB_E_INVALID;
-    const size_t smem = (32 + 8 + 64 * 8 + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15);
+    if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY && params->mode != ORBM_MODE_INIT) return ORB_E_INVALID;
+    if (params->mode == ORBM_MODE_INIT && cap_q > 65534) return ORB_E_INVALID;
+    const size_t smem = (32 + 8 + 64 * 8 + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15) + (params->mode == ORBM_MODE_INIT ? (size_t)cap_k * 4 : 0);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     SbpArgs A;
     A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = d_occupied0; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm = *params; A.q_match = d_q_match; A.kp_match = d_kp_match; A.nmatches = d_nmatches; A.work = (uint32_t*)d_work;
+    A.chi2_gate = 0; A.q_dist = nullptr;
+    for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
     hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return launch_status();
@@ -599,5 +857,39 @@ extern "C" int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_v
     A.kf = *kf; A.f = *f; A.kf_valid = d_kf_valid; A.nn_ratio = nn_ratio; A.check_orientation = check_orientation;
     A.f_match = d_f_match; A.nmatches = d_nmatches;
     hipLaunchKernelGGL(k_bow, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    return launch_status();
+}
+
+extern "C" int orbm_fuse(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const int32_t* d_nkp, int count_stride,
+                         int cap_k, const int32_t* d_grid_start, const int32_t* d_grid_idx, const orbm_query* d_queries,
+                         const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch, const orbm_fuse_params* params,
+                         int32_t* d_q_match, int32_t* d_q_dist, int32_t* d_nfused, void* stream) {
+    if (!d_kps || !d_desc || !d_nkp || !d_grid_start || !d_grid_idx || !d_queries || !d_qdesc || !d_nq || !params || !d_q_match || !d_q_dist ||
+        !d_nfused || cap_k < 1 || cap_k > 65535 || cap_q < 1 || batch < 1 || count_stride < 1)
+        return ORB_E_INVALID;
+    SbpArgs A;
+    A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = nullptr; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;
+    A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
+    A.prm.mode = ORBM_MODE_BEST_ONLY; A.prm.th_dist = params->th_dist; A.prm.nn_ratio = 1.f; A.prm.check_orientation = 0; A.prm.grid = params->grid;
+    A.q_match = d_q_match; A.kp_match = nullptr; A.nmatches = d_nfused; A.work = nullptr; A.q_dist = d_q_dist;
+    A.chi2_gate = params->chi2_gate ? 1 : 0;
+    for (int i = 0; i < 16; i++) A.inv_sigma2[i] = params->inv_level_sigma2[i];
+    if (hipMemsetAsync(d_nfused, 0, (size_t)batch * 4, (hipStream_t)stream) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_fuse, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
+    return launch_status();
+}
+
+extern "C" int orbm_search_for_triangulation(const orbm_tri_side* kf1, const orbm_tri_side* kf2, const orbm_tri_pair* d_pairs, int batch,
+                                             int only_stereo, int coarse, int check_orientation, int32_t* d_match12, int32_t* d_nmatches,
+                                             void* stream) {
+    if (!kf1 || !kf2 || !d_pairs || !d_match12 || !d_nmatches || batch < 1 || kf1->cap_f < 1 || kf2->cap_f < 1 || kf1->cap_nodes < 1 ||
+        kf2->cap_nodes < 1 || !kf1->kps || !kf2->kps || !kf1->desc || !kf2->desc || !kf1->has_mp || !kf2->has_mp)
+        return ORB_E_INVALID;
+    const size_t smem = (32 + 8 + (size_t)kf1->cap_nodes) * 4 + (((size_t)kf1->cap_f + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    TriArgs A;
+    A.k1 = *kf1; A.k2 = *kf2; A.pairs = d_pairs; A.only_stereo = only_stereo; A.coarse = coarse; A.check_orientation = check_orientation;
+    A.match12 = d_match12; A.nmatches = d_nmatches;
+    hipLaunchKernelGGL(k_tri, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
     return launch_status();
 }

@@ -13,7 +13,7 @@ from ._lib import OrbHipError
 
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:36-38
 GRID_COLS, GRID_ROWS = 64, 48                 # Frame.h:38-39
-MODE_LOCAL_MAP, MODE_BEST_ONLY = 0, 1
+MODE_LOCAL_MAP, MODE_BEST_ONLY, MODE_INIT = 0, 1, 2
 Q_VALID, Q_STEREO, Q_HAS_OBS = 1, 2, 4
 
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("angle", "<f4"),
@@ -33,6 +33,20 @@ class SearchParams(C.Structure):
 class BowSide(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("angle", C.c_void_p), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
                 ("feat_idx", C.c_void_p), ("n_nodes", C.c_void_p), ("cap_f", C.c_int32), ("cap_nodes", C.c_int32)]
+
+
+class FuseParams(C.Structure):
+    _fields_ = [("th_dist", C.c_int32), ("chi2_gate", C.c_int32), ("grid", GridParams), ("inv_level_sigma2", C.c_float * 16)]
+
+
+class TriSide(C.Structure):
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("has_mp", C.c_void_p), ("node_id", C.c_void_p),
+                ("node_start", C.c_void_p), ("feat_idx", C.c_void_p), ("n_nodes", C.c_void_p), ("cap_f", C.c_int32), ("cap_nodes", C.c_int32)]
+
+
+TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep", "<f4", (2,)), ("level_sigma2_2", "<f4", (16,)), ("scale_factors_2", "<f4", (16,)),
+                           ("reserved", "<f4")])
+assert TRI_PAIR_DTYPE.itemsize == 176
 
 
 def _ptr(a):
@@ -70,6 +84,8 @@ def bind(lib):
         "orbm_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
                                             vp, vp, vp, vp, vp]),
         "orbm_search_by_bow": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), i32, f32, i32, vp, vp, vp]),
+        "orbm_fuse": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(FuseParams), vp, vp, vp, vp]),
+        "orbm_search_for_triangulation": (i32, [C.POINTER(TriSide), C.POINTER(TriSide), vp, i32, i32, i32, i32, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -144,3 +160,61 @@ class ORBmatcher:
         self._check(self._L.orbm_search_by_bow(C.byref(a), _ptr(kf_valid), C.byref(b), B, self.mfNNratio, int(self.mbCheckOrientation),
                                                _ptr(f_match), _ptr(nmatches), _stream(f["desc"])))
         return f_match, nmatches
+
+    # -- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:838-979)
+    def SearchForInitialization(self, kps1, desc1, n1, kps2, desc2, n2, grid_start2, grid_idx2, prev_matched, grid, windowSize=10):
+        """kps1/kps2 [B,cap,7] f32 (mvKeysUn), prev_matched [B,cap1,2] f32 (vbPrevMatched, updated in place like the reference).
+        -> (vnMatches12 [B,cap1] int32, nmatches [B])"""
+        B, cap1 = kps1.shape[0], kps1.shape[1]
+        if isinstance(kps1, np.ndarray):
+            q = np.zeros((B, cap1), QUERY_DTYPE)
+            q["u"], q["v"], q["radius"], q["angle"] = prev_matched[..., 0], prev_matched[..., 1], float(windowSize), kps1[..., 3]
+            q["flags"] = np.where(kps1.view(np.int32)[..., 5] == 0, Q_VALID, 0)
+            queries = q.view(np.uint8).reshape(B, -1)
+        else:
+            import torch
+            q = torch.zeros((B, cap1, 7), dtype=torch.float32, device=kps1.device)
+            q[..., 0], q[..., 1], q[..., 2], q[..., 4] = prev_matched[..., 0], prev_matched[..., 1], float(windowSize), kps1[..., 3]
+            q.view(torch.int32)[..., 6] = (kps1.view(torch.int32)[..., 5] == 0).to(torch.int32) * Q_VALID
+            queries = q
+        q_match, _, nm = self.SearchByProjection(kps2, desc2, n2, grid_start2, grid_idx2, queries, desc1, n1, grid, MODE_INIT, TH_LOW)
+        # :972-975  vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt for the matched ones
+        if isinstance(kps1, np.ndarray):
+            bi, qi = np.nonzero(q_match >= 0)
+            prev_matched[bi, qi] = kps2[bi, q_match[bi, qi], :2]
+        else:
+            import torch
+            bi, qi = torch.nonzero(q_match >= 0, as_tuple=True)
+            prev_matched[bi, qi] = kps2[bi, q_match[bi, qi].long(), :2]
+        return q_match, nm
+
+    # -- Fuse (search half; ORBmatcher.cc:1630-1882 with chi2_gate, :1884-2006 without)
+    def Fuse(self, kps, desc, counts, grid_start, grid_idx, queries, qdesc, nq, grid, inv_level_sigma2=None, u_right=None, th_dist=TH_LOW,
+             count_stride=1):
+        B, cap_k = kps.shape[0], kps.shape[1]
+        cap_q = qdesc.shape[1]
+        q_match = _like(kps, (B, cap_q), np.int32)
+        q_dist = _like(kps, (B, cap_q), np.int32)
+        nfused = _like(kps, (B,), np.int32)
+        prm = FuseParams(th_dist, 0 if inv_level_sigma2 is None else 1, GridParams(*grid),
+                         (C.c_float * 16)(*([float(v) for v in inv_level_sigma2] + [0.0] * 16)[:16] if inv_level_sigma2 is not None else [0.0] * 16))
+        self._check(self._L.orbm_fuse(_ptr(kps), _ptr(desc), _ptr(u_right), _ptr(counts), count_stride, cap_k, _ptr(grid_start), _ptr(grid_idx),
+                                      _ptr(queries), _ptr(qdesc), _ptr(nq), cap_q, B, C.byref(prm), _ptr(q_match), _ptr(q_dist), _ptr(nfused),
+                                      _stream(kps)))
+        return q_match, q_dist, nfused
+
+    # -- SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:1138-1428), pinhole / one camera
+    def SearchForTriangulation(self, kf1, kf2, pairs, bOnlyStereo=False, bCoarse=False):
+        """kf1 / kf2: dict(kps [B,cap,7], desc [B,cap,32], u_right [B,cap] or None, has_mp [B,cap] u8, node_id, node_start, feat_idx, n_nodes);
+        pairs: u8 view of TRI_PAIR_DTYPE[B].  -> (vMatches12 [B,cap1] int32, nmatches [B])"""
+        def side(d):
+            return TriSide(_ptr(d["kps"]).value, _ptr(d["desc"]).value, _ptr(d.get("u_right")).value if d.get("u_right") is not None else None,
+                           _ptr(d["has_mp"]).value, _ptr(d["node_id"]).value, _ptr(d["node_start"]).value, _ptr(d["feat_idx"]).value,
+                           _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1])
+        B = kf1["desc"].shape[0]
+        m12 = _like(kf1["desc"], (B, kf1["desc"].shape[1]), np.int32)
+        nm = _like(kf1["desc"], (B,), np.int32)
+        a, b = side(kf1), side(kf2)
+        self._check(self._L.orbm_search_for_triangulation(C.byref(a), C.byref(b), _ptr(pairs), B, int(bOnlyStereo), int(bCoarse),
+                                                          int(self.mbCheckOrientation), _ptr(m12), _ptr(nm), _stream(kf1["desc"])))
+        return m12, nm

@@ -154,7 +154,7 @@ typedef struct orbm_query {
 #define ORBM_Q_HAS_OBS 4u    /* pMP->Observations() > 0: once matched, the keypoint is skipped by later queries */
 
 typedef struct orbm_search_params {
-    int32_t mode;              /* ORBM_MODE_LOCAL_MAP or ORBM_MODE_BEST_ONLY */
+    int32_t mode;              /* ORBM_MODE_LOCAL_MAP, ORBM_MODE_BEST_ONLY or ORBM_MODE_INIT */
     int32_t th_dist;           /* TH_HIGH (100), or ORBdist of the relocalisation variant */
     float nn_ratio;            /* mfNNratio (LOCAL_MAP only) */
     int32_t check_orientation; /* mbCheckOrientation: rotation-histogram cull (BEST_ONLY only, as in the reference) */
@@ -166,6 +166,13 @@ typedef struct orbm_search_params {
                                 *   occupied0 = (mvpMapPoints[i] != NULL), every query ORBM_Q_HAS_OBS;
                                 * SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th, ratioHamming) :593-824 with
                                 *   check_orientation = 0, th_dist = floor(TH_LOW*ratioHamming), levels [L-1, L] */
+
+#define ORBM_MODE_INIT 2       /* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  ORBmatcher.cc:838-979:
+                                *   one query per F1 keypoint (VALID iff octave == 0; u,v = vbPrevMatched[i1]; radius = windowSize;
+                                *   min_level = max_level = 0; angle = F1 keypoint angle), th_dist = TH_LOW, nn_ratio, check_orientation.
+                                *   A candidate is skipped while vMatchedDistance[i2] <= dist; an accepted match displaces the previous
+                                *   holder of i2.  q_match = vnMatches12, kp_match = vnMatches21 (before the orientation cull).
+                                *   Histogram factor HISTO_LENGTH/360 (this fork, :852).  cap_q <= 65534. */
 
 /* Windowed projection search, results identical to the reference's serial loop (queries are resolved in index
  * order; a keypoint claimed by an earlier query with ORBM_Q_HAS_OBS is skipped by later ones).
@@ -181,6 +188,53 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
                               const orbm_query* d_queries, const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch,
                               const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
                               void* d_work, void* stream);
+
+/* ORBmatcher::Fuse — the search half of both overloads: per projected map point the best keypoint of the key frame.
+ *   chi2_gate = 1: Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight)           ORBmatcher.cc:1630-1882 (search :1770-1830)
+ *   chi2_gate = 0: Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint)      ORBmatcher.cc:1884-2006 (search :1960-1985)
+ * A query = what the reference computes per map point before KeyFrame::GetFeaturesInArea (KeyFrame.cc:810-854): u,v = uv,
+ * u_right = uv.x - bf*invz, radius = th*mvScaleFactors[nPredictedLevel], min_level = nPredictedLevel-1, max_level = nPredictedLevel,
+ * flags = ORBM_Q_VALID iff the point passed the frustum / distance / normal gates (:1700-1765).  Queries are independent (several map
+ * points may select the same keypoint; the Replace / AddObservation mutations stay in the host adapter, applied in index order).
+ * Outputs: q_match[b][q] = bestIdx if bestDist <= th_dist else -1; q_dist[b][q] = bestDist (256: empty window); nfused[b]. */
+typedef struct orbm_fuse_params {
+    int32_t th_dist;              /* TH_LOW */
+    int32_t chi2_gate;
+    orbm_grid_params grid;
+    float inv_level_sigma2[16];   /* pKF->mvInvLevelSigma2 (chi2_gate only) */
+} orbm_fuse_params;
+int orbm_fuse(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const int32_t* d_nkp, int count_stride, int cap_k,
+              const int32_t* d_grid_start, const int32_t* d_grid_idx, const orbm_query* d_queries, const uint8_t* d_qdesc,
+              const int32_t* d_nq, int cap_q, int batch, const orbm_fuse_params* params, int32_t* d_q_match, int32_t* d_q_dist,
+              int32_t* d_nfused, void* stream);
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:1138-1428; call sites
+ * LocalMapping.cc:628, Tracking.cc:3812) for pinhole key frames without a second camera.  Both FeatureVectors as CSR like
+ * orbm_bow_side; has_mp[i] != 0 where pKF->GetMapPoint(i) != NULL; u_right = mvuRight (NULL = monocular).
+ * Per pair: the fundamental matrix Pinhole::epipolarConstrain builds (Pinhole.cpp:157-160, row-major F12 = K1^-T [t12]x R12 K2^-1;
+ * the adapter evaluates that cv::Mat expression once per pair), the epipole ep (ORBmatcher.cc:1152) and pKF2's mvLevelSigma2 /
+ * mvScaleFactors.  Output match12[b][i1] = idx2 or -1 (vMatches12 after the orientation cull), nmatches[b]. */
+typedef struct orbm_tri_side {
+    const orb_keypoint* kps;      /* [batch][cap_f]  mvKeysUn */
+    const uint8_t* desc;          /* [batch][cap_f][32] */
+    const float* u_right;         /* [batch][cap_f] or NULL */
+    const uint8_t* has_mp;        /* [batch][cap_f] */
+    const int32_t* node_id;       /* [batch][cap_nodes] ascending */
+    const int32_t* node_start;    /* [batch][cap_nodes+1] */
+    const int32_t* feat_idx;      /* [batch][cap_f] */
+    const int32_t* n_nodes;       /* [batch] */
+    int32_t cap_f, cap_nodes;
+} orbm_tri_side;
+typedef struct orbm_tri_pair {
+    float F12[9];
+    float ep[2];
+    float level_sigma2_2[16];     /* pKF2->mvLevelSigma2 */
+    float scale_factors_2[16];    /* pKF2->mvScaleFactors */
+    float reserved;
+} orbm_tri_pair;
+int orbm_search_for_triangulation(const orbm_tri_side* kf1, const orbm_tri_side* kf2, const orbm_tri_pair* d_pairs, int batch,
+                                  int only_stereo, int coarse, int check_orientation, int32_t* d_match12, int32_t* d_nmatches,
+                                  void* stream);
 
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:323-587, Nleft == -1 branch).
  * FeatureVector of each side as CSR: node ids ascending (std::map order), node_start[k..k+1] delimit feat_idx[] (the

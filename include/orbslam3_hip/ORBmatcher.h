@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "../orbhip.h"
@@ -98,11 +99,117 @@ public:
         return nmatches;
     }
 
+    // ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.h:71, ORBmatcher.cc:838-979).
+    // vbPrevMatched: x,y pairs per F1 keypoint, updated in place for the matched ones (:972-975).
+    int SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<float>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10) {
+        std::vector<orbm_query> q(F1.N);
+        for (int i = 0; i < F1.N; i++) {
+            q[i] = orbm_query{vbPrevMatched[2 * i], vbPrevMatched[2 * i + 1], (float)windowSize, 0.f, F1.keysUn[i].angle, 0, 0,
+                              F1.keysUn[i].octave == 0 ? ORBM_Q_VALID : 0u};
+        }
+        std::vector<uint8_t> qd(F1.descriptors, F1.descriptors + (size_t)F1.N * 32);
+        std::vector<int> vnMatches21;
+        const int n = SearchByProjection(F2, q, qd, ORBM_MODE_INIT, TH_LOW, vnMatches21, vnMatches12);
+        for (int i = 0; i < F1.N; i++)
+            if (vnMatches12[i] >= 0) { vbPrevMatched[2 * i] = F2.keysUn[vnMatches12[i]].x; vbPrevMatched[2 * i + 1] = F2.keysUn[vnMatches12[i]].y; }
+        return n;
+    }
+
+    // The search half of ORBmatcher::Fuse (ORBmatcher.h:85-88).  The caller computes per map point what the reference computes before
+    // KeyFrame::GetFeaturesInArea (uv, ur, radius = th*mvScaleFactors[nPredictedLevel], levels [nPredictedLevel-1, nPredictedLevel];
+    // flags = ORBM_Q_VALID iff the point passed the gates of ORBmatcher.cc:1700-1765 / :1910-1955) and afterwards applies
+    // Replace / AddObservation / vpReplacePoint in index order on bestIdx[i] >= 0 (ORBmatcher.cc:1832-1855 / :1987-2000).
+    // invLevelSigma2 != nullptr selects the KeyFrame overload's chi2 gate (:1791-1815); nullptr = the Sim3 overload.
+    int Fuse(const FrameView& KF, const std::vector<orbm_query>& queries, const std::vector<uint8_t>& qdesc, const float* invLevelSigma2,
+             int nLevels, std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+        const int n = KF.N, nq = (int)queries.size();
+        bestIdx.assign(nq, -1);
+        bestDist.assign(nq, 256);
+        if (n == 0 || nq == 0) return 0;
+        const orb_keypoint* dk = kps_.upload(KF.keysUn, n);
+        const uint8_t* dd = desc_.upload(KF.descriptors, (size_t)n * 32);
+        const float* dur = KF.uRight ? ur_.upload(KF.uRight, n) : nullptr;
+        const orbm_query* dq = q_.upload(queries.data(), nq);
+        const uint8_t* dqd = qd_.upload(qdesc.data(), (size_t)nq * 32);
+        int32_t counts[2] = {n, nq};
+        const int32_t* dc = cnt_.upload(counts, 2);
+        int32_t* gs = (int32_t*)gs_.ensure((ORBM_GRID_COLS * ORBM_GRID_ROWS + 1) * 4);
+        int32_t* gi = (int32_t*)gi_.ensure((size_t)n * 4);
+        int32_t* dqm = (int32_t*)qm_.ensure((size_t)nq * 4);
+        int32_t* dqdist = (int32_t*)km_.ensure((size_t)nq * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        if (orbm_grid_build(dk, dc, 1, n, 1, &KF.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build");
+        orbm_fuse_params prm{};
+        prm.th_dist = TH_LOW; prm.chi2_gate = invLevelSigma2 ? 1 : 0; prm.grid = KF.grid;
+        for (int i = 0; i < 16 && i < nLevels && invLevelSigma2; i++) prm.inv_level_sigma2[i] = invLevelSigma2[i];
+        if (orbm_fuse(dk, dd, dur, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dqdist, dnm, nullptr) != ORB_OK) throw std::runtime_error("orbm_fuse");
+        int nFused = 0;
+        orb_memcpy_d2h(bestIdx.data(), dqm, (size_t)nq * 4, nullptr);
+        orb_memcpy_d2h(bestDist.data(), dqdist, (size_t)nq * 4, nullptr);
+        orb_memcpy_d2h(&nFused, dnm, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        return nFused;
+    }
+
+    // One key frame as SearchForTriangulation reads it: mvKeysUn, mDescriptors, mvuRight, GetMapPoint(i) != NULL, and mFeatVec as CSR
+    // (node ids ascending = std::map order; featIdx = the concatenated per-node index vectors).
+    struct KeyFrameView {
+        int N = 0;
+        const orb_keypoint* keysUn = nullptr;
+        const uint8_t* descriptors = nullptr;
+        const float* uRight = nullptr;
+        const uint8_t* hasMapPoint = nullptr;
+        std::vector<int32_t> nodeId, nodeStart, featIdx;
+    };
+    // ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.h:74, ORBmatcher.cc:1138-1428)
+    // for pinhole key frames without mpCamera2.  F12: row-major K1^-T [t12]x R12 K2^-1 (the expression of Pinhole.cpp:157-160, evaluated
+    // by the caller with the same cv::Mat arithmetic); ep: pKF2->mpCamera->project(R2w*Cw+t2w) (:1149-1152).
+    int SearchForTriangulation(const KeyFrameView& K1, const KeyFrameView& K2, const float F12[9], const float ep[2], const float* levelSigma2_2,
+                               const float* scaleFactors_2, int nLevels, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bOnlyStereo,
+                               bool bCoarse = false) {
+        vMatchedPairs.clear();
+        if (K1.N == 0 || K2.N == 0 || K1.nodeId.empty() || K2.nodeId.empty()) return 0;
+        orbm_tri_side s[2];
+        const KeyFrameView* K[2] = {&K1, &K2};
+        int32_t nn[2] = {(int32_t)K1.nodeId.size(), (int32_t)K2.nodeId.size()};
+        const int32_t* dnn = cnt_.upload(nn, 2);
+        for (int i = 0; i < 2; i++) {
+            s[i].kps = tk_[i].upload(K[i]->keysUn, K[i]->N);
+            s[i].desc = td_[i].upload(K[i]->descriptors, (size_t)K[i]->N * 32);
+            s[i].u_right = K[i]->uRight ? tu_[i].upload(K[i]->uRight, K[i]->N) : nullptr;
+            s[i].has_mp = tm_[i].upload(K[i]->hasMapPoint, K[i]->N);
+            s[i].node_id = tn_[i].upload(K[i]->nodeId.data(), K[i]->nodeId.size());
+            s[i].node_start = ts_[i].upload(K[i]->nodeStart.data(), K[i]->nodeStart.size());
+            s[i].feat_idx = tf_[i].upload(K[i]->featIdx.data(), K[i]->featIdx.size());
+            s[i].n_nodes = dnn + i;
+            s[i].cap_f = K[i]->N; s[i].cap_nodes = nn[i];
+        }
+        orbm_tri_pair P{};
+        for (int i = 0; i < 9; i++) P.F12[i] = F12[i];
+        P.ep[0] = ep[0]; P.ep[1] = ep[1];
+        for (int i = 0; i < 16 && i < nLevels; i++) { P.level_sigma2_2[i] = levelSigma2_2[i]; P.scale_factors_2[i] = scaleFactors_2[i]; }
+        const orbm_tri_pair* dP = q_.upload(&P, 1);
+        int32_t* dm = (int32_t*)qm_.ensure((size_t)K1.N * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        if (orbm_search_for_triangulation(&s[0], &s[1], dP, 1, bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0, mbCheckOrientation ? 1 : 0, dm, dnm, nullptr) != ORB_OK)
+            throw std::runtime_error("orbm_search_for_triangulation");
+        std::vector<int32_t> m12(K1.N);
+        int nmatches = 0;
+        orb_memcpy_d2h(m12.data(), dm, (size_t)K1.N * 4, nullptr);
+        orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        for (int i = 0; i < K1.N; i++)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));   // :1415-1422
+        return nmatches;
+    }
+
     float mfNNratio;
     bool mbCheckOrientation;
 
 private:
     detail::DevBuf kps_, desc_, ur_, occ_, q_, qd_, cnt_, gs_, gi_, qm_, km_, nm_, work_;
+    detail::DevBuf tk_[2], td_[2], tu_[2], tm_[2], tn_[2], ts_[2], tf_[2];
 };
 
 }  // namespace orbslam3_hip

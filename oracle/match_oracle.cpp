@@ -13,6 +13,7 @@
 //   Frame::ComputeStereoFishEyeMatches' knnMatch      src/Frame.cc:1300 (cv::BFMatcher NORM_HAMMING, k=2)
 // line by line, with the pointer-graph reads replaced by the flattened fields.  Parity for this stage is pinned
 // by the reference source itself (integer Hamming + float compares), except knnMatch's tie rule [recalled].
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -277,6 +278,204 @@ void omo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out_i
         out_idx[2 * i] = i0; out_idx[2 * i + 1] = i1;
         out_dist[2 * i] = d0; out_dist[2 * i + 1] = d1;
     }
+}
+
+// ---- SURVEY N1 / rows M11, M12 -----------------------------------------------------------------------------------------------
+// M11 ORBmatcher::SearchForInitialization (ORBmatcher.cc:838-979).  prev: vbPrevMatched [n1][2] (updated in place, :972-975).
+// NOTE this fork computes the histogram bin with factor = HISTO_LENGTH/360.0f here (:852), unlike the other searches.
+int omo_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_, const uint8_t* desc2, int n2,
+                                  float minX, float minY, float gwInv, float ghInv, float* prev, int windowSize, float nnratio,
+                                  int checkOri, int32_t* matches12) {
+    const KeyPoint* kps1 = (const KeyPoint*)kps1_;
+    FrameView F2{n2, (const KeyPoint*)kps2_, desc2, nullptr, minX, minY, gwInv, ghInv};
+    F2.AssignFeaturesToGrid();
+    int nmatches = 0;
+    std::vector<int> vnMatches12(n1, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    std::vector<int> vMatchedDistance(n2, INT_MAX);
+    std::vector<int> vnMatches21(n2, -1);
+    for (size_t i1 = 0, iend1 = n1; i1 < iend1; i1++) {
+        KeyPoint kp1 = kps1[i1];
+        int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(prev[2 * i1], prev[2 * i1 + 1], windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = desc1 + i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (std::vector<size_t>::iterator vit = vIndices2.begin(); vit != vIndices2.end(); vit++) {
+            size_t i2 = *vit;
+            int dist = DescriptorDistance(d1, desc2 + i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) { bestDist2 = dist; }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = (int)i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = kps1[i1].angle - F2.kps[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back((int)i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (size_t i1 = 0; i1 < (size_t)n1; i1++) {
+        matches12[i1] = vnMatches12[i1];
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = F2.kps[vnMatches12[i1]].x; prev[2 * i1 + 1] = F2.kps[vnMatches12[i1]].y; }
+    }
+    return nmatches;
+}
+
+// M12 ORBmatcher::Fuse — the search half of both overloads (the pointer-graph mutations Replace/AddObservation stay on the host):
+//   chi2_gate=1: Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight)  ORBmatcher.cc:1630-1882 (:1770-1830 is restated here)
+//   chi2_gate=0: Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint)  ORBmatcher.cc:1884-2006 (:1960-1985)
+// A query carries what the reference computes per map point before GetFeaturesInArea: uv, ur, radius, nPredictedLevel (=max_level;
+// min_level = nPredictedLevel-1).  KeyFrame::GetFeaturesInArea (KeyFrame.cc:810-854) has no level filter.
+// q_match[q] = bestIdx if bestDist <= th_dist else -1; q_dist[q] = bestDist (256 when the window was empty).  Returns nFused.
+int omo_fuse(const void* kps, const uint8_t* desc, const float* uRight, int n, float minX, float minY, float gwInv, float ghInv,
+             const void* queries_, const uint8_t* qdesc, int nq, int th_dist, int chi2_gate, const float* invLevelSigma2, int32_t* q_match,
+             int32_t* q_dist) {
+    FrameView F{n, (const KeyPoint*)kps, desc, uRight, minX, minY, gwInv, ghInv};
+    F.AssignFeaturesToGrid();
+    const Query* Q = (const Query*)queries_;
+    int nFused = 0;
+    for (int i = 0; i < nq; i++) {
+        q_match[i] = -1; q_dist[i] = 256;
+        const Query& q = Q[i];
+        if (!(q.flags & Q_VALID)) continue;
+        const int nPredictedLevel = q.max_level;
+        const float ur = q.u_right;
+        const std::vector<size_t> vIndices = F.GetFeaturesInArea(q.u, q.v, q.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = qdesc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            size_t idx = *vit;
+            const KeyPoint& kp = F.kps[idx];
+            const int& kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2_gate) {
+                if (F.uRight && F.uRight[idx] >= 0) {
+                    const float ex = q.u - kp.x, ey = q.v - kp.y, er = ur - F.uRight[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = q.u - kp.x, ey = q.v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = DescriptorDistance(dMP, F.desc + idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        q_dist[i] = bestDist;
+        if (bestDist <= th_dist) { q_match[i] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
+// M12 ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)  ORBmatcher.cc:1138-1428, for pinhole
+// key frames without a second camera (mpCamera2 == NULL).  The epipolar gate is Pinhole::epipolarConstrain (Pinhole.cpp:155-177) with
+// its fundamental matrix F12 = K1^-T [t12]x R12 K2^-1 passed in (it is a constant of the key-frame pair; the reference recomputes it
+// per candidate with cv::Mat arithmetic).  has_mp*: pKF->GetMapPoint(idx) != NULL.  Note vbMatched2 is never set by the reference.
+struct TriSide {
+    const KeyPoint* kps; const uint8_t* desc; const float* uRight; const uint8_t* has_mp;
+    const int32_t* node_id; const int32_t* node_start; const int32_t* feat; int n_nodes, N;
+};
+int omo_search_for_triangulation(const void* s1_, const void* s2_, const float* F12, const float* ep, const float* levelSigma2_2,
+                                 const float* scaleFactors_2, int bOnlyStereo, int bCoarse, int checkOri, int32_t* matches12) {
+    const TriSide& K1 = *(const TriSide*)s1_;
+    const TriSide& K2 = *(const TriSide*)s2_;
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(K2.N, false);
+    std::vector<int> vMatches12(K1.N, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto lower_bound = [](const int32_t* ids, int n, int key) { int lo = 0, hi = n; while (lo < hi) { int m = (lo + hi) / 2; if (ids[m] < key) lo = m + 1; else hi = m; } return lo; };
+    auto epipolarConstrain = [&](const KeyPoint& kp1, const KeyPoint& kp2, const float unc) {   // Pinhole.cpp:162-176
+        const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+        const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+        const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+        const float num = a * kp2.x + b * kp2.y + c;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return dsqr < 3.84 * unc;
+    };
+    int f1 = 0, f2 = 0;
+    while (f1 != K1.n_nodes && f2 != K2.n_nodes) {
+        if (K1.node_id[f1] == K2.node_id[f2]) {
+            for (int i1 = K1.node_start[f1]; i1 < K1.node_start[f1 + 1]; i1++) {
+                const size_t idx1 = K1.feat[i1];
+                if (K1.has_mp[idx1]) continue;
+                const bool bStereo1 = K1.uRight && K1.uRight[idx1] >= 0;
+                if (bOnlyStereo) if (!bStereo1) continue;
+                const KeyPoint& kp1 = K1.kps[idx1];
+                const uint8_t* d1 = K1.desc + idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = K2.node_start[f2]; i2 < K2.node_start[f2 + 1]; i2++) {
+                    size_t idx2 = K2.feat[i2];
+                    if (vbMatched2[idx2] || K2.has_mp[idx2]) continue;
+                    const bool bStereo2 = K2.uRight && K2.uRight[idx2] >= 0;
+                    if (bOnlyStereo) if (!bStereo2) continue;
+                    const int dist = DescriptorDistance(d1, K2.desc + idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = K2.kps[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ep[0] - kp2.x, distey = ep[1] - kp2.y;
+                        if (distex * distex + distey * distey < 100 * scaleFactors_2[kp2.octave]) continue;
+                    }
+                    if (epipolarConstrain(kp1, kp2, levelSigma2_2[kp2.octave]) || bCoarse) { bestIdx2 = (int)idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    const KeyPoint& kp2 = K2.kps[bestIdx2];
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back((int)idx1);
+                    }
+                }
+            }
+            f1++; f2++;
+        } else if (K1.node_id[f1] < K2.node_id[f2]) {
+            f1 = lower_bound(K1.node_id, K1.n_nodes, K2.node_id[f2]);
+        } else {
+            f2 = lower_bound(K2.node_id, K2.n_nodes, K1.node_id[f1]);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < K1.N; i++) matches12[i] = vMatches12[i];
+    return nmatches;
 }
 
 }  // extern "C"

@@ -20,6 +20,13 @@ void olb_build_system(const double*, const int32_t*, int, const double*, int, co
                       double*, double*, double*, double*, double*, double*, double*, double*, double*);
 void olb_optimize(double*, const int32_t*, int, double*, int, const void*, int, const void*, double, double, int, double*);
 int opo_pose_optimize(const double*, const void*, int, const void*, double*, uint8_t*);
+int omo_search_for_initialization(const void*, const uint8_t*, int, const void*, const uint8_t*, int, float, float, float, float, float*, int, float,
+                                  int, int32_t*);
+int omo_fuse(const void*, const uint8_t*, const float*, int, float, float, float, float, const void*, const uint8_t*, int, int, int, const float*,
+             int32_t*, int32_t*);
+struct OTriSide { const void* kps; const uint8_t* desc; const float* uRight; const uint8_t* has_mp; const int32_t* node_id; const int32_t* node_start;
+                  const int32_t* feat; int n_nodes, N; };
+int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
@@ -83,6 +90,63 @@ int main() {
     CHECK(nm == onm && nm > 40);
     CHECK(std::memcmp(okm.data(), kpMatch.data(), okm.size() * 4) == 0 && std::memcmp(oq.data(), qMatch.data(), oq.size() * 4) == 0);
     CHECK(orbslam3_hip::ORBmatcher::DescriptorDistance(dA.data(), dA.data()) == 0);
+    // ---- rows M11 / M12 through the adapters vs the oracle
+    {
+        orbslam3_hip::FrameView FA;
+        FA.N = (int)kA.size(); FA.keysUn = kA.data(); FA.descriptors = dA.data(); FA.grid = F.grid;
+        std::vector<float> prev(kA.size() * 2), oprev;
+        for (size_t i = 0; i < kA.size(); i++) { prev[2 * i] = kA[i].x; prev[2 * i + 1] = kA[i].y; }
+        oprev = prev;
+        std::vector<int> m12;
+        orbslam3_hip::ORBmatcher mi(0.9f, true);
+        const int ni = mi.SearchForInitialization(FA, F, prev, m12, 100);
+        std::vector<int32_t> om12(kA.size());
+        const int oni = omo_search_for_initialization(kA.data(), dA.data(), FA.N, kB.data(), dB.data(), F.N, 0.f, 0.f, 64.f / W, 48.f / H, oprev.data(), 100,
+                                                      0.9f, 1, om12.data());
+        CHECK(ni == oni && ni > 20);
+        CHECK(std::memcmp(om12.data(), m12.data(), om12.size() * 4) == 0 && std::memcmp(oprev.data(), prev.data(), prev.size() * 4) == 0);
+        // Fuse (KeyFrame overload gate) with the motion-model queries re-levelled to [L-1, L]
+        std::vector<orbm_query> fq = q;
+        float invS2[8];
+        for (int l = 0; l < 8; l++) invS2[l] = 1.0f / (sf[l] * sf[l]);
+        for (size_t i = 0; i < fq.size(); i++) {
+            fq[i].radius = 3.0f * sf[kA[i].octave]; fq[i].min_level = (int16_t)(kA[i].octave - 1); fq[i].max_level = (int16_t)kA[i].octave;
+            fq[i].u_right = fq[i].u - 12.f; fq[i].flags = ORBM_Q_VALID;
+        }
+        std::vector<int> bi, bd;
+        const int nf = m.Fuse(F, fq, dA, invS2, 8, bi, bd);
+        std::vector<int32_t> obi(fq.size()), obd(fq.size());
+        const int onf = omo_fuse(kB.data(), dB.data(), nullptr, F.N, 0.f, 0.f, 64.f / W, 48.f / H, fq.data(), dA.data(), (int)fq.size(), 50, 1, invS2,
+                                 obi.data(), obd.data());
+        CHECK(nf == onf && nf > 20);
+        CHECK(std::memcmp(obi.data(), bi.data(), obi.size() * 4) == 0 && std::memcmp(obd.data(), bd.data(), obd.size() * 4) == 0);
+        // SearchForTriangulation: vocabulary node = a hash of descriptor bits; pure image-plane translation geometry
+        orbslam3_hip::ORBmatcher::KeyFrameView K1, K2;
+        std::vector<uint8_t> mp1(kA.size(), 0), mp2(kB.size(), 0);
+        auto build = [](orbslam3_hip::ORBmatcher::KeyFrameView& K, const std::vector<orb_keypoint>& kp, const std::vector<uint8_t>& d, std::vector<uint8_t>& mp) {
+            K.N = (int)kp.size(); K.keysUn = kp.data(); K.descriptors = d.data(); K.hasMapPoint = mp.data();
+            std::vector<std::vector<int32_t>> nodes(40);
+            for (int i = 0; i < K.N; i++) { nodes[((d[(size_t)i * 32] >> 4) * 7 + (d[(size_t)i * 32 + 9] >> 5) * 3) % 40].push_back(i); if (i % 5 == 0) mp[i] = 1; }
+            K.nodeStart.push_back(0);
+            for (int n = 0; n < 40; n++)
+                if (!nodes[n].empty()) { K.nodeId.push_back(n); K.featIdx.insert(K.featIdx.end(), nodes[n].begin(), nodes[n].end()); K.nodeStart.push_back((int32_t)K.featIdx.size()); }
+        };
+        build(K1, kA, dA, mp1); build(K2, kB, dB, mp2);
+        const float F12[9] = {0, 0, -0.03f, 0, 0, -0.05f, 0.03f, 0.05f, 0}, ep[2] = {-5000.f, -5000.f};   // image B = A shifted by (5,-3)
+        float sig2[8];
+        for (int l = 0; l < 8; l++) sig2[l] = sf[l] * sf[l];
+        std::vector<std::pair<size_t, size_t>> pairs;
+        const int nt = m.SearchForTriangulation(K1, K2, F12, ep, sig2, sf.data(), 8, pairs, false, false);
+        OTriSide o1{kA.data(), dA.data(), nullptr, mp1.data(), K1.nodeId.data(), K1.nodeStart.data(), K1.featIdx.data(), (int)K1.nodeId.size(), K1.N};
+        OTriSide o2{kB.data(), dB.data(), nullptr, mp2.data(), K2.nodeId.data(), K2.nodeStart.data(), K2.featIdx.data(), (int)K2.nodeId.size(), K2.N};
+        std::vector<int32_t> ot(kA.size());
+        const int ont = omo_search_for_triangulation(&o1, &o2, F12, ep, sig2, sf.data(), 0, 0, 1, ot.data());
+        CHECK(nt == ont && nt > 10 && (int)pairs.size() == nt);
+        size_t pi = 0;
+        for (size_t i = 0; i < ot.size(); i++)
+            if (ot[i] >= 0) { CHECK(pairs[pi].first == i && pairs[pi].second == (size_t)ot[i]); pi++; }
+        std::printf("adapter N1: init %d, fuse %d, triangulation %d\n", ni, nf, nt);
+    }
     // ---- stage 3: a toy window (4 KFs, first fixed; 30 points) through LbaLinearizer
     orbslam3_hip::LbaLinearizer L;
     lba_camera cam{};

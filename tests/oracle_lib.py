@@ -292,3 +292,59 @@ def pose_optimize(pose, edges, cameras):
     out = np.zeros(7); outl = np.zeros(max(len(edges), 1), np.uint8)
     n = L.opo_pose_optimize(_p(pose), _p(edges), len(edges), _p(cams), _p(out), _p(outl))
     return out, outl[:len(edges)], n
+
+
+# ---- SURVEY N1 rows (oracle/match_oracle.cpp) -------------------------------------------------------------------------------
+def search_for_initialization(kps1, desc1, kps2, desc2, grid, prev_matched, window_size, nnratio, check_ori):
+    """-> (vnMatches12, nmatches, vbPrevMatched after the call)"""
+    L = lib()
+    L.omo_search_for_initialization.restype = C.c_int
+    L.omo_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2); desc1 = np.ascontiguousarray(desc1); desc2 = np.ascontiguousarray(desc2)
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(len(kps1), 1), np.int32)
+    n = L.omo_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2), *[float(g) for g in grid], _p(prev),
+                                        int(window_size), nnratio, int(check_ori), _p(m12))
+    return m12[:len(kps1)], n, prev
+
+
+def fuse(kps, desc, queries, qdesc, grid, th_dist, inv_level_sigma2=None, u_right=None):
+    L = lib()
+    L.omo_fuse.restype = C.c_int
+    L.omo_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                           C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc); queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc)
+    s2 = np.zeros(16, np.float32)
+    if inv_level_sigma2 is not None:
+        s2[:len(inv_level_sigma2)] = inv_level_sigma2
+    qm = np.zeros(max(len(queries), 1), np.int32); qd = np.zeros(max(len(queries), 1), np.int32)
+    n = L.omo_fuse(_p(kps), _p(desc), _p(np.ascontiguousarray(u_right, np.float32)) if u_right is not None else None, len(kps),
+                   *[float(g) for g in grid], _p(queries), _p(qdesc), len(queries), th_dist, 0 if inv_level_sigma2 is None else 1, _p(s2), _p(qm), _p(qd))
+    return qm[:len(queries)], qd[:len(queries)], n
+
+
+class _TriSide(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("kps", "desc", "uRight", "has_mp", "node_id", "node_start", "feat")] + [("n_nodes", C.c_int), ("N", C.c_int)]
+
+
+def search_for_triangulation(k1, k2, F12, ep, level_sigma2_2, scale_factors_2, only_stereo, coarse, check_ori):
+    """k1/k2: dict(kps, desc, u_right|None, has_mp, node_id, node_start, feat_idx, n_nodes) of ONE key frame each -> (vMatches12, nmatches)"""
+    L = lib()
+    L.omo_search_for_triangulation.restype = C.c_int
+    L.omo_search_for_triangulation.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+    keep = []
+
+    def side(d):
+        arrs = [np.ascontiguousarray(d["kps"]), np.ascontiguousarray(d["desc"]),
+                np.ascontiguousarray(d["u_right"], np.float32) if d.get("u_right") is not None else None, np.ascontiguousarray(d["has_mp"], np.uint8),
+                np.ascontiguousarray(d["node_id"], np.int32), np.ascontiguousarray(d["node_start"], np.int32), np.ascontiguousarray(d["feat_idx"], np.int32)]
+        keep.append(arrs)
+        return _TriSide(*[(a.ctypes.data if a is not None else None) for a in arrs], int(d["n_nodes"]), len(arrs[1]))
+    a, b = side(k1), side(k2)
+    F12 = np.ascontiguousarray(F12, np.float32).reshape(9); ep = np.ascontiguousarray(ep, np.float32)
+    ls = np.zeros(16, np.float32); ls[:len(level_sigma2_2)] = level_sigma2_2
+    sf = np.zeros(16, np.float32); sf[:len(scale_factors_2)] = scale_factors_2
+    m12 = np.zeros(max(a.N, 1), np.int32)
+    n = L.omo_search_for_triangulation(C.byref(a), C.byref(b), _p(F12), _p(ep), _p(ls), _p(sf), int(only_stereo), int(coarse), int(check_ori), _p(m12))
+    return m12[:a.N], n
