@@ -31,6 +31,7 @@ static __constant__ int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 static __constant__ int c_umax[16];
+static __constant__ uint32_t c_icmask[16][12];   // [|v|][dword k of the patch row]: 0xFF where |col - 21| <= umax[|v|] (IC_Angle's circular patch)
 
 // ============================================================================================================
 // E1  pyramid level:  dst(level l) = cv::resize(src(level l-1), INTER_LINEAR)  — 11-bit fixed point
@@ -230,11 +231,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const int maxY = min(iniY + L.hCell + 6, L.h - ORBX_MINB);
     const int iniX = ORBX_MINB + T.cell0 * L.wCell;
     const int maxX = min(ORBX_MINB + (T.cell0 + T.nCells) * L.wCell + 6, L.w - ORBX_MINB);
-    const int xal = iniX & ~3;
+    // LDS column 0 = image column iniX-1, so that the detection region starts at byte 4 of every LDS row: detection column c
+    // lives in dword 1 + c/4, which lets stage 1 treat one dword = 4 pixels per lane (rows are staged with a byte shift).
+    const int xal = iniX - 1;
     const int pitch = ((maxX - xal) + 3) & ~3;
     const int rows = maxY - iniY;
     // detection region of the tile, local coordinates (cv::FAST skips a 3-px frame of each ROI; ROIs overlap by 6)
-    const int dx0 = iniX + 3 - xal, dxe = maxX - 3 - xal;
+    const int dx0 = 4, dxe = maxX - 3 - xal;
     const int dy0 = 3, dye = rows - 3;
     const int detW = dxe - dx0, detH = dye - dy0;
     if (detW <= 0 || detH <= 0) return;
@@ -248,13 +251,15 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     int* sh = (int*)(colTab + FAST_TW);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
 
     {   // stage the tile (coalesced aligned dword row loads) and clear the score map
-        const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + xal;
+        const uint32_t sh8 = (uint32_t)(xal & 3);
+        const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + (xal & ~3);
         const int p4 = pitch >> 2;
         const int n4 = rows * p4;
         int r = tid / p4, c = tid - r * p4;
         const int dr = 256 / p4, dc = 256 - dr * p4;
         for (int i = tid; i < n4; i += 256) {
-            ((uint32_t*)img)[i] = *(const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
+            const uint32_t* g = (const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
+            ((uint32_t*)img)[i] = __builtin_amdgcn_alignbyte(g[1], g[0], sh8);   // g[1] ends <= 10 columns before the row end
             ((uint32_t*)smap)[i] = 0;
             r += dr; c += dc;
             if (c >= p4) { c -= p4; r++; }
@@ -272,27 +277,59 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     // Stages 1-3 are wave-private: wave w owns columns (w&1)*64.. of the rows with parity (w>>1), compacts its own survivors
     // and corners into its own slices of q1 / q2 and scores them itself -> no workgroup barrier and no LDS atomic until NMS.
     const int wave = tid >> 6;
-    const int col = tid & (FAST_TW - 1), rsub = tid / FAST_TW;
-    const bool colOk = col < detW;
-    uint16_t* q1w = q1 + wave * (FAST_QCAP / 4);        // 512 entries: 8 rows x 64 columns per chunk, exact bound
+    const int dcol = lane & 31, rsub = lane >> 5;       // stage 1: lane = one LDS dword (4 detection columns) of one row
+    uint16_t* q1w = q1 + wave * (FAST_QCAP / 4);        // 512 entries: 4 rows x 128 columns per chunk, exact bound
     uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);
     int n2w = 0;                                        // corners of this wave (wave-uniform)
     bool ovf = false;
+    typedef unsigned short u16x2 __attribute__((vector_size(4)));
+    typedef short i16x2 __attribute__((vector_size(4)));
+    const i16x2 T0 = {(short)t0, (short)t0};
     for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK) {
         // ---- stage 1: 4-point pre-test.  Any 9-arc of the 16-ring contains >= 2 of the compass points 0,4,8,12, so a
-        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t.  Survivors -> this wave's q1 slice.
+        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t, i.e. the second largest of the four
+        //      exceeds v+t or the second smallest is below v-t.  Four pixels per lane on packed u16 pairs (v_pk_min/max_u16).
+        //      Wave w owns rows r0+4w .. r0+4w+3 of the chunk.  Survivors -> this wave's q1 slice.
         const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
-        const uint8_t* c = img + (dy0 + r0 + rsub) * pitch + dx0 + col;
-        uint32_t mask = 0;   // bit k: row r0 + rsub + k*(256/FAST_TW) of this lane's column passed
-        int kbit = 0;
-        for (int ry = r0 + rsub; ry < rend; ry += 256 / FAST_TW, c += (256 / FAST_TW) * pitch, kbit++) {
-            if (colOk) {
-                const int v = c[0];
-                const int lo = v - t0, hi = v + t0;
-                const int a = c[3 * pitch], b = c[3], d = c[-3 * pitch], e = c[-3];
-                const int nd = (a < lo) + (b < lo) + (d < lo) + (e < lo);
-                const int nb = (a > hi) + (b > hi) + (d > hi) + (e > hi);
-                mask |= (uint32_t)(nd >= 2 || nb >= 2) << kbit;
+        uint32_t mask = 0;   // bit 4*k + t: column 4*dcol + t of row r0 + 4*wave + rsub + 2k passed
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int ry = r0 + 4 * wave + rsub + 2 * k;
+            if (ry < rend && 4 * dcol < detW) {
+                const uint32_t* cw = (const uint32_t*)(img + (dy0 + ry) * pitch) + 1 + dcol;
+                const int p4 = pitch >> 2;
+                const uint32_t C = cw[0], Cp = cw[-1], Cn = cw[1], U = cw[-3 * p4], D = cw[3 * p4];
+                const u16x2 v01 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, C, 0x0c010c00u));
+                const u16x2 v23 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, C, 0x0c030c02u));
+                const u16x2 l01 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(C, Cp, 0x0c020c01u));   // x-3
+                const u16x2 l23 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(C, Cp, 0x0c040c03u));
+                const u16x2 r01 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(Cn, C, 0x0c040c03u));   // x+3
+                const u16x2 r23 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(Cn, C, 0x0c060c05u));
+                const u16x2 u01 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, U, 0x0c010c00u));
+                const u16x2 u23 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, U, 0x0c030c02u));
+                const u16x2 d01 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, D, 0x0c010c00u));
+                const u16x2 d23 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, D, 0x0c030c02u));
+                uint32_t bits;
+                {
+                    const u16x2 Pm = l01 > r01 ? l01 : r01, Qm = u01 > d01 ? u01 : d01, Rm = l01 < r01 ? l01 : r01, Sm = u01 < d01 ? u01 : d01;
+                    const u16x2 X = Pm < Qm ? Pm : Qm, Y = Rm > Sm ? Rm : Sm;
+                    const u16x2 hi2 = X > Y ? X : Y, lo2 = X < Y ? X : Y;      // second largest / second smallest of the four
+                    const i16x2 dh = (i16x2)(hi2 - v01), dl = (i16x2)(v01 - lo2);
+                    const i16x2 z = T0 - (dh > dl ? dh : dl);                   // negative <=> passes
+                    bits = (__builtin_bit_cast(uint32_t, z) >> 15) & 0x10001u;
+                }
+                {
+                    const u16x2 Pm = l23 > r23 ? l23 : r23, Qm = u23 > d23 ? u23 : d23, Rm = l23 < r23 ? l23 : r23, Sm = u23 < d23 ? u23 : d23;
+                    const u16x2 X = Pm < Qm ? Pm : Qm, Y = Rm > Sm ? Rm : Sm;
+                    const u16x2 hi2 = X > Y ? X : Y, lo2 = X < Y ? X : Y;
+                    const i16x2 dh = (i16x2)(hi2 - v23), dl = (i16x2)(v23 - lo2);
+                    const i16x2 z = T0 - (dh > dl ? dh : dl);
+                    bits |= ((__builtin_bit_cast(uint32_t, z) >> 15) & 0x10001u) << 2;
+                }
+                bits = (bits | (bits >> 15)) & 0xFu;
+                const int nvalid = detW - 4 * dcol;                             // columns of this dword inside the detection region
+                if (nvalid < 4) bits &= (1u << nvalid) - 1u;
+                mask |= bits << (4 * k);
             }
         }
         const int cnt = __popc(mask);
@@ -308,7 +345,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             while (mask) {
                 const int k = __ffs((int)mask) - 1;
                 mask &= mask - 1;
-                q1w[slot++] = (uint16_t)(((r0 + rsub + k * (256 / FAST_TW)) << 8) | col);
+                q1w[slot++] = (uint16_t)(((r0 + 4 * wave + rsub + 2 * (k >> 2)) << 8) | (4 * dcol + (k & 3)));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -323,12 +360,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 ent = q1w[i];
                 const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
                 const int v = cc[0];
-                const int lo = v - t0, hi = v + t0;
-                uint32_t md = 0, mb = 0;
-#define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; md = __builtin_amdgcn_alignbit(md, (uint32_t)(x - lo), 31); mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(hi - x), 31); }
+                // z = ((v+t - x) << 16) + (x - (v-t)) in one v_mad_i32_i24: bit 31 = brighter than v+t, bit 15 = darker than v-t (a
+                // negative low half borrows 1 from a high half that is then >= 2t, so the two signs never disturb each other)
+                const int K = ((v + t0) << 16) - (v - t0);
+                uint32_t acc = 0;   // after 16 steps: bits 31..16 = brighter mask, bits 15..0 = darker mask (ring position 0 in the LSB)
+#define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; const uint32_t z = (uint32_t)(x * -65535 + K); acc = (acc >> 1) | (z & 0x80008000u); }
                 RING16(CL)
 #undef CL
-                corner = ring_has9(md) || ring_has9(mb);
+                corner = ring_has9(acc >> 16) || ring_has9(acc & 0xFFFFu);
             }
             const unsigned long long m = __ballot(corner);
             const int slot = n2w + __popcll(m & ((1ull << lane) - 1ull));
@@ -872,35 +911,52 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     }
     __syncthreads();
     float angle = 0.f;
+    int* vflag = (int*)(orb_smem + 4 * DESC_WAVE_STRIDE);   // [4] this wave holds a keypoint
+    if (lane == 0) vflag[wave] = valid ? 1 : 0;
     if (valid) {
-        // lane r owns patch row r: 12 aligned dword LDS reads, realigned by the wave-uniform column offset ox, serve both
-        // IC_Angle (rows 6..36) and the Gaussian row pass (all 43 rows) from registers
-        uint32_t px[DP];
+        // lane r owns patch row r: 12 aligned dword LDS reads, realigned by the wave-uniform column offset ox into packed dwords
+        // e[k] = patch bytes 4k..4k+3; both IC_Angle (rows 6..36) and the Gaussian row pass (all 43 rows) run on packed bytes
+        // with v_dot4_u32_u8
         int m10 = 0, m01 = 0;
         if (lane < DP) {
             const uint32_t* rw = (const uint32_t*)(patch + lane * DPP);
-            uint32_t d[12];
+            uint32_t d[12], e[11];
 #pragma unroll
             for (int k = 0; k < 12; k++) d[k] = rw[k];
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const uint32_t e = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ox);   // bytes ox+4k .. ox+4k+3 of the row
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (4 * k + t < DP) px[4 * k + t] = (e >> (8 * t)) & 255u;
-            }
-            // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15; row v = lane - 21
+            for (int k = 0; k < 11; k++) e[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ox);
+            // IC_Angle (ORBextractor.cc:75-102): integer moments over the circular patch of radius 15; row v = lane - 21,
+            // column u = byte index - 21.  m10 = sum u*I = sum (u+15)*I - 15*sum I over the row's masked bytes (weights 0..30 fit u8).
             const int v = lane - 21;
-            if (v >= -15 && v <= 15) {
-                const int dmax = c_umax[v < 0 ? -v : v];
-                int rs = 0;
+            const int av = v < 0 ? -v : v;
+            if (av <= 15) {
+                const uint32_t* mk = c_icmask[av];
+                uint32_t s1 = 0, sw = 0;
 #pragma unroll
-                for (int u = -15; u <= 15; u++) {
-                    const int I = (u >= -dmax && u <= dmax) ? (int)px[21 + u] : 0;
-                    m10 += u * I;
-                    rs += I;
+                for (int k = 1; k <= 9; k++) {
+                    uint32_t W = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { const int j = 4 * k + t; if (j >= 6 && j <= 36) W |= (uint32_t)(j - 6) << (8 * t); }
+                    const uint32_t m = e[k] & mk[k];
+                    s1 = __builtin_amdgcn_udot4(m, 0x01010101u, s1, false);
+                    sw = __builtin_amdgcn_udot4(m, W, sw, false);
                 }
-                m01 = v * rs;
+                m10 = (int)sw - 15 * (int)s1;
+                m01 = v * (int)s1;
+            }
+            // Gaussian row pass: k = cvRound(256*g) = {18,34,49,55,49,34,18}; out(c) = dot4(bytes c..c+3, k[0..3]) + dot4(bytes c+4..c+7,
+            // {k[4..6],0}); sums <= 255*257 fit u16
+            const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+            uint32_t A[41];   // A[c] = bytes c..c+3
+#pragma unroll
+            for (int c = 0; c < 41; c++) A[c] = (c & 3) == 0 ? e[c >> 2] : __builtin_amdgcn_alignbyte(e[(c >> 2) + 1], e[c >> 2], (uint32_t)(c & 3));
+            uint32_t* o = (uint32_t*)(rowp + lane * DRP);
+#pragma unroll
+            for (int c = 0; c < DB; c += 2) {
+                const uint32_t a = __builtin_amdgcn_udot4(A[c], K0, __builtin_amdgcn_udot4(A[c + 4], K1, 0u, false), false);
+                uint32_t b = 0;
+                if (c + 1 < DB) b = __builtin_amdgcn_udot4(A[c + 1], K0, __builtin_amdgcn_udot4(A[c + 5], K1, 0u, false), false);
+                o[c >> 1] = a | (b << 16);
             }
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -908,28 +964,24 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
             m01 += __shfl_xor(m01, off);
         }
         angle = fast_atan2_deg((float)m01, (float)m10);
-        // Gaussian row pass, sliding window in registers: k = cvRound(256*g) = {18,34,49,55,49,34,18}; sums <= 255*257 fit u16
-        if (lane < DP) {
-            uint32_t* o = (uint32_t*)(rowp + lane * DRP);
-#pragma unroll
-            for (int c = 0; c < DB; c += 2) {
-                const uint32_t a = 18 * (px[c] + px[c + 6]) + 34 * (px[c + 1] + px[c + 5]) + 49 * (px[c + 2] + px[c + 4]) + 55 * px[c + 3];
-                uint32_t b = 0;
-                if (c + 1 < DB) b = 18 * (px[c + 1] + px[c + 7]) + 34 * (px[c + 2] + px[c + 6]) + 49 * (px[c + 3] + px[c + 5]) + 55 * px[c + 4];
-                o[c >> 1] = a | (b << 16);
-            }
-        }
     }
     __syncthreads();
-    if (valid && lane < DB) {
-        // column pass, lane = column: out = (sum + 32768) >> 16, saturated
-        uint32_t rp[DP];
+    // column pass, block-cooperative: 4 keypoints x 37 columns x 2 row halves = 296 independent tasks over 256 threads
+    // (a wave-private lane-per-column pass keeps only 37 of 64 lanes busy); out = (sum + 32768) >> 16, saturated
+    for (int t = threadIdx.x; t < 4 * 2 * DB; t += 256) {
+        const int w = t / (2 * DB), rem = t - w * (2 * DB);
+        const int half = rem >= DB ? 1 : 0, col = rem - half * DB;
+        if (!vflag[w]) continue;
+        const uint16_t* rp_ = (const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DP * DPP);
+        uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE;
+        const int r0 = half ? 19 : 0, nout = half ? DB - 19 : 19;
+        uint32_t rp[25];
 #pragma unroll
-        for (int r = 0; r < DP; r++) rp[r] = rowp[r * DRP + lane];
+        for (int r = 0; r < 25; r++) rp[r] = (r0 + r < DP) ? rp_[(r0 + r) * DRP + col] : 0u;
 #pragma unroll
-        for (int r = 0; r < DB; r++) {
+        for (int r = 0; r < 19; r++) {
             const uint32_t acc = 18 * (rp[r] + rp[r + 6]) + 34 * (rp[r + 1] + rp[r + 5]) + 49 * (rp[r + 2] + rp[r + 4]) + 55 * rp[r + 3];
-            blur[r * DBP + lane] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+            if (r < nout) bl[(r0 + r) * DBP + col] = (uint8_t)min((acc + 32768u) >> 16, 255u);
         }
     }
     __syncthreads();
@@ -1293,6 +1345,16 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_desc1, (size_t)maxKp * 32));
     CK(hipMalloc((void**)&h->d_counts1, 2 * sizeof(int32_t)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
+    {
+        uint32_t icmask[16][12];
+        for (int v = 0; v < 16; v++)
+            for (int k = 0; k < 12; k++) {
+                uint32_t m = 0;
+                for (int t = 0; t < 4; t++) { const int u = 4 * k + t - 21; if (u >= -h->umax[v] && u <= h->umax[v]) m |= 0xFFu << (8 * t); }
+                icmask[v][k] = m;
+            }
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(c_icmask), icmask, sizeof(icmask)));
+    }
 #undef CK
     *out = h;
     return ORB_OK;
@@ -1388,7 +1450,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
         D.sel = h->d_sel; D.selAux = h->d_selAux; D.selFrame = h->selFrame; D.selCount = h->d_selCount; D.lapCount = h->d_lapCount;
         D.nlevels = nl; D.kps = d_kps; D.desc = d_desc; D.cap = cap_per_frame; D.counts = d_counts;
-        hipLaunchKernelGGL(k_describe, dim3((h->maxKp + 3) / 4, batch), dim3(256), 4 * DESC_WAVE_STRIDE, st, D);
+        hipLaunchKernelGGL(k_describe, dim3((h->maxKp + 3) / 4, batch), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
     }
     HIPCHK(h, hipEventRecord(h->ev[4], st));
     h->timed = true;

@@ -251,6 +251,21 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
 inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {   // v_perm_b32 (selectors 0-7 and 0x0c only)
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned c = (sel >> (8 * i)) & 255u;
+        const unsigned b = c < 8 ? (unsigned)((src >> (8 * c)) & 255u) : (c == 0x0c ? 0u : 0xFFu);
+        r |= b << (8 * i);
+    }
+    return r;
+}
+inline int __builtin_amdgcn_mad_i32_i24_emu(int a, int b, int c) { return a * b + c; }
+inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return c;
+}
 using std::max;
 using std::min;
 
