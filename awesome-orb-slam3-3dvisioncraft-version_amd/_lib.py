@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+LIB_PATH = os.environ.get("ORBHIP_LIB", os.path.join(_HERE, "liborbhip.so"))   # explicit override for kernel experiments
 
 ORB_OK, ORB_E_EMPTY_IMAGE, ORB_E_CAPACITY, ORB_E_INVALID, ORB_E_HIP, ORB_E_NOMEM, ORB_E_ABORTED = 0, -1, -2, -3, -4, -5, -6
 

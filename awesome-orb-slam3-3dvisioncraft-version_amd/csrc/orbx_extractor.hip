@@ -140,6 +140,92 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
     }
 }
 
+// Separable form of the same arithmetic for scale factors <= 1.3 (every ORB-SLAM3 configuration: 1.2): one workgroup = one 64 x 32
+// destination tile.  H pass: every staged source row is filtered once per destination column (t = p0*a0 + p1*a1 as one
+// v_dot2_u32_u16; cv::resize's ">> 4" applied, stored << 9 so that the V pass is one v_mul_hi_u32_u24 per tap:
+// ((b << 7) * ((t >> 4) << 9)) >> 32 == (b * (t >> 4)) >> 16).  V pass: 4 adjacent pixels per thread from two 16-byte LDS reads.
+#define R2_TH 32
+#define R2_ROWS 44        // 32 * 1.3 + 2
+#define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks)
+#define R2_SMEM ((2 * RS_TW + 2 * R2_TH) * 4 + R2_ROWS * RS_PITCH + R2_ROWS * R2_HP * 4)
+static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    typedef unsigned short u16x2 __attribute__((vector_size(4)));
+    int* cxs = (int*)orb_smem;                 // [64] source column of each destination column of the tile
+    int* cxw = cxs + RS_TW;                    // [64] a0 | a1 << 16
+    int* cys = cxw + RS_TW;                    // [32] source row (unclipped)
+    int* cyw = cys + R2_TH;                    // [32] b0 | b1 << 16
+    uint32_t* hbuf = (uint32_t*)(cyw + R2_TH); // [R2_ROWS][R2_HP]  ((p0*a0 + p1*a1) >> 4) << 9
+    uint8_t* tile = (uint8_t*)(hbuf + R2_ROWS * R2_HP);   // [R2_ROWS][RS_PITCH]
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * R2_TH;
+    const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
+    if (tid < RS_TW) {
+        int s0, w0, w1;
+        resize_coef(min(bx0 + tid, P.dw - 1), P.scale_x, P.sw, true, s0, w0, w1);
+        cxs[tid] = s0; cxw[tid] = (w0 & 0xFFFF) | (w1 << 16);
+    } else if (tid < RS_TW + R2_TH) {
+        const int t = tid - RS_TW;
+        int s0, w0, w1;
+        resize_coef(min(by0 + t, P.dh - 1), P.scale_y, P.sh, false, s0, w0, w1);
+        cys[t] = s0; cyw[t] = (w0 & 0xFFFF) | (w1 << 16);
+    }
+    __syncthreads();
+    const int xal = cxs[0] & ~3;
+    const int xend = min(cxs[RS_TW - 1] + 1, P.sw - 1);
+    const int ylo = max(cys[0], 0), yhi = min(cys[R2_TH - 1] + 1, P.sh - 1);
+    const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;   // host guarantees ndw*4 <= RS_PITCH, nrows <= R2_ROWS
+    {
+        int r = tid / ndw, c = tid - r * ndw;
+        const int dr = 256 / ndw, dc = 256 - dr * ndw;
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            *(uint32_t*)(tile + r * RS_PITCH + 4 * c) = *(const uint32_t*)(S + (size_t)(ylo + r) * P.sStride + xal + 4 * c);
+            r += dr; c += dc;
+            if (c >= ndw) { c -= ndw; r++; }
+        }
+    }
+    __syncthreads();
+    {   // H pass: thread = destination column (tid & 63), rows tid>>6, +4, ...
+        const int x = tid & 63;
+        const int o = cxs[x] - xal;
+        const u16x2 aw = __builtin_bit_cast(u16x2, (uint32_t)cxw[x]);   // weights are in [0, 2048]
+        // the right neighbour of the last source column carries weight 0 (resize_coef clamps): reading the next LDS byte is harmless
+        for (int r = tid >> 6; r < nrows; r += 4) {
+            const uint8_t* row = tile + r * RS_PITCH + o;
+            const uint32_t pp = (uint32_t)row[0] | ((uint32_t)row[1] << 16);
+            const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), aw, 0u, false);
+            hbuf[r * R2_HP + x] = (t & ~15u) << 5;
+        }
+    }
+    __syncthreads();
+    const int xg = tid & 15;
+    const int dx0 = bx0 + xg * 4;
+    if (dx0 >= P.dw) return;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int ty = (tid >> 4) + 16 * k, dy = by0 + ty;
+        if (dy >= P.dh) break;
+        int sy0 = cys[ty];
+        const uint32_t bw = (uint32_t)cyw[ty];
+        const uint32_t b0 = (bw & 0xFFFFu) << 7, b1 = (bw >> 16) << 7;
+        int sy1 = sy0 + 1;
+        sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
+        sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
+        const uint4 T0 = *(const uint4*)(hbuf + (sy0 - ylo) * R2_HP + xg * 4);
+        const uint4 T1 = *(const uint4*)(hbuf + (sy1 - ylo) * R2_HP + xg * 4);
+#define R2_PIX(t0, t1) (((uint32_t)(((uint64_t)b0 * ((t0) & 0xFFFFFFu)) >> 32) + (uint32_t)(((uint64_t)b1 * ((t1) & 0xFFFFFFu)) >> 32) + 2u) >> 2)
+        const uint32_t out = (R2_PIX(T0.x, T1.x) & 255u) | ((R2_PIX(T0.y, T1.y) & 255u) << 8) | ((R2_PIX(T0.z, T1.z) & 255u) << 16) |
+                             (R2_PIX(T0.w, T1.w) << 24);
+#undef R2_PIX
+        uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)dy * P.dStride + dx0;
+        if (dx0 + 3 < P.dw) {
+            *(uint32_t*)D = out;  // dStride and dx0 are multiples of 4
+        } else {
+            for (int j = 0; j < 4 && dx0 + j < P.dw; j++) D[j] = (uint8_t)(out >> (8 * j));
+        }
+    }
+}
+
 // ============================================================================================================
 // E2  FAST-9/16 + per-cell NMS + per-cell minThFAST retry
 // ============================================================================================================
@@ -220,6 +306,9 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+#ifndef FAST_EXP
+#define FAST_EXP 9
+#endif
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -295,7 +384,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int ry = r0 + 4 * wave + rsub + 2 * k;
-            if (ry < rend && 4 * dcol < detW) {
+            if (FAST_EXP != 3 && ry < rend && 4 * dcol < detW) {
                 const uint32_t* cw = (const uint32_t*)(img + (dy0 + ry) * pitch) + 1 + dcol;
                 const int p4 = pitch >> 2;
                 const uint32_t C = cw[0], Cp = cw[-1], Cn = cw[1], U = cw[-3 * p4], D = cw[3 * p4];
@@ -339,7 +428,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
+#if FAST_EXP == 0
+        const int n1 = 0;
+#elif FAST_EXP == 1
+        const int n1 = 0; if (incl == 12345) sh[7] = 1;
+#else
         const int n1 = __shfl(incl, 63);
+#endif
         {
             int slot = incl - cnt;
             while (mask) {
@@ -381,6 +476,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     n2w = min(n2w, FAST_Q2CAP / 4);
+#if FAST_EXP == 2
+    if (n2w == 12345) sh[7] = 1; n2w = 0;
+#endif
     // ---- stage 3: exact score of this wave's corners (dense)
     for (int i = lane; i < n2w; i += 64) {
         const int ent = q2w[i];
@@ -388,6 +486,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
     }
     __syncthreads();
+#if FAST_EXP == 4
+    if (sh[4] != 77) return;
+#endif
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
     if (!overflow) {
@@ -1403,8 +1504,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.dst = h->d_pyr + h->lv[l].planeOff; R.dFrame = h->pyrFrame; R.dStride = h->lv[l].stride;
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
-        dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
+        if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
+            dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + R2_TH - 1) / R2_TH, batch);
+            hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
+        } else {
+            dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
+            hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
+        }
     }
     HIPCHK(h, hipEventRecord(h->ev[1], st));
     // E2 FAST

@@ -262,6 +262,8 @@ inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) { 
     return r;
 }
 inline int __builtin_amdgcn_mad_i32_i24_emu(int a, int b, int c) { return a * b + c; }
+typedef unsigned short emu_u16x2 __attribute__((vector_size(4)));
+inline unsigned __builtin_amdgcn_udot2(emu_u16x2 a, emu_u16x2 b, unsigned c, bool) { return c + (unsigned)a[0] * b[0] + (unsigned)a[1] * b[1]; }
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
     return c;

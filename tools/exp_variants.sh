@@ -1,0 +1,11 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: builds -D variants of the library into /tmp and times the headline bench with each (kernel experiments).
+# usage: tools/exp_variants.sh "-DFAST_EXP=1" "-DFAST_EXP=2" ...
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+for v in "" "$@"; do
+  out=/tmp/liborbhip_exp.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+    -I$R/include $R/awesome-orb-slam3-3dvisioncraft-version_amd/csrc/*.hip -o $out $v 2>/dev/null || { echo "build failed: $v"; continue; }
+  ORBHIP_LIB=$out python bench.py --headline-only --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant [$v]', d['value'], d['kernel_ms'])"
+done
