@@ -40,11 +40,12 @@ struct ResizeParams {
     const uint8_t* src; size_t sFrame; int sStride, sw, sh;
     uint8_t* dst; size_t dFrame; int dStride, dw, dh;
     double scale_x, scale_y;   // 1 / ((double)dw / sw), 1 / ((double)dh / sh)  — cv::resize's scale_x / scale_y
+    const int* coef;           // k_resize2: per-level tables xs[dw] | xw[dw] | ys[dh] | yw[dh] (resize_coef of every column / row)
 };
 
 // cv::resize coefficient of one destination coordinate, computed in-kernel with the same IEEE
 // double/float operations as OpenCV's table setup (no table loads on the critical path): source index + the two 11-bit weights.
-static __device__ __forceinline__ void resize_coef(int d, double scale, int slen, bool clampIndex, int& s0, int& w0, int& w1) {
+static __host__ __device__ __forceinline__ void resize_coef(int d, double scale, int slen, bool clampIndex, int& s0, int& w0, int& w1) {
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int si = (int)floorf(f);
     f -= (float)si;
@@ -53,10 +54,10 @@ static __device__ __forceinline__ void resize_coef(int d, double scale, int slen
         if (si >= slen - 1) { f = 0.f; si = slen - 1; }
     }
     s0 = si;
-    w0 = __float2int_rn((1.f - f) * 2048.f);
-    w1 = __float2int_rn(f * 2048.f);
-    w0 = max(-32768, min(32767, w0));
-    w1 = max(-32768, min(32767, w1));
+    w0 = (int)rintf((1.f - f) * 2048.f);   // cvRound: round half to even (default rounding mode)
+    w1 = (int)rintf(f * 2048.f);
+    w0 = w0 < -32768 ? -32768 : (w0 > 32767 ? 32767 : w0);
+    w1 = w1 < -32768 ? -32768 : (w1 > 32767 ? 32767 : w1);
 }
 
 // One workgroup = one 64 x 16 destination tile: the <= 21 x 84 source footprint is staged in LDS with coalesced aligned dword
@@ -141,87 +142,112 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 }
 
 // Separable form of the same arithmetic for scale factors <= 1.3 (every ORB-SLAM3 configuration: 1.2): one workgroup = one 64 x 32
-// destination tile.  H pass: every staged source row is filtered once per destination column (t = p0*a0 + p1*a1 as one
-// v_dot2_u32_u16; cv::resize's ">> 4" applied, stored << 9 so that the V pass is one v_mul_hi_u32_u24 per tap:
-// ((b << 7) * ((t >> 4) << 9)) >> 32 == (b * (t >> 4)) >> 16).  V pass: 4 adjacent pixels per thread from two 16-byte LDS reads.
+// destination tile.  The per-column / per-row coefficients come from per-level tables built once at orbx_create with the same
+// resize_coef() (host side, same IEEE operations).  H pass: every staged source row is filtered once per destination column
+// (t = p0*a0 + p1*a1 as one v_dot2_u32_u16 on a byte pair picked by v_perm from an 8-byte window; cv::resize's ">> 4" applied,
+// stored << 9 so that the V pass is one v_mul_hi_u32_u24 per tap: ((b << 7) * ((t >> 4) << 9)) >> 32 == (b * (t >> 4)) >> 16).
+// V pass: 4 adjacent pixels per thread from two 16-byte LDS reads.
 #define R2_TH 32
-#define R2_ROWS 44        // 32 * 1.3 + 2
-#define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks)
-#define R2_SMEM ((2 * RS_TW + 2 * R2_TH) * 4 + R2_ROWS * RS_PITCH + R2_ROWS * R2_HP * 4)
+#define R2_ROWS 46        // 32 * 1.3 + 2 taps + 2 slack (estimated footprint)
+#define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks, 16-byte aligned)
+#define R2_SMEM ((RS_TW * 2 + R2_TH * 4) * 4 + R2_ROWS * R2_HP * 4 + R2_ROWS * RS_PITCH)
 static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     typedef unsigned short u16x2 __attribute__((vector_size(4)));
     int* cxs = (int*)orb_smem;                 // [64] source column of each destination column of the tile
     int* cxw = cxs + RS_TW;                    // [64] a0 | a1 << 16
-    int* cys = cxw + RS_TW;                    // [32] source row (unclipped)
-    int* cyw = cys + R2_TH;                    // [32] b0 | b1 << 16
-    uint32_t* hbuf = (uint32_t*)(cyw + R2_TH); // [R2_ROWS][R2_HP]  ((p0*a0 + p1*a1) >> 4) << 9
+    uint4* rowt = (uint4*)(cxw + RS_TW);       // [32] {hbuf byte offset of source row 0, of source row 1, b0 << 7, b1 << 7}
+    uint32_t* hbuf = (uint32_t*)(rowt + R2_TH);   // [R2_ROWS][R2_HP]  ((p0*a0 + p1*a1) >> 4) << 9
     uint8_t* tile = (uint8_t*)(hbuf + R2_ROWS * R2_HP);   // [R2_ROWS][RS_PITCH]
     const int tid = threadIdx.x;
     const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * R2_TH;
     const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
-    if (tid < RS_TW) {
-        int s0, w0, w1;
-        resize_coef(min(bx0 + tid, P.dw - 1), P.scale_x, P.sw, true, s0, w0, w1);
-        cxs[tid] = s0; cxw[tid] = (w0 & 0xFFFF) | (w1 << 16);
-    } else if (tid < RS_TW + R2_TH) {
-        const int t = tid - RS_TW;
-        int s0, w0, w1;
-        resize_coef(min(by0 + t, P.dh - 1), P.scale_y, P.sh, false, s0, w0, w1);
-        cys[t] = s0; cyw[t] = (w0 & 0xFFFF) | (w1 << 16);
-    }
-    __syncthreads();
-    const int xal = cxs[0] & ~3;
-    const int xend = min(cxs[RS_TW - 1] + 1, P.sw - 1);
-    const int ylo = max(cys[0], 0), yhi = min(cys[R2_TH - 1] + 1, P.sh - 1);
-    const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;   // host guarantees ndw*4 <= RS_PITCH, nrows <= R2_ROWS
-    {
-        int r = tid / ndw, c = tid - r * ndw;
-        const int dr = 256 / ndw, dc = 256 - dr * ndw;
-        for (int i = tid; i < nrows * ndw; i += 256) {
-            *(uint32_t*)(tile + r * RS_PITCH + 4 * c) = *(const uint32_t*)(S + (size_t)(ylo + r) * P.sStride + xal + 4 * c);
-            r += dr; c += dc;
-            if (c >= ndw) { c -= ndw; r++; }
+    const int* xs = P.coef; const int* xw = xs + P.dw; const int* ys = xw + P.dw; const int* yw = ys + P.dh;
+    // Source footprint of the tile from a float estimate of the first / last coefficient, widened by one column / row on each
+    // side (the exact indices come from the double-precision tables and can differ by one): the staging loads then do not wait
+    // for the table loads — both global round trips are in flight together.
+    const float fsx = (float)P.scale_x, fsy = (float)P.scale_y;
+    const int xlo = max((int)floorf(((float)bx0 + 0.5f) * fsx - 0.5f) - 1, 0);
+    const int xal = xlo & ~3;
+    const int xend = min((int)floorf(((float)(min(bx0 + RS_TW, P.dw) - 1) + 0.5f) * fsx - 0.5f) + 2, P.sw - 1);
+    const int ylo = max((int)floorf(((float)by0 + 0.5f) * fsy - 0.5f) - 1, 0);
+    const int yhi = min((int)floorf(((float)(min(by0 + R2_TH, P.dh) - 1) + 0.5f) * fsy - 0.5f) + 2, P.sh - 1);
+    const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;       // <= RS_PITCH/4, <= R2_ROWS for scale <= 1.3
+    {   // stage the source footprint: lane = dword column, 8 rows per pass (coalesced aligned row segments)
+        const int c = tid & 31, r0 = tid >> 5;
+        uint32_t v[(R2_ROWS + 7) / 8];
+        const bool on = c < ndw;
+        const uint8_t* g = S + (size_t)(ylo + r0) * P.sStride + xal + 4 * c;
+#pragma unroll
+        for (int k = 0; k < (R2_ROWS + 7) / 8; k++)
+            if (on && r0 + 8 * k < nrows) v[k] = *(const uint32_t*)(g + (size_t)(8 * k) * P.sStride);
+        if (tid < RS_TW) {
+            const int x = min(bx0 + tid, P.dw - 1);
+            cxs[tid] = xs[x]; cxw[tid] = xw[x];
+        } else if (tid < RS_TW + R2_TH) {
+            const int t = tid - RS_TW, y = min(by0 + t, P.dh - 1);
+            int sy0 = ys[y];
+            const uint32_t bw = (uint32_t)yw[y];
+            int sy1 = sy0 + 1;
+            sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);   // rows are clipped after the weights are fixed (resize.cpp)
+            sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
+            rowt[t] = make_uint4((uint32_t)((sy0 - ylo) * R2_HP * 4), (uint32_t)((sy1 - ylo) * R2_HP * 4), (bw & 0xFFFFu) << 7, (bw >> 16) << 7);
         }
+        uint8_t* t = tile + r0 * RS_PITCH + 4 * c;
+#pragma unroll
+        for (int k = 0; k < (R2_ROWS + 7) / 8; k++)
+            if (on && r0 + 8 * k < nrows) *(uint32_t*)(t + 8 * k * RS_PITCH) = v[k];
     }
     __syncthreads();
-    {   // H pass: thread = destination column (tid & 63), rows tid>>6, +4, ...
-        const int x = tid & 63;
-        const int o = cxs[x] - xal;
-        const u16x2 aw = __builtin_bit_cast(u16x2, (uint32_t)cxw[x]);   // weights are in [0, 2048]
-        // the right neighbour of the last source column carries weight 0 (resize_coef clamps): reading the next LDS byte is harmless
-        for (int r = tid >> 6; r < nrows; r += 4) {
-            const uint8_t* row = tile + r * RS_PITCH + o;
-            const uint32_t pp = (uint32_t)row[0] | ((uint32_t)row[1] << 16);
-            const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), aw, 0u, false);
-            hbuf[r * R2_HP + x] = (t & ~15u) << 5;
+    {   // H pass: thread = 4 adjacent destination columns of one source row, 16 rows per pass
+        const int x0 = (tid & 15) * 4;
+        const int c0 = cxs[x0], o0 = c0 - xal;
+        const uint32_t sh = (uint32_t)(o0 & 3);
+        uint32_t sel[4]; u16x2 aw[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t off = (uint32_t)(cxs[x0 + j] - c0);   // 0..4 for scale <= 1.3: both bytes of every pair lie inside the 8-byte window
+            sel[j] = off | ((off + 1u) << 16) | 0x0c000c00u;
+            aw[j] = __builtin_bit_cast(u16x2, (uint32_t)cxw[x0 + j]);   // weights are in [0, 2048]
+        }
+        const uint32_t* rowp = (const uint32_t*)(tile + (o0 & ~3)) ;
+        for (int r = tid >> 4; r < nrows; r += 16) {
+            const uint32_t* d = (const uint32_t*)((const uint8_t*)rowp + r * RS_PITCH);
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+            const uint32_t W0 = __builtin_amdgcn_alignbyte(d1, d0, sh), W1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            uint4 T;
+            uint32_t* Tp = (uint32_t*)&T;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pp = __builtin_amdgcn_perm(W1, W0, sel[j]);
+                const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), aw[j], 0u, false);
+                Tp[j] = (t & ~15u) << 5;
+            }
+            *(uint4*)(hbuf + r * R2_HP + x0) = T;
         }
     }
     __syncthreads();
     const int xg = tid & 15;
     const int dx0 = bx0 + xg * 4;
     if (dx0 >= P.dw) return;
+    uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const int ty = (tid >> 4) + 16 * k, dy = by0 + ty;
-        if (dy >= P.dh) break;
-        int sy0 = cys[ty];
-        const uint32_t bw = (uint32_t)cyw[ty];
-        const uint32_t b0 = (bw & 0xFFFFu) << 7, b1 = (bw >> 16) << 7;
-        int sy1 = sy0 + 1;
-        sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);
-        sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
-        const uint4 T0 = *(const uint4*)(hbuf + (sy0 - ylo) * R2_HP + xg * 4);
-        const uint4 T1 = *(const uint4*)(hbuf + (sy1 - ylo) * R2_HP + xg * 4);
+        const int ty = (tid >> 4) + 16 * k;
+        if (by0 + ty >= P.dh) break;
+        const uint4 rt = rowt[ty];
+        const uint32_t b0 = rt.z, b1 = rt.w;
+        const uint4 T0 = *(const uint4*)((const uint8_t*)hbuf + rt.x + xg * 16);
+        const uint4 T1 = *(const uint4*)((const uint8_t*)hbuf + rt.y + xg * 16);
 #define R2_PIX(t0, t1) (((uint32_t)(((uint64_t)b0 * ((t0) & 0xFFFFFFu)) >> 32) + (uint32_t)(((uint64_t)b1 * ((t1) & 0xFFFFFFu)) >> 32) + 2u) >> 2)
         const uint32_t out = (R2_PIX(T0.x, T1.x) & 255u) | ((R2_PIX(T0.y, T1.y) & 255u) << 8) | ((R2_PIX(T0.z, T1.z) & 255u) << 16) |
                              (R2_PIX(T0.w, T1.w) << 24);
 #undef R2_PIX
-        uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)dy * P.dStride + dx0;
+        uint8_t* Dk = D + (size_t)(16 * k) * P.dStride;
         if (dx0 + 3 < P.dw) {
-            *(uint32_t*)D = out;  // dStride and dx0 are multiples of 4
+            *(uint32_t*)Dk = out;  // dStride and dx0 are multiples of 4
         } else {
-            for (int j = 0; j < 4 && dx0 + j < P.dw; j++) D[j] = (uint8_t)(out >> (8 * j));
+            for (int j = 0; j < 4 && dx0 + j < P.dw; j++) Dk[j] = (uint8_t)(out >> (8 * j));
         }
     }
 }
@@ -1303,6 +1329,7 @@ struct orbx_extractor {
     size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
     int nTiles = 0, fastImgBytes = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
+    int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
     FastTile* d_tiles = nullptr;
@@ -1336,7 +1363,7 @@ static int orbx_fail(orbx_extractor* h, int code, const std::string& msg) {
 static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* bufs[] = {h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
+    void* bufs[] = {h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
                     h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1431,6 +1458,20 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     for (auto& e : h->ev) CK(hipEventCreate(&e));
     const size_t B = (size_t)max_batch;
     CK(hipMalloc((void**)&h->d_pyr, std::max<size_t>(B * h->pyrFrame, 256)));
+    {   // per-level cv::resize coefficient tables (xs | xw | ys | yw), identical arithmetic to the in-kernel resize_coef of k_resize
+        std::vector<int> tab;
+        for (int l = 1; l < nl; l++) {
+            const int sw = h->lv[l - 1].w, sh = h->lv[l - 1].h, dw = h->lv[l].w, dh = h->lv[l].h;
+            const double sx = 1. / ((double)dw / sw), sy = 1. / ((double)dh / sh);
+            h->coefOff[l] = tab.size();
+            tab.resize(tab.size() + 2 * (size_t)dw + 2 * (size_t)dh);
+            int* xs = tab.data() + h->coefOff[l]; int* xw = xs + dw; int* ys = xw + dw; int* yw = ys + dh;
+            for (int x = 0; x < dw; x++) { int s0, w0, w1; resize_coef(x, sx, sw, true, s0, w0, w1); xs[x] = s0; xw[x] = (w0 & 0xFFFF) | (w1 << 16); }
+            for (int y = 0; y < dh; y++) { int s0, w0, w1; resize_coef(y, sy, sh, false, s0, w0, w1); ys[y] = s0; yw[y] = (w0 & 0xFFFF) | (w1 << 16); }
+        }
+        CK(hipMalloc((void**)&h->d_coef, std::max<size_t>(tab.size() * 4, 256)));
+        if (!tab.empty()) CK(hipMemcpy(h->d_coef, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc((void**)&h->d_cand, B * h->candFrame * 4));
     CK(hipMalloc((void**)&h->d_keyNode, B * h->candFrame * 2));
     CK(hipMalloc((void**)&h->d_candCount, B * nl * 4));
@@ -1504,6 +1545,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.dst = h->d_pyr + h->lv[l].planeOff; R.dFrame = h->pyrFrame; R.dStride = h->lv[l].stride;
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
+        R.coef = h->d_coef + h->coefOff[l];
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + R2_TH - 1) / R2_TH, batch);
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
