@@ -332,9 +332,6 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-#ifndef FAST_EXP
-#define FAST_EXP 9
-#endif
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -410,7 +407,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int ry = r0 + 4 * wave + rsub + 2 * k;
-            if (FAST_EXP != 3 && ry < rend && 4 * dcol < detW) {
+            if (ry < rend && 4 * dcol < detW) {
                 const uint32_t* cw = (const uint32_t*)(img + (dy0 + ry) * pitch) + 1 + dcol;
                 const int p4 = pitch >> 2;
                 const uint32_t C = cw[0], Cp = cw[-1], Cn = cw[1], U = cw[-3 * p4], D = cw[3 * p4];
@@ -454,13 +451,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-#if FAST_EXP == 0
-        const int n1 = 0;
-#elif FAST_EXP == 1
-        const int n1 = 0; if (incl == 12345) sh[7] = 1;
-#else
         const int n1 = __shfl(incl, 63);
-#endif
         {
             int slot = incl - cnt;
             while (mask) {
@@ -502,9 +493,6 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     n2w = min(n2w, FAST_Q2CAP / 4);
-#if FAST_EXP == 2
-    if (n2w == 12345) sh[7] = 1; n2w = 0;
-#endif
     // ---- stage 3: exact score of this wave's corners (dense)
     for (int i = lane; i < n2w; i += 64) {
         const int ent = q2w[i];
@@ -512,9 +500,6 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
     }
     __syncthreads();
-#if FAST_EXP == 4
-    if (sh[4] != 77) return;
-#endif
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
     if (!overflow) {
