@@ -30,6 +30,10 @@
 static __constant__ int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
+static const int8_t h_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+static __constant__ float4 c_patternf[256];   // the same pairs as floats (x0, y0, x1, y1): no per-keypoint int8 -> float conversions
 static __constant__ int c_umax[16];
 static __constant__ uint32_t c_icmask[16][12];   // [|v|][dword k of the patch row]: 0xFF where |col - 21| <= umax[|v|] (IC_Angle's circular patch)
 
@@ -963,9 +967,9 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 #define DP 43            // source patch edge (radius 21 = 18 pattern reach + 3 blur taps)
 #define DPP 52           // patch pitch in bytes (13 dwords: odd -> lane-per-row accesses are bank-conflict free)
 #define DB 37            // blurred edge (radius 18)
-#define DRP 38           // row-pass pitch in u16 (19 dwords, odd)
+#define DRP 46           // row-pass buffer: 37 columns x 46 rows of u16 (transposed; 23 dwords per column, odd)
 #define DBP 40           // blurred pitch
-#define DESC_WAVE_STRIDE 5504   // 43*52 (patch; reused for the 37x40 blurred tile once the row pass is done) + 43*38*2 (row pass)
+#define DESC_WAVE_STRIDE 5648   // 43*52 (patch; reused for the 37x40 blurred tile once the row pass is done) + 37*46*2 (row pass) + pad to 16
 
 static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
@@ -1007,10 +1011,19 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
             // interior: 43 rows x 12 aligned dwords (48 B cover the 43 columns at any alignment), coalesced per row
             const int x0 = xs & ~3;
             ox = xs - x0;
-            const uint8_t* src = img + (size_t)ys * L.rowStride + x0;
-            for (int i = lane; i < DP * 12; i += 64) {
-                const int r = i / 12, c = i - r * 12;
-                *(uint32_t*)(patch + r * DPP + 4 * c) = *(const uint32_t*)(src + (size_t)r * L.rowStride + 4 * c);
+            // lanes 0..59 = 5 rows x 12 dwords per pass, 9 passes (rows 43, 44 of the last pass are skipped); all loads are issued
+            // before the first LDS store
+            const int c = lane % 12, r5 = lane / 12;
+            const uint8_t* src = img + (size_t)(ys + r5) * L.rowStride + x0 + 4 * c;
+            uint8_t* dstp = patch + r5 * DPP + 4 * c;
+            uint32_t v[9];
+            if (lane < 60) {
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < 8 || r5 < 3) v[k] = *(const uint32_t*)(src + (size_t)(5 * k) * L.rowStride);
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < 8 || r5 < 3) *(uint32_t*)(dstp + 5 * k * DPP) = v[k];
             }
         } else {
             // the 7x7 blur taps may cross the image border: BORDER_REFLECT_101 at load (GaussianBlur on the un-bordered clone)
@@ -1062,14 +1075,11 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
             uint32_t A[41];   // A[c] = bytes c..c+3
 #pragma unroll
             for (int c = 0; c < 41; c++) A[c] = (c & 3) == 0 ? e[c >> 2] : __builtin_amdgcn_alignbyte(e[(c >> 2) + 1], e[c >> 2], (uint32_t)(c & 3));
-            uint32_t* o = (uint32_t*)(rowp + lane * DRP);
+            // stored transposed, rowp[c][r] (u16, pitch DRP): the column pass then reads vertical neighbours as packed pairs
+            uint16_t* o = rowp + lane;
 #pragma unroll
-            for (int c = 0; c < DB; c += 2) {
-                const uint32_t a = __builtin_amdgcn_udot4(A[c], K0, __builtin_amdgcn_udot4(A[c + 4], K1, 0u, false), false);
-                uint32_t b = 0;
-                if (c + 1 < DB) b = __builtin_amdgcn_udot4(A[c + 1], K0, __builtin_amdgcn_udot4(A[c + 5], K1, 0u, false), false);
-                o[c >> 1] = a | (b << 16);
-            }
+            for (int c = 0; c < DB; c++)
+                o[c * DRP] = (uint16_t)__builtin_amdgcn_udot4(A[c], K0, __builtin_amdgcn_udot4(A[c + 4], K1, 0u, false), false);
         }
         for (int off = 32; off > 0; off >>= 1) {
             m10 += __shfl_xor(m10, off);
@@ -1079,21 +1089,32 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     }
     __syncthreads();
     // column pass, block-cooperative: 4 keypoints x 37 columns x 2 row halves = 296 independent tasks over 256 threads
-    // (a wave-private lane-per-column pass keeps only 37 of 64 lanes busy); out = (sum + 32768) >> 16, saturated
+    // (a wave-private lane-per-column pass keeps only 37 of 64 lanes busy).  A task filters 19 rows of one column with
+    // v_dot2_u32_u16 on vertical pairs (rows 0..18, or 18..36 so that the pair loads stay dword aligned; row 18 is written twice
+    // with the same value); out = (sum + 32768) >> 16, saturated
     for (int t = threadIdx.x; t < 4 * 2 * DB; t += 256) {
         const int w = t / (2 * DB), rem = t - w * (2 * DB);
         const int half = rem >= DB ? 1 : 0, col = rem - half * DB;
         if (!vflag[w]) continue;
-        const uint16_t* rp_ = (const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DP * DPP);
-        uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE;
-        const int r0 = half ? 19 : 0, nout = half ? DB - 19 : 19;
-        uint32_t rp[25];
+        const int r0 = half ? 18 : 0;
+        const uint32_t* cp = (const uint32_t*)((const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DP * DPP) + col * DRP + r0);
+        uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE + r0 * DBP + col;
+        typedef unsigned short u16x2 __attribute__((vector_size(4)));
+        uint32_t E[13], O[12];   // E[k] = rows (r0+2k, r0+2k+1), O[k] = rows (r0+2k+1, r0+2k+2)
 #pragma unroll
-        for (int r = 0; r < 25; r++) rp[r] = (r0 + r < DP) ? rp_[(r0 + r) * DRP + col] : 0u;
+        for (int k = 0; k < 13; k++) E[k] = cp[k];
 #pragma unroll
-        for (int r = 0; r < 19; r++) {
-            const uint32_t acc = 18 * (rp[r] + rp[r + 6]) + 34 * (rp[r + 1] + rp[r + 5]) + 49 * (rp[r + 2] + rp[r + 4]) + 55 * rp[r + 3];
-            if (r < nout) bl[(r0 + r) * DBP + col] = (uint8_t)min((acc + 32768u) >> 16, 255u);
+        for (int k = 0; k < 12; k++) O[k] = __builtin_amdgcn_alignbyte(E[k + 1], E[k], 2u);
+        const u16x2 Wa = {18, 34}, Wb = {49, 55}, Wc = {49, 34}, Wd = {18, 0};
+#pragma unroll
+        for (int j = 0; j < 19; j++) {
+            const uint32_t* Q = (j & 1) ? O : E;
+            const int m = j >> 1;
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[m]), Wa, 32768u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[m + 1]), Wb, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[m + 2]), Wc, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[m + 3]), Wd, acc, false);
+            bl[j * DBP] = (uint8_t)min(acc >> 16, 255u);
         }
     }
     __syncthreads();
@@ -1105,8 +1126,8 @@ static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     uint32_t nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int8_t* pt = c_pattern + (lane * 4 + j) * 4;
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const float4 pt = c_patternf[lane * 4 + j];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
         const int t0 = blur[(18 + r0) * DBP + 18 + q0], t1 = blur[(18 + r1) * DBP + 18 + q1];
@@ -1472,6 +1493,11 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_desc1, (size_t)maxKp * 32));
     CK(hipMalloc((void**)&h->d_counts1, 2 * sizeof(int32_t)));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
+    {
+        float pf[1024];
+        for (int i = 0; i < 1024; i++) pf[i] = (float)h_pattern[i];
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(c_patternf), pf, sizeof(pf)));
+    }
     {
         uint32_t icmask[16][12];
         for (int v = 0; v < 16; v++)

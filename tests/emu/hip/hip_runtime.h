@@ -42,6 +42,7 @@ struct int2 { int x, y; };
 struct ushort2 { unsigned short x, y; };
 struct uchar4 { unsigned char x, y, z, w; };
 struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
