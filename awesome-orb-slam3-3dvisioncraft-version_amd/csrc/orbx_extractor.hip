@@ -27,9 +27,6 @@
 #define FAST_QCAP 2048        // corner queue entries (u16) per chunk
 #define FAST_MAXCELLS 32
 
-static __constant__ int8_t c_pattern[1024] = {
-#include "orb_pattern.inc"
-};
 static const int8_t h_pattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -613,38 +610,51 @@ struct OctParams {
     uint32_t* sel; uint32_t* selAux; int selFrame;   // [frame][selFrame]
     int* selCount; int* lapCount;      // [frame][nlevels]
     int nodeCap;                       // LDS node capacity C
+    int keyCap, keyOff;                // LDS key cache: capacity (keys) and byte offset inside the dynamic LDS block
     int lap0, lap1;
 };
 
-// In-place exclusive scan of a[0..n) (LDS) by the whole 256-thread block; returns the total.
+// In-place exclusive scan of a[0..n) (LDS) by the whole OCT_T-thread block; returns the total.  Thread-serial chunks, one
+// shuffle scan per wave, wave totals through LDS: two workgroup barriers per call (the octree calls this ~5 times per round).
+#ifndef OCT_T
+#define OCT_T 256   // threads per (frame, level) octree problem
+#endif
 static __device__ int block_scan_excl(int* a, int n, int* scratch) {
-    const int tid = threadIdx.x;
-    const int chunk = (n + 255) >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + OCT_T - 1) / OCT_T;
     const int s0 = tid * chunk, s1 = min(s0 + chunk, n);
     int sum = 0;
     for (int i = s0; i < s1; i++) sum += a[i];
-    scratch[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        int v = tid >= off ? scratch[tid - off] : 0;
-        __syncthreads();
-        scratch[tid] += v;
-        __syncthreads();
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
-    const int total = scratch[255];
-    int run = scratch[tid] - sum;
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_T / 64; w++) { const int v = scratch[w]; base += w < wave ? v : 0; total += v; }
+    int run = base + incl - sum;
     for (int i = s0; i < s1; i++) { const int t = a[i]; a[i] = run; run += t; }
     __syncthreads();
     return total;
 }
 
 struct ONode { short x0, y0, x1, y1; };
+#ifndef OCT_KEYCAP
+#define OCT_KEYCAP 0      // candidates per (frame, level) cached in LDS (6 B each).  Measured on MI355X (batch 512): a 3072-key cache
+                          // shortens a workgroup's life ~1.8x but halves the workgroups per CU (36 vs 18 KB of LDS): 0.277 ms vs 0.253 ms
+                          // without -> off by default; levels with more candidates than the cache always take the global-memory path
+#endif
 
-static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
+// The list algorithm proper.  keys / keyNode live either in LDS (the usual case: every round walks all keys twice, and the
+// per-workgroup critical path — the big levels — is latency bound) or in global memory (more candidates than the LDS cache holds).
+static __device__ __forceinline__ void octree_run(const OctParams& P, const OctLevel& L, const int level, const int frame, const int nk,
+                                                  const uint32_t* keys, uint16_t* keyNode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x;
-    const int level = blockIdx.x, frame = blockIdx.y;
-    const OctLevel& L = P.lv[level];
     const int C = P.nodeCap;
     // LDS carve-up (all int-aligned)
     int* scratch = (int*)orb_smem;                 // 256
@@ -663,27 +673,19 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     int* pb = lp; lp += C;                         // [C] push base per processed node
     uint16_t* childPos = (uint16_t*)lp;            // [C][4]
 
-    int nk = P.candCount[(size_t)frame * P.nlevels + level];
-    nk = min(nk, L.candCap);
-    const uint32_t* keys = P.cand + (size_t)frame * P.candFrame + L.candOff;
-    uint16_t* keyNode = P.keyNode + (size_t)frame * P.candFrame + L.candOff;
     int* selCountOut = P.selCount + (size_t)frame * P.nlevels + level;
     int* lapCountOut = P.lapCount + (size_t)frame * P.nlevels + level;
-    if (nk == 0) {
-        if (tid == 0) { *selCountOut = 0; *lapCountOut = 0; }
-        return;
-    }
     const int N = L.N;
     int cur = 0;
     // ---- roots (ORBextractor.cc:550-561) and key assignment by kp.pt.x/hX (:564-568)
-    for (int i = tid; i < L.nIni; i += 256) {
+    for (int i = tid; i < L.nIni; i += OCT_T) {
         ONode n;
         n.x0 = (short)(int)(L.hX * (float)i); n.y0 = 0;
         n.x1 = (short)(int)(L.hX * (float)(i + 1)); n.y1 = (short)L.H;
         rect[0][i] = n; cnt[0][i] = 0; seq[0][i] = i;
     }
     __syncthreads();
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += OCT_T) {
         const float x = (float)(keys[k] & 0xFFF);
         int r = (int)(x / L.hX);
         r = min(r, L.nIni - 1);
@@ -692,13 +694,13 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     }
     __syncthreads();
     // drop empty roots (:572-583), keep order
-    for (int i = tid; i < L.nIni; i += 256) sb[i] = cnt[0][i] > 0 ? 1 : 0;
+    for (int i = tid; i < L.nIni; i += OCT_T) sb[i] = cnt[0][i] > 0 ? 1 : 0;
     __syncthreads();
     int size = block_scan_excl(sb, L.nIni, scratch);
-    for (int i = tid; i < L.nIni; i += 256)
+    for (int i = tid; i < L.nIni; i += OCT_T)
         if (cnt[0][i] > 0) { const int np = sb[i]; rect[1][np] = rect[0][i]; cnt[1][np] = cnt[0][i]; seq[1][np] = seq[0][i]; }
     __syncthreads();
-    for (int k = tid; k < nk; k += 256) keyNode[k] = (uint16_t)sb[keyNode[k]];
+    for (int k = tid; k < nk; k += OCT_T) keyNode[k] = (uint16_t)sb[keyNode[k]];
     __syncthreads();
     cur = 1;
     int seqCounter = L.nIni;
@@ -709,15 +711,15 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
         const ONode* R = rect[cur];
         const int* CN = cnt[cur];
         // 1. expandable nodes E (count > 1), list order
-        for (int i = tid; i < size; i += 256) { sb[i] = CN[i] > 1 ? 1 : 0; nchild[i] = 0; }
+        for (int i = tid; i < size; i += OCT_T) { sb[i] = CN[i] > 1 ? 1 : 0; nchild[i] = 0; }
         __syncthreads();
         const int nE = block_scan_excl(sb, size, scratch);
         if (nE == 0) break;  // nothing can be divided: size stays == prevSize (:667)
-        for (int i = tid; i < size; i += 256)
+        for (int i = tid; i < size; i += OCT_T)
             if (CN[i] > 1) { elist[sb[i]] = i; cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; }
         __syncthreads();
         // 2. child key counts (DivideNode :479-535)
-        for (int k = tid; k < nk; k += 256) {
+        for (int k = tid; k < nk; k += OCT_T) {
             const int nd = keyNode[k];
             if (CN[nd] > 1) {
                 const ONode n = R[nd];
@@ -728,7 +730,7 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
             }
         }
         __syncthreads();
-        for (int e = tid; e < nE; e += 256) {
+        for (int e = tid; e < nE; e += OCT_T) {
             const int i = elist[e];
             nchild[i] = (cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0);
         }
@@ -736,11 +738,11 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
         // 3. processing order and cut
         int nProc = nE;
         if (!sortedMode) {
-            for (int e = tid; e < nE; e += 256) porder[e] = elist[e];
+            for (int e = tid; e < nE; e += OCT_T) porder[e] = elist[e];
             __syncthreads();
         } else {
             // descending (size, creation seq): rule R1 replaces the reference's pointer tie-break (:679-683)
-            for (int e = tid; e < nE; e += 256) {
+            for (int e = tid; e < nE; e += OCT_T) {
                 const int i = elist[e];
                 const int ci = CN[i], si = seq[cur][i];
                 int rank = 0;
@@ -753,12 +755,12 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
             }
             __syncthreads();
             // early break once lNodes.size() >= N (:728-729): running size after each division
-            for (int e = tid; e < nE; e += 256) pb[e] = nchild[porder[e]] - 1;
+            for (int e = tid; e < nE; e += OCT_T) pb[e] = nchild[porder[e]] - 1;
             __syncthreads();
             block_scan_excl(pb, nE, scratch);  // pb[e] = growth before processing e
             if (tid == 0) ctl[0] = nE;
             __syncthreads();
-            for (int e = tid; e < nE; e += 256) {
+            for (int e = tid; e < nE; e += OCT_T) {
                 const int after = prevSize + pb[e] + nchild[porder[e]] - 1;
                 if (after >= N) atomicMin(&ctl[0], e + 1);
             }
@@ -767,14 +769,14 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
             __syncthreads();
         }
         // 4. push bases (children are push_front'ed in processing order, n1..n4)
-        for (int i = tid; i < size; i += 256) sb[i] = 1;  // 1 = survives
-        for (int e = tid; e < nProc; e += 256) pb[e] = nchild[porder[e]];
+        for (int i = tid; i < size; i += OCT_T) sb[i] = 1;  // 1 = survives
+        for (int e = tid; e < nProc; e += OCT_T) pb[e] = nchild[porder[e]];
         __syncthreads();
-        for (int e = tid; e < nProc; e += 256) sb[porder[e]] = 0;
+        for (int e = tid; e < nProc; e += OCT_T) sb[porder[e]] = 0;
         __syncthreads();
         const int totalPushed = block_scan_excl(pb, nProc, scratch);
         // dflag lives in nchild's sign: remember divided nodes before sb is scanned
-        for (int i = tid; i < size; i += 256) if (sb[i] == 0) nchild[i] |= 0x100;
+        for (int i = tid; i < size; i += OCT_T) if (sb[i] == 0) nchild[i] |= 0x100;
         __syncthreads();
         const int nSurv = block_scan_excl(sb, size, scratch);
         const int newSize = totalPushed + nSurv;
@@ -782,7 +784,7 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
         const int nxt = cur ^ 1;
         if (tid == 0) ctl[1] = 0;
         __syncthreads();
-        for (int e = tid; e < nProc; e += 256) {
+        for (int e = tid; e < nProc; e += OCT_T) {
             const int i = porder[e];
             const ONode n = R[i];
             const int hx = (n.x1 - n.x0 + 1) >> 1, hy = (n.y1 - n.y0 + 1) >> 1;
@@ -804,14 +806,14 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
             }
             if (nexp) atomicAdd(&ctl[1], nexp);
         }
-        for (int i = tid; i < size; i += 256)
+        for (int i = tid; i < size; i += OCT_T)
             if (!(nchild[i] & 0x100)) {
                 const int np = totalPushed + sb[i];
                 if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; }
             }
         __syncthreads();
         // 6. move keys
-        for (int k = tid; k < nk; k += 256) {
+        for (int k = tid; k < nk; k += OCT_T) {
             const int nd = keyNode[k];
             if (nchild[nd] & 0x100) {
                 const ONode n = R[nd];
@@ -837,11 +839,11 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     // Original order = cell-row-major, then row-major inside the cell's detection region.
     int* bestS = cc;            // [C]
     int* bestO = cc + C;        // [C]
-    for (int i = tid; i < size; i += 256) { bestS[i] = -1; bestO[i] = 0x7FFFFFFF; }
+    for (int i = tid; i < size; i += OCT_T) { bestS[i] = -1; bestO[i] = 0x7FFFFFFF; }
     __syncthreads();
-    for (int k = tid; k < nk; k += 256) atomicMax(&bestS[keyNode[k]], (int)(keys[k] >> 24));
+    for (int k = tid; k < nk; k += OCT_T) atomicMax(&bestS[keyNode[k]], (int)(keys[k] >> 24));
     __syncthreads();
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += OCT_T) {
         const uint32_t key = keys[k];
         const int nd = keyNode[k];
         if ((int)(key >> 24) == bestS[nd]) {
@@ -854,7 +856,7 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     __syncthreads();
     uint32_t* sel = P.sel + (size_t)frame * P.selFrame + L.selOff;
     uint32_t* selAux = P.selAux + (size_t)frame * P.selFrame + L.selOff;
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += OCT_T) {
         const uint32_t key = keys[k];
         const int nd = keyNode[k];
         if ((int)(key >> 24) == bestS[nd]) {
@@ -867,7 +869,7 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     __syncthreads();
     // ---- E8 ordering ranks: lapping keypoints are written from the back (ORBextractor.cc:1137-1152)
     const int nsel = min(size, L.selCap);
-    for (int i = tid; i < nsel; i += 256) {
+    for (int i = tid; i < nsel; i += OCT_T) {
         float xs = (float)((int)(sel[i] & 0xFFF) + ORBX_MINB);
         if (level != 0) xs = xs * L.scale;
         sb[i] = (xs >= (float)P.lap0 && xs <= (float)P.lap1) ? 1 : 0;
@@ -875,12 +877,39 @@ static __global__ __launch_bounds__(256) void k_octree(OctParams P) {
     }
     __syncthreads();
     const int nLap = block_scan_excl(sb, nsel, scratch);
-    for (int i = tid; i < nsel; i += 256) {
+    for (int i = tid; i < nsel; i += OCT_T) {
         const int lap = nchild[i];
         const int rank = lap ? sb[i] : (i - sb[i]);
         selAux[i] = (uint32_t)rank | ((uint32_t)lap << 31);
     }
     if (tid == 0) { *selCountOut = nsel; *lapCountOut = nLap; }
+}
+
+static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int tid = threadIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs by linear id: with (level, frame) = (id % nlevels, id / nlevels) and 8 levels
+    // every XCD would own ONE level (XCD 0 all the level-0 problems, 4x the work of level 7).  Rotating the level by the frame
+    // index gives each XCD an even mix.
+    const int frame = blockIdx.x / P.nlevels;
+    const int level = (blockIdx.x - frame * P.nlevels + frame) % P.nlevels;
+    const OctLevel& L = P.lv[level];
+    int nk = P.candCount[(size_t)frame * P.nlevels + level];
+    nk = min(nk, L.candCap);
+    const uint32_t* gkeys = P.cand + (size_t)frame * P.candFrame + L.candOff;
+    if (nk == 0) {
+        if (tid == 0) { P.selCount[(size_t)frame * P.nlevels + level] = 0; P.lapCount[(size_t)frame * P.nlevels + level] = 0; }
+        return;
+    }
+    if (nk <= P.keyCap) {
+        uint32_t* lkeys = (uint32_t*)(orb_smem + P.keyOff);
+        uint16_t* lnode = (uint16_t*)(lkeys + P.keyCap);
+        for (int k = tid; k < nk; k += OCT_T) lkeys[k] = gkeys[k];
+        __syncthreads();
+        octree_run(P, L, level, frame, nk, lkeys, lnode);
+    } else {
+        octree_run(P, L, level, frame, nk, gkeys, P.keyNode + (size_t)frame * P.candFrame + L.candOff);
+    }
 }
 
 // ============================================================================================================
@@ -1333,7 +1362,7 @@ struct orbx_extractor {
     std::vector<float> scale, invScale, sigma2, invSigma2; std::vector<int> nfeat; int umax[16];
     LevelHost lv[ORBX_MAX_LEVELS];
     size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
-    int nTiles = 0, fastImgBytes = 0; size_t fastSmem = 0, octSmem = 0;
+    int nTiles = 0, fastImgBytes = 0, octKeyOff = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
@@ -1455,8 +1484,12 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->nTiles = (int)tiles.size();
     h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
     h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
-    h->octSmem = (size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8);
+    h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8) + 15) & ~(size_t)15);
+    h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
+    if (h->octSmem > 64 * 1024 && hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octSmem) != hipSuccess) {
+        orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipFuncSetAttribute(k_octree) failed");
+    }
 
     if (hipSetDevice(device) != hipSuccess) { orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipSetDevice failed"); }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::string m = std::string(#call) + ": " + hipGetErrorString(e_); orbx_free(h); return orbx_fail(nullptr, e_ == hipErrorOutOfMemory ? ORB_E_NOMEM : ORB_E_HIP, m); } } while (0)
@@ -1594,8 +1627,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
         O.cand = h->d_cand; O.candFrame = h->candFrame; O.candCount = h->d_candCount; O.nlevels = nl; O.keyNode = h->d_keyNode;
         O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
-        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1;
-        hipLaunchKernelGGL(k_octree, dim3(nl, batch), dim3(256), h->octSmem, st, O);
+        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = OCT_KEYCAP; O.keyOff = h->octKeyOff;
+        hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), h->octSmem, st, O);
     }
     HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly

@@ -74,6 +74,18 @@ def test_emulated_fast_tile_fallback_path():
             _run_case(lib, case)
 
 
+def test_emulated_octree_lds_key_cache_path():
+    """OCT_KEYCAP (off by default, see csrc) selects an LDS-resident copy of a level's candidates; a 1500-key cache is hit by the small
+    levels and missed by the big ones, so both octree paths run inside one extraction.  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("OCT_KEYCAP=1500",), tag="keycap1500")))
+    for case in CASES:
+        if case[0] in ("euroc_752x480", "noise_tile_overflow"):
+            _run_case(lib, case)
+
+
 def test_empty_image_returns_minus_one(emu_lib):
     e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=emu_lib)
     mono, k, d = e(np.zeros((0, 0), np.uint8))
