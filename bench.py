@@ -295,6 +295,38 @@ def main():
             for b in range(16):
                 O.pose_optimize(pf["poses"][b], pf["edges"][b, :pf["n_edges"][b]], pf["cameras"])
             extra["pose_optimization"]["cpu_port_frames_per_s_1core"] = round(16 / (time.perf_counter() - tc), 1)
+        # ---- extra leg 4 (SURVEY N2 + M6, BASELINE configs[2] shape): Frame::ComputeBoW on a k=10, L=6 vocabulary (the stock ORBvoc shape,
+        #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
+        from orbhip.bow import ORBVocabulary, synth_vocabulary_fast
+        kps, desc = out[0], out[1]
+        voc = ORBVocabulary(synth_vocabulary_fast(5, 10, 6, sample_desc=desc[0, :int(counts[0, 0])].cpu().numpy()), device=dev.index or 0)
+        nfeat = out[2][:, 0].contiguous()
+        bw = voc.transform(desc, nfeat, 4)
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(3):
+            bw = voc.transform(desc, nfeat, 4)
+        barrier()
+        dtb = (time.perf_counter() - t5) / 3
+        ang = kps[:, :, 3].contiguous()
+        sideA = dict(desc=desc[0::2].contiguous(), angle=ang[0::2].contiguous(), node_id=bw["fv_node_id"][0::2].contiguous(),
+                     node_start=bw["fv_node_start"][0::2].contiguous(), feat_idx=bw["fv_feat_idx"][0::2].contiguous(), n_nodes=bw["fv_n_nodes"][0::2].contiguous())
+        sideB = dict(desc=desc[1::2].contiguous(), angle=ang[1::2].contiguous(), node_id=bw["fv_node_id"][1::2].contiguous(),
+                     node_start=bw["fv_node_start"][1::2].contiguous(), feat_idx=bw["fv_feat_idx"][1::2].contiguous(), n_nodes=bw["fv_n_nodes"][1::2].contiguous())
+        kvalid = torch.ones((B // 2, desc.shape[1]), dtype=torch.uint8, device=dev)
+        mb = orbhip.ORBmatcher(0.7, True)
+        fm, nmb = mb.SearchByBoW(sideA, kvalid, sideB)
+        barrier()
+        t6 = time.perf_counter()
+        for _ in range(3):
+            fm, nmb = mb.SearchByBoW(sideA, kvalid, sideB)
+        barrier()
+        dts = (time.perf_counter() - t6) / 3
+        extra["bow"] = {"compute_bow_frames_per_s": round(B / dtb, 1), "compute_bow_ms_per_batch": round(dtb * 1e3, 3),
+                        "search_by_bow_pairs_per_s": round((B // 2) / dts, 1), "search_by_bow_ms_per_batch": round(dts * 1e3, 3),
+                        "mean_matches_per_pair": float(nmb.float().mean().item()), "mean_words_per_frame": float(bw["bv_n"].float().mean().item()),
+                        "vocabulary": "synthetic k=10 L=6 (%d nodes, %d words), levelsup=4" % (voc.n_nodes, voc.n_words),
+                        "extract_bow_match_frames_per_s": round(B / (dt / args.steps + dtb + dts), 1)}
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)

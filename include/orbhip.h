@@ -253,6 +253,36 @@ int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const
                        float nn_ratio, int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * SURVEY.md N2 — the DBoW2 step between the extractor and SearchByBoW: Frame::ComputeBoW (reference src/Frame.cc:865-872) =
+ * TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup = 4)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1137-1206; per-descriptor tree descent :1231-1272 with FORB::distance, FORB.cpp:81-101),
+ * on a vocabulary in the binary format System.cc:83 loads (loadFromBinaryFile, TemplatedVocabulary.h:1442-1480:
+ * header u32 nb_nodes, u32 size_node, i32 k, i32 L, i32 scoring, i32 weighting; then nb_nodes records
+ * {i32 parent, 32 B descriptor, f32 weight, u8 is_leaf}; node ids 1..nb_nodes in file order, word ids in leaf order).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct bow_vocab* bow_vocab_handle;
+/* Parses the file image (host memory) and uploads the tree.  ORB_E_INVALID for a short or inconsistent file. */
+int bow_vocab_load_binary(const void* file_bytes, size_t n_bytes, int device, bow_vocab_handle* out);
+/* out6 = {k, L, scoring (DBoW2::ScoringType), weighting (DBoW2::WeightingType), nodes (without the root), words} */
+int bow_vocab_info(bow_vocab_handle v, int32_t* out6);
+void bow_vocab_destroy(bow_vocab_handle v);
+
+/* Outputs of one transform() per frame, fixed-capacity slabs (device pointers; frame b uses x + b*cap_f, ...):
+ *   per feature i (what transform(feature, id, w, &nid, levelsup) returns): word_id, node_id (NodeId at level L - levelsup), weight;
+ *   FeatureVector (std::map<NodeId, vector<uint>>) as the CSR orbm_search_by_bow / orbm_search_for_triangulation consume:
+ *     fv_node_id[b][cap_f] ascending, fv_node_start[b][cap_f+1], fv_feat_idx[b][cap_f] (ascending inside a node), fv_n_nodes[b];
+ *   BowVector (std::map<WordId, double>) as bv_word[b][cap_f] ascending, bv_value[b][cap_f], bv_n[b] — summed / normalised in
+ *     the reference's order (BowVector.cpp:34-84), so the doubles are bit-identical.
+ * Features whose word weight is 0 ("stopped") appear in neither vector.  cap_f <= 4096. */
+typedef struct bow_result {
+    int32_t* word_id; int32_t* node_id; double* weight;
+    int32_t* fv_node_id; int32_t* fv_node_start; int32_t* fv_feat_idx; int32_t* fv_n_nodes;
+    int32_t* bv_word; double* bv_value; int32_t* bv_n;
+} bow_result;
+int bow_transform(bow_vocab_handle v, const uint8_t* d_desc, const int32_t* d_n, int count_stride, int cap_f, int batch, int levelsup,
+                  const bow_result* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Stage 3 — Optimizer::LocalBundleAdjustment's linearisation  (reference src/Optimizer.cc:1957-2344 graph,
  * src/OptimizableTypes.{h,cpp} edges, Thirdparty/g2o core/block_solver.hpp:502-560 buildSystem,
  * core/base_binary_edge.hpp:55-120 constructQuadraticForm, core/robust_kernel_impl.cpp:78-91 Huber).

@@ -9,6 +9,7 @@
 #include "orbslam3_hip/ORBextractor.h"
 #include "orbslam3_hip/ORBmatcher.h"
 #include "orbslam3_hip/Optimizer.h"
+#include "orbslam3_hip/ORBVocabulary.h"
 
 extern "C" {
 void* oro_create(int, float, int, int, int);
@@ -26,6 +27,9 @@ int omo_fuse(const void*, const uint8_t*, const float*, int, float, float, float
              int32_t*, int32_t*);
 struct OTriSide { const void* kps; const uint8_t* desc; const float* uRight; const uint8_t* has_mp; const int32_t* node_id; const int32_t* node_start;
                   const int32_t* feat; int n_nodes, N; };
+void* obw_load_binary(const uint8_t*, size_t);
+void obw_destroy(void*);
+int obw_transform(void*, const uint8_t*, int, int, int32_t*, int32_t*, double*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, double*);
 int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
@@ -146,6 +150,55 @@ int main() {
         for (size_t i = 0; i < ot.size(); i++)
             if (ot[i] >= 0) { CHECK(pairs[pi].first == i && pairs[pi].second == (size_t)ot[i]); pi++; }
         std::printf("adapter N1: init %d, fuse %d, triangulation %d\n", ni, nf, nt);
+    }
+    // ---- N2: ORBVocabulary::transform through the adapter vs the oracle (a 5-ary, 3-level vocabulary built around the frame's descriptors)
+    {
+        std::vector<uint8_t> blob(24);
+        const int K = 5, LV = 3;
+        std::vector<int> parentOf; std::vector<std::vector<uint8_t>> nd; std::vector<int> depth;
+        std::vector<int> cur(1, 0);
+        std::vector<std::vector<uint8_t>> dsc(1, std::vector<uint8_t>(32, 0));
+        for (int lev = 1; lev <= LV; lev++) {
+            std::vector<int> nxt;
+            for (int p : cur)
+                for (int c = 0; c < K; c++) {
+                    std::vector<uint8_t> d = dsc[p];
+                    if (lev == 1) { const size_t q = rnd() % kA.size(); d.assign(dA.begin() + 32 * q, dA.begin() + 32 * q + 32); }
+                    for (int fl = 0; fl < (40 >> lev); fl++) { const unsigned bp = rnd() % 256; d[bp >> 3] ^= (uint8_t)(1u << (bp & 7)); }
+                    parentOf.push_back(p); depth.push_back(lev); dsc.push_back(d); nxt.push_back((int)dsc.size() - 1);
+                }
+            cur = nxt;
+        }
+        const uint32_t nbn = (uint32_t)parentOf.size(), szn = 41;
+        const int32_t hdr[4] = {K, LV, 0, 0};
+        std::memcpy(&blob[0], &nbn, 4); std::memcpy(&blob[4], &szn, 4); std::memcpy(&blob[8], hdr, 16);
+        for (uint32_t i = 0; i < nbn; i++) {
+            uint8_t rec[41];
+            const int32_t par = parentOf[i];
+            const float w = depth[i] == LV ? (i % 13 == 0 ? 0.f : 0.5f + (float)(rnd() % 800) / 100.f) : 0.f;
+            std::memcpy(rec, &par, 4); std::memcpy(rec + 4, dsc[i + 1].data(), 32); std::memcpy(rec + 36, &w, 4); rec[40] = depth[i] == LV;
+            blob.insert(blob.end(), rec, rec + 41);
+        }
+        orbslam3_hip::ORBVocabulary voc;
+        CHECK(voc.loadFromMemory(blob.data(), blob.size()) && voc.getBranchingFactor() == K && voc.getDepthLevels() == LV);
+        orbslam3_hip::BowVector bv; orbslam3_hip::FeatureVector fv;
+        const int NF = (int)kA.size();
+        voc.transform(dA.data(), NF, bv, fv, 1);
+        void* ov = obw_load_binary(blob.data(), blob.size());
+        CHECK(ov != nullptr);
+        std::vector<int32_t> w1(NF), n1(NF), fn(NF), fs(NF + 1), ff(NF), bw(NF); std::vector<double> wt(NF), bvv(NF); int32_t nn = 0;
+        const int nbv = obw_transform(ov, dA.data(), NF, 1, w1.data(), n1.data(), wt.data(), fn.data(), fs.data(), ff.data(), &nn, bw.data(), bvv.data());
+        obw_destroy(ov);
+        CHECK((int)bv.size() == nbv && (int)fv.size() == nn && nbv > 10 && nn > 5);
+        int i = 0;
+        for (auto& kv : bv) { CHECK((int)kv.first == bw[i] && kv.second == bvv[i]); i++; }
+        i = 0;
+        for (auto& kv : fv) {
+            CHECK((int)kv.first == fn[i] && (int)kv.second.size() == fs[i + 1] - fs[i]);
+            for (size_t j = 0; j < kv.second.size(); j++) CHECK((int)kv.second[j] == ff[fs[i] + j]);
+            i++;
+        }
+        std::printf("adapter N2: %d words, %d feature-vector nodes\n", nbv, nn);
     }
     // ---- stage 3: a toy window (4 KFs, first fixed; 30 points) through LbaLinearizer
     orbslam3_hip::LbaLinearizer L;

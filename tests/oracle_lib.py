@@ -348,3 +348,49 @@ def search_for_triangulation(k1, k2, F12, ep, level_sigma2_2, scale_factors_2, o
     m12 = np.zeros(max(a.N, 1), np.int32)
     n = L.omo_search_for_triangulation(C.byref(a), C.byref(b), _p(F12), _p(ep), _p(ls), _p(sf), int(only_stereo), int(coarse), int(check_ori), _p(m12))
     return m12[:a.N], n
+
+
+# ---- DBoW2 vocabulary + transform (oracle/bow_oracle.cpp) --------------------------------------------------------------
+class OracleVocabulary:
+    def __init__(self, file_bytes):
+        L = lib()
+        L.obw_load_binary.restype = C.c_void_p
+        L.obw_load_binary.argtypes = [C.c_void_p, C.c_size_t]
+        buf = np.frombuffer(file_bytes, np.uint8)
+        self.h = L.obw_load_binary(_p(buf), buf.size)
+        if not self.h:
+            raise ValueError("inconsistent vocabulary file")
+        info = np.zeros(6, np.int32)
+        L.obw_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.obw_info(self.h, _p(info))
+        self.k, self.L, self.scoring, self.weighting, self.n_nodes, self.n_words = [int(x) for x in info]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L = lib()
+            L.obw_destroy.argtypes = [C.c_void_p]
+            L.obw_destroy(self.h)
+            self.h = None
+
+    def transform(self, desc, levelsup=4):
+        L = lib()
+        L.obw_transform.restype = C.c_int
+        L.obw_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        m = max(n, 1)
+        o = dict(word_id=np.zeros(m, np.int32), node_id=np.zeros(m, np.int32), weight=np.zeros(m), fv_node_id=np.zeros(m, np.int32),
+                 fv_node_start=np.zeros(m + 1, np.int32), fv_feat_idx=np.zeros(m, np.int32), fv_n_nodes=np.zeros(1, np.int32),
+                 bv_word=np.zeros(m, np.int32), bv_value=np.zeros(m))
+        o["bv_n"] = L.obw_transform(self.h, _p(desc), n, levelsup, *[_p(o[k]) for k in ("word_id", "node_id", "weight", "fv_node_id", "fv_node_start",
+                                                                                       "fv_feat_idx", "fv_n_nodes", "bv_word", "bv_value")])
+        o["fv_n_nodes"] = int(o["fv_n_nodes"][0])
+        return o
+
+
+def bow_score_l1(w1, v1, w2, v2):
+    L = lib()
+    L.obw_score_l1.restype = C.c_double
+    L.obw_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    w1 = np.ascontiguousarray(w1, np.int32); w2 = np.ascontiguousarray(w2, np.int32); v1 = np.ascontiguousarray(v1); v2 = np.ascontiguousarray(v2)
+    return L.obw_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
