@@ -119,25 +119,28 @@ static __device__ __forceinline__ bool pos_in_grid(const orb_keypoint& kp, const
     return true;
 }
 
+// cells = GRID_CELLS (single camera) or 2*GRID_CELLS (fisheye rig: keypoints >= nleft go to the second half = mGridRight, Frame.cc:470-476)
 static __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* kps, const int32_t* nkp, int cstride, int cap_k,
-                                                          orbm_grid_params g, int32_t* grid_start, int32_t* grid_idx) {
+                                                          orbm_grid_params g, int32_t* grid_start, int32_t* grid_idx, const int32_t* nleft_p,
+                                                          int cells) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    int* cnt = (int*)orb_smem;            // [GRID_CELLS] counts -> starts
-    int* fill = cnt + GRID_CELLS;         // [GRID_CELLS]
-    int* scratch = fill + GRID_CELLS;     // [256]
+    int* cnt = (int*)orb_smem;            // [cells] counts -> starts
+    int* fill = cnt + cells;              // [cells]
+    int* scratch = fill + cells;          // [256]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min(nkp[(size_t)b * cstride], cap_k);
-    kps += (size_t)b * cap_k; grid_start += (size_t)b * (GRID_CELLS + 1); grid_idx += (size_t)b * cap_k;
-    for (int c = tid; c < GRID_CELLS; c += 256) { cnt[c] = 0; fill[c] = 0; }
+    const int nleft = nleft_p ? nleft_p[b] : n;
+    kps += (size_t)b * cap_k; grid_start += (size_t)b * (cells + 1); grid_idx += (size_t)b * cap_k;
+    for (int c = tid; c < cells; c += 256) { cnt[c] = 0; fill[c] = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         int cell;
-        if (pos_in_grid(kps[i], g, cell)) atomicAdd(&cnt[cell], 1);
+        if (pos_in_grid(kps[i], g, cell)) atomicAdd(&cnt[cell + (i >= nleft ? GRID_CELLS : 0)], 1);
     }
     __syncthreads();
-    // exclusive scan of 3072 counts: 12 per thread
+    // exclusive scan of the counts: cells/256 per thread
     {
-        const int per = GRID_CELLS / 256;
+        const int per = cells / 256;
         int sum = 0;
         for (int k = 0; k < per; k++) sum += cnt[tid * per + k];
         scratch[tid] = sum;
@@ -150,18 +153,18 @@ static __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* k
         }
         int run = scratch[tid] - sum;
         for (int k = 0; k < per; k++) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; run += c; }
-        if (tid == 255) grid_start[GRID_CELLS] = run;
+        if (tid == 255) grid_start[cells] = run;
     }
     __syncthreads();
-    for (int c = tid; c < GRID_CELLS; c += 256) grid_start[c] = cnt[c];
+    for (int c = tid; c < cells; c += 256) grid_start[c] = cnt[c];
     for (int i = tid; i < n; i += 256) {
         int cell;
-        if (pos_in_grid(kps[i], g, cell)) grid_idx[cnt[cell] + atomicAdd(&fill[cell], 1)] = i;
+        if (pos_in_grid(kps[i], g, cell)) { cell += i >= nleft ? GRID_CELLS : 0; grid_idx[cnt[cell] + atomicAdd(&fill[cell], 1)] = i; }
     }
     __threadfence_block();
     __syncthreads();
     // restore insertion order inside each cell (cells hold a handful of entries)
-    for (int c = tid; c < GRID_CELLS; c += 256) {
+    for (int c = tid; c < cells; c += 256) {
         const int s = cnt[c], m = fill[c];
         for (int a = 1; a < m; a++) {
             const int v = grid_idx[s + a];
@@ -183,6 +186,8 @@ struct SbpArgs {
     orbm_search_params prm;
     int32_t* q_match; int32_t* kp_match; int32_t* nmatches;
     uint32_t* work;
+    int cells;                  // grid cells per frame: GRID_CELLS, or 2*GRID_CELLS for a fisheye rig (second half = right camera)
+    const int32_t* kp_link;     // rig: global index of each keypoint's stereo partner or -1 (mvLeftToRightMatch / mvRightToLeftMatch)
     int chi2_gate;              // Fuse: reprojection gate of ORBmatcher.cc:1791-1815
     float inv_sigma2[16];
     int32_t* q_dist;
@@ -190,7 +195,7 @@ struct SbpArgs {
 
 // Wave-level enumeration of Frame::GetFeaturesInArea(u, v, radius, minLevel, maxLevel) in the reference's order
 // (ix outer, iy inner, insertion order inside a cell == CSR order inside one grid column segment), with the
-// candidate filters that do not depend on matches made during the call.  sink(pass, idx, dist, octave) is called
+// candidate filters that do not depend on matches made during the call.  sink(pass, idx, dist, octave, inArea) is called
 // wave-uniformly for every 64-entry chunk (lane = entry).
 template <class Sink>
 static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b, const orbm_query& Q, const Desc& qd, int n, Sink&& sink) {
@@ -211,15 +216,17 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
     const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
     const uint8_t* desc = A.desc + (size_t)b * A.cap_k * 32;
     const float* ur = A.u_right ? A.u_right + (size_t)b * A.cap_k : nullptr;
-    const uint8_t* occ0 = A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
-    const int32_t* gs = A.grid_start + (size_t)b * (GRID_CELLS + 1);
+    // the initial occupancy is a call constant (a keypoint that starts blocked can never be matched, so it stays blocked) — except on a rig
+    // with stereo links, where a partner copy overwrites a blocked keypoint unconditionally: then only the resolver's live state applies
+    const uint8_t* occ0 = (A.occupied0 && !A.kp_link) ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
+    const int32_t* gs = A.grid_start + (size_t)b * (A.cells + 1) + ((Q.flags & ORBM_Q_RIGHT) ? GRID_CELLS : 0);
     const int32_t* gi = A.grid_idx + (size_t)b * A.cap_k;
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
         if (nMaxCellY < nMinCellY) break;
         const int s = gs[ix * ORBM_GRID_ROWS + nMinCellY], e = gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
         for (int base = s; base < e; base += 64) {
             const int p = base + lane;
-            bool pass = false;
+            bool pass = false, area = false;   // area: returned by GetFeaturesInArea (level + box); pass: also survives the call-constant filters
             int idx = 0, dist = 256, oct = 0;
             if (p < e) {
                 idx = gi[p];
@@ -233,6 +240,7 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
                     }
                     const float distx = kp.x - Q.u, disty = kp.y - Q.v;
                     if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
+                    area = pass;
                     if (pass && occ0 && occ0[idx]) pass = false;
                     if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
                         const float uR = ur[idx];
@@ -253,7 +261,7 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
                     if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
                 }
             }
-            sink(pass, idx, dist, oct);
+            sink(pass, idx, dist, oct, area);
         }
     }
 }
@@ -267,18 +275,20 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
     const orbm_query Q = A.queries[(size_t)b * A.cap_q + q];
     uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
     int count = 0;
+    bool anyArea = false;   // vIndices.empty() of the reference refers to this, not to the filtered list
     if (Q.flags & ORBM_Q_VALID) {
         const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-        enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+        enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct, bool area) {
             const unsigned long long m = __ballot(pass);
             if (pass) {
                 const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
                 if (pos < SBP_CAPC) w[2 + pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
             }
             count += __popcll(m);
+            anyArea |= __ballot(area) != 0ull;
         });
     }
-    if (lane == 0) { w[0] = (uint32_t)count; w[1] = 0xFFFFFFFFu; }
+    if (lane == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
 }
 
 // M12 Fuse (search half): queries are independent -> one wave per query, first minimum of (dist, enumeration position).
@@ -295,7 +305,7 @@ static __global__ __launch_bounds__(256) void k_fuse(SbpArgs A) {
             const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
             uint32_t k1 = 0xFFFFFFFFu;
             int i1 = -1, seen = 0;
-            enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+            enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct, bool) {
                 const unsigned long long m = __ballot(pass);
                 if (pass) {
                     const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)((seen + __popcll(m & ((1ull << lane) - 1ull))) & 0xFFFFF);
@@ -351,25 +361,35 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
     const orbm_query* queries = A.queries + (size_t)b * A.cap_q;
     int nmatches = 0;
+    bool skipTwin = false;
+    const int32_t* link = A.kp_link ? A.kp_link + (size_t)b * A.cap_k : nullptr;
     for (int q0 = 0; q0 < nq; q0 += 64) {
         {   // stage this block of queries (lane-parallel loads)
             const int q = q0 + lane;
-            int c = 0, obs = 0;
+            int c = 0, obs = 0, fl = 0;
             if (q < nq) {
                 const uint32_t* w = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q;
-                c = (int)w[0];
-                obs = (queries[q].flags & ORBM_Q_HAS_OBS) ? 1 : 0;
+                c = (int)(w[0] & 0x7FFFFFFFu);
+                const uint32_t qf = queries[q].flags;
+                obs = (qf & ORBM_Q_HAS_OBS) ? 1 : 0;
+                // bit 29: GetFeaturesInArea returned something; bit 28: right-camera twin of the previous query; bit 27: right camera
+                fl = (int)((w[0] >> 31) << 29) | ((qf & ORBM_Q_TWIN) ? 1 << 28 : 0) | ((qf & ORBM_Q_RIGHT) ? 1 << 27 : 0);
                 const int m = min(c, SBP_STAGE);
                 for (int k = 0; k < m; k++) sEnt[lane * SBP_STAGE + k] = w[2 + k];
             }
-            sCnt[lane] = c | (obs << 30);
+            sCnt[lane] = c | (obs << 30) | fl;
         }
         __syncthreads();
         const int qend = min(64, nq - q0);
         for (int i = 0; i < qend; i++) {
             const int q = q0 + i;
             const int cw = sCnt[i];
-            const int count = cw & 0x3FFFFFFF;
+            const int count = cw & 0x07FFFFFF;
+            // rig twins (ORBmatcher.cc:166-167 / :2332): a `continue` taken while handling the left camera skips the right camera too
+            const bool twin = (cw >> 28) & 1, rightCam = (cw >> 27) & 1;
+            if (!twin) skipTwin = false;
+            if (twin && skipTwin) continue;
+            if (mode == ORBM_MODE_BEST_ONLY && !rightCam && !((cw >> 29) & 1)) skipTwin = true;   // left window empty
             if (count == 0) continue;
             // per-lane two smallest keys; key = dist<<20 | enumeration position  (first minimum wins, strict '<')
             uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;
@@ -384,7 +404,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 const orbm_query Q = queries[q];
                 const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
                 int seen = 0;
-                enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct) {
+                enumerate_window(A, b, Q, qd, n, [&](bool pass, int idx, int dist, int oct, bool) {
                     const unsigned long long m = __ballot(pass);
                     if (pass && !(initMode ? (int)mdist[idx] <= dist : occ[idx] != 0)) {
                         const uint32_t pos = (uint32_t)(seen + __popcll(m & ((1ull << lane) - 1ull)));
@@ -414,7 +434,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     const int bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
                     const int bestLevel2 = m2 == 0xFFFFFFFFu ? -1 : (int)((eb2 >> 25) & 0x3F);
                     // ORBmatcher.cc:160-178
-                    if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) accept = false;
+                    if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) { accept = false; if (!rightCam) skipTwin = true; }
                     else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
                 } else if (initMode) {   // ORBmatcher.cc:914-918: bestDist < (float)bestDist2*mfNNratio, bestDist2 = INT_MAX when alone
                     const uint32_t m2 = wave_min_u32(iBest ? k2 : k1);
@@ -448,10 +468,14 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 __syncthreads();
             } else if (accept) {
                 nmatches++;
+                // rig, local-map search: the match is copied to the keypoint's stereo partner in the other camera (:172-176, :239-243)
+                const int partner = (link && mode == ORBM_MODE_LOCAL_MAP) ? link[bestIdx] : -1;
+                if (partner >= 0) nmatches++;
                 if (lane == 0) {
-                    occ[bestIdx] = (uint8_t)(cw >> 30);
+                    occ[bestIdx] = (uint8_t)((cw >> 30) & 1);
                     kp_match[bestIdx] = q;
                     q_match[q] = bestIdx;
+                    if (partner >= 0) { occ[partner] = (uint8_t)((cw >> 30) & 1); kp_match[partner] = q; }
                 }
                 __syncthreads();  // single-wave block: orders lane 0's LDS write before the next query's reads
             }
@@ -569,6 +593,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
     const float* fang = A.f.angle + (size_t)b * A.f.cap_f;
     const uint8_t* kvalid = A.kf_valid + (size_t)b * A.kf.cap_f;
     int32_t* f_match = A.f_match + (size_t)b * A.f.cap_f;
+    const int nleft = A.f.n_left ? A.f.n_left[b] : -1;
     if (tid < 32) hist[tid] = 0;
     if (tid < 8) ctl[tid] = 0;
     for (int i = tid; i < A.f.cap_f; i += 256) { f_match[i] = -1; fbin[i] = -1; }
@@ -589,40 +614,61 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
             const int realIdxKF = kfe[iKF];
             if (!kvalid[realIdxKF]) continue;
             const Desc dKF = load_desc(kdesc + (size_t)realIdxKF * 32);
-            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-            int idx1 = -1;
+            // per-lane best/second keys (dist << 20 | position in the node) for the left camera's features (all of them for a single
+            // camera) and, on a fisheye rig, separately for the right camera's (realIdxF >= Nleft), ORBmatcher.cc:411-436
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu;
+            int idx1 = -1, idxr = -1;
             for (int base = fs; base < fe; base += 64) {
                 const int p = base + lane;
                 if (p < fe) {
                     const int realIdxF = ffe[p];
                     if (fbin[realIdxF] == -1 && f_match[realIdxF] < 0) {   // !vpMapPointMatches[realIdxF]
                         const uint32_t key = ((uint32_t)hamming(dKF, load_desc(fdesc + (size_t)realIdxF * 32)) << 20) | (uint32_t)(p - fs);
-                        if (key < k1) { k2 = k1; k1 = key; idx1 = realIdxF; }
-                        else if (key < k2) { k2 = key; }
+                        if (nleft < 0 || realIdxF < nleft) {
+                            if (key < k1) { k2 = k1; k1 = key; idx1 = realIdxF; }
+                            else if (key < k2) { k2 = key; }
+                        } else {
+                            if (key < r1) { r2 = r1; r1 = key; idxr = realIdxF; }
+                            else if (key < r2) { r2 = key; }
+                        }
                     }
                 }
             }
             const uint32_t m1 = wave_min_u32(k1);
-            if (m1 == 0xFFFFFFFFu) continue;
+            if (m1 == 0xFFFFFFFFu) continue;   // bestDist1 stays 256 > TH_LOW: neither camera is matched (:453)
             const bool iBest = k1 == m1;
             const uint32_t m2 = wave_min_u32(iBest ? k2 : k1);
             const int l1 = __ffsll((long long)__ballot(iBest)) - 1;
             const int bestIdxF = __shfl(idx1, l1);
             const int bestDist1 = (int)(m1 >> 20), bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
-            if (bestDist1 <= ORBM_TH_LOW && (float)bestDist1 < A.nn_ratio * (float)bestDist2) {  // :464-470
-                myMatches++;
+            if (bestDist1 > ORBM_TH_LOW) continue;
+            const bool accL = (float)bestDist1 < A.nn_ratio * (float)bestDist2;   // :455
+            int bestIdxFR = -1;
+            if (nleft >= 0) {   // right camera: accepted whenever bestDist1R <= TH_LOW (the ratio test is short-circuited by `|| true`, :509)
+                const uint32_t mr = wave_min_u32(r1);
+                if (mr != 0xFFFFFFFFu && (int)(mr >> 20) <= ORBM_TH_LOW) {
+                    const int lr = __ffsll((long long)__ballot(r1 == mr)) - 1;
+                    bestIdxFR = __shfl(idxr, lr);
+                }
+            }
+            if (accL || bestIdxFR >= 0) {
+                myMatches += (accL ? 1 : 0) + (bestIdxFR >= 0 ? 1 : 0);
                 if (lane == 0) {
-                    f_match[bestIdxF] = realIdxKF;
-                    int bin = 30;  // "accepted, orientation unchecked"
-                    if (A.check_orientation) {
-                        float rot = kang[realIdxKF] - fang[bestIdxF];
-                        if (rot < 0.0f) rot += 360.0f;
-                        bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
-                        if (bin == ORBM_HISTO_LENGTH) bin = 0;
-                        bin = max(0, min(bin, 29));
-                        atomicAdd(&hist[bin], 1);
+                    for (int side = 0; side < 2; side++) {
+                        const int idxF = side == 0 ? (accL ? bestIdxF : -1) : bestIdxFR;
+                        if (idxF < 0) continue;
+                        f_match[idxF] = realIdxKF;
+                        int bin = 30;  // "accepted, orientation unchecked"
+                        if (A.check_orientation) {
+                            float rot = kang[realIdxKF] - fang[idxF];
+                            if (rot < 0.0f) rot += 360.0f;
+                            bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                            bin = max(0, min(bin, 29));
+                            atomicAdd(&hist[bin], 1);
+                        }
+                        fbin[idxF] = (int8_t)bin;
                     }
-                    fbin[bestIdxF] = (int8_t)bin;
                 }
                 __threadfence_block();
                 __builtin_amdgcn_wave_barrier();  // lane 0's LDS write is program-ordered before the next feature's reads
@@ -818,33 +864,60 @@ extern "C" int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, 
                                const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
     if (!d_kps || !d_nkp || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
     hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (2 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
-                       *gp, d_grid_start, d_grid_idx);
+                       *gp, d_grid_start, d_grid_idx, (const int32_t*)nullptr, GRID_CELLS);
+    return launch_status();
+}
+
+extern "C" int orbm_grid_build_rig(const orb_keypoint* d_kps, const int32_t* d_nkp, const int32_t* d_nleft, int count_stride, int cap_k, int batch,
+                                   const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
+    if (!d_kps || !d_nkp || !d_nleft || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
+    hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (4 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
+                       *gp, d_grid_start, d_grid_idx, d_nleft, 2 * GRID_CELLS);
     return launch_status();
 }
 
 extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4; }
 
-extern "C" int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
-                                         const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start,
-                                         const int32_t* d_grid_idx, const orbm_query* d_queries, const uint8_t* d_qdesc,
-                                         const int32_t* d_nq, int cap_q, int batch, const orbm_search_params* params,
-                                         int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches, void* d_work, void* stream) {
+static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0, const int32_t* d_kp_link,
+                      int cells, const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start, const int32_t* d_grid_idx,
+                      const orbm_query* d_queries, const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch,
+                      const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches, void* d_work, void* stream) {
     if (!d_kps || !d_desc || !d_nkp || !d_grid_start || !d_grid_idx || !d_queries || !d_qdesc || !d_nq || !params || !d_q_match ||
         !d_kp_match || !d_nmatches || !d_work || cap_k < 1 || cap_k > 65535 || cap_q < 1 || batch < 1 || count_stride < 1)
         return ORB_E_INVALID;
     if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY && params->mode != ORBM_MODE_INIT) return ORB_E_INVALID;
-    if (params->mode == ORBM_MODE_INIT && cap_q > 65534) return ORB_E_INVALID;
+    if (params->mode == ORBM_MODE_INIT && (cap_q > 65534 || cells != GRID_CELLS)) return ORB_E_INVALID;
     const size_t smem = (32 + 8 + 64 * 8 + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15) + (params->mode == ORBM_MODE_INIT ? (size_t)cap_k * 4 : 0);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     SbpArgs A;
     A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = d_occupied0; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm = *params; A.q_match = d_q_match; A.kp_match = d_kp_match; A.nmatches = d_nmatches; A.work = (uint32_t*)d_work;
+    A.cells = cells; A.kp_link = d_kp_link;
     A.chi2_gate = 0; A.q_dist = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
     hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return launch_status();
+}
+
+extern "C" int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
+                                         const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start,
+                                         const int32_t* d_grid_idx, const orbm_query* d_queries, const uint8_t* d_qdesc,
+                                         const int32_t* d_nq, int cap_q, int batch, const orbm_search_params* params,
+                                         int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches, void* d_work, void* stream) {
+    return sbp_launch(d_kps, d_desc, d_u_right, d_occupied0, nullptr, GRID_CELLS, d_nkp, count_stride, cap_k, d_grid_start, d_grid_idx, d_queries,
+                      d_qdesc, d_nq, cap_q, batch, params, d_q_match, d_kp_match, d_nmatches, d_work, stream);
+}
+
+extern "C" int orbm_search_by_projection_rig(const orb_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_occupied0,
+                                             const int32_t* d_kp_link, const int32_t* d_nkp, int count_stride, int cap_k,
+                                             const int32_t* d_grid_start, const int32_t* d_grid_idx, const orbm_query* d_queries,
+                                             const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch, const orbm_search_params* params,
+                                             int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches, void* d_work, void* stream) {
+    if (params && params->mode == ORBM_MODE_INIT) return ORB_E_INVALID;
+    return sbp_launch(d_kps, d_desc, nullptr, d_occupied0, d_kp_link, 2 * GRID_CELLS, d_nkp, count_stride, cap_k, d_grid_start, d_grid_idx, d_queries,
+                      d_qdesc, d_nq, cap_q, batch, params, d_q_match, d_kp_match, d_nmatches, d_work, stream);
 }
 
 extern "C" int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch, float nn_ratio,
@@ -872,7 +945,7 @@ extern "C" int orbm_fuse(const orb_keypoint* d_kps, const uint8_t* d_desc, const
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm.mode = ORBM_MODE_BEST_ONLY; A.prm.th_dist = params->th_dist; A.prm.nn_ratio = 1.f; A.prm.check_orientation = 0; A.prm.grid = params->grid;
     A.q_match = d_q_match; A.kp_match = nullptr; A.nmatches = d_nfused; A.work = nullptr; A.q_dist = d_q_dist;
-    A.chi2_gate = params->chi2_gate ? 1 : 0;
+    A.chi2_gate = params->chi2_gate ? 1 : 0; A.cells = GRID_CELLS; A.kp_link = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = params->inv_level_sigma2[i];
     if (hipMemsetAsync(d_nfused, 0, (size_t)batch * 4, (hipStream_t)stream) != hipSuccess) return ORB_E_HIP;
     hipLaunchKernelGGL(k_fuse, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);

@@ -14,7 +14,7 @@ from ._lib import OrbHipError
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30   # ORBmatcher.cc:36-38
 GRID_COLS, GRID_ROWS = 64, 48                 # Frame.h:38-39
 MODE_LOCAL_MAP, MODE_BEST_ONLY, MODE_INIT = 0, 1, 2
-Q_VALID, Q_STEREO, Q_HAS_OBS = 1, 2, 4
+Q_VALID, Q_STEREO, Q_HAS_OBS, Q_RIGHT, Q_TWIN = 1, 2, 4, 8, 16
 
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("angle", "<f4"),
                         ("min_level", "<i2"), ("max_level", "<i2"), ("flags", "<u4")])
@@ -32,7 +32,7 @@ class SearchParams(C.Structure):
 
 class BowSide(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("angle", C.c_void_p), ("node_id", C.c_void_p), ("node_start", C.c_void_p),
-                ("feat_idx", C.c_void_p), ("n_nodes", C.c_void_p), ("cap_f", C.c_int32), ("cap_nodes", C.c_int32)]
+                ("feat_idx", C.c_void_p), ("n_nodes", C.c_void_p), ("cap_f", C.c_int32), ("cap_nodes", C.c_int32), ("n_left", C.c_void_p)]
 
 
 class FuseParams(C.Structure):
@@ -84,6 +84,9 @@ def bind(lib):
         "orbm_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
                                             vp, vp, vp, vp, vp]),
         "orbm_search_by_bow": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), i32, f32, i32, vp, vp, vp]),
+        "orbm_grid_build_rig": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(GridParams), vp, vp, vp]),
+        "orbm_search_by_projection_rig": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
+                                                vp, vp, vp, vp, vp]),
         "orbm_fuse": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(FuseParams), vp, vp, vp, vp]),
         "orbm_search_for_triangulation": (i32, [C.POINTER(TriSide), C.POINTER(TriSide), vp, i32, i32, i32, i32, vp, vp, vp]),
     }
@@ -147,12 +150,39 @@ class ORBmatcher:
                                                       _ptr(work), _stream(kps)))
         return q_match, kp_match, nmatches
 
+    # -- fisheye rig (Nleft != -1): kps/desc = [left | right] concatenated, n_left [B]; grid with 2*64*48 cells
+    def grid_build_rig(self, kps, counts, n_left, grid, count_stride=1):
+        B, cap = kps.shape[0], kps.shape[1]
+        gs = _like(kps, (B, 2 * GRID_COLS * GRID_ROWS + 1), np.int32)
+        gi = _like(kps, (B, cap), np.int32)
+        gp = GridParams(*grid)
+        self._check(self._L.orbm_grid_build_rig(_ptr(kps), _ptr(counts), _ptr(n_left), count_stride, cap, B, C.byref(gp), _ptr(gs), _ptr(gi),
+                                                _stream(kps)))
+        return gs, gi
+
+    def SearchByProjectionRig(self, kps, desc, counts, grid_start, grid_idx, queries, qdesc, nq, grid, mode, th_dist=TH_HIGH, kp_link=None,
+                              occupied0=None, count_stride=1):
+        """Rig twins of SearchByProjection (ORBmatcher.cc:184-251 / :2403-2460): queries in map-point order, a right-camera query flagged
+        Q_RIGHT | Q_TWIN directly after its left one."""
+        B, cap_k = kps.shape[0], kps.shape[1]
+        cap_q = qdesc.shape[1]
+        q_match = _like(kps, (B, cap_q), np.int32)
+        kp_match = _like(kps, (B, cap_k), np.int32)
+        nmatches = _like(kps, (B,), np.int32)
+        work = _like(kps, (self._L.orbm_search_workspace_bytes(B, cap_q),), np.uint8)
+        prm = SearchParams(mode, th_dist, self.mfNNratio, int(self.mbCheckOrientation), GridParams(*grid))
+        self._check(self._L.orbm_search_by_projection_rig(_ptr(kps), _ptr(desc), _ptr(occupied0), _ptr(kp_link), _ptr(counts), count_stride, cap_k,
+                                                          _ptr(grid_start), _ptr(grid_idx), _ptr(queries), _ptr(qdesc), _ptr(nq), cap_q, B,
+                                                          C.byref(prm), _ptr(q_match), _ptr(kp_match), _ptr(nmatches), _ptr(work), _stream(kps)))
+        return q_match, kp_match, nmatches
+
     # -- SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:323-587) on FeatureVector CSRs
     def SearchByBoW(self, kf, kf_valid, f):
         """kf / f: dict(desc [B,cap,32], angle [B,cap], node_id [B,capn], node_start [B,capn+1], feat_idx [B,cap], n_nodes [B])"""
         def side(d):
             return BowSide(_ptr(d["desc"]).value, _ptr(d["angle"]).value, _ptr(d["node_id"]).value, _ptr(d["node_start"]).value,
-                           _ptr(d["feat_idx"]).value, _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1])
+                           _ptr(d["feat_idx"]).value, _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1],
+                           _ptr(d["n_left"]).value if d.get("n_left") is not None else None)
         B = kf["desc"].shape[0]
         f_match = _like(f["desc"], (B, f["desc"].shape[1]), np.int32)
         nmatches = _like(f["desc"], (B,), np.int32)

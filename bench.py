@@ -123,7 +123,12 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
     ap.add_argument("--lm-windows", type=int, default=64, help="LBA windows per GPU per step in the full-LM leg")
+    ap.add_argument("--size", default="752x480", help="frame size WxH (the headline is 752x480; 1280x720 is BASELINE configs[3]'s frame shape)")
+    ap.add_argument("--nfeatures", type=int, default=1000, help="ORBextractor nFeatures (1500 with --size 1280x720)")
     args = ap.parse_args()
+    global W, H, NFEAT
+    W, H = [int(v) for v in args.size.lower().split("x")]
+    NFEAT = args.nfeatures
 
     import torch
     import torch.distributed as dist
@@ -344,15 +349,15 @@ def main():
         traffic = None  # HBM bytes per launch of the dominant kernel from the last committed PMC pass (profiles/pmc_latest.json)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if B == 512:  # the PMC pass ran the default batch
+            if B == 512 and (W, H, NFEAT) == (752, 480, 1000):  # the PMC pass ran the default workload
                 traffic = pm["kernels"]["k_" + dom]["traffic_corrected"]
         except Exception:
             pass
         res = {
-            "metric": "frames/sec ORB extract (752x480, 1000 kp)", "value": round(fps, 1), "unit": "frames/s",
+            "metric": "frames/sec ORB extract (%dx%d, %d kp)" % (W, H, NFEAT), "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 752x480 grayscale batch, ORBextractor only, nFeatures=1000, 8 levels, "
+            "config": {"workload": "configs[1]: synthetic %dx%d grayscale batch, ORBextractor only, nFeatures=%d, 8 levels, " % (W, H, NFEAT) +
                                    "bit-exact vs CPU oracle", "frames_per_gpu_per_step": B, "mean_keypoints": float(counts[:, 0].mean()),
                        "parallelism": "frames sharded, %d rank(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

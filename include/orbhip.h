@@ -152,6 +152,8 @@ typedef struct orbm_query {
 #define ORBM_Q_VALID 1u      /* mbTrackInView && !isBad ... : query takes part */
 #define ORBM_Q_STEREO 2u     /* apply the |u_right - mvuRight[idx]| <= radius gate where mvuRight[idx] > 0 */
 #define ORBM_Q_HAS_OBS 4u    /* pMP->Observations() > 0: once matched, the keypoint is skipped by later queries */
+#define ORBM_Q_RIGHT 8u      /* fisheye rig: search the right camera's grid (GetFeaturesInArea(..., bRight = true)) */
+#define ORBM_Q_TWIN 16u      /* fisheye rig: right-camera query of the same map point as the previous query */
 
 typedef struct orbm_search_params {
     int32_t mode;              /* ORBM_MODE_LOCAL_MAP, ORBM_MODE_BEST_ONLY or ORBM_MODE_INIT */
@@ -188,6 +190,24 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
                               const orbm_query* d_queries, const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch,
                               const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
                               void* d_work, void* stream);
+
+/* Fisheye-rig (F.Nleft != -1) variants.  Keypoints / descriptors are the concatenation [mvKeys | mvKeysRight] like the reference's
+ * N-sized arrays; d_nleft[b] = Nleft.  The grid has 2 x 64 x 48 cells per frame (second half = mGridRight, entries are global indices):
+ * grid_start [batch][2*64*48+1].  d_kp_link[b][i] = global index of keypoint i's stereo partner (mvLeftToRightMatch[i] + Nleft, or
+ * mvRightToLeftMatch[i - Nleft]) or -1; may be NULL.  A map point seen by both cameras contributes two consecutive queries: the left
+ * one, then the right one flagged ORBM_Q_RIGHT | ORBM_Q_TWIN.  Reproduced quirks:
+ *   ORBM_MODE_LOCAL_MAP (ORBmatcher.cc:59-258): the `continue` of the left ratio test (:166-167) also skips the right camera; an
+ *     accepted match is copied to the stereo partner and counted twice (:172-176, :239-243); u_right gating does not apply to rigs;
+ *   ORBM_MODE_BEST_ONLY (:2244-2509): an empty left window (`if(vIndices2.empty()) continue;` :2332) or an invalid left query skips
+ *     the right camera of that map point. */
+int orbm_grid_build_rig(const orb_keypoint* d_kps, const int32_t* d_nkp, const int32_t* d_nleft, int count_stride, int cap_k, int batch,
+                        const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream);
+int orbm_search_by_projection_rig(const orb_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_occupied0, const int32_t* d_kp_link,
+                                  const int32_t* d_nkp, int count_stride, int cap_k,
+                                  const int32_t* d_grid_start, const int32_t* d_grid_idx,
+                                  const orbm_query* d_queries, const uint8_t* d_qdesc, const int32_t* d_nq, int cap_q, int batch,
+                                  const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
+                                  void* d_work, void* stream);
 
 /* ORBmatcher::Fuse — the search half of both overloads: per projected map point the best keypoint of the key frame.
  *   chi2_gate = 1: Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight)           ORBmatcher.cc:1630-1882 (search :1770-1830)
@@ -248,6 +268,10 @@ typedef struct orbm_bow_side {
     const int32_t* feat_idx;      /* [batch][cap_f] */
     const int32_t* n_nodes;       /* [batch] */
     int32_t cap_f, cap_nodes;
+    const int32_t* n_left;        /* frame side only: [batch] F.Nleft of a fisheye rig (features >= Nleft belong to the right camera), or
+                                   * NULL / -1 for a single camera.  Rig frames take the `F.Nleft != -1` branch of ORBmatcher.cc:411-436:
+                                   * separate best/second for the left and the right features of a node; the right match is accepted
+                                   * whenever the left best passed TH_LOW and bestDist1R <= TH_LOW (the `|| true` of :509) */
 } orbm_bow_side;
 int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch,
                        float nn_ratio, int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream);

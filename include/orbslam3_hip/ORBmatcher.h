@@ -41,6 +41,11 @@ struct FrameView {
     const float* uRight = nullptr;            // mvuRight or nullptr (monocular)
     const uint8_t* occupied = nullptr;        // 1 where mvpMapPoints[i] && ->Observations()>0 before the call (or nullptr)
     orbm_grid_params grid{0, 0, 0, 0};
+    // fisheye rig (Frame::Nleft != -1): keysUn / descriptors = [mvKeys | mvKeysRight] (N entries), Nleft as in the reference, kpLink[i] =
+    // mvLeftToRightMatch[i] + Nleft for i < Nleft, mvRightToLeftMatch[i - Nleft] otherwise (or -1); queries then come as left/right twins
+    // (ORBM_Q_RIGHT | ORBM_Q_TWIN, see orbhip.h)
+    int Nleft = -1;
+    const int32_t* kpLink = nullptr;
 };
 
 class ORBmatcher {
@@ -81,16 +86,24 @@ public:
         const uint8_t* dqd = qd_.upload(qdesc.data(), (size_t)nq * 32);
         int32_t counts[2] = {n, nq};
         const int32_t* dc = cnt_.upload(counts, 2);
-        int32_t* gs = (int32_t*)gs_.ensure((ORBM_GRID_COLS * ORBM_GRID_ROWS + 1) * 4);
+        int32_t* gs = (int32_t*)gs_.ensure((2 * ORBM_GRID_COLS * ORBM_GRID_ROWS + 1) * 4);
         int32_t* gi = (int32_t*)gi_.ensure((size_t)n * 4);
         int32_t* dqm = (int32_t*)qm_.ensure((size_t)nq * 4);
         int32_t* dkm = (int32_t*)km_.ensure((size_t)n * 4);
         int32_t* dnm = (int32_t*)nm_.ensure(4);
         void* work = work_.ensure(orbm_search_workspace_bytes(1, nq));
-        if (orbm_grid_build(dk, dc, 1, n, 1, &F.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build");
         orbm_search_params prm{mode, thDist, mfNNratio, mbCheckOrientation ? 1 : 0, F.grid};
-        if (orbm_search_by_projection(dk, dd, dur, docc, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
-            throw std::runtime_error("orbm_search_by_projection");
+        if (F.Nleft == -1) {
+            if (orbm_grid_build(dk, dc, 1, n, 1, &F.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build");
+            if (orbm_search_by_projection(dk, dd, dur, docc, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
+                throw std::runtime_error("orbm_search_by_projection");
+        } else {
+            const int32_t* dnl = nl_.upload(&F.Nleft, 1);
+            const int32_t* dlk = F.kpLink ? lk_.upload(F.kpLink, n) : nullptr;
+            if (orbm_grid_build_rig(dk, dc, dnl, 1, n, 1, &F.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build_rig");
+            if (orbm_search_by_projection_rig(dk, dd, docc, dlk, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
+                throw std::runtime_error("orbm_search_by_projection_rig");
+        }
         int nmatches = 0;
         orb_memcpy_d2h(kpMatch.data(), dkm, (size_t)n * 4, nullptr);
         orb_memcpy_d2h(queryMatch.data(), dqm, (size_t)nq * 4, nullptr);
@@ -204,12 +217,46 @@ public:
         return nmatches;
     }
 
+    // ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (ORBmatcher.h:67, ORBmatcher.cc:323-587).
+    // KF / F as KeyFrameView (descriptors + mFeatVec CSR; hasMapPoint on the KF side = "pKF map point exists and is not bad");
+    // angleKF / angleF = keypoint angles (mvKeysUn / mvKeys / mvKeysRight as the reference picks them); nLeftF = F.Nleft (-1: one camera).
+    // fMatch[j] = index of the KF feature whose map point lands in vpMapPointMatches[j], or -1.
+    int SearchByBoW(const KeyFrameView& KF, const float* angleKF, const KeyFrameView& F, const float* angleF, int nLeftF, std::vector<int>& fMatch) {
+        fMatch.assign(F.N, -1);
+        if (KF.N == 0 || F.N == 0 || KF.nodeId.empty() || F.nodeId.empty()) return 0;
+        orbm_bow_side s[2];
+        const KeyFrameView* K[2] = {&KF, &F};
+        const float* ang[2] = {angleKF, angleF};
+        int32_t nn[3] = {(int32_t)KF.nodeId.size(), (int32_t)F.nodeId.size(), nLeftF};
+        const int32_t* dnn = cnt_.upload(nn, 3);
+        for (int i = 0; i < 2; i++) {
+            s[i].desc = td_[i].upload(K[i]->descriptors, (size_t)K[i]->N * 32);
+            s[i].angle = ta_[i].upload(ang[i], K[i]->N);
+            s[i].node_id = tn_[i].upload(K[i]->nodeId.data(), K[i]->nodeId.size());
+            s[i].node_start = ts_[i].upload(K[i]->nodeStart.data(), K[i]->nodeStart.size());
+            s[i].feat_idx = tf_[i].upload(K[i]->featIdx.data(), K[i]->featIdx.size());
+            s[i].n_nodes = dnn + i;
+            s[i].cap_f = K[i]->N; s[i].cap_nodes = nn[i];
+            s[i].n_left = nullptr;
+        }
+        if (nLeftF != -1) s[1].n_left = dnn + 2;
+        const uint8_t* dv = tm_[0].upload(KF.hasMapPoint, KF.N);
+        int32_t* dm = (int32_t*)qm_.ensure((size_t)F.N * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        if (orbm_search_by_bow(&s[0], dv, &s[1], 1, mfNNratio, mbCheckOrientation ? 1 : 0, dm, dnm, nullptr) != ORB_OK) throw std::runtime_error("orbm_search_by_bow");
+        int nmatches = 0;
+        orb_memcpy_d2h(fMatch.data(), dm, (size_t)F.N * 4, nullptr);
+        orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        return nmatches;
+    }
+
     float mfNNratio;
     bool mbCheckOrientation;
 
 private:
     detail::DevBuf kps_, desc_, ur_, occ_, q_, qd_, cnt_, gs_, gi_, qm_, km_, nm_, work_;
-    detail::DevBuf tk_[2], td_[2], tu_[2], tm_[2], tn_[2], ts_[2], tf_[2];
+    detail::DevBuf tk_[2], td_[2], tu_[2], tm_[2], tn_[2], ts_[2], tf_[2], nl_, lk_, ta_[2];
 };
 
 }  // namespace orbslam3_hip

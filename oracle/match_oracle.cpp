@@ -28,7 +28,7 @@ struct Query {  // == orbm_query
     int16_t min_level, max_level;
     uint32_t flags;
 };
-enum { Q_VALID = 1, Q_STEREO = 2, Q_HAS_OBS = 4 };
+enum { Q_VALID = 1, Q_STEREO = 2, Q_HAS_OBS = 4, Q_RIGHT = 8, Q_TWIN = 16 };
 const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;
 const int GRID_COLS = 64, GRID_ROWS = 48;
 
@@ -51,7 +51,9 @@ struct FrameView {
     const uint8_t* desc;
     const float* uRight;  // may be null
     float mnMinX, mnMinY, gwInv, ghInv;
+    int Nleft = -1;   // fisheye rig: keypoints [0, Nleft) = mvKeys (left), [Nleft, N) = mvKeysRight; -1 = single camera
     std::vector<int> mGrid[GRID_COLS][GRID_ROWS];
+    std::vector<int> mGridRight[GRID_COLS][GRID_ROWS];   // holds right-local indices (i - Nleft), Frame.cc:470-476
 
     bool PosInGrid(const KeyPoint& kp, int& posX, int& posY) const {  // Frame.cc:852-862
         posX = (int)std::round((kp.x - mnMinX) * gwInv);
@@ -61,14 +63,17 @@ struct FrameView {
     }
     void AssignFeaturesToGrid() {  // Frame.cc:444-478
         for (int i = 0; i < GRID_COLS; i++)
-            for (int j = 0; j < GRID_ROWS; j++) mGrid[i][j].clear();
+            for (int j = 0; j < GRID_ROWS; j++) { mGrid[i][j].clear(); mGridRight[i][j].clear(); }
         for (int i = 0; i < N; i++) {
             int gx, gy;
-            if (PosInGrid(kps[i], gx, gy)) mGrid[gx][gy].push_back(i);
+            if (PosInGrid(kps[i], gx, gy)) {
+                if (Nleft == -1 || i < Nleft) mGrid[gx][gy].push_back(i);
+                else mGridRight[gx][gy].push_back(i - Nleft);
+            }
         }
     }
     std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
-                                          const int maxLevel) const {  // Frame.cc:755-850
+                                          const int maxLevel, const bool bRight = false) const {  // Frame.cc:755-850
         std::vector<size_t> vIndices;
         float factorX = r, factorY = r;
         const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - factorX) * gwInv));
@@ -82,9 +87,9 @@ struct FrameView {
         const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
         for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
             for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
-                const std::vector<int>& vCell = mGrid[ix][iy];
+                const std::vector<int>& vCell = (!bRight) ? mGrid[ix][iy] : mGridRight[ix][iy];
                 for (size_t j = 0; j < vCell.size(); j++) {
-                    const KeyPoint& kpUn = kps[vCell[j]];
+                    const KeyPoint& kpUn = (Nleft == -1) ? kps[vCell[j]] : (!bRight) ? kps[vCell[j]] : kps[vCell[j] + Nleft];
                     if (bCheckLevels) {
                         if (kpUn.octave < minLevel) continue;
                         if (maxLevel >= 0)
@@ -211,7 +216,7 @@ int omo_search_by_projection(const void* kps, const uint8_t* desc, const float* 
 int omo_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_valid, const int32_t* kf_node_id,
                       const int32_t* kf_node_start, const int32_t* kf_feat, int kf_nodes, const uint8_t* f_desc,
                       const float* f_angle, int fN, const int32_t* f_node_id, const int32_t* f_node_start,
-                      const int32_t* f_feat, int f_nodes, float nnratio, int checkOri, int32_t* f_match) {
+                      const int32_t* f_feat, int f_nodes, float nnratio, int checkOri, int32_t* f_match, int f_nleft) {
     std::vector<int> vpMapPointMatches(fN, -1);
     int nmatches = 0;
     std::vector<int> rotHist[HISTO_LENGTH];
@@ -225,12 +230,20 @@ int omo_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
                 if (!kf_valid[realIdxKF]) continue;  // !pMP || pMP->isBad()
                 const uint8_t* dKF = kf_desc + (size_t)realIdxKF * 32;
                 int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
                 for (int iF = f_node_start[Fit]; iF < f_node_start[Fit + 1]; iF++) {
                     const unsigned int realIdxF = f_feat[iF];
                     if (vpMapPointMatches[realIdxF] >= 0) continue;
                     const int dist = DescriptorDistance(dKF, f_desc + (size_t)realIdxF * 32);
-                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
-                    else if (dist < bestDist2) { bestDist2 = dist; }
+                    if (f_nleft == -1) {
+                        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                        else if (dist < bestDist2) { bestDist2 = dist; }
+                    } else {   // :411-436
+                        if ((int)realIdxF < f_nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                        else if ((int)realIdxF < f_nleft && dist < bestDist2) { bestDist2 = dist; }
+                        if ((int)realIdxF >= f_nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                        else if ((int)realIdxF >= f_nleft && dist < bestDist2R) { bestDist2R = dist; }
+                    }
                 }
                 if (bestDist1 <= TH_LOW) {
                     if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
@@ -243,6 +256,19 @@ int omo_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
                             rotHist[bin].push_back(bestIdxF);
                         }
                         nmatches++;
+                    }
+                    if (bestDist1R <= TH_LOW) {   // :505-540
+                        if (static_cast<float>(bestDist1R) < nnratio * static_cast<float>(bestDist2R) || true) {
+                            vpMapPointMatches[bestIdxFR] = realIdxKF;
+                            if (checkOri) {
+                                float rot = kf_angle[realIdxKF] - f_angle[bestIdxFR];
+                                if (rot < 0.0) rot += 360.0f;
+                                int bin = (int)std::round(rot * factor);
+                                if (bin == HISTO_LENGTH) bin = 0;
+                                rotHist[bin].push_back(bestIdxFR);
+                            }
+                            nmatches++;
+                        }
                     }
                 }
             }
@@ -278,6 +304,106 @@ void omo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out_i
         out_idx[2 * i] = i0; out_idx[2 * i + 1] = i1;
         out_dist[2 * i] = d0; out_dist[2 * i + 1] = d1;
     }
+}
+
+// ---- fisheye rig (F.Nleft != -1) twins of the two projection searches -----------------------------------------------------------
+// Grid of a rig frame as CSR with 2 x 64 x 48 cells: cells [0, G) = mGrid, [G, 2G) = mGridRight; entries are GLOBAL keypoint indices.
+void omo_grid_build_rig(const void* kps, int n, int nleft, float minX, float minY, float gwInv, float ghInv, int32_t* grid_start, int32_t* grid_idx) {
+    FrameView F{n, (const KeyPoint*)kps, nullptr, nullptr, minX, minY, gwInv, ghInv};
+    F.Nleft = nleft;
+    F.AssignFeaturesToGrid();
+    int pos = 0;
+    for (int side = 0; side < 2; side++)
+        for (int ix = 0; ix < GRID_COLS; ix++)
+            for (int iy = 0; iy < GRID_ROWS; iy++) {
+                grid_start[side * GRID_COLS * GRID_ROWS + ix * GRID_ROWS + iy] = pos;
+                const std::vector<int>& c = side ? F.mGridRight[ix][iy] : F.mGrid[ix][iy];
+                for (int v : c) grid_idx[pos++] = side ? v + nleft : v;
+            }
+    grid_start[2 * GRID_COLS * GRID_ROWS] = pos;
+}
+
+// SearchByProjection on a rig frame.  Queries come in map-point order; a map point seen by both cameras contributes its left query
+// followed by its right query (Q_RIGHT | Q_TWIN).  link[i] = global index of the stereo partner of keypoint i
+// (mvLeftToRightMatch[i] + Nleft for i < Nleft, mvRightToLeftMatch[i - Nleft] otherwise) or -1.
+//   mode 0: ORBmatcher.cc:59-258 — the `continue` of the left ratio test (:166-167) also skips the right camera of that map point;
+//           an accepted match is copied to the stereo partner (:172-176, :239-243) and counted twice.
+//   mode 1: ORBmatcher.cc:2244-2509 — `if(vIndices2.empty()) continue;` (:2332) skips the right camera when the left window is empty.
+int omo_search_by_projection_rig(const void* kps, const uint8_t* desc, const uint8_t* occupied0, int n, int nleft, const int32_t* link,
+                                 float minX, float minY, float gwInv, float ghInv, const void* queries_, const uint8_t* qdesc, int nq, int mode,
+                                 int th_dist, float nnratio, int checkOri, int32_t* q_match, int32_t* kp_match) {
+    FrameView F{n, (const KeyPoint*)kps, desc, nullptr, minX, minY, gwInv, ghInv};
+    F.Nleft = nleft;
+    F.AssignFeaturesToGrid();
+    const Query* Q = (const Query*)queries_;
+    std::vector<int> holder(n, -1);
+    std::vector<char> holderObs(n, 0);
+    for (int i = 0; i < n; i++) { kp_match[i] = -1; if (occupied0 && occupied0[i]) holderObs[i] = 1; }
+    for (int q = 0; q < nq; q++) q_match[q] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    bool skipTwin = false;
+    for (int iq = 0; iq < nq; iq++) {
+        const Query& pMP = Q[iq];
+        const bool twin = (pMP.flags & Q_TWIN) != 0, bRight = (pMP.flags & Q_RIGHT) != 0;
+        if (!twin) skipTwin = false;
+        if (!(pMP.flags & Q_VALID)) {
+            if (mode == 1 && !twin) skipTwin = true;   // pMP == NULL / outlier / behind the camera / outside the image: `continue` (:2262-2290)
+            continue;
+        }
+        if (twin && skipTwin) continue;
+        const std::vector<size_t> vIndices = F.GetFeaturesInArea(pMP.u, pMP.v, pMP.radius, pMP.min_level, pMP.max_level, bRight);
+        if (vIndices.empty()) {
+            if (mode == 1 && !bRight) skipTwin = true;   // :2332
+            continue;
+        }
+        const uint8_t* MPdescriptor = qdesc + (size_t)iq * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const size_t idx = bRight ? vIndices[k] + nleft : vIndices[k];
+            if (holderObs[idx]) continue;
+            const int dist = DescriptorDistance(MPdescriptor, F.desc + idx * 32);
+            if (mode == 0) {
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.kps[idx].octave; bestIdx = (int)idx; }
+                else if (dist < bestDist2) { bestLevel2 = F.kps[idx].octave; bestDist2 = dist; }
+            } else {
+                if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+            }
+        }
+        if (bestDist <= th_dist) {
+            const char obs = (pMP.flags & Q_HAS_OBS) ? 1 : 0;
+            if (mode == 0) {
+                if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) { if (!bRight) skipTwin = true; continue; }
+                holder[bestIdx] = iq; holderObs[bestIdx] = obs;
+                q_match[iq] = bestIdx;
+                nmatches++;
+                if (link && link[bestIdx] != -1) { holder[link[bestIdx]] = iq; holderObs[link[bestIdx]] = obs; nmatches++; }
+            } else {
+                holder[bestIdx] = iq; holderObs[bestIdx] = obs;
+                q_match[iq] = bestIdx;
+                nmatches++;
+                if (checkOri) {
+                    float rot = pMP.angle - F.kps[bestIdx].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdx);
+                }
+            }
+        }
+    }
+    if (mode == 1 && checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { holder[rotHist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < n; i++) kp_match[i] = holder[i];
+    for (int q = 0; q < nq; q++)
+        if (q_match[q] >= 0 && holder[q_match[q]] != q) q_match[q] = -1;
+    return nmatches;
 }
 
 // ---- SURVEY N1 / rows M11, M12 -----------------------------------------------------------------------------------------------

@@ -30,6 +30,8 @@ struct OTriSide { const void* kps; const uint8_t* desc; const float* uRight; con
 void* obw_load_binary(const uint8_t*, size_t);
 void obw_destroy(void*);
 int obw_transform(void*, const uint8_t*, int, int, int32_t*, int32_t*, double*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, double*);
+int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
+                      const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
 int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
@@ -149,6 +151,22 @@ int main() {
         size_t pi = 0;
         for (size_t i = 0; i < ot.size(); i++)
             if (ot[i] >= 0) { CHECK(pairs[pi].first == i && pairs[pi].second == (size_t)ot[i]); pi++; }
+        // SearchByBoW on the same CSRs, single camera and as a rig frame (features >= Nleft = right camera)
+        std::vector<float> angA(kA.size()), angB(kB.size());
+        for (size_t i = 0; i < kA.size(); i++) angA[i] = kA[i].angle;
+        for (size_t i = 0; i < kB.size(); i++) angB[i] = kB[i].angle;
+        std::vector<uint8_t> valid(kA.size(), 1);
+        K1.hasMapPoint = valid.data();
+        for (int nl : {-1, (int)kB.size() / 2}) {
+            std::vector<int> fm;
+            orbslam3_hip::ORBmatcher mb(0.7f, true);
+            const int nb = mb.SearchByBoW(K1, angA.data(), K2, angB.data(), nl, fm);
+            std::vector<int32_t> ofm(kB.size());
+            const int onb = omo_search_by_bow(dA.data(), angA.data(), valid.data(), K1.nodeId.data(), K1.nodeStart.data(), K1.featIdx.data(), (int)K1.nodeId.size(),
+                                              dB.data(), angB.data(), K2.N, K2.nodeId.data(), K2.nodeStart.data(), K2.featIdx.data(), (int)K2.nodeId.size(),
+                                              0.7f, 1, ofm.data(), nl);
+            CHECK(nb == onb && nb > 10 && std::memcmp(ofm.data(), fm.data(), ofm.size() * 4) == 0);
+        }
         std::printf("adapter N1: init %d, fuse %d, triangulation %d\n", ni, nf, nt);
     }
     // ---- N2: ORBVocabulary::transform through the adapter vs the oracle (a 5-ary, 3-level vocabulary built around the frame's descriptors)

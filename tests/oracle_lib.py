@@ -205,15 +205,15 @@ def search_by_projection(kps, desc, queries, qdesc, grid, mode, th_dist, nnratio
     return q_match[:len(queries)], kp_match[:len(kps)], n
 
 
-def search_by_bow(kf, kf_valid, f, nnratio, check_ori):
+def search_by_bow(kf, kf_valid, f, nnratio, check_ori, f_nleft=-1):
     L = lib()
     L.omo_search_by_bow.restype = C.c_int
-    L.omo_search_by_bow.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    L.omo_search_by_bow.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]
     fN = f["desc"].shape[0]
     f_match = np.zeros(max(fN, 1), np.int32)
     n = L.omo_search_by_bow(_p(kf["desc"]), _p(kf["angle"]), _p(kf_valid), _p(kf["node_id"]), _p(kf["node_start"]), _p(kf["feat_idx"]),
                             int(kf["n_nodes"]), _p(f["desc"]), _p(f["angle"]), fN, _p(f["node_id"]), _p(f["node_start"]), _p(f["feat_idx"]),
-                            int(f["n_nodes"]), nnratio, int(check_ori), _p(f_match))
+                            int(f["n_nodes"]), nnratio, int(check_ori), _p(f_match), int(f_nleft))
     return f_match[:fN], n
 
 
@@ -394,3 +394,28 @@ def bow_score_l1(w1, v1, w2, v2):
     L.obw_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     w1 = np.ascontiguousarray(w1, np.int32); w2 = np.ascontiguousarray(w2, np.int32); v1 = np.ascontiguousarray(v1); v2 = np.ascontiguousarray(v2)
     return L.obw_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
+
+
+def grid_build_rig(kps, nleft, grid):
+    kps = np.ascontiguousarray(kps)
+    gs = np.zeros(2 * 64 * 48 + 1, np.int32)
+    gi = np.zeros(max(len(kps), 1), np.int32)
+    L = lib()
+    L.omo_grid_build_rig.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.omo_grid_build_rig(_p(kps), len(kps), int(nleft), *[float(g) for g in grid], _p(gs), _p(gi))
+    return gs, gi
+
+
+def search_by_projection_rig(kps, desc, nleft, link, queries, qdesc, grid, mode, th_dist, nnratio, check_ori, occupied0=None):
+    L = lib()
+    L.omo_search_by_projection_rig.restype = C.c_int
+    L.omo_search_by_projection_rig.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                               C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc); queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc)
+    link = None if link is None else np.ascontiguousarray(link, np.int32)
+    q_match = np.zeros(max(len(queries), 1), np.int32)
+    kp_match = np.zeros(max(len(kps), 1), np.int32)
+    n = L.omo_search_by_projection_rig(_p(kps), _p(desc), _p(occupied0) if occupied0 is not None else None, len(kps), int(nleft),
+                                       _p(link) if link is not None else None, *[float(g) for g in grid], _p(queries), _p(qdesc), len(queries),
+                                       mode, th_dist, nnratio, int(check_ori), _p(q_match), _p(kp_match))
+    return q_match[:len(queries)], kp_match[:len(kps)], n

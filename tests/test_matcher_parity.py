@@ -212,7 +212,16 @@ def feature_vector(desc, n_nodes=100):
     return ids.astype(np.int32), np.array(start, np.int32), np.array(feat, np.int32)
 
 
-def _bow_case(lib, backend, nnratio, ori):
+def _bow_sides(S):
+    ka, da, kb, db = S["ka"], S["da"], S["kb"], S["db"]
+    kid, kst, kfe = feature_vector(da)
+    fid, fst, ffe = feature_vector(db)
+    okf = dict(desc=da, angle=np.ascontiguousarray(ka["angle"]), node_id=kid, node_start=kst, feat_idx=kfe, n_nodes=len(kid))
+    of = dict(desc=db, angle=np.ascontiguousarray(kb["angle"]), node_id=fid, node_start=fst, feat_idx=ffe, n_nodes=len(fid))
+    return okf, np.ones(len(ka), np.uint8), of
+
+
+def _bow_case(lib, backend, nnratio, ori, nleft=-1):
     S = scene()
     rng = np.random.default_rng(3)
     ka, da, kb, db = S["ka"], S["da"], S["kb"], S["db"]
@@ -229,7 +238,7 @@ def _bow_case(lib, backend, nnratio, ori):
     kvalid = (rng.random(len(ka)) < 0.8).astype(np.uint8)
     okf = dict(desc=da, angle=np.ascontiguousarray(ka["angle"]), node_id=kid, node_start=kst, feat_idx=kfe, n_nodes=len(kid))
     of = dict(desc=db, angle=np.ascontiguousarray(kb["angle"]), node_id=fid, node_start=fst, feat_idx=ffe, n_nodes=len(fid))
-    om, on = O.search_by_bow(okf, kvalid, of, nnratio, ori)
+    om, on = O.search_by_bow(okf, kvalid, of, nnratio, ori, nleft)
     B = 2
 
     def slab(d, cap_f, cap_n):
@@ -239,9 +248,12 @@ def _bow_case(lib, backend, nnratio, ori):
         out["desc"][:, :n] = d["desc"]; out["angle"][:, :n] = d["angle"]; out["node_id"][:, :d["n_nodes"]] = d["node_id"]
         out["node_start"][:, :d["n_nodes"] + 1] = d["node_start"]; out["feat_idx"][:, :len(d["feat_idx"])] = d["feat_idx"]
         return {k: to_dev(v, backend) for k, v in out.items()}
+    fslab = slab(of, len(kb) + 2, 110)
+    if nleft >= 0:
+        fslab["n_left"] = to_dev(np.full(B, nleft, np.int32), backend)
     kv = np.zeros((B, len(ka) + 4), np.uint8); kv[:, :len(ka)] = kvalid
     m = orbhip.ORBmatcher(nnratio, ori, lib=lib)
-    fm, nm = [to_host(x) for x in m.SearchByBoW(slab(okf, len(ka) + 4, 128), to_dev(kv, backend), slab(of, len(kb) + 2, 110))]
+    fm, nm = [to_host(x) for x in m.SearchByBoW(slab(okf, len(ka) + 4, 128), to_dev(kv, backend), fslab)]
     for b in range(B):
         assert nm[b] == on and np.array_equal(fm[b, :len(kb)], om)
     assert on > 20
@@ -250,6 +262,21 @@ def _bow_case(lib, backend, nnratio, ori):
 @pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.9, False)])
 def test_emu_search_by_bow(emu_lib, ratio, ori):
     _bow_case(emu_lib, "emu", ratio, ori)
+
+
+def test_emu_search_by_bow_fisheye_rig(emu_lib):
+    """F.Nleft != -1 (ORBmatcher.cc:411-436, 505-540): features >= Nleft are the right camera's; separate best/second per camera, the
+    right match rides on the left best passing TH_LOW and skips the ratio test (`|| true`)."""
+    S = scene()
+    n_mono = O.search_by_bow(*_bow_sides(S), 0.7, True)[1]
+    _bow_case(emu_lib, "emu", 0.7, True, nleft=int(0.55 * len(S["kb"])))
+    assert n_mono > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frac", [0.55, 0.0, 1.0])
+def test_hip_search_by_bow_fisheye_rig(hip_lib, frac):
+    _bow_case(hip_lib, "hip", 0.7, True, nleft=int(frac * len(scene()["kb"])))
 
 
 @pytest.mark.gpu
