@@ -256,7 +256,7 @@ def _bow_case(lib, backend, nnratio, ori, nleft=-1):
     fm, nm = [to_host(x) for x in m.SearchByBoW(slab(okf, len(ka) + 4, 128), to_dev(kv, backend), fslab)]
     for b in range(B):
         assert nm[b] == on and np.array_equal(fm[b, :len(kb)], om)
-    assert on > 20
+    assert on > 20 or nleft == 0   # Nleft == 0: no left candidates -> bestDist1 stays 256 and nothing is accepted (:453)
 
 
 @pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.9, False)])
