@@ -140,7 +140,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # ORBHIP_BENCH_BACKEND=gloo + ORBHIP_BENCH_ONE_DEVICE=1: run the N>1 code path with all ranks on ONE GPU (how the multi-rank legs
+        # were exercised on the 1-GPU development box); the driver's runs use the defaults = RCCL, one GPU per rank
+        backend = os.environ.get("ORBHIP_BENCH_BACKEND", "nccl")
+        if os.environ.get("ORBHIP_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -177,161 +185,215 @@ def main():
         kern[k] = v
     counts = out[2].cpu().numpy()
 
-    # ---- extra leg 0: the single-image host-buffer entry point (ORBextractor::operator() drop-in): PCIe + sync inclusive
     extra = {}
-    if not args.headline_only:
-        ex1 = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
-        ex1(frames[0], None, (0, 1000))
-        th = time.perf_counter()
-        nh = 100
-        for i in range(nh):
-            ex1(frames[i % B], None, (0, 1000))
-        extra["host_api"] = {"frames_per_s": round(nh / (time.perf_counter() - th), 1),
-                             "what": "orbx_extract: one 752x480 host image per call, H2D 361 kB + 4 kernels + D2H 60 kB, synchronous (never `value`)"}
-    # ---- extra leg 1: extract + match (grid build + motion-model SearchByProjection against the partner frame)
-    if not args.headline_only:
-        m = orbhip.ORBmatcher(0.9, True)
-        cap = out[0].shape[1]
-        q, nq, src = build_match_queries(out[0].cpu().numpy(), counts, ex.GetScaleFactors(), cap)
-        d_q = torch.from_numpy(q.view(np.uint8).reshape(B, cap, 28)).to(dev)
-        d_nq = torch.from_numpy(nq).to(dev)
-        d_qdesc = out[1][torch.from_numpy(src).to(dev)].contiguous()      # partner descriptors (prepared once, resident in HBM)
-        grid = (0.0, 0.0, float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H)))
-        work = torch.empty(m._L.orbm_search_workspace_bytes(B, cap), dtype=torch.uint8, device=dev)
-        res = None
+    try:
+        # ---- extra leg 0: the single-image host-buffer entry point (ORBextractor::operator() drop-in): PCIe + sync inclusive
+        if not args.headline_only:
+            ex1 = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank)
+            ex1(frames[0], None, (0, 1000))
+            th = time.perf_counter()
+            nh = 100
+            for i in range(nh):
+                ex1(frames[i % B], None, (0, 1000))
+            extra["host_api"] = {"frames_per_s": round(nh / (time.perf_counter() - th), 1),
+                                 "what": "orbx_extract: one 752x480 host image per call, H2D 361 kB + 4 kernels + D2H 60 kB, synchronous (never `value`)"}
+        # ---- extra leg 1: extract + match (grid build + motion-model SearchByProjection against the partner frame)
+        if not args.headline_only:
+            m = orbhip.ORBmatcher(0.9, True)
+            cap = out[0].shape[1]
+            q, nq, src = build_match_queries(out[0].cpu().numpy(), counts, ex.GetScaleFactors(), cap)
+            d_q = torch.from_numpy(q.view(np.uint8).reshape(B, cap, 28)).to(dev)
+            d_nq = torch.from_numpy(nq).to(dev)
+            d_qdesc = out[1][torch.from_numpy(src).to(dev)].contiguous()      # partner descriptors (prepared once, resident in HBM)
+            grid = (0.0, 0.0, float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H)))
+            work = torch.empty(m._L.orbm_search_workspace_bytes(B, cap), dtype=torch.uint8, device=dev)
+            res = None
 
-        def step_match():
-            nonlocal out, res
-            out = ex.extract_batch(d_frames, (0, 1000), out=out)
-            cnt = out[2].view(-1)
-            gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
-            res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
-        for _ in range(2):
-            step_match()
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t1 = time.perf_counter()
-        msteps = max(3, args.steps // 4)
-        for i in range(msteps):
-            if i == msteps - 1:
+            def step_match():
+                nonlocal out, res
                 out = ex.extract_batch(d_frames, (0, 1000), out=out)
-                ev0.record()
                 cnt = out[2].view(-1)
                 gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
                 res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
-                ev1.record()
-            else:
+            for _ in range(2):
                 step_match()
-        barrier()
-        dtm = time.perf_counter() - t1
-        nm = res[2].cpu().numpy()
-        extra["extract_match"] = {"frames_per_s": round(B * msteps / dtm, 1), "ms_per_step": round(dtm / msteps * 1e3, 4),
-                                  "match_only_ms": round(ev0.elapsed_time(ev1), 4), "mean_matches_per_frame": float(nm.mean()),
-                                  "queries_per_frame": float(nq.mean()), "search": "SearchByProjection motion model th=15, TH_HIGH, rot. histogram"}
-        # ---- extra leg 2: LocalBundleAdjustment linearisations (C5-size windows: 100 KF / 20k landmarks)
-        from orbhip.lba import LbaWindows, synth_window
-        nwin = args.lba_windows
-        wins, cams = [], None
-        for i in range(min(nwin, 2)):
-            w, cams = synth_window(100 + i + 10 * rank, 100, 20, 20000, 8, "mono")
-            wins.append(w)
-        wins = [wins[i % len(wins)] for i in range(nwin)]
-        Lw = LbaWindows(wins, cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
-        outs = ("Hpp", "bp", "Hll", "bl", "Hpl", "chi2")
-        for _ in range(2):
-            Lw.build_system(outs)
-        barrier()
-        lsteps = max(3, args.steps // 2)
-        t2 = time.perf_counter()
-        for _ in range(lsteps):
-            Lw.build_system(outs)
-        barrier()
-        dtl = time.perf_counter() - t2
-        E = float(np.mean([len(w["edges"]) for w in wins]))
-        lba_bytes = E * (28 + 144) + 20000 * (24 + 72 + 24) + 80 * (56 + 288 + 48)    # SURVEY.md §8(d) A_lba with the realised E
-        extra["lba"] = {"linearizations_per_s": round(nwin * lsteps / dtl, 1), "ms_per_step": round(dtl / lsteps * 1e3, 4), "windows_per_step": nwin,
-                        "edges_per_window": E, "algorithmic_GBps": round(lba_bytes * nwin * lsteps / dtl / 1e9, 2),
-                        "hbm_frac": round(lba_bytes * nwin * lsteps / dtl / 1e9 / HBM_PEAK_GBS, 5),
-                        "what": "BlockSolver::buildSystem equivalent (residuals, Huber, Jacobians, Hpp/Hll/Hpl/b) for 100-KF/20k-landmark windows"}
-        # full LM iterations: optimizer.optimize(5) per window = linearise + Schur + Cholesky + update + rho test, GPU resident
-        if args.lm_windows != nwin:   # the LM leg batches more windows: its dense Cholesky is one workgroup per window
-            Lw = LbaWindows([wins[i % len(wins)] for i in range(args.lm_windows)], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
-        p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
-        Lw.optimize(5)
-        barrier()
-        osteps = 2
-        t3 = time.perf_counter()
-        for _ in range(osteps):
-            Lw.d["poses"].copy_(p0); Lw.d["points"].copy_(x0)
-            stats = Lw.optimize(5)
-        barrier()
-        dto = time.perf_counter() - t3
-        extra["lba"]["lm_iterations_per_s"] = round(float(stats[:, 0].sum()) * osteps / dto, 1)
-        extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
-        extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
-        extra["lba"]["lm_windows_per_step"] = args.lm_windows
-        if world == 1 and not args.no_cpu_baseline:   # the oracle's LM (reference algorithm restated, dense Schur/Cholesky) on one host core
-            import oracle_lib as O
-            from orbhip.lba import HUBER_MONO, HUBER_STEREO
-            tc = time.perf_counter()
-            _, _, ost = O.lba_optimize(wins[0], cams, (HUBER_MONO, HUBER_STEREO), 2)
-            extra["lba"]["cpu_port_lm_iterations_per_s_1core"] = round(float(ost[0]) / (time.perf_counter() - tc), 2)
-        # ---- extra leg 3: Optimizer::PoseOptimization, one workgroup per frame, 4 x optimize(10) in a single launch
-        from orbhip.lba import pose_optimization, synth_pose_frames
-        pf = synth_pose_frames(seed=40 + rank, batch=64, n_pts=400, kind="stereo")
-        PB = 2048
-        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * (PB // 64)))).to(dev)
-        pP, pE, pN = rep(pf["poses"]), rep(pf["edges"].view(np.uint8).reshape(64, -1)), rep(pf["n_edges"])
-        pC = torch.from_numpy(np.ascontiguousarray(pf["cameras"]).view(np.uint8)).to(dev)
-        pose_optimization(pP, pE, pN, pC)
-        barrier()
-        psteps = 3
-        t4 = time.perf_counter()
-        for _ in range(psteps):
-            po = pose_optimization(pP, pE, pN, pC)
-        barrier()
-        dtp = time.perf_counter() - t4
-        extra["pose_optimization"] = {"frames_per_s": round(PB * psteps / dtp, 1), "ms_per_batch": round(dtp / psteps * 1e3, 3), "frames_per_batch": PB,
-                                      "edges_per_frame": float(pf["n_edges"].mean()), "mean_inliers": float(po[2].float().mean().item()),
-                                      "what": "Optimizer::PoseOptimization (4 rounds x LM optimize(10), outlier re-classification) per frame"}
-        if world == 1 and not args.no_cpu_baseline:
-            import oracle_lib as O
-            tc = time.perf_counter()
-            for b in range(16):
-                O.pose_optimize(pf["poses"][b], pf["edges"][b, :pf["n_edges"][b]], pf["cameras"])
-            extra["pose_optimization"]["cpu_port_frames_per_s_1core"] = round(16 / (time.perf_counter() - tc), 1)
-        # ---- extra leg 4 (SURVEY N2 + M6, BASELINE configs[2] shape): Frame::ComputeBoW on a k=10, L=6 vocabulary (the stock ORBvoc shape,
-        #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
-        from orbhip.bow import ORBVocabulary, synth_vocabulary_fast
-        kps, desc = out[0], out[1]
-        voc = ORBVocabulary(synth_vocabulary_fast(5, 10, 6, sample_desc=desc[0, :int(counts[0, 0])].cpu().numpy()), device=dev.index or 0)
-        nfeat = out[2][:, 0].contiguous()
-        bw = voc.transform(desc, nfeat, 4)
-        barrier()
-        t5 = time.perf_counter()
-        for _ in range(3):
+            barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            msteps = max(3, args.steps // 4)
+            for i in range(msteps):
+                if i == msteps - 1:
+                    out = ex.extract_batch(d_frames, (0, 1000), out=out)
+                    ev0.record()
+                    cnt = out[2].view(-1)
+                    gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
+                    res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
+                    ev1.record()
+                else:
+                    step_match()
+            barrier()
+            dtm = time.perf_counter() - t1
+            nm = res[2].cpu().numpy()
+            extra["extract_match"] = {"frames_per_s": round(B * msteps / dtm, 1), "ms_per_step": round(dtm / msteps * 1e3, 4),
+                                      "match_only_ms": round(ev0.elapsed_time(ev1), 4), "mean_matches_per_frame": float(nm.mean()),
+                                      "queries_per_frame": float(nq.mean()), "search": "SearchByProjection motion model th=15, TH_HIGH, rot. histogram"}
+            # ---- extra leg 2: LocalBundleAdjustment linearisations (C5-size windows: 100 KF / 20k landmarks)
+            from orbhip.lba import LbaWindows, synth_window
+            nwin = args.lba_windows
+            wins, cams = [], None
+            for i in range(min(nwin, 2)):
+                w, cams = synth_window(100 + i + 10 * rank, 100, 20, 20000, 8, "mono")
+                wins.append(w)
+            wins = [wins[i % len(wins)] for i in range(nwin)]
+            Lw = LbaWindows(wins, cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+            outs = ("Hpp", "bp", "Hll", "bl", "Hpl", "chi2")
+            for _ in range(2):
+                Lw.build_system(outs)
+            barrier()
+            lsteps = max(3, args.steps // 2)
+            t2 = time.perf_counter()
+            for _ in range(lsteps):
+                Lw.build_system(outs)
+            barrier()
+            dtl = time.perf_counter() - t2
+            E = float(np.mean([len(w["edges"]) for w in wins]))
+            lba_bytes = E * (28 + 144) + 20000 * (24 + 72 + 24) + 80 * (56 + 288 + 48)    # SURVEY.md §8(d) A_lba with the realised E
+            extra["lba"] = {"linearizations_per_s": round(nwin * lsteps / dtl, 1), "ms_per_step": round(dtl / lsteps * 1e3, 4), "windows_per_step": nwin,
+                            "edges_per_window": E, "algorithmic_GBps": round(lba_bytes * nwin * lsteps / dtl / 1e9, 2),
+                            "hbm_frac": round(lba_bytes * nwin * lsteps / dtl / 1e9 / HBM_PEAK_GBS, 5),
+                            "what": "BlockSolver::buildSystem equivalent (residuals, Huber, Jacobians, Hpp/Hll/Hpl/b) for 100-KF/20k-landmark windows"}
+            # full LM iterations: optimizer.optimize(5) per window = linearise + Schur + Cholesky + update + rho test, GPU resident
+            if args.lm_windows != nwin:   # the LM leg batches more windows: its dense Cholesky is one workgroup per window
+                Lw = LbaWindows([wins[i % len(wins)] for i in range(args.lm_windows)], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+            p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
+            Lw.optimize(5)
+            barrier()
+            osteps = 2
+            t3 = time.perf_counter()
+            for _ in range(osteps):
+                Lw.d["poses"].copy_(p0); Lw.d["points"].copy_(x0)
+                stats = Lw.optimize(5)
+            barrier()
+            dto = time.perf_counter() - t3
+            extra["lba"]["lm_iterations_per_s"] = round(float(stats[:, 0].sum()) * osteps / dto, 1)
+            extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
+            extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
+            extra["lba"]["lm_windows_per_step"] = args.lm_windows
+            if world == 1 and not args.no_cpu_baseline:   # the oracle's LM (reference algorithm restated, dense Schur/Cholesky) on one host core
+                import oracle_lib as O
+                from orbhip.lba import HUBER_MONO, HUBER_STEREO
+                tc = time.perf_counter()
+                _, _, ost = O.lba_optimize(wins[0], cams, (HUBER_MONO, HUBER_STEREO), 2)
+                extra["lba"]["cpu_port_lm_iterations_per_s_1core"] = round(float(ost[0]) / (time.perf_counter() - tc), 2)
+            # ---- extra leg 3: Optimizer::PoseOptimization, one workgroup per frame, 4 x optimize(10) in a single launch
+            from orbhip.lba import pose_optimization, synth_pose_frames
+            pf = synth_pose_frames(seed=40 + rank, batch=64, n_pts=400, kind="stereo")
+            PB = 2048
+            rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * (PB // 64)))).to(dev)
+            pP, pE, pN = rep(pf["poses"]), rep(pf["edges"].view(np.uint8).reshape(64, -1)), rep(pf["n_edges"])
+            pC = torch.from_numpy(np.ascontiguousarray(pf["cameras"]).view(np.uint8)).to(dev)
+            pose_optimization(pP, pE, pN, pC)
+            barrier()
+            psteps = 3
+            t4 = time.perf_counter()
+            for _ in range(psteps):
+                po = pose_optimization(pP, pE, pN, pC)
+            barrier()
+            dtp = time.perf_counter() - t4
+            extra["pose_optimization"] = {"frames_per_s": round(PB * psteps / dtp, 1), "ms_per_batch": round(dtp / psteps * 1e3, 3), "frames_per_batch": PB,
+                                          "edges_per_frame": float(pf["n_edges"].mean()), "mean_inliers": float(po[2].float().mean().item()),
+                                          "what": "Optimizer::PoseOptimization (4 rounds x LM optimize(10), outlier re-classification) per frame"}
+            if world == 1 and not args.no_cpu_baseline:
+                import oracle_lib as O
+                tc = time.perf_counter()
+                for b in range(16):
+                    O.pose_optimize(pf["poses"][b], pf["edges"][b, :pf["n_edges"][b]], pf["cameras"])
+                extra["pose_optimization"]["cpu_port_frames_per_s_1core"] = round(16 / (time.perf_counter() - tc), 1)
+            # ---- extra leg 4 (SURVEY N2 + M6, BASELINE configs[2] shape): Frame::ComputeBoW on a k=10, L=6 vocabulary (the stock ORBvoc shape,
+            #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
+            from orbhip.bow import ORBVocabulary, synth_vocabulary_fast
+            kps, desc = out[0], out[1]
+            voc = ORBVocabulary(synth_vocabulary_fast(5, 10, 6, sample_desc=desc[0, :int(counts[0, 0])].cpu().numpy()), device=dev.index or 0)
+            nfeat = out[2][:, 0].contiguous()
             bw = voc.transform(desc, nfeat, 4)
-        barrier()
-        dtb = (time.perf_counter() - t5) / 3
-        ang = kps[:, :, 3].contiguous()
-        sideA = dict(desc=desc[0::2].contiguous(), angle=ang[0::2].contiguous(), node_id=bw["fv_node_id"][0::2].contiguous(),
-                     node_start=bw["fv_node_start"][0::2].contiguous(), feat_idx=bw["fv_feat_idx"][0::2].contiguous(), n_nodes=bw["fv_n_nodes"][0::2].contiguous())
-        sideB = dict(desc=desc[1::2].contiguous(), angle=ang[1::2].contiguous(), node_id=bw["fv_node_id"][1::2].contiguous(),
-                     node_start=bw["fv_node_start"][1::2].contiguous(), feat_idx=bw["fv_feat_idx"][1::2].contiguous(), n_nodes=bw["fv_n_nodes"][1::2].contiguous())
-        kvalid = torch.ones((B // 2, desc.shape[1]), dtype=torch.uint8, device=dev)
-        mb = orbhip.ORBmatcher(0.7, True)
-        fm, nmb = mb.SearchByBoW(sideA, kvalid, sideB)
-        barrier()
-        t6 = time.perf_counter()
-        for _ in range(3):
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(3):
+                bw = voc.transform(desc, nfeat, 4)
+            barrier()
+            dtb = (time.perf_counter() - t5) / 3
+            ang = kps[:, :, 3].contiguous()
+            sideA = dict(desc=desc[0::2].contiguous(), angle=ang[0::2].contiguous(), node_id=bw["fv_node_id"][0::2].contiguous(),
+                         node_start=bw["fv_node_start"][0::2].contiguous(), feat_idx=bw["fv_feat_idx"][0::2].contiguous(), n_nodes=bw["fv_n_nodes"][0::2].contiguous())
+            sideB = dict(desc=desc[1::2].contiguous(), angle=ang[1::2].contiguous(), node_id=bw["fv_node_id"][1::2].contiguous(),
+                         node_start=bw["fv_node_start"][1::2].contiguous(), feat_idx=bw["fv_feat_idx"][1::2].contiguous(), n_nodes=bw["fv_n_nodes"][1::2].contiguous())
+            kvalid = torch.ones((B // 2, desc.shape[1]), dtype=torch.uint8, device=dev)
+            mb = orbhip.ORBmatcher(0.7, True)
             fm, nmb = mb.SearchByBoW(sideA, kvalid, sideB)
-        barrier()
-        dts = (time.perf_counter() - t6) / 3
-        extra["bow"] = {"compute_bow_frames_per_s": round(B / dtb, 1), "compute_bow_ms_per_batch": round(dtb * 1e3, 3),
-                        "search_by_bow_pairs_per_s": round((B // 2) / dts, 1), "search_by_bow_ms_per_batch": round(dts * 1e3, 3),
-                        "mean_matches_per_pair": float(nmb.float().mean().item()), "mean_words_per_frame": float(bw["bv_n"].float().mean().item()),
-                        "vocabulary": "synthetic k=10 L=6 (%d nodes, %d words), levelsup=4" % (voc.n_nodes, voc.n_words),
-                        "extract_bow_match_frames_per_s": round(B / (dt / args.steps + dtb + dts), 1)}
+            barrier()
+            t6 = time.perf_counter()
+            for _ in range(3):
+                fm, nmb = mb.SearchByBoW(sideA, kvalid, sideB)
+            barrier()
+            dts = (time.perf_counter() - t6) / 3
+            extra["bow"] = {"compute_bow_frames_per_s": round(B / dtb, 1), "compute_bow_ms_per_batch": round(dtb * 1e3, 3),
+                            "search_by_bow_pairs_per_s": round((B // 2) / dts, 1), "search_by_bow_ms_per_batch": round(dts * 1e3, 3),
+                            "mean_matches_per_pair": float(nmb.float().mean().item()), "mean_words_per_frame": float(bw["bv_n"].float().mean().item()),
+                            "vocabulary": "synthetic k=10 L=6 (%d nodes, %d words), levelsup=4" % (voc.n_nodes, voc.n_words),
+                            "extract_bow_match_frames_per_s": round(B / (dt / args.steps + dtb + dts), 1)}
+    except Exception as ex:   # an extra leg must never cost the headline line
+        import traceback
+        extra["error"] = "%s: %s" % (type(ex).__name__, ex)
+        sys.stderr.write(traceback.format_exc())
+    # ---- N > 1 only: the two exchange steps of the path on RCCL — descriptor blocks for cross-rank matching, and the
+    #      landmark-sharded LBA linearisation (all-reduce of the pose-side system, all-gather of the pose blocks)
+    if world > 1 and not args.headline_only:
+        try:
+            from orbhip import dist as D
+            from orbhip.lba import LbaWindows, synth_window
+            barrier()
+            D.allgather_frame_blocks(out[0], out[1], out[2])
+            barrier()
+            tx = time.perf_counter()
+            for _ in range(3):
+                ak, ad, ac = D.allgather_frame_blocks(out[0], out[1], out[2])
+            barrier()
+            dtx = (time.perf_counter() - tx) / 3
+            blk = out[0].shape[1] * 60 + 8
+            extra["exchange"] = {"allgather_frame_blocks_ms": round(dtx * 1e3, 3), "bytes_per_rank": int(B * blk),
+                                 "GBps_into_each_rank": round((world - 1) * B * blk / dtx / 1e9, 2),
+                                 "frames_visible_to_each_rank": int(ak.shape[0]), "what": "one all_gather_into_tensor of per-frame blocks [desc|kps|count]"}
+            w, cams = synth_window(77, 100, 20, 20000, 8, "mono")   # the same window on every rank, landmarks sharded
+            llo, lhi = D.shard(len(w["points"]), rank, world)
+            e = w["edges"]
+            wl = dict(w, edges=e[(e["point"] >= llo) & (e["point"] < lhi)].copy())
+            Ls = LbaWindows([wl], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+            nfree = int((w["pose_hidx"] >= 0).sum())
+            plo, phi = D.shard(nfree, rank, world)
+            free_idx = torch.from_numpy(np.nonzero(w["pose_hidx"] >= 0)[0][plo:phi]).to(dev)
+
+            def lba_step():
+                o = Ls.build_system(("Hpp", "bp", "Hll", "bl", "Hpl", "chi2"))
+                Hs, bs = D.allreduce_pose_system(o["Hpp"][0, :nfree], o["bp"][0, :nfree])
+                pad = torch.zeros((-(-nfree // world), 7), dtype=torch.float64, device=dev)
+                mine = Ls.d["poses"][0][free_idx]
+                pad[:mine.shape[0]] = mine
+                return Hs, D.allgather_pose_blocks(pad)
+            lba_step()
+            barrier()
+            ty = time.perf_counter()
+            for _ in range(5):
+                Hs, allp = lba_step()
+            barrier()
+            dty = (time.perf_counter() - ty) / 5
+            extra["lba_sharded"] = {"ms_per_linearization": round(dty * 1e3, 3), "linearizations_per_s": round(1.0 / dty, 1),
+                                    "edges_this_rank": int(len(wl["edges"])), "landmarks_this_rank": int(lhi - llo),
+                                    "what": "ONE 100-KF / 20k-landmark window, landmarks sharded over %d ranks: local build + all-reduce of H_pp/b_p "
+                                            "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
+        except Exception as ex:
+            import traceback
+            extra["exchange_error"] = "%s: %s" % (type(ex).__name__, ex)
+            sys.stderr.write(traceback.format_exc())
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
                          dtype=torch.float64, device=dev)
