@@ -287,6 +287,24 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
             count += __popcll(m);
             anyArea |= __ballot(area) != 0ull;
         });
+        if (count > 1 && count <= SBP_CAPC) {
+            // sort the cached list by (distance, enumeration position): the resolver then takes "first unblocked" instead of min-reducing.
+            // Wave-wide bitonic sort of (dist << 6 | pos) << 32 | entry; the wave re-reads its own just-written list.
+            __threadfence_block();   // the list was written by other lanes of this wave (global memory): workgroup-scope release/acquire
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long key = ~0ull;
+            if (lane < count) { const uint32_t e = w[2 + lane]; key = ((unsigned long long)((((e >> 16) & 0x1FFu) << 6) | (uint32_t)lane) << 32) | e; }
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned long long other = __shfl_xor(key, j);
+                    const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
+                    key = keepMin ? (key < other ? key : other) : (key > other ? key : other);
+                }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < count) w[2 + lane] = (uint32_t)key;
+        }
     }
     if (lane == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
 }
@@ -391,16 +409,25 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
             if (twin && skipTwin) continue;
             if (mode == ORBM_MODE_BEST_ONLY && !rightCam && !((cw >> 29) & 1)) skipTwin = true;   // left window empty
             if (count == 0) continue;
-            // per-lane two smallest keys; key = dist<<20 | enumeration position  (first minimum wins, strict '<')
-            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;
+            // best / second-best among the candidates that are not blocked by the live state.  The cached list is sorted by
+            // (distance, enumeration position) — the order in which the reference's strict-'<' scan would rank them — so the best is
+            // simply the first unblocked entry and the second-best the next one: one ballot instead of wave-wide min reductions.
+            uint32_t eb1 = 0, eb2 = 0;
+            bool have2 = false;
             if (count <= SBP_CAPC) {
+                uint32_t e = 0;
+                bool unb = false;
                 if (lane < count) {
-                    const uint32_t e = count <= SBP_STAGE ? sEnt[i * SBP_STAGE + lane]
-                                                          : A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2 + lane];
-                    const bool blocked = initMode ? (uint32_t)mdist[e & 0xFFFF] <= ((e >> 16) & 0x1FF) : occ[e & 0xFFFF] != 0;
-                    if (!blocked) { k1 = (((e >> 16) & 0x1FF) << 20) | (uint32_t)lane; e1 = e; }
+                    e = count <= SBP_STAGE ? sEnt[i * SBP_STAGE + lane] : A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2 + lane];
+                    unb = !(initMode ? (uint32_t)mdist[e & 0xFFFF] <= ((e >> 16) & 0x1FF) : occ[e & 0xFFFF] != 0);
                 }
-            } else {  // rare: re-enumerate this query against the live occupancy
+                const unsigned long long um = __ballot(unb);
+                if (um == 0ull) continue;  // every candidate already holds an observed point
+                eb1 = __shfl(e, __ffsll((long long)um) - 1);
+                const unsigned long long um2 = um & (um - 1ull);
+                if (um2) { have2 = true; eb2 = __shfl(e, __ffsll((long long)um2) - 1); }
+            } else {  // rare: more candidates than the cache holds -> re-enumerate this query against the live state
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;   // per-lane two smallest keys; key = dist<<20 | enumeration position
                 const orbm_query Q = queries[q];
                 const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
                 int seen = 0;
@@ -415,30 +442,27 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     }
                     seen += __popcll(m);
                 });
+                const uint32_t m1 = wave_min_u32(k1);
+                if (m1 == 0xFFFFFFFFu) continue;
+                const bool iBest = k1 == m1;
+                eb1 = __shfl(e1, __ffsll((long long)__ballot(iBest)) - 1);
+                const uint32_t c2 = iBest ? k2 : k1;
+                const uint32_t m2 = wave_min_u32(c2);
+                const unsigned long long bm2 = __ballot(c2 == m2 && m2 != 0xFFFFFFFFu);
+                if (bm2) { have2 = true; eb2 = __shfl(iBest ? e2 : e1, __ffsll((long long)bm2) - 1); }
             }
-            const uint32_t m1 = wave_min_u32(k1);
-            if (m1 == 0xFFFFFFFFu) continue;  // every candidate already holds an observed point
-            const bool iBest = k1 == m1;
-            const int l1 = __ffsll((long long)__ballot(iBest)) - 1;
-            const uint32_t eb1 = __shfl(e1, l1);
-            const int bestDist = (int)(m1 >> 20), bestIdx = (int)(eb1 & 0xFFFF);
+            const int bestDist = (int)((eb1 >> 16) & 0x1FF), bestIdx = (int)(eb1 & 0xFFFF);
             bool accept = false;
             if (bestDist <= th) {
                 if (mode == ORBM_MODE_LOCAL_MAP) {
-                    const uint32_t c2 = iBest ? k2 : k1;
-                    const uint32_t m2 = wave_min_u32(c2);
-                    const unsigned long long bm2 = __ballot(c2 == m2 && m2 != 0xFFFFFFFFu);
-                    uint32_t eb2 = 0;
-                    if (bm2) { const int l2 = __ffsll((long long)bm2) - 1; eb2 = __shfl(iBest ? e2 : e1, l2); }
                     const int bestLevel = (int)((eb1 >> 25) & 0x3F);
-                    const int bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
-                    const int bestLevel2 = m2 == 0xFFFFFFFFu ? -1 : (int)((eb2 >> 25) & 0x3F);
+                    const int bestDist2 = have2 ? (int)((eb2 >> 16) & 0x1FF) : 256;
+                    const int bestLevel2 = have2 ? (int)((eb2 >> 25) & 0x3F) : -1;
                     // ORBmatcher.cc:160-178
                     if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) { accept = false; if (!rightCam) skipTwin = true; }
                     else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
                 } else if (initMode) {   // ORBmatcher.cc:914-918: bestDist < (float)bestDist2*mfNNratio, bestDist2 = INT_MAX when alone
-                    const uint32_t m2 = wave_min_u32(iBest ? k2 : k1);
-                    const float bestDist2 = m2 == 0xFFFFFFFFu ? (float)INT_MAX : (float)(int)(m2 >> 20);
+                    const float bestDist2 = have2 ? (float)(int)((eb2 >> 16) & 0x1FF) : (float)INT_MAX;
                     accept = (float)bestDist < bestDist2 * ratio;
                 } else {
                     accept = true;  // ORBmatcher.cc:2372
