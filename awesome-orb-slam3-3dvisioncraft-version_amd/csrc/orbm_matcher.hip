@@ -399,16 +399,35 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
         }
         __syncthreads();
         const int qend = min(64, nq - q0);
-        for (int i = 0; i < qend; i++) {
+        // accept rule of one query given its best / second-best unblocked candidates (updates the rig twin-skip state)
+        auto decide = [&](uint32_t eb1, bool have2, uint32_t eb2, bool rightCam) -> bool {
+            const int bestDist = (int)((eb1 >> 16) & 0x1FF);
+            if (bestDist > th) return false;
+            if (mode == ORBM_MODE_LOCAL_MAP) {
+                const int bestLevel = (int)((eb1 >> 25) & 0x3F);
+                const int bestDist2 = have2 ? (int)((eb2 >> 16) & 0x1FF) : 256;
+                const int bestLevel2 = have2 ? (int)((eb2 >> 25) & 0x3F) : -1;
+                // ORBmatcher.cc:160-178
+                if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) { if (!rightCam) skipTwin = true; return false; }
+                return bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2;
+            }
+            if (initMode) {   // ORBmatcher.cc:914-918: bestDist < (float)bestDist2*mfNNratio, bestDist2 = INT_MAX when alone
+                const float bestDist2 = have2 ? (float)(int)((eb2 >> 16) & 0x1FF) : (float)INT_MAX;
+                return (float)bestDist < bestDist2 * ratio;
+            }
+            return true;  // ORBmatcher.cc:2372
+        };
+        // one query resolved by the whole wave (any candidate count, every mode)
+        auto resolve_one = [&](const int i) {
             const int q = q0 + i;
             const int cw = sCnt[i];
             const int count = cw & 0x07FFFFFF;
             // rig twins (ORBmatcher.cc:166-167 / :2332): a `continue` taken while handling the left camera skips the right camera too
             const bool twin = (cw >> 28) & 1, rightCam = (cw >> 27) & 1;
             if (!twin) skipTwin = false;
-            if (twin && skipTwin) continue;
+            if (twin && skipTwin) return;
             if (mode == ORBM_MODE_BEST_ONLY && !rightCam && !((cw >> 29) & 1)) skipTwin = true;   // left window empty
-            if (count == 0) continue;
+            if (count == 0) return;
             // best / second-best among the candidates that are not blocked by the live state.  The cached list is sorted by
             // (distance, enumeration position) — the order in which the reference's strict-'<' scan would rank them — so the best is
             // simply the first unblocked entry and the second-best the next one: one ballot instead of wave-wide min reductions.
@@ -422,10 +441,10 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     unb = !(initMode ? (uint32_t)mdist[e & 0xFFFF] <= ((e >> 16) & 0x1FF) : occ[e & 0xFFFF] != 0);
                 }
                 const unsigned long long um = __ballot(unb);
-                if (um == 0ull) continue;  // every candidate already holds an observed point
-                eb1 = __shfl(e, __ffsll((long long)um) - 1);
+                if (um == 0ull) return;  // every candidate already holds an observed point
+                eb1 = (uint32_t)__builtin_amdgcn_readlane((int)e, __ffsll((long long)um) - 1);   // wave-uniform lane index -> v_readlane, no LDS round trip
                 const unsigned long long um2 = um & (um - 1ull);
-                if (um2) { have2 = true; eb2 = __shfl(e, __ffsll((long long)um2) - 1); }
+                if (um2) { have2 = true; eb2 = (uint32_t)__builtin_amdgcn_readlane((int)e, __ffsll((long long)um2) - 1); }
             } else {  // rare: more candidates than the cache holds -> re-enumerate this query against the live state
                 uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, e1 = 0, e2 = 0;   // per-lane two smallest keys; key = dist<<20 | enumeration position
                 const orbm_query Q = queries[q];
@@ -443,7 +462,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     seen += __popcll(m);
                 });
                 const uint32_t m1 = wave_min_u32(k1);
-                if (m1 == 0xFFFFFFFFu) continue;
+                if (m1 == 0xFFFFFFFFu) return;
                 const bool iBest = k1 == m1;
                 eb1 = __shfl(e1, __ffsll((long long)__ballot(iBest)) - 1);
                 const uint32_t c2 = iBest ? k2 : k1;
@@ -452,22 +471,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 if (bm2) { have2 = true; eb2 = __shfl(iBest ? e2 : e1, __ffsll((long long)bm2) - 1); }
             }
             const int bestDist = (int)((eb1 >> 16) & 0x1FF), bestIdx = (int)(eb1 & 0xFFFF);
-            bool accept = false;
-            if (bestDist <= th) {
-                if (mode == ORBM_MODE_LOCAL_MAP) {
-                    const int bestLevel = (int)((eb1 >> 25) & 0x3F);
-                    const int bestDist2 = have2 ? (int)((eb2 >> 16) & 0x1FF) : 256;
-                    const int bestLevel2 = have2 ? (int)((eb2 >> 25) & 0x3F) : -1;
-                    // ORBmatcher.cc:160-178
-                    if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) { accept = false; if (!rightCam) skipTwin = true; }
-                    else if (bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2) accept = true;
-                } else if (initMode) {   // ORBmatcher.cc:914-918: bestDist < (float)bestDist2*mfNNratio, bestDist2 = INT_MAX when alone
-                    const float bestDist2 = have2 ? (float)(int)((eb2 >> 16) & 0x1FF) : (float)INT_MAX;
-                    accept = (float)bestDist < bestDist2 * ratio;
-                } else {
-                    accept = true;  // ORBmatcher.cc:2372
-                }
-            }
+            const bool accept = decide(eb1, have2, eb2, rightCam);
             if (accept && initMode) {
                 const int prev = holder[bestIdx];   // vnMatches21[bestIdx2] (:920-924): the displaced F1 keypoint loses its match
                 if (prev != 0xFFFF) nmatches--;
@@ -503,6 +507,52 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 }
                 __syncthreads();  // single-wave block: orders lane 0's LDS write before the next query's reads
             }
+                };
+        for (int i = 0; i < qend;) {
+            // Batched fast path (occupancy modes): up to 8 consecutive queries with <= SBP_STAGE cached candidates each are laid out over
+            // the wave, 8 lanes per query; ONE read of the occupancy serves all of them, the queries are then decided in order with
+            // scalar work only (ballot byte -> first / second unblocked lane), and an accepted keypoint is broadcast to the later queries'
+            // lanes in registers (`unb` update) instead of through LDS.
+            int nb = 0;
+            if (!initMode) {
+                const int cq = (lane < 8 && i + lane < qend) ? (sCnt[i + lane] & 0x07FFFFFF) : SBP_STAGE + 1;
+                nb = min(__ffsll((long long)__ballot(cq > SBP_STAGE)) - 1, 8);
+            }
+            if (nb < 2) { resolve_one(i); i++; continue; }
+            const int g = lane >> 3, sl = lane & 7;
+            const int cwl = g < nb ? sCnt[i + g] : 0;
+            const bool valid = g < nb && sl < (cwl & 0x07FFFFFF);
+            const uint32_t e = valid ? sEnt[(i + g) * SBP_STAGE + sl] : 0u;
+            const int cidx = (int)(e & 0xFFFF);
+            bool unb = valid && occ[cidx] == 0;
+            for (int j = 0; j < nb; j++) {
+                const int q = q0 + i + j;
+                const int cw = __builtin_amdgcn_readlane(cwl, j * 8);
+                const bool twin = (cw >> 28) & 1, rightCam = (cw >> 27) & 1;
+                if (!twin) skipTwin = false;
+                if (twin && skipTwin) continue;
+                if (mode == ORBM_MODE_BEST_ONLY && !rightCam && !((cw >> 29) & 1)) skipTwin = true;
+                const uint32_t um = (uint32_t)((__ballot(unb) >> (8 * j)) & 0xFFull);
+                if (um == 0u) continue;   // no candidates, or every candidate already holds an observed point
+                const uint32_t eb1 = (uint32_t)__builtin_amdgcn_readlane((int)e, 8 * j + __ffs((int)um) - 1);
+                const uint32_t um2 = um & (um - 1u);
+                const bool have2 = um2 != 0u;
+                const uint32_t eb2 = have2 ? (uint32_t)__builtin_amdgcn_readlane((int)e, 8 * j + __ffs((int)um2) - 1) : 0u;
+                if (!decide(eb1, have2, eb2, rightCam)) continue;
+                const int bestIdx = (int)(eb1 & 0xFFFF), obs = (cw >> 30) & 1;
+                nmatches++;
+                const int partner = (link && mode == ORBM_MODE_LOCAL_MAP) ? link[bestIdx] : -1;
+                if (partner >= 0) nmatches++;
+                if (lane == 0) {
+                    occ[bestIdx] = (uint8_t)obs;
+                    kp_match[bestIdx] = q;
+                    q_match[q] = bestIdx;
+                    if (partner >= 0) { occ[partner] = (uint8_t)obs; kp_match[partner] = q; }
+                }
+                if (valid && (cidx == bestIdx || cidx == partner)) unb = obs == 0;   // what the later queries of this batch will see
+            }
+            __syncthreads();   // lane 0's occupancy writes are ordered before the next batch's reads
+            i += nb;
         }
         __syncthreads();  // the staging area is rewritten by the next block
     }

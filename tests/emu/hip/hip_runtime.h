@@ -246,6 +246,7 @@ template <class T> inline T __shfl_up(T v, int d, int width = 64) {
     int l = emu::lane();
     return __shfl(v, (l - d >= 0 ? l - d : l), 64);
 }
+inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l, 64); }   // lane index must be wave-uniform
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
 }
