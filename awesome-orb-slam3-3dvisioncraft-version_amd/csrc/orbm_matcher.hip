@@ -221,48 +221,65 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
     const uint8_t* occ0 = (A.occupied0 && !A.kp_link) ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
     const int32_t* gs = A.grid_start + (size_t)b * (A.cells + 1) + ((Q.flags & ORBM_Q_RIGHT) ? GRID_CELLS : 0);
     const int32_t* gi = A.grid_idx + (size_t)b * A.cap_k;
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-        if (nMaxCellY < nMinCellY) break;
-        const int s = gs[ix * ORBM_GRID_ROWS + nMinCellY], e = gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
-        for (int base = s; base < e; base += 64) {
-            const int p = base + lane;
-            bool pass = false, area = false;   // area: returned by GetFeaturesInArea (level + box); pass: also survives the call-constant filters
-            int idx = 0, dist = 256, oct = 0;
-            if (p < e) {
-                idx = gi[p];
-                if (idx >= 0 && idx < n) {
-                    const orb_keypoint kp = kps[idx];
-                    oct = kp.octave;
-                    pass = true;
-                    if (bCheckLevels) {
-                        if (oct < minLevel) pass = false;
-                        if (maxLevel >= 0 && oct > maxLevel) pass = false;
-                    }
-                    const float distx = kp.x - Q.u, disty = kp.y - Q.v;
-                    if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
-                    area = pass;
-                    if (pass && occ0 && occ0[idx]) pass = false;
-                    if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
-                        const float uR = ur[idx];
-                        if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
-                    }
-                    if (pass && A.chi2_gate) {   // ORBmatcher.cc:1791-1815 (float e2 * float sigma, compared as double)
-                        const float ex = Q.u - kp.x, ey = Q.v - kp.y;
-                        const float s2 = A.inv_sigma2[oct & 15];
-                        if (ur && ur[idx] >= 0) {
-                            const float er = Q.u_right - ur[idx];
-                            const float e2 = ex * ex + ey * ey + er * er;
-                            if ((double)(e2 * s2) > 7.8) pass = false;
-                        } else {
-                            const float e2 = ex * ex + ey * ey;
-                            if ((double)(e2 * s2) > 5.99) pass = false;
-                        }
-                    }
-                    if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
-                }
-            }
-            sink(pass, idx, dist, oct, area);
+    if (nMaxCellY < nMinCellY) return;
+    // The window's grid columns are contiguous CSR ranges [s_c, e_c).  Instead of walking them one after the other (a chain of dependent
+    // global loads per column, a handful of entries each), their lengths are scanned across the wave and the concatenation — which is
+    // exactly the reference's enumeration order, ix outer / iy inner / insertion order inside a cell — is processed 64 entries at a time.
+    const int ncol = nMaxCellX - nMinCellX + 1;   // <= 64
+    int cs = 0, ce = 0;
+    if (lane < ncol) { cs = gs[(nMinCellX + lane) * ORBM_GRID_ROWS + nMinCellY]; ce = gs[(nMinCellX + lane) * ORBM_GRID_ROWS + nMaxCellY + 1]; }
+    int incl = ce - cs;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int excl = incl - (ce - cs);
+    for (int base = 0; base < total; base += 64) {
+        const int t = base + lane;
+        int p = -1;
+        for (int c = 0; c < ncol; c++) {   // wave-uniform walk over the columns: lane t belongs to the column whose scan interval holds it
+            const int xc = __builtin_amdgcn_readlane(excl, c), ic = __builtin_amdgcn_readlane(incl, c), sc = __builtin_amdgcn_readlane(cs, c);
+            if (t >= xc && t < ic) p = sc + (t - xc);
+            if (ic >= base + 64) break;       // later columns start beyond this chunk
         }
+        bool pass = false, area = false;   // area: returned by GetFeaturesInArea (level + box); pass: also survives the call-constant filters
+        int idx = 0, dist = 256, oct = 0;
+        if (p >= 0) {
+            idx = gi[p];
+            if (idx >= 0 && idx < n) {
+                const orb_keypoint kp = kps[idx];
+                oct = kp.octave;
+                pass = true;
+                if (bCheckLevels) {
+                    if (oct < minLevel) pass = false;
+                    if (maxLevel >= 0 && oct > maxLevel) pass = false;
+                }
+                const float distx = kp.x - Q.u, disty = kp.y - Q.v;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
+                area = pass;
+                if (pass && occ0 && occ0[idx]) pass = false;
+                if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
+                    const float uR = ur[idx];
+                    if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
+                }
+                if (pass && A.chi2_gate) {   // ORBmatcher.cc:1791-1815 (float e2 * float sigma, compared as double)
+                    const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                    const float s2 = A.inv_sigma2[oct & 15];
+                    if (ur && ur[idx] >= 0) {
+                        const float er = Q.u_right - ur[idx];
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * s2) > 7.8) pass = false;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * s2) > 5.99) pass = false;
+                    }
+                }
+                if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
+            }
+        }
+        sink(pass, idx, dist, oct, area);
     }
 }
 
