@@ -713,7 +713,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
                 const int p = base + lane;
                 if (p < fe) {
                     const int realIdxF = ffe[p];
-                    if (fbin[realIdxF] == -1 && f_match[realIdxF] < 0) {   // !vpMapPointMatches[realIdxF]
+                    if (fbin[realIdxF] == -1) {   // !vpMapPointMatches[realIdxF]  (fbin != -1 <=> matched during this call; LDS only on the serial chain)
                         const uint32_t key = ((uint32_t)hamming(dKF, load_desc(fdesc + (size_t)realIdxF * 32)) << 20) | (uint32_t)(p - fs);
                         if (nleft < 0 || realIdxF < nleft) {
                             if (key < k1) { k2 = k1; k1 = key; idx1 = realIdxF; }

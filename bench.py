@@ -341,9 +341,36 @@ def main():
                             "mean_matches_per_pair": float(nmb.float().mean().item()), "mean_words_per_frame": float(bw["bv_n"].float().mean().item()),
                             "vocabulary": "synthetic k=10 L=6 (%d nodes, %d words), levelsup=4" % (voc.n_nodes, voc.n_words),
                             "extract_bow_match_frames_per_s": round(B / (dt / args.steps + dtb + dts), 1)}
-    except Exception as ex:   # an extra leg must never cost the headline line
+        # ---- extra leg 5 (row M9, BASELINE configs[2] is a stereo sequence): rectified stereo = extraction of the right image of every frame
+        #      (a 12..40 px horizontal-disparity copy of the left one) + Frame::ComputeStereoMatches on the two pyramids
+        if not args.headline_only:
+            from orbhip.extractor import stereo_matches
+            exR = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
+            disp = 12 + (torch.arange(B, device=dev) % 8) * 4
+            d_right = torch.stack([torch.roll(d_frames[i], shifts=-int(disp[i]), dims=1) for i in range(B)]).contiguous()
+            outR = exR.extract_batch(d_right, (0, 1000))
+            outL = ex.extract_batch(d_frames, (0, 1000), out=out)
+            ur, dp = stereo_matches(ex, exR, outL, outR, 0.11, 47.9)
+            barrier()
+            t7 = time.perf_counter()
+            for _ in range(3):
+                ur, dp = stereo_matches(ex, exR, outL, outR, 0.11, 47.9)
+            barrier()
+            dtsm = (time.perf_counter() - t7) / 3
+            t8 = time.perf_counter()
+            for _ in range(3):
+                outR = exR.extract_batch(d_right, (0, 1000), out=outR)
+                outL = ex.extract_batch(d_frames, (0, 1000), out=outL)
+                ur, dp = stereo_matches(ex, exR, outL, outR, 0.11, 47.9)
+            barrier()
+            dtst = (time.perf_counter() - t8) / 3
+            nst = (ur[:, :NFEAT] > 0).sum(1).float().mean().item()
+            extra["stereo"] = {"compute_stereo_matches_ms_per_batch": round(dtsm * 1e3, 3), "stereo_frames_per_s": round(B / dtst, 1),
+                               "mean_stereo_points_per_frame": round(nst, 1),
+                               "what": "2 x ORBextractor + Frame::ComputeStereoMatches per stereo frame (bf = 47.9, baseline 0.11 m)"}
+    except Exception as err:   # an extra leg must never cost the headline line
         import traceback
-        extra["error"] = "%s: %s" % (type(ex).__name__, ex)
+        extra["error"] = "%s: %s" % (type(err).__name__, err)
         sys.stderr.write(traceback.format_exc())
     # ---- N > 1 only: the two exchange steps of the path on RCCL — descriptor blocks for cross-rank matching, and the
     #      landmark-sharded LBA linearisation (all-reduce of the pose-side system, all-gather of the pose blocks)
@@ -390,9 +417,9 @@ def main():
                                     "edges_this_rank": int(len(wl["edges"])), "landmarks_this_rank": int(lhi - llo),
                                     "what": "ONE 100-KF / 20k-landmark window, landmarks sharded over %d ranks: local build + all-reduce of H_pp/b_p "
                                             "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
-        except Exception as ex:
+        except Exception as err:
             import traceback
-            extra["exchange_error"] = "%s: %s" % (type(ex).__name__, ex)
+            extra["exchange_error"] = "%s: %s" % (type(err).__name__, err)
             sys.stderr.write(traceback.format_exc())
     if world > 1:
         t = torch.tensor([dt] + [extra.get("extract_match", {}).get("ms_per_step", 0.0), extra.get("lba", {}).get("ms_per_step", 0.0)],
