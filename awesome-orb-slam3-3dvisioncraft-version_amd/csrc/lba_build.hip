@@ -1,7 +1,7 @@
 // lba_build.hip — stage 3 of the hot path on gfx950: the linearisation of Optimizer::LocalBundleAdjustment
 // (reference src/Optimizer.cc:1957-2344 graph; g2o BlockSolver::buildSystem block_solver.hpp:502-560).
 //
-//   k_lba_landmarks  one thread per landmark walks its (contiguous, landmark-major) edges: computeError +
+//   k_lba_landmarks  one thread per EDGE (workgroup = 32 consecutive landmarks = a contiguous run of the landmark-major edges): computeError +
 //                    linearizeOplus + the landmark half of constructQuadraticForm (H_ll, b_l accumulated in registers in
 //                    the reference's edge order) and the pose-landmark block H_pl of every edge.
 //   k_lba_poses      one wave per free pose walks the pose's edge list (CSR built once per optimize(), like
@@ -219,62 +219,100 @@ static __device__ __forceinline__ SE3 load_pose(const double* p) {
 
 struct LbaArgs { lba_problem P; lba_system S; };
 
-static __global__ __launch_bounds__(128) void k_lba_landmarks(LbaArgs A) {
+// Landmark half of buildSystem, one THREAD PER EDGE.  A workgroup owns LBA_LB consecutive landmarks and therefore a contiguous run of
+// the landmark-major edge array; every thread linearises one edge (error, Huber, Jacobians), writes the per-edge outputs (H_pl block,
+// err, chi2, rho, depth) and parks its H_ll / b_l contribution in LDS; one thread per landmark then adds its edges' contributions in
+// edge order — the same summation order as a serial walk, so H_ll / b_l are bit-identical to the thread-per-landmark formulation, but
+// the expensive part runs with 8x more parallelism (a landmark has ~8 observations) and coalesced edge loads.
+#define LBA_LB 32      // landmarks per workgroup
+#define LBA_CT 256     // edges per chunk = threads per workgroup
+static __global__ __launch_bounds__(LBA_CT) void k_lba_landmarks(LbaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
     const lba_problem& P = A.P;
-    const int b = blockIdx.y;
-    const int l = blockIdx.x * 128 + threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int nl = min(P.n_points[b], P.cap_l);
-    if (l >= nl) return;
+    const int l0 = blockIdx.x * LBA_LB;
+    if (l0 >= nl) return;
+    const int l1 = min(l0 + LBA_LB, nl);
     const int ne = min(P.n_edges[b], P.cap_e);
     const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
     const double* poses = P.poses + (size_t)b * P.cap_p * 7;
     const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
-    const double* Xp = P.points + ((size_t)b * P.cap_l + l) * 3;
-    const double X[3] = {Xp[0], Xp[1], Xp[2]};
-    const int e0 = P.lm_start[(size_t)b * (P.cap_l + 1) + l], e1 = min(P.lm_start[(size_t)b * (P.cap_l + 1) + l + 1], ne);
+    const double* points = P.points + (size_t)b * P.cap_l * 3;
+    const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+    const int eBegin = min(lms[l0], ne), eEnd = min(lms[l1], ne);
+    // landmark thread j: landmark l0 + j, its edge range, its accumulators
+    const int myL = l0 + tid;
+    int ls = 0, le = 0;
+    if (tid < LBA_LB && myL < l1) { ls = min(lms[myL], ne); le = min(lms[myL + 1], ne); }
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int ei = e0; ei < e1; ei++) {
-        const lba_edge E = edges[ei];
-        const SE3 T = load_pose(poses + (size_t)E.pose * 7);
-        Lin L;
-        edge_linearize<true>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
-        const size_t eo = (size_t)b * P.cap_e + ei;
-        if (A.S.err) { A.S.err[eo * 3] = L.e[0]; A.S.err[eo * 3 + 1] = L.e[1]; A.S.err[eo * 3 + 2] = L.e[2]; }
-        if (A.S.chi2) A.S.chi2[eo] = L.chi2;
-        if (A.S.rho) { A.S.rho[eo * 2] = L.rho0; A.S.rho[eo * 2 + 1] = L.rho1; }
-        if (A.S.depth) A.S.depth[eo] = L.depth;
-        // constructQuadraticForm, robust branch (base_binary_edge.hpp:91-113): omega_r = -Omega e rho1; wOmega = rho1 Omega
-        const double s = (double)E.inv_sigma2, w = L.rho1 * s;
-        double om[3];
-        for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
+    for (int c0 = eBegin; c0 < eEnd; c0 += LBA_CT) {
+        const int ei = c0 + tid;
+        if (ei < eEnd) {
+            const lba_edge E = edges[ei];
+            const SE3 T = load_pose(poses + (size_t)E.pose * 7);
+            const double* Xp = points + (size_t)E.point * 3;
+            const double X[3] = {Xp[0], Xp[1], Xp[2]};
+            Lin L;
+            edge_linearize<true>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+            const size_t eo = (size_t)b * P.cap_e + ei;
+            if (A.S.err) { A.S.err[eo * 3] = L.e[0]; A.S.err[eo * 3 + 1] = L.e[1]; A.S.err[eo * 3 + 2] = L.e[2]; }
+            if (A.S.chi2) A.S.chi2[eo] = L.chi2;
+            if (A.S.rho) { A.S.rho[eo * 2] = L.rho0; A.S.rho[eo * 2 + 1] = L.rho1; }
+            if (A.S.depth) A.S.depth[eo] = L.depth;
+            // constructQuadraticForm, robust branch (base_binary_edge.hpp:91-113): omega_r = -Omega e rho1; wOmega = rho1 Omega
+            const double s = (double)E.inv_sigma2, w = L.rho1 * s;
+            double om[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double acc = 0;
-            for (int r = 0; r < 3; r++) acc += L.A[r * 3 + c] * om[r];
-            bl[c] += acc;
+            for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
 #pragma unroll
-            for (int c2 = 0; c2 < 3; c2++) {
-                double h = 0;
-                for (int r = 0; r < 3; r++) h += L.A[r * 3 + c] * w * L.A[r * 3 + c2];
-                H[c2 * 3 + c] += h;
+            for (int c = 0; c < 3; c++) {
+                double acc = 0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) acc += L.A[r * 3 + c] * om[r];
+                contrib[tid][9 + c] = acc;
+#pragma unroll
+                for (int c2 = 0; c2 < 3; c2++) {
+                    double h = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) h += L.A[r * 3 + c] * w * L.A[r * 3 + c2];
+                    contrib[tid][c2 * 3 + c] = h;
+                }
+            }
+            if (A.S.Hpl) {
+                double* hp = A.S.Hpl + eo * 18;
+                const bool freePose = hidx[E.pose] >= 0;
+#pragma unroll
+                for (int c2 = 0; c2 < 3; c2++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double h = 0;
+                        if (freePose) {
+#pragma unroll
+                            for (int r = 0; r < 3; r++) h += L.B[r * 6 + c] * w * L.A[r * 3 + c2];
+                        }
+                        hp[c2 * 6 + c] = h;   // logical 6x3 block (pose, landmark), column-major (_hessianTransposed)
+                    }
             }
         }
-        if (A.S.Hpl) {
-            double* hp = A.S.Hpl + eo * 18;
-            const bool freePose = hidx[E.pose] >= 0;
+        __syncthreads();
+        if (tid < LBA_LB) {   // H_ll += A^T wOmega A, b_l += A^T omega_r in edge order
+            const int a0 = max(ls, c0), a1 = min(le, c0 + LBA_CT);
+            for (int e = a0; e < a1; e++) {
+                const double* cb = contrib[e - c0];
 #pragma unroll
-            for (int c2 = 0; c2 < 3; c2++)
+                for (int i = 0; i < 9; i++) H[i] += cb[i];
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double h = 0;
-                    if (freePose)
-                        for (int r = 0; r < 3; r++) h += L.B[r * 6 + c] * w * L.A[r * 3 + c2];
-                    hp[c2 * 6 + c] = h;   // logical 6x3 block (pose, landmark), column-major (_hessianTransposed)
-                }
+                for (int i = 0; i < 3; i++) bl[i] += cb[9 + i];
+            }
         }
+        __syncthreads();
     }
-    if (A.S.Hll) { double* o = A.S.Hll + ((size_t)b * P.cap_l + l) * 9; for (int i = 0; i < 9; i++) o[i] = H[i]; }
-    if (A.S.bl) { double* o = A.S.bl + ((size_t)b * P.cap_l + l) * 3; for (int i = 0; i < 3; i++) o[i] = bl[i]; }
+    if (tid < LBA_LB && myL < l1) {
+        if (A.S.Hll) { double* o = A.S.Hll + ((size_t)b * P.cap_l + myL) * 9; for (int i = 0; i < 9; i++) o[i] = H[i]; }
+        if (A.S.bl) { double* o = A.S.bl + ((size_t)b * P.cap_l + myL) * 3; for (int i = 0; i < 3; i++) o[i] = bl[i]; }
+    }
 }
 
 static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
@@ -379,7 +417,7 @@ extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_sy
     // blocks of fixed poses / rows >= n are defined as zero
     if (out->Hpp && hipMemsetAsync(out->Hpp, 0, (size_t)batch * prob->cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
     if (out->bp && hipMemsetAsync(out->bp, 0, (size_t)batch * prob->cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-    hipLaunchKernelGGL(k_lba_landmarks, dim3((prob->cap_l + 127) / 128, batch), dim3(128), 0, st, A);
+    hipLaunchKernelGGL(k_lba_landmarks, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 13 * 8, st, A);
     if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses, dim3(prob->cap_p, batch), dim3(64), 0, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
@@ -934,7 +972,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             L.P = P; L.S = A.S;
             if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + 127) / 128, batch), dim3(128), 0, st, L);
+            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 13 * 8, st, L);
             hipLaunchKernelGGL(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
         }
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
