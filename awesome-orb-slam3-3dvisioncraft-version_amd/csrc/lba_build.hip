@@ -461,6 +461,8 @@ struct LmArgs {
     double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
+    int32_t* pairCnt; int32_t* pairOff; int2* pairList; int pairCap;   // co-visibility lists, see k_lm_pairs
+    int32_t* pairOvf;                       // [batch] 1: the window's lists did not fit -> table-lookup Schur kernel
 };
 
 static __global__ void k_lm_init(LmArgs A, int batch) {
@@ -584,10 +586,154 @@ static __global__ __launch_bounds__(256) void k_lm_obs(LmArgs A, int* obs) {
 // observation table of pose i2 and accumulate  -B_i Dinv B_j^T  in registers; a fixed butterfly adds the 64 partials ->
 // deterministic, no f64 atomics, every block written exactly once (block_solver.hpp:398-432).  The diagonal wave also produces
 // the _bschur rows  b_p - sum_e B_i (Dinv b_l).
+// Co-visibility lists (built once per lba_optimize call: the graph structure is constant over all iterations and lambda trials).
+// For every lower-triangle block (i1, i2) of the reduced camera system: the (e1, e2) pairs "edge e1 of pose i1 and the first edge e2 of
+// pose i2 on the same landmark", in the order of pose i1's edge list.  k_lm_pairs<false> counts them, k_lm_pairs_scan turns the
+// counts into offsets, k_lm_pairs<true> fills the lists (wave per block; ballot compaction keeps the order deterministic).
+// The per-trial Schur kernel then streams its list instead of probing the landmark x pose table for every edge of pose i1
+// (~9x fewer probes: a block of two poses typically shares 10-20 % of pose i1's landmarks, and the probes were random 4-byte reads).
+template <bool FILL>
+static __global__ __launch_bounds__(256) void k_lm_pairs(LmArgs A, const int* obs) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
+    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
+    if (i1 >= P.cap_p) return;
+    int32_t* cnt = A.pairCnt + (size_t)b * P.cap_p * P.cap_p;
+    bool live = i1 < np && i2 < np;
+    if (live) {
+        const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
+        const int h1 = hidx[i1], h2 = hidx[i2];
+        live = h1 >= 0 && h2 >= 0 && h1 >= h2;
+    }
+    if (!live) { if (!FILL && lane == 0) cnt[pairId] = 0; return; }
+    if (FILL && A.pairOvf[b]) return;
+    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
+    const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
+    const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
+    const int* ob = obs + (size_t)b * P.cap_l * P.cap_p;
+    int2* list = FILL ? A.pairList + (size_t)b * A.pairCap + A.pairOff[(size_t)b * (P.cap_p * P.cap_p + 1) + pairId] : nullptr;
+    int n = 0;
+    for (int k0 = s0; k0 < s1; k0 += 64) {
+        const int k = k0 + lane;
+        int e1 = 0, e2 = 0;
+        bool hit = false;
+        if (k < s1) {
+            e1 = pe[k];
+            e2 = ob[(size_t)edges[e1].point * P.cap_p + i2];
+            hit = e2 < ne;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (FILL && hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(e1, e2);
+        n += __popcll(m);
+    }
+    if (!FILL && lane == 0) cnt[pairId] = n;
+}
+
+static __global__ __launch_bounds__(256) void k_lm_pairs_scan(LmArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* scratch = (int*)orb_smem;   // [256]
+    const lba_problem& P = A.P;
+    const int b = blockIdx.x, tid = threadIdx.x, nblk = P.cap_p * P.cap_p;
+    const int32_t* cnt = A.pairCnt + (size_t)b * nblk;
+    int32_t* off = A.pairOff + (size_t)b * (nblk + 1);
+    const int per = (nblk + 255) / 256, s0 = tid * per, s1 = min(s0 + per, nblk);
+    int sum = 0;
+    for (int i = s0; i < s1; i++) sum += cnt[i];
+    scratch[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? scratch[tid - o] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    int run = scratch[tid] - sum;
+    for (int i = s0; i < s1; i++) { off[i] = run; run += cnt[i]; }
+    if (tid == 255) { off[nblk] = scratch[255]; A.pairOvf[b] = scratch[255] > A.pairCap ? 1 : 0; }
+}
+
+// Schur complement from the co-visibility lists: same arithmetic as k_lm_schur_blocks, the list replaces walk + table probe.
+static __global__ __launch_bounds__(256) void k_lm_schur_lists(LmArgs A) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    if (!A.st[b].needTrial || A.pairOvf[b]) return;
+    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
+    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
+    if (i1 >= np || i2 >= np) return;
+    const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
+    const int h1 = hidx[i1], h2 = hidx[i2];
+    if (h1 < 0 || h2 < 0 || h1 < h2) return;
+    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
+    const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+    const int32_t* off = A.pairOff + (size_t)b * (P.cap_p * P.cap_p + 1);
+    const int2* list = A.pairList + (size_t)b * A.pairCap;
+    const int s0 = off[pairId], s1 = off[pairId + 1];
+    const bool diag = i1 == i2;
+    double acc[36], coef[6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) coef[k] = 0;
+    for (int k = s0 + lane; k < s1; k += 64) {
+        const int2 pr = list[k];
+        const int e1 = pr.x;
+        int e2 = pr.y;
+        const int l = edges[e1].point;
+        // B_i * Dinv (block_solver.hpp:404), 6x3 column-major, recomputed here instead of stored per edge
+        const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
+        const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
+        double BDi[18];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) BDi[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
+        const int m1 = min(lms[l + 1], ne);
+        for (; e2 < m1 && edges[e2].pose == i2; e2++) {       // the edges of one pose on a landmark are adjacent (mono + body twin)
+            const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + e2) * 18;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
+        }
+        if (diag) {
+            const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
+#pragma unroll
+            for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++)
+        for (int off2 = 32; off2 > 0; off2 >>= 1) acc[k] += __shfl_xor(acc[k], off2);
+    const int np6 = A.np6;
+    double* Hs = A.Hs + (size_t)b * np6 * np6;
+    if (diag) {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            for (int off2 = 32; off2 > 0; off2 >>= 1) coef[k] += __shfl_xor(coef[k], off2);
+        if (lane < 6) {
+            double c = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (lane == k) c = coef[k];
+            A.xp[(size_t)b * np6 + h1 * 6 + lane] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + lane] - c;
+        }
+    }
+    if (lane < 36) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 36; k++) if (lane == k) v = acc[k];
+        if (diag) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + lane] + ((lane % 7 == 0) ? A.st[b].lambda : 0.0);   // _Hpp->add(_Hschur) + setLambda
+        const int c = lane / 6, r = lane - c * 6;
+        Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
+    }
+}
+
 static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const int* obs) {
     const lba_problem& P = A.P;
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    if (!A.st[b].needTrial) return;
+    if (!A.st[b].needTrial || !A.pairOvf[b]) return;   // fallback for windows whose co-visibility lists did not fit the workspace
     const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
     const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
@@ -894,6 +1040,7 @@ static __global__ void k_lm_end(LmArgs A, int batch) {
 
 static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+#define LM_PAIRS_PER_EDGE 8   // list capacity per window = 8 x cap_e (e1, e2) pairs; a window that needs more takes the table-probe kernel
 extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     if (!p || batch < 1) return 0;
     const size_t B = (size_t)batch, np6 = (size_t)p->cap_p * 6;
@@ -907,6 +1054,8 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
     s += lm_align(B * p->cap_l * p->cap_p * 4);                                       // observation table
+    s += lm_align(B * (size_t)p->cap_p * p->cap_p * 4) + lm_align(B * ((size_t)p->cap_p * p->cap_p + 1) * 4) + lm_align(B * 4);   // pair counts, offsets, overflow
+    s += lm_align(B * (size_t)p->cap_e * LM_PAIRS_PER_EDGE * 8);                      // co-visibility lists
     return s;
 }
 
@@ -935,6 +1084,9 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
     int* obs = (int*)take(B * P.cap_l * P.cap_p * 4);
+    A.pairCnt = (int32_t*)take(B * (size_t)P.cap_p * P.cap_p * 4); A.pairOff = (int32_t*)take(B * ((size_t)P.cap_p * P.cap_p + 1) * 4);
+    A.pairOvf = (int32_t*)take(B * 4);
+    A.pairCap = P.cap_e * LM_PAIRS_PER_EDGE; A.pairList = (int2*)take(B * (size_t)A.pairCap * 8);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     // number of free poses per window (Hessian size) from pose_hidx
@@ -962,6 +1114,12 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     if (hipMemsetAsync(obs, 0x7F, B * P.cap_l * P.cap_p * 4, st) != hipSuccess) return ORB_E_HIP;   // 0x7F7F7F7F > any edge index
     hipLaunchKernelGGL(k_lm_obs, gE, dim3(256), 0, st, A, obs);
+    {   // co-visibility lists of the reduced camera system's blocks (structure only: once per call)
+        const dim3 gP((P.cap_p * P.cap_p + 3) / 4, batch);
+        hipLaunchKernelGGL(k_lm_pairs<false>, gP, dim3(256), 0, st, A, (const int*)obs);
+        hipLaunchKernelGGL(k_lm_pairs_scan, dim3(batch), dim3(256), 256 * 4, st, A);
+        hipLaunchKernelGGL(k_lm_pairs<true>, gP, dim3(256), 0, st, A, (const int*)obs);
+    }
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
         // computeActiveErrors + activeRobustChi2, buildSystem
@@ -981,7 +1139,8 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_blocks, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A, (const int*)obs);
+            hipLaunchKernelGGL(k_lm_schur_lists, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(k_lm_schur_blocks, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A, (const int*)obs);   // overflow windows only
             hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);

@@ -159,3 +159,13 @@ def test_emu_lba_optimize_matches_oracle(emu_lib, kinds, its):
 @pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono", "mono", "stereo"), 10)], ids=["mono+stereo_5it", "3win_10it"])
 def test_hip_lba_optimize_matches_oracle(hip_lib, kinds, its):
     check_optimize(hip_lib, "hip", kinds, its)
+
+
+def test_emu_lba_optimize_schur_fallback_path():
+    """LM_PAIRS_PER_EDGE=1 makes every window's co-visibility lists overflow their workspace slab, so the Schur complement runs through the
+    table-probe kernel (the fallback of k_lm_schur_lists); the optimisation must come out the same."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_PAIRS_PER_EDGE=1",), tag="pairs1")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
