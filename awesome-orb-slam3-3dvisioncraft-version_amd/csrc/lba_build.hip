@@ -817,7 +817,7 @@ static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t*
     const int n = nfreeArr[b] * 6, ld = A.np6;
     double* pan = (double*)orb_smem;                    // [ld][CH_LD] panel rows kb.. (row r of the panel = matrix row kb + r)
     double* red = pan + (size_t)ld * CH_LD;             // [256] reduction scratch
-    int* bad = (int*)(red + 256);
+    int* bad = (int*)(red + 256 + ld + CH_NB * CH_LD);
     double* S = A.Hs + (size_t)b * ld * ld;
     double* x = A.xp + (size_t)b * ld;
     if (tid == 0) *bad = 0;
@@ -862,26 +862,67 @@ static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t*
     }
     __syncthreads();
     if (*bad) { if (tid == 0) A.st[b].ok = 0; return; }
-    // L y = b (forward, column-oriented), then L^T x = y (backward, row-oriented dot products)
-    for (int k = 0; k < n; k++) {
-        if (tid == 0) x[k] = x[k] / S[(size_t)k * ld + k];
-        __threadfence_block();
+    // L y = b, then L^T x = y, blocked by CH_NB: the right-hand side lives in LDS; per block step wave 0 solves the CH_NB x CH_NB
+    // triangle (staged in LDS) and all threads apply the block's columns to the remaining rows with coalesced column reads of L —
+    // two barriers per 16 unknowns instead of a global-memory round trip per unknown.
+    double* xs = red + 256;                               // [ld]
+    double* blk = xs + ld;                                // [CH_NB][CH_LD] diagonal block, blk[r][c] = L(kb+r, kb+c)
+    for (int i = tid; i < n; i += 256) xs[i] = x[i];
+    __syncthreads();
+    for (int kb = 0; kb < n; kb += CH_NB) {               // forward substitution
+        const int nb = min(CH_NB, n - kb);
+        if (tid < CH_NB * CH_NB) { const int r = tid & (CH_NB - 1), c = tid >> 4; blk[r * CH_LD + c] = (r < nb && c < nb && r >= c) ? S[(size_t)(kb + c) * ld + kb + r] : 0.0; }
         __syncthreads();
-        const double xk = x[k];
-        for (int i = k + 1 + tid; i < n; i += 256) x[i] -= S[(size_t)k * ld + i] * xk;
-        __threadfence_block();
+        if (wave == 0) {
+            double v = lane < nb ? xs[kb + lane] : 0.0;
+            for (int c = 0; c < nb; c++) {
+                const double xc = __shfl(v, c) / blk[c * CH_LD + c];
+                if (lane == c) v = xc;
+                else if (lane > c && lane < nb) v -= blk[lane * CH_LD + c] * xc;
+            }
+            if (lane < nb) xs[kb + lane] = v;
+        }
+        __syncthreads();
+        for (int i = kb + nb + tid; i < n; i += 256) {
+            double acc = xs[i];
+            for (int c = 0; c < nb; c++) acc -= S[(size_t)(kb + c) * ld + i] * xs[kb + c];
+            xs[i] = acc;
+        }
         __syncthreads();
     }
-    for (int k = n - 1; k >= 0; k--) {
-        double sum = 0;
-        for (int i = k + 1 + tid; i < n; i += 256) sum += S[(size_t)k * ld + i] * x[i];
-        red[tid] = sum;
+    for (int kb = ((n - 1) / CH_NB) * CH_NB; kb >= 0; kb -= CH_NB) {   // backward substitution with L^T
+        const int nb = min(CH_NB, n - kb);
+        double part[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) part[c] = 0.0;
+        for (int i = kb + nb + tid; i < n; i += 256) {
+            const double xi = xs[i];
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++)
+                if (c < nb) part[c] += S[(size_t)(kb + c) * ld + i] * xi;
+        }
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++)
+            for (int off = 32; off > 0; off >>= 1) part[c] += __shfl_xor(part[c], off);
+        if (tid < CH_NB * CH_NB) { const int r = tid & (CH_NB - 1), c = tid >> 4; blk[r * CH_LD + c] = (r < nb && c < nb && r >= c) ? S[(size_t)(kb + c) * ld + kb + r] : 0.0; }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++) red[wave * CH_NB + c] = part[c];
+        }
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
-        if (tid == 0) x[k] = (x[k] - red[0]) / S[(size_t)k * ld + k];
-        __threadfence_block();
+        if (wave == 0) {
+            double v = 0.0;
+            if (lane < nb) v = xs[kb + lane] - (((red[lane] + red[CH_NB + lane]) + red[2 * CH_NB + lane]) + red[3 * CH_NB + lane]);
+            for (int c = nb - 1; c >= 0; c--) {          // x_c = (v_c - sum_{r>c} L(r,c) x_r) / L(c,c): lane r > c holds x_r
+                double t = (lane > c && lane < nb) ? blk[lane * CH_LD + c] * v : 0.0;
+                for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                if (lane == c) v = (v - t) / blk[c * CH_LD + c];
+            }
+            if (lane < nb) xs[kb + lane] = v;
+        }
         __syncthreads();
     }
+    for (int i = tid; i < n; i += 256) x[i] = xs[i];
 }
 
 static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {
@@ -1103,7 +1144,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
         if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
     }
-    const size_t cholSmem = (np6 * CH_LD + 256) * 8 + 16;
+    const size_t cholSmem = (np6 * CH_LD + 256 + np6 + CH_NB * CH_LD) * 8 + 16;
     if (cholSmem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
         return ORB_E_HIP;
