@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
-    ap.add_argument("--lm-windows", type=int, default=64, help="LBA windows per GPU per step in the full-LM leg")
+    ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
     ap.add_argument("--size", default="752x480", help="frame size WxH (the headline is 752x480; 1280x720 is BASELINE configs[3]'s frame shape)")
     ap.add_argument("--nfeatures", type=int, default=1000, help="ORBextractor nFeatures (1500 with --size 1280x720)")
     args = ap.parse_args()
