@@ -655,6 +655,14 @@ struct OrbOracle {
         _keypoints.clear();
         descriptors.clear();
         if (!image || cols <= 0 || rows <= 0) return -1;
+        // Geometries on which the reference itself has undefined behaviour are reported (-3) instead of reproduced: a level without a
+        // FAST cell (width/30 == 0 -> division by zero, ORBextractor.cc:779-785) or with nIni == round(W/H) == 0 root nodes
+        // (hX = W/0, vpIniNodes[kp.pt.x/hX] on an empty vector, :541-568).  The product rejects the same cases in orbx_create.
+        for (int level = 0; level < nlevels; ++level) {
+            const int w = cvRound((float)cols * mvInvScaleFactor[level]), h = cvRound((float)rows * mvInvScaleFactor[level]);
+            const float fw = (float)(w - 2 * (EDGE_THRESHOLD - 3)), fh = (float)(h - 2 * (EDGE_THRESHOLD - 3));
+            if (fw / 30.f < 1.f || fh / 30.f < 1.f || (int)std::round(fw / fh) < 1) return -3;
+        }
         ComputePyramid(image, cols, rows, stride);
         ComputeKeyPointsOctTree();
         int nkeypoints = 0;

@@ -89,6 +89,8 @@ class OrbOracle:
         mono = self.L.oro_extract(self.h, _p(img), W, H, W, lap0, lap1, _p(kps), _p(desc), cap, C.byref(n))
         if mono == -2:
             return self.extract(img, lap0, lap1, cap=n.value + 8)
+        if mono == -3:
+            raise ValueError("geometry on which the reference has undefined behaviour (no FAST cell or no octree root at some level)")
         if mono < 0:
             return mono, kps[:0], desc[:0]
         return mono, kps[:n.value].copy(), desc[:n.value].copy()
