@@ -92,8 +92,8 @@ def run_sbp(lib, backend, S, q, mode, th_dist, nnratio, check_ori, u_right=None,
     return to_host(gs), to_host(gi), to_host(qm), to_host(km), to_host(nm)
 
 
-def check_sbp(lib, backend, mode, th, nnratio, check_ori, stereo=False, occupied=False, seed=0):
-    S = scene()
+def check_sbp(lib, backend, mode, th, nnratio, check_ori, stereo=False, occupied=False, seed=0, scene_kw=None):
+    S = scene(**(scene_kw or {}))
     rng = np.random.default_rng(seed)
     q = make_queries(S, mode, th, rng, stereo)
     kb = S["kb"]
@@ -110,7 +110,7 @@ def check_sbp(lib, backend, mode, th, nnratio, check_ori, stereo=False, occupied
         assert nm[b] == on, (nm[b], on)
         assert np.array_equal(km[b, :len(kb)], ok), "mvpMapPoints"
         assert np.array_equal(qm[b, :len(q)], oq), "per-query match"
-    assert on > 50  # the scene really matches
+    assert on > (50 if scene_kw is None else 5)  # the scene really matches
 
 
 SBP_CASES = [
@@ -134,6 +134,18 @@ def test_emu_search_by_projection(emu_lib, case):
 def test_hip_search_by_projection(hip_lib, case):
     _, mode, th, ratio, ori, stereo, occ = case
     check_sbp(hip_lib, "hip", mode, th, ratio, ori, stereo, occ)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(12))
+def test_hip_fuzz_search_by_projection(hip_lib, i):
+    """Random scenes (size, feature count, inter-frame shift) x random search parameters; both modes; stereo gate / occupancy on or off."""
+    rng = np.random.default_rng(500 + i)
+    kw = dict(W=int(rng.integers(320, 900)), H=int(rng.integers(240, 600)), nf=int(rng.choice([300, 600, 1200])), seed=int(rng.integers(1000)),
+              shift=(int(rng.integers(-9, 10)), int(rng.integers(-9, 10))))
+    mode = MODE_BEST_ONLY if i % 2 else MODE_LOCAL_MAP
+    check_sbp(hip_lib, "hip", mode, int(rng.choice([1, 3, 7, 15, 30])), float(rng.choice([0.6, 0.8, 0.9])), bool(rng.integers(2)),
+              stereo=bool(rng.integers(2)), occupied=bool(rng.integers(2)), seed=i, scene_kw=kw)
 
 
 def _overflow_case(lib, backend):
