@@ -130,23 +130,23 @@ def test_hip_lba_c5_size_window(hip_lib):
 
 
 # ---- the LM loop (Schur complement + Cholesky + rho test) ------------------------------------------------------------
-def check_optimize(lib, backend, kinds, iterations):
+def check_optimize(lib, backend, kinds, iterations, huber=HUBER):
     ws, cams = [], None
     for i, kind in enumerate(kinds):
         w, cams = window(kind, seed=10 + i, n_kf=10 + i, n_pts=200 + 31 * i)
         ws.append(w)
-    L = LbaWindows(ws, cams, to_dev(backend), lib=lib, huber=HUBER)
+    L = LbaWindows(ws, cams, to_dev(backend), lib=lib, huber=huber)
     stats = L.optimize(iterations)
     poses, points = to_host(L.d["poses"]), to_host(L.d["points"])
     for b, w in enumerate(ws):
-        op, ox, ost = O.lba_optimize(w, cams, HUBER, iterations)
+        op, ox, ost = O.lba_optimize(w, cams, huber, iterations)
         npz, nl = len(w["poses"]), len(w["points"])
         assert stats[b, 0] == ost[0] and stats[b, 3] == ost[3], (stats[b], ost)          # same iterations / lambda trials
         assert abs(stats[b, 1] - ost[1]) < 1e-6 * ost[1]
         # north_star bar: 1e-4 on BA poses; double arithmetic in both, different summation orders
         assert np.abs(poses[b, :npz] - op).max() < 1e-7, np.abs(poses[b, :npz] - op).max()
         assert np.abs(points[b, :nl] - ox).max() < 1e-6
-        assert ost[1] < 0.9 * O.lba_build_system(w, cams, HUBER)["robust_chi2_sum"][0]                                # it really optimised
+        assert ost[1] < 0.9 * O.lba_build_system(w, cams, huber)["robust_chi2_sum"][0]                                # it really optimised
         assert np.abs(poses[b, :npz][w["pose_hidx"] < 0] - w["poses"][w["pose_hidx"] < 0]).max() == 0    # fixed KFs untouched
 
 
@@ -169,3 +169,15 @@ def test_emu_lba_optimize_schur_fallback_path():
     from orbhip import _lib
     lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_PAIRS_PER_EDGE=1",), tag="pairs1")))
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+def test_emu_global_ba_parameterisation(emu_lib):
+    """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (Optimizer.cc:66-458) builds the same graph as the local BA — EdgeSE3ProjectXYZ,
+    EdgeStereoSE3ProjectXYZ, EdgeSE3ProjectXYZToBody, first key frame fixed — and runs optimizer.optimize(nIterations); with bRobust == false
+    the edges carry no robust kernel.  That is lba_optimize with huber deltas 0 (delta > 0 gates the kernel)."""
+    check_optimize(emu_lib, "emu", ("mono", "stereo"), 10, huber=(0.0, 0.0))
+
+
+@pytest.mark.gpu
+def test_hip_global_ba_parameterisation(hip_lib):
+    check_optimize(hip_lib, "hip", ("mono", "stereo", "body"), 10, huber=(0.0, 0.0))
