@@ -1208,12 +1208,71 @@ struct StereoParams {
     float invScale[ORBX_MAX_LEVELS];
     const orb_keypoint *kpsL, *kpsR; const uint8_t *descL, *descR; const int32_t *cntL, *cntR;
     int cap; float mb, mbf; float* uRight; float* depth; int32_t* sad; int nRows;
+    int32_t* rowStart; int32_t* rowIdx; int rowCap;   // vRowIndices as CSR per frame: [nRows + 1], [rowCap] right keypoint indices (ascending per row)
 };
 
 static __device__ __forceinline__ int stereo_pix(const DescLevel& L, int frame, int y, int x) {
     // mvImagePyramid[level] is the ROI of a BORDER_REFLECT_101 parent: reads a few pixels outside the ROI see the reflection
     y = reflect101(y, L.h); x = reflect101(x, L.w);
     return L.base[(size_t)frame * L.frameStride + (size_t)y * L.rowStride + x];
+}
+
+// vRowIndices (Frame.cc:972-982): every right keypoint is listed in the rows [floor(y - r), ceil(y + r)], r = 2 * scale[octave], in
+// increasing keypoint index.  One workgroup per frame: LDS counting sort over the image rows, insertion order restored per row.
+static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* cnt = (int*)orb_smem;             // [nRows] counts -> starts
+    int* fill = cnt + P.nRows;             // [nRows]
+    int* scratch = fill + P.nRows;         // [256]
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int Nr = min(P.cntR[2 * frame], P.cap);
+    const orb_keypoint* kps = P.kpsR + (size_t)frame * P.cap;
+    int32_t* rs = P.rowStart + (size_t)frame * (P.nRows + 1);
+    int32_t* ri = P.rowIdx + (size_t)frame * P.rowCap;
+    for (int r = tid; r < P.nRows; r += 256) { cnt[r] = 0; fill[r] = 0; }
+    __syncthreads();
+    for (int i = tid; i < Nr; i += 256) {
+        const orb_keypoint kp = kps[i];
+        const float r = 2.0f * P.lvL[kp.octave].scale;
+        const int maxr = min((int)ceilf(kp.y + r), P.nRows - 1), minr = max((int)floorf(kp.y - r), 0);
+        for (int y = minr; y <= maxr; y++) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    {
+        const int per = (P.nRows + 255) / 256, s0 = tid * per, s1 = min(s0 + per, P.nRows);
+        int sum = 0;
+        for (int k = s0; k < s1; k++) sum += cnt[k];
+        scratch[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? scratch[tid - off] : 0;
+            __syncthreads();
+            scratch[tid] += v;
+            __syncthreads();
+        }
+        int run = scratch[tid] - sum;
+        for (int k = s0; k < s1; k++) { const int c = cnt[k]; cnt[k] = run; run += c; }
+        if (tid == 255) rs[P.nRows] = min(run, P.rowCap);
+    }
+    __syncthreads();
+    for (int r = tid; r < P.nRows; r += 256) rs[r] = min(cnt[r], P.rowCap);
+    for (int i = tid; i < Nr; i += 256) {
+        const orb_keypoint kp = kps[i];
+        const float r = 2.0f * P.lvL[kp.octave].scale;
+        const int maxr = min((int)ceilf(kp.y + r), P.nRows - 1), minr = max((int)floorf(kp.y - r), 0);
+        for (int y = minr; y <= maxr; y++) { const int p = cnt[y] + atomicAdd(&fill[y], 1); if (p < P.rowCap) ri[p] = i; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int r = tid; r < P.nRows; r += 256) {   // restore ascending keypoint order inside each row (rows hold a few dozen entries)
+        const int s = cnt[r], m = min(fill[r], max(P.rowCap - s, 0));
+        for (int a = 1; a < m; a++) {
+            const int v = ri[s + a];
+            int p = a - 1;
+            while (p >= 0 && ri[s + p] > v) { ri[s + p + 1] = ri[s + p]; p--; }
+            ri[s + p + 1] = v;
+        }
+    }
 }
 
 static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
@@ -1235,13 +1294,16 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
     uint32_t best = 0xFFFFFFFFu;
     if (!(maxU < 0) && rowL >= 0 && rowL < P.nRows) {
         const Desc dL = load_desc16(P.descL + ((size_t)frame * P.cap + iL) * 32);
-        for (int base = 0; base < Nr; base += 64) {
-            const int iR = base + lane;
-            if (iR < Nr) {
+        // candidates = vRowIndices[vL] (Frame.cc:1004), ascending right keypoint index
+        const int32_t* rs = P.rowStart + (size_t)frame * (P.nRows + 1);
+        const int32_t* ri = P.rowIdx + (size_t)frame * P.rowCap;
+        const int c0 = rs[rowL], c1 = rs[rowL + 1];
+        for (int base = c0; base < c1; base += 64) {
+            const int c = base + lane;
+            if (c < c1) {
+                const int iR = ri[c];
                 const orb_keypoint kpR = P.kpsR[(size_t)frame * P.cap + iR];
-                const float r = 2.0f * P.lvL[kpR.octave].scale;
-                const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
-                if (rowL >= minr && rowL <= maxr && !(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) && kpR.x >= minU && kpR.x <= maxU) {
+                if (!(kpR.octave < levelL - 1 || kpR.octave > levelL + 1) && kpR.x >= minU && kpR.x <= maxU) {
                     const Desc dR = load_desc16(P.descR + ((size_t)frame * P.cap + iR) * 32);
                     int dist = 0;
 #pragma unroll
@@ -1364,6 +1426,7 @@ struct orbx_extractor {
     size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
     int nTiles = 0, fastImgBytes = 0, octKeyOff = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
+    int32_t* d_rowStart = nullptr; int32_t* d_rowIdx = nullptr; int rowCapAlloc = 0;   // ComputeStereoMatches row buckets (lazy)
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
@@ -1398,7 +1461,7 @@ static int orbx_fail(orbx_extractor* h, int code, const std::string& msg) {
 static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* bufs[] = {h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
+    void* bufs[] = {h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
                     h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -1701,7 +1764,17 @@ extern "C" int orbx_stereo_matches(orbx_handle left, orbx_handle right, const or
     }
     S.kpsL = d_kps_l; S.kpsR = d_kps_r; S.descL = d_desc_l; S.descR = d_desc_r; S.cntL = d_counts_l; S.cntR = d_counts_r;
     S.cap = cap_per_frame; S.mb = mb; S.mbf = mbf; S.uRight = d_u_right; S.depth = d_depth; S.sad = d_work; S.nRows = h->H;
+    // a keypoint is listed in at most 2 * ceil(2 * scale[top level]) + 3 rows: the slab can never overflow
+    const int rowCap = cap_per_frame * (2 * (int)std::ceil(2.0f * h->scale[h->cfg.nlevels - 1]) + 3);
+    if (!h->d_rowStart || h->rowCapAlloc < rowCap) {   // lazily sized for max_batch frames
+        if (h->d_rowStart) { (void)hipFree(h->d_rowStart); (void)hipFree(h->d_rowIdx); h->d_rowStart = nullptr; h->d_rowIdx = nullptr; }
+        HIPCHK(h, hipMalloc((void**)&h->d_rowStart, (size_t)h->maxBatch * (h->H + 1) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->d_rowIdx, (size_t)h->maxBatch * rowCap * 4));
+        h->rowCapAlloc = rowCap;
+    }
+    S.rowStart = h->d_rowStart; S.rowIdx = h->d_rowIdx; S.rowCap = rowCap;
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stereo_rows, dim3(batch), dim3(256), (size_t)(2 * h->H + 256) * 4, st, S);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 0, st, S);
     hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(cap_per_frame + 2) * 4, st, S);
     HIPCHK(h, hipGetLastError());
