@@ -1336,18 +1336,29 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
                 pa[t] = p / 11; pb[t] = p - pa[t] * 11;
                 il[t] = p < 121 ? stereo_pix(PL, frame, scaledvL - w + pa[t], scaleduL - w + pb[t]) - cLv : 0;
             }
+            // the 11 right patches are shifted copies of one 11 x 21 strip of the right image: staged once per keypoint in LDS
+            extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+            uint8_t* strip = orb_smem + wave * (11 * 24);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int p = lane + 64 * t;
+                if (p < 11 * 21) { const int r = p / 21, c = p - r * 21; strip[r * 24 + c] = (uint8_t)stereo_pix(PR, frame, scaledvL - w + r, scaleduR0 - Lw - w + c); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float vDists[11];
             int bestSad = 2147483647, bestincR = 0;
 #pragma unroll
             for (int inc = 0; inc < 11; inc++) {
                 const int incR = inc - Lw;
-                const int cRv = stereo_pix(PR, frame, scaledvL, scaleduR0 + incR);
+                const int cRv = strip[w * 24 + inc + w];
                 int sum = 0;
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int p = lane + 64 * t;
                     if (p < 121) {
-                        const int v = stereo_pix(PR, frame, scaledvL - w + pa[t], scaleduR0 + incR - w + pb[t]) - cRv;
+                        const int v = (int)strip[pa[t] * 24 + inc + pb[t]] - cRv;
                         const int dd = il[t] - v;
                         sum += dd < 0 ? -dd : dd;
                     }
@@ -1357,6 +1368,7 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
                 if (dist < (float)bestSad) { bestSad = (int)dist; bestincR = incR; }
                 vDists[inc] = dist;
             }
+            __builtin_amdgcn_wave_barrier();
             if (!(bestincR == -Lw || bestincR == Lw)) {
                 float dist1 = 0, dist2 = 0, dist3 = 0;
 #pragma unroll
@@ -1775,7 +1787,7 @@ extern "C" int orbx_stereo_matches(orbx_handle left, orbx_handle right, const or
     S.rowStart = h->d_rowStart; S.rowIdx = h->d_rowIdx; S.rowCap = rowCap;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_stereo_rows, dim3(batch), dim3(256), (size_t)(2 * h->H + 256) * 4, st, S);
-    hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 4 * 11 * 24, st, S);
     hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(cap_per_frame + 2) * 4, st, S);
     HIPCHK(h, hipGetLastError());
     return ORB_OK;
