@@ -1353,22 +1353,33 @@ struct PoseOptArgs {
 
 // block-wide sum of NV doubles per thread, result broadcast to every thread (fixed order: butterfly inside a wave, waves 0..3)
 template <int NV>
+#ifndef POSE_T
+#define POSE_T 64    // threads per frame: a frame has a few hundred edges, and at 256 VGPRs one wave per SIMD is all that fits — one-wave
+                     // workgroups put four frames on a CU instead of one and need no cross-wave reduction step
+#endif
 static __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++)
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
-    __syncthreads();
-    if (lane == 0) {
+    if (POSE_T > 64) {
+        __syncthreads();
+        if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; k++) scratch[wave * NV + k] = v[k];
+            for (int k = 0; k < NV; k++) scratch[wave * NV + k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double t = scratch[k];
+#pragma unroll
+            for (int w = 1; w < POSE_T / 64; w++) t += scratch[w * NV + k];
+            v[k] = t;
+        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = ((scratch[k] + scratch[NV + k]) + scratch[2 * NV + k]) + scratch[3 * NV + k];
 }
 
-static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
+static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int ne = min(A.nEdges[b], A.capE);
@@ -1378,7 +1389,7 @@ static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
     uint8_t* outl = level + A.capE;                       // [capE]
     const pose_edge* edges = A.edges + (size_t)b * A.capE;
     const SE3 T0 = load_pose(A.posesIn + (size_t)b * 7);
-    for (int e = tid; e < ne; e += 256) { chiLast[e] = 0; level[e] = 0; outl[e] = 0; }
+    for (int e = tid; e < ne; e += POSE_T) { chiLast[e] = 0; level[e] = 0; outl[e] = 0; }
     __syncthreads();
     const double deltaMono = (double)sqrtf(5.991f), deltaStereo = (double)sqrtf(7.815f);
     SE3 T = T0;
@@ -1388,11 +1399,11 @@ static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
         for (int it = 0; it < 4; it++) {
             T = T0;
             double na[1] = {0};
-            for (int e = tid; e < ne; e += 256) na[0] += level[e] == 0 ? 1.0 : 0.0;
+            for (int e = tid; e < ne; e += POSE_T) na[0] += level[e] == 0 ? 1.0 : 0.0;
             block_sum<1>(na, scratch);
             auto evalErrors = [&](const SE3& Tc) {   // computeActiveErrors + activeRobustChi2
                 double s[1] = {0};
-                for (int e = tid; e < ne; e += 256) {
+                for (int e = tid; e < ne; e += POSE_T) {
                     if (level[e] != 0) continue;
                     const pose_edge E = edges[e];
                     PLin L;
@@ -1414,7 +1425,7 @@ static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
                     double acc[27];   // 21 lower-triangle entries of H (column-major order c2 <= c) + 6 of b
 #pragma unroll
                     for (int k = 0; k < 27; k++) acc[k] = 0;
-                    for (int e = tid; e < ne; e += 256) {
+                    for (int e = tid; e < ne; e += POSE_T) {
                         if (level[e] != 0) continue;
                         const pose_edge E = edges[e];
                         PLin L;
@@ -1493,7 +1504,7 @@ static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
             // classification (Optimizer.cc:1142-1246)
             double nb[1] = {0};
             const float th2 = 5.991f, th3 = 7.815f;
-            for (int e = tid; e < ne; e += 256) {
+            for (int e = tid; e < ne; e += POSE_T) {
                 const pose_edge E = edges[e];
                 if (outl[e]) { PLin L; pose_linearize<false>(E, T, A.cams[E.cam], L); chiLast[e] = L.chi2; }
                 const float chi2 = (float)chiLast[e];
@@ -1506,7 +1517,7 @@ static __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs A) {
             if (ne < 10) break;
         }
     }
-    for (int e = tid; e < A.capE; e += 256) A.outlier[(size_t)b * A.capE + e] = e < ne ? outl[e] : 0;
+    for (int e = tid; e < A.capE; e += POSE_T) A.outlier[(size_t)b * A.capE + e] = e < ne ? outl[e] : 0;
     if (tid == 0) {
         double* o = A.posesOut + (size_t)b * 7;
         o[0] = T.t[0]; o[1] = T.t[1]; o[2] = T.t[2]; o[3] = T.r.x; o[4] = T.r.y; o[5] = T.r.z; o[6] = T.r.w;
@@ -1522,6 +1533,6 @@ extern "C" int pose_optimize(const double* d_poses_in, const pose_edge* d_edges,
     const size_t smem = (size_t)4 * 28 * 8 + (size_t)cap_e * 8 + 2 * (((size_t)cap_e + 15) & ~(size_t)15);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     PoseOptArgs A{d_poses_in, d_edges, d_n_edges, cap_e, d_cameras, d_poses_out, d_outlier, d_n_good};
-    hipLaunchKernelGGL(k_pose_opt, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_pose_opt, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
