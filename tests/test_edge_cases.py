@@ -1,0 +1,75 @@
+"""Empty and degenerate inputs through the C ABI (the reference's own edge cases: frames without keypoints, windows without candidates,
+key frames without shared vocabulary nodes, vocabularies hit by zero features).  Nothing may crash; counts must be zero / arrays -1."""
+import numpy as np
+import pytest
+
+import orbhip
+from orbhip.bow import ORBVocabulary, synth_vocabulary
+from orbhip.lba import POSE_EDGE_DTYPE, pose_optimization, synth_pose_frames
+from orbhip.matcher import MODE_BEST_ONLY, MODE_INIT, MODE_LOCAL_MAP, Q_VALID, QUERY_DTYPE, TRI_PAIR_DTYPE
+from test_matcher_parity import to_dev, to_host
+
+GRID = (0.0, 0.0, 64 / 640.0, 48 / 480.0)
+
+
+def _run(lib, backend):
+    d = lambda a: to_dev(a, backend)
+    m = orbhip.ORBmatcher(0.8, True, lib=lib)
+    B, ck, cq = 3, 16, 9
+    rng = np.random.default_rng(0)
+    kps = np.zeros((B, ck, 7), np.float32)
+    kps[..., 0] = rng.uniform(20, 600, (B, ck)); kps[..., 1] = rng.uniform(20, 440, (B, ck))
+    desc = rng.integers(0, 256, (B, ck, 32), dtype=np.uint8)
+    nk = np.array([0, ck, 5], np.int32)              # frame 0 has no keypoints at all
+    q = np.zeros((B, cq), QUERY_DTYPE)
+    q["u"] = 300; q["v"] = 200; q["radius"] = 50; q["min_level"] = -1; q["max_level"] = -1; q["flags"] = Q_VALID
+    q["flags"][1, 3:] = 0                                  # invalid queries
+    q["u"][2] = -5000                                      # windows entirely outside the grid
+    nq = np.array([cq, cq, 0], np.int32)             # frame 2 has no queries
+    qd = rng.integers(0, 256, (B, cq, 32), dtype=np.uint8)
+    dk, dn = d(kps), d(nk)
+    gs, gi = m.grid_build(dk, dn, GRID)
+    gs = to_host(gs)
+    assert gs[0].max() == 0 and gs[1][-1] == ck and gs[2][-1] == 5
+    gs, gi = m.grid_build(dk, dn, GRID)
+    dq = d(q.view(np.uint8).reshape(B, cq, 28))
+    for mode in (MODE_LOCAL_MAP, MODE_BEST_ONLY, MODE_INIT):
+        qm, km, nm = [to_host(x) for x in m.SearchByProjection(dk, d(desc), dn, gs, gi, dq, d(qd), d(nq), GRID, mode, 256)]
+        assert nm[0] == 0 and nm[2] == 0 and (qm[0] == -1).all() and (qm[2] == -1).all() and (km[0] == -1).all() and (km[2] == -1).all()
+        assert nm[1] == (qm[1] >= 0).sum() and (qm[1, 3:] == -1).all()
+    qm, qdist, nf = [to_host(x) for x in m.Fuse(dk, d(desc), dn, gs, gi, dq, d(qd), d(nq), GRID, th_dist=256)]
+    assert nf[0] == 0 and nf[2] == 0 and (qm[0] == -1).all() and (qdist[0] == 256).all() and nf[1] == (qm[1] >= 0).sum()
+    # BoW search / triangulation with no nodes on one side and with disjoint node sets
+    side = lambda n_nodes, ids: dict(kps=d(kps), desc=d(desc), angle=d(np.zeros((B, ck), np.float32)), u_right=None,
+                                     has_mp=d(np.zeros((B, ck), np.uint8)), node_id=d(np.tile(np.array(ids, np.int32), (B, 1))),
+                                     node_start=d(np.tile(np.arange(5, dtype=np.int32) * 4, (B, 1))), feat_idx=d(np.tile(np.arange(ck, dtype=np.int32), (B, 1))),
+                                     n_nodes=d(np.array(n_nodes, np.int32)))
+    a, b = side([4, 0, 4], [1, 2, 3, 4]), side([4, 4, 4], [7, 8, 9, 10])
+    fm, nm = [to_host(x) for x in m.SearchByBoW(a, d(np.ones((B, ck), np.uint8)), b)]
+    assert (nm == 0).all() and (fm == -1).all()
+    pairs = np.zeros(B, TRI_PAIR_DTYPE)
+    m12, nm = [to_host(x) for x in m.SearchForTriangulation(a, b, d(pairs.view(np.uint8).reshape(B, -1)), False, True)]
+    assert (nm == 0).all() and (m12 == -1).all()
+    # knn with an empty train set
+    idx, dist = [to_host(x) for x in m.knnMatch2(d(qd), d(nq), d(desc), d(np.zeros(B, np.int32)))]
+    assert (idx == -1).all() and (dist == 256).all()
+    # vocabulary: frames without features
+    V = ORBVocabulary(synth_vocabulary(1, 4, 2), lib=lib)
+    r = {k: to_host(v) for k, v in V.transform(d(desc), d(np.array([0, ck, 1], np.int32)), 1).items()}
+    assert r["bv_n"][0] == 0 and r["fv_n_nodes"][0] == 0 and r["fv_node_start"][0, 0] == 0
+    assert r["bv_n"][2] <= 1 and r["fv_n_nodes"][2] <= 1
+    # PoseOptimization: frames with 0, 1, 2 correspondences return 0 and leave the pose untouched
+    f = synth_pose_frames(seed=2, batch=3, n_pts=20, kind="mono")
+    f["n_edges"][:] = [0, 1, 2]
+    out, outl, ng = [to_host(x) for x in pose_optimization(d(f["poses"]), d(f["edges"].view(np.uint8).reshape(3, -1)), d(f["n_edges"]),
+                                                           d(np.ascontiguousarray(f["cameras"]).view(np.uint8)), lib=lib)]
+    assert (ng == 0).all() and np.array_equal(out, f["poses"]) and (outl == 0).all()
+
+
+def test_emu_empty_and_degenerate_inputs(emu_lib):
+    _run(emu_lib, "emu")
+
+
+@pytest.mark.gpu
+def test_hip_empty_and_degenerate_inputs(hip_lib):
+    _run(hip_lib, "hip")
