@@ -1278,7 +1278,7 @@ static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P) {
 static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frame = blockIdx.y, iL = blockIdx.x * 4 + wave;
-    const int N = min(P.cntL[2 * frame], P.cap), Nr = min(P.cntR[2 * frame], P.cap);
+    const int N = min(P.cntL[2 * frame], P.cap);
     if (iL >= P.cap) return;
     float* uRo = P.uRight + (size_t)frame * P.cap + iL;
     float* dpo = P.depth + (size_t)frame * P.cap + iL;
