@@ -399,9 +399,10 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     typedef short i16x2 __attribute__((vector_size(4)));
     const i16x2 T0 = {(short)t0, (short)t0};
     for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK) {
-        // ---- stage 1: 4-point pre-test.  Any 9-arc of the 16-ring contains >= 2 of the compass points 0,4,8,12, so a
-        //      corner needs >= 2 of them darker than v-t or >= 2 brighter than v+t, i.e. the second largest of the four
-        //      exceeds v+t or the second smallest is below v-t.  Four pixels per lane on packed u16 pairs (v_pk_min/max_u16).
+        // ---- stage 1: 4-point pre-test.  A 9-arc of the 16-ring contains at least one member of every antipodal pair {i, i+8}, so a
+        //      corner needs a brighter (> v+t) member in BOTH compass pairs {0,8} and {4,12}, or a darker (< v-t) one in both:
+        //      min(max(N,S), max(E,W)) > v+t  or  max(min(N,S), min(E,W)) < v-t  (cv::FAST's own "high-speed test" on two pairs).
+        //      Four pixels per lane on packed u16 pairs (v_pk_min/max_u16).
         //      Wave w owns rows r0+4w .. r0+4w+3 of the chunk.  Survivors -> this wave's q1 slice.
         const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
         uint32_t mask = 0;   // bit 4*k + t: column 4*dcol + t of row r0 + 4*wave + rsub + 2k passed
@@ -425,17 +426,15 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 uint32_t bits;
                 {
                     const u16x2 Pm = l01 > r01 ? l01 : r01, Qm = u01 > d01 ? u01 : d01, Rm = l01 < r01 ? l01 : r01, Sm = u01 < d01 ? u01 : d01;
-                    const u16x2 X = Pm < Qm ? Pm : Qm, Y = Rm > Sm ? Rm : Sm;
-                    const u16x2 hi2 = X > Y ? X : Y, lo2 = X < Y ? X : Y;      // second largest / second smallest of the four
-                    const i16x2 dh = (i16x2)(hi2 - v01), dl = (i16x2)(v01 - lo2);
+                    const u16x2 X = Pm < Qm ? Pm : Qm, Y = Rm > Sm ? Rm : Sm;   // X: the weaker of the two pair maxima, Y: the stronger of the two pair minima
+                    const i16x2 dh = (i16x2)(X - v01), dl = (i16x2)(v01 - Y);
                     const i16x2 z = T0 - (dh > dl ? dh : dl);                   // negative <=> passes
                     bits = (__builtin_bit_cast(uint32_t, z) >> 15) & 0x10001u;
                 }
                 {
                     const u16x2 Pm = l23 > r23 ? l23 : r23, Qm = u23 > d23 ? u23 : d23, Rm = l23 < r23 ? l23 : r23, Sm = u23 < d23 ? u23 : d23;
                     const u16x2 X = Pm < Qm ? Pm : Qm, Y = Rm > Sm ? Rm : Sm;
-                    const u16x2 hi2 = X > Y ? X : Y, lo2 = X < Y ? X : Y;
-                    const i16x2 dh = (i16x2)(hi2 - v23), dl = (i16x2)(v23 - lo2);
+                    const i16x2 dh = (i16x2)(X - v23), dl = (i16x2)(v23 - Y);
                     const i16x2 z = T0 - (dh > dl ? dh : dl);
                     bits |= ((__builtin_bit_cast(uint32_t, z) >> 15) & 0x10001u) << 2;
                 }
