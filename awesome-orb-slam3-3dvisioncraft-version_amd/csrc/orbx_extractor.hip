@@ -643,9 +643,12 @@ static __device__ int block_scan_excl(int* a, int n, int* scratch) {
 
 struct ONode { short x0, y0, x1, y1; };
 #ifndef OCT_KEYCAP
-#define OCT_KEYCAP 0      // candidates per (frame, level) cached in LDS (6 B each).  Measured on MI355X (batch 512): a 3072-key cache
-                          // shortens a workgroup's life ~1.8x but halves the workgroups per CU (36 vs 18 KB of LDS): 0.277 ms vs 0.253 ms
-                          // without -> off by default; levels with more candidates than the cache always take the global-memory path
+#define OCT_KEYCAP 4096   // candidates per (frame, level) that the LDS key cache holds (6 B each); levels with more take the global-memory path
+#endif
+#ifndef OCT_CACHE_MAX_BATCH
+#define OCT_CACHE_MAX_BATCH 48   // the cache is used for batches up to this size.  It shortens a workgroup's life ~1.8x (every round walks all keys
+                                 // twice: latency of the single-frame drop-in call) but costs 24 KB of LDS, i.e. half the workgroups per CU:
+                                 // at batch 512 on MI355X 0.277 ms with it vs 0.253 ms without -> large batches run without it
 #endif
 
 // The list algorithm proper.  keys / keyNode live either in LDS (the usual case: every round walks all keys twice, and the
@@ -1559,7 +1562,8 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
     h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
     h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8) + 15) & ~(size_t)15);
-    h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;
+    h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;   // with the key cache; launches without it pass octKeyOff bytes
+    if (h->octSmem > 150 * 1024) h->octSmem = (size_t)h->octKeyOff;   // node arrays of a very large nFeatures leave no room: no cache
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
     if (h->octSmem > 64 * 1024 && hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octSmem) != hipSuccess) {
         orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipFuncSetAttribute(k_octree) failed");
@@ -1701,8 +1705,9 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
         O.cand = h->d_cand; O.candFrame = h->candFrame; O.candCount = h->d_candCount; O.nlevels = nl; O.keyNode = h->d_keyNode;
         O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
-        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = OCT_KEYCAP; O.keyOff = h->octKeyOff;
-        hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), h->octSmem, st, O);
+        const bool cache = batch <= OCT_CACHE_MAX_BATCH && h->octSmem > (size_t)h->octKeyOff;
+        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
+        hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
     HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly

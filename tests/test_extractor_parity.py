@@ -75,8 +75,9 @@ def test_emulated_fast_tile_fallback_path():
 
 
 def test_emulated_octree_lds_key_cache_path():
-    """OCT_KEYCAP (off by default, see csrc) selects an LDS-resident copy of a level's candidates; a 1500-key cache is hit by the small
-    levels and missed by the big ones, so both octree paths run inside one extraction.  Results must not change."""
+    """The octree keeps a level's candidates in an LDS cache for small batches (OCT_KEYCAP keys; bigger levels and big batches read them from
+    global memory).  A 1500-key cache is hit by the small levels and missed by the big ones, so both paths run inside one extraction.
+    Results must not change."""
     import ctypes
     import build_emu
     from orbhip import _lib
