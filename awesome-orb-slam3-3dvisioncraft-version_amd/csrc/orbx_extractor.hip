@@ -721,14 +721,22 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             if (CN[i] > 1) { elist[sb[i]] = i; cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; }
         __syncthreads();
         // 2. child key counts (DivideNode :479-535)
-        for (int k = tid; k < nk; k += OCT_T) {
-            const int nd = keyNode[k];
-            if (CN[nd] > 1) {
-                const ONode n = R[nd];
-                const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-                const int x = keys[k] & 0xFFF, y = (keys[k] >> 12) & 0xFFF;
-                const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                atomicAdd(&cc[4 * nd + q], 1);
+        // (key walks are unrolled by 4 with the loads hoisted: the walk is a chain of global-memory round trips otherwise, and a
+        // workgroup's lifetime — not its instruction count — is what bounds this kernel)
+        for (int k0 = tid; k0 < nk; k0 += 4 * OCT_T) {
+            int ndv[4]; uint32_t kyv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int nd = ndv[u];
+                if (nd >= 0 && CN[nd] > 1) {
+                    const ONode n = R[nd];
+                    const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                    const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
+                    const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                    atomicAdd(&cc[4 * nd + q], 1);
+                }
             }
         }
         __syncthreads();
@@ -815,16 +823,23 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             }
         __syncthreads();
         // 6. move keys
-        for (int k = tid; k < nk; k += OCT_T) {
-            const int nd = keyNode[k];
-            if (nchild[nd] & 0x100) {
-                const ONode n = R[nd];
-                const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-                const int x = keys[k] & 0xFFF, y = (keys[k] >> 12) & 0xFFF;
-                const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                keyNode[k] = childPos[4 * nd + q];
-            } else {
-                keyNode[k] = (uint16_t)(totalPushed + sb[nd]);
+        for (int k0 = tid; k0 < nk; k0 += 4 * OCT_T) {
+            int ndv[4]; uint32_t kyv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int nd = ndv[u], k = k0 + u * OCT_T;
+                if (nd < 0) continue;
+                if (nchild[nd] & 0x100) {
+                    const ONode n = R[nd];
+                    const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                    const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
+                    const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                    keyNode[k] = childPos[4 * nd + q];
+                } else {
+                    keyNode[k] = (uint16_t)(totalPushed + sb[nd]);
+                }
             }
         }
         const int nToExpand = ctl[1];
