@@ -609,6 +609,7 @@ struct OctParams {
     uint32_t* sel; uint32_t* selAux; int selFrame;   // [frame][selFrame]
     int* selCount; int* lapCount;      // [frame][nlevels]
     int nodeCap;                       // LDS node capacity C
+    int merge;                         // 1: second child-count buffer present (key move counts the next round's children)
     int keyCap, keyOff;                // LDS key cache: capacity (keys) and byte offset inside the dynamic LDS block
     int lap0, lap1;
 };
@@ -645,6 +646,9 @@ struct ONode { short x0, y0, x1, y1; };
 #ifndef OCT_KEYCAP
 #define OCT_KEYCAP 4096   // candidates per (frame, level) that the LDS key cache holds (6 B each); levels with more take the global-memory path
 #endif
+#ifndef OCT_U
+#define OCT_U 4   // key-walk unroll: loads of OCT_U strides are issued before any is consumed
+#endif
 #ifndef OCT_CACHE_MAX_BATCH
 #define OCT_CACHE_MAX_BATCH 48   // the cache is used for batches up to this size.  It shortens a workgroup's life ~1.8x (every round walks all keys
                                  // twice: latency of the single-frame drop-in call) but costs 24 KB of LDS, i.e. half the workgroups per CU:
@@ -667,7 +671,8 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     rect[1] = (ONode*)lp; lp += 2 * C;
     int* cnt[2]; cnt[0] = lp; lp += C; cnt[1] = lp; lp += C;
     int* seq[2]; seq[0] = lp; lp += C; seq[1] = lp; lp += C;
-    int* cc = lp; lp += 4 * C;                     // [C][4] child key counts
+    int* ccb[2]; ccb[0] = lp; lp += 4 * C; ccb[1] = lp; if (P.merge) lp += 4 * C;   // [C][4] child key counts, double-buffered: the key move of round r
+                                                                       // already counts the children of round r+1 (one key walk per round)
     int* nchild = lp; lp += C;                     // [C] #non-empty children of an expandable node | 0x100 if divided
     int* sb = lp; lp += C;                         // [C] scan buffer (survivor positions)
     int* elist = lp; lp += C;                      // [C] expandable node indices (list order)
@@ -707,9 +712,13 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     cur = 1;
     int seqCounter = L.nIni;
     bool sortedMode = false;
+    int ccCur = 0;
+    bool haveCounts = false;
 
     for (;;) {
         const int prevSize = size;
+        int* cc = ccb[ccCur];
+        int* ccn = ccb[ccCur ^ 1];
         const ONode* R = rect[cur];
         const int* CN = cnt[cur];
         // 1. expandable nodes E (count > 1), list order
@@ -718,17 +727,18 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         const int nE = block_scan_excl(sb, size, scratch);
         if (nE == 0) break;  // nothing can be divided: size stays == prevSize (:667)
         for (int i = tid; i < size; i += OCT_T)
-            if (CN[i] > 1) { elist[sb[i]] = i; cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; }
+            if (CN[i] > 1) { elist[sb[i]] = i; if (!haveCounts) { cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; } }
         __syncthreads();
         // 2. child key counts (DivideNode :479-535)
         // (key walks are unrolled by 4 with the loads hoisted: the walk is a chain of global-memory round trips otherwise, and a
         // workgroup's lifetime — not its instruction count — is what bounds this kernel)
-        for (int k0 = tid; k0 < nk; k0 += 4 * OCT_T) {
-            int ndv[4]; uint32_t kyv[4];
+        if (!haveCounts)
+        for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
+            int ndv[OCT_U]; uint32_t kyv[OCT_U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+            for (int u = 0; u < OCT_U; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < OCT_U; u++) {
                 const int nd = ndv[u];
                 if (nd >= 0 && CN[nd] > 1) {
                     const ONode n = R[nd];
@@ -752,16 +762,22 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             __syncthreads();
         } else {
             // descending (size, creation seq): rule R1 replaces the reference's pointer tie-break (:679-683)
+            // (sb / pb are free here: the (count, seq) sort keys are staged list-order so the rank loop reads two broadcast words per
+            // step instead of chasing elist -> CN / seq)
+            for (int e = tid; e < nE; e += OCT_T) { const int i = elist[e]; sb[e] = CN[i]; pb[e] = seq[cur][i]; }
+            __syncthreads();
             for (int e = tid; e < nE; e += OCT_T) {
-                const int i = elist[e];
-                const int ci = CN[i], si = seq[cur][i];
+                const int ci = sb[e], si = pb[e];
                 int rank = 0;
-                for (int f = 0; f < nE; f++) {
-                    const int j = elist[f];
-                    const int cj = CN[j];
-                    rank += (cj > ci) || (cj == ci && seq[cur][j] > si);
+                int f = 0;
+                for (; f + 4 <= nE; f += 4) {
+                    const int c0 = sb[f], c1 = sb[f + 1], c2 = sb[f + 2], c3 = sb[f + 3];
+                    const int s0 = pb[f], s1 = pb[f + 1], s2 = pb[f + 2], s3 = pb[f + 3];
+                    rank += ((c0 > ci) || (c0 == ci && s0 > si)) + ((c1 > ci) || (c1 == ci && s1 > si)) +
+                            ((c2 > ci) || (c2 == ci && s2 > si)) + ((c3 > ci) || (c3 == ci && s3 > si));
                 }
-                porder[rank] = i;
+                for (; f < nE; f++) { const int cj = sb[f]; rank += (cj > ci) || (cj == ci && pb[f] > si); }
+                porder[rank] = elist[e];
             }
             __syncthreads();
             // early break once lNodes.size() >= N (:728-729): running size after each division
@@ -809,7 +825,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
                 ch.y0 = (q & 2) ? (short)(n.y0 + hy) : n.y0;
                 ch.y1 = (q & 2) ? n.y1 : (short)(n.y0 + hy);
                 const int np = totalPushed - 1 - p;
-                if (np < C) { rect[nxt][np] = ch; cnt[nxt][np] = c; seq[nxt][np] = seqCounter + p; }
+                if (np < C) { rect[nxt][np] = ch; cnt[nxt][np] = c; seq[nxt][np] = seqCounter + p; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
                 childPos[4 * i + q] = (uint16_t)np;
                 nexp += c > 1;
                 p++;
@@ -819,32 +835,45 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         for (int i = tid; i < size; i += OCT_T)
             if (!(nchild[i] & 0x100)) {
                 const int np = totalPushed + sb[i];
-                if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; }
+                if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
             }
         __syncthreads();
-        // 6. move keys
-        for (int k0 = tid; k0 < nk; k0 += 4 * OCT_T) {
-            int ndv[4]; uint32_t kyv[4];
+        // 6. move keys, and count them into the children of their NEW node (next round's step 2)
+        {
+            const ONode* Rn = rect[nxt];
+            const int* CNn = cnt[nxt];
+            for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
+                int ndv[OCT_U]; uint32_t kyv[OCT_U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+                for (int u = 0; u < OCT_U; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int nd = ndv[u], k = k0 + u * OCT_T;
-                if (nd < 0) continue;
-                if (nchild[nd] & 0x100) {
-                    const ONode n = R[nd];
-                    const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                for (int u = 0; u < OCT_U; u++) {
+                    const int nd = ndv[u], k = k0 + u * OCT_T;
+                    if (nd < 0) continue;
                     const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
-                    const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                    keyNode[k] = childPos[4 * nd + q];
-                } else {
-                    keyNode[k] = (uint16_t)(totalPushed + sb[nd]);
+                    int nn;
+                    if (nchild[nd] & 0x100) {
+                        const ONode n = R[nd];
+                        const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                        const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                        nn = childPos[4 * nd + q];
+                    } else {
+                        nn = totalPushed + sb[nd];
+                    }
+                    keyNode[k] = (uint16_t)nn;
+                    if (P.merge && nn < C && CNn[nn] > 1) {
+                        const ONode n = Rn[nn];
+                        const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                        const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                        atomicAdd(&ccn[4 * nn + q], 1);
+                    }
                 }
             }
         }
         const int nToExpand = ctl[1];
         __syncthreads();
         cur = nxt;
+        if (P.merge) { ccCur ^= 1; haveCounts = true; }
         size = min(newSize, C);
         seqCounter += totalPushed;
         // 7. termination (:667-671, :731-732)
@@ -854,34 +883,35 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
 
     // ---- best key per node: max response, first in vToDistributeKeys order on ties (:737-758).
     // Original order = cell-row-major, then row-major inside the cell's detection region.
-    int* bestS = cc;            // [C]
-    int* bestO = cc + C;        // [C]
-    for (int i = tid; i < size; i += OCT_T) { bestS[i] = -1; bestO[i] = 0x7FFFFFFF; }
+    // One walk: a 64-bit LDS atomicMax on (response << 32 | ~order) picks both; order encodes the key's position, so the winning key is
+    // rebuilt from the payload by the node's thread instead of two more walks over the candidates.
+    unsigned long long* best = (unsigned long long*)ccb[0];   // [C] (cc holds 4C ints, 16-byte aligned)
+    for (int i = tid; i < size; i += OCT_T) best[i] = 0ull;
     __syncthreads();
-    for (int k = tid; k < nk; k += OCT_T) atomicMax(&bestS[keyNode[k]], (int)(keys[k] >> 24));
-    __syncthreads();
-    for (int k = tid; k < nk; k += OCT_T) {
-        const uint32_t key = keys[k];
-        const int nd = keyNode[k];
-        if ((int)(key >> 24) == bestS[nd]) {
+    for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
+        int ndv[OCT_U]; uint32_t kyv[OCT_U];
+#pragma unroll
+        for (int u = 0; u < OCT_U; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+#pragma unroll
+        for (int u = 0; u < OCT_U; u++) {
+            if (ndv[u] < 0) continue;
+            const uint32_t key = kyv[u];
             const int x = (int)(key & 0xFFF) - 3, y = (int)((key >> 12) & 0xFFF) - 3;
             const int cj = x / L.wCell, ci = y / L.hCell;
-            const int ord = (((ci * L.nCols + cj) * 64 + (y - ci * L.hCell)) * 64) + (x - cj * L.wCell);
-            atomicMin(&bestO[nd], ord);
+            const uint32_t ord = (uint32_t)((((ci * L.nCols + cj) * 128 + (y - ci * L.hCell)) * 128) + (x - cj * L.wCell));  // cell sides < 70
+            atomicMax(&best[ndv[u]], ((unsigned long long)((key >> 24) + 1u) << 32) | (0x7FFFFFFFu - ord));
         }
     }
     __syncthreads();
     uint32_t* sel = P.sel + (size_t)frame * P.selFrame + L.selOff;
     uint32_t* selAux = P.selAux + (size_t)frame * P.selFrame + L.selOff;
-    for (int k = tid; k < nk; k += OCT_T) {
-        const uint32_t key = keys[k];
-        const int nd = keyNode[k];
-        if ((int)(key >> 24) == bestS[nd]) {
-            const int x = (int)(key & 0xFFF) - 3, y = (int)((key >> 12) & 0xFFF) - 3;
-            const int cj = x / L.wCell, ci = y / L.hCell;
-            const int ord = (((ci * L.nCols + cj) * 64 + (y - ci * L.hCell)) * 64) + (x - cj * L.wCell);
-            if (ord == bestO[nd] && nd < L.selCap) sel[nd] = key;
-        }
+    for (int i = tid; i < min(size, L.selCap); i += OCT_T) {
+        const unsigned long long b = best[i];
+        const uint32_t ord = 0x7FFFFFFFu - (uint32_t)(b & 0xFFFFFFFFu);
+        const int cell = (int)(ord >> 14), dy = (int)((ord >> 7) & 127), dx = (int)(ord & 127);
+        const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+        const uint32_t x = (uint32_t)(cj * L.wCell + dx + 3), y = (uint32_t)(ci * L.hCell + dy + 3);
+        sel[i] = (((uint32_t)(b >> 32) - 1u) << 24) | (y << 12) | x;
     }
     __syncthreads();
     // ---- E8 ordering ranks: lapping keypoints are written from the back (ORBextractor.cc:1137-1152)
@@ -1453,7 +1483,7 @@ struct orbx_extractor {
     std::vector<float> scale, invScale, sigma2, invSigma2; std::vector<int> nfeat; int umax[16];
     LevelHost lv[ORBX_MAX_LEVELS];
     size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
-    int nTiles = 0, fastImgBytes = 0, octKeyOff = 0; size_t fastSmem = 0, octSmem = 0;
+    int nTiles = 0, fastImgBytes = 0, octKeyOff = 0, octMerge = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
     int32_t* d_rowStart = nullptr; int32_t* d_rowIdx = nullptr; int rowCapAlloc = 0;   // ComputeStereoMatches row buckets (lazy)
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
@@ -1576,7 +1606,9 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->nTiles = (int)tiles.size();
     h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
     h->fastSmem = (size_t)2 * h->fastImgBytes + FAST_QCAP * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
-    h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (2 * 8 + 2 * 4 + 2 * 4 + 16 + 5 * 4 + 8) + 15) & ~(size_t)15);
+    // 92 B per node with the second child-count buffer, 76 without: very large nFeatures fall back to two key walks per round
+    h->octMerge = (size_t)(256 + 16) * 4 + (size_t)nodeCap * 92 + 15 <= 150 * 1024 ? 1 : 0;
+    h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (h->octMerge ? 92 : 76) + 15) & ~(size_t)15);
     h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;   // with the key cache; launches without it pass octKeyOff bytes
     if (h->octSmem > 150 * 1024) h->octSmem = (size_t)h->octKeyOff;   // node arrays of a very large nFeatures leave no room: no cache
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
@@ -1721,7 +1753,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         O.cand = h->d_cand; O.candFrame = h->candFrame; O.candCount = h->d_candCount; O.nlevels = nl; O.keyNode = h->d_keyNode;
         O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
         const bool cache = batch <= OCT_CACHE_MAX_BATCH && h->octSmem > (size_t)h->octKeyOff;
-        O.nodeCap = h->nodeCap; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
+        O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
         hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
     HIPCHK(h, hipEventRecord(h->ev[3], st));

@@ -39,6 +39,7 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct short2 { short x, y; };
 struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
 struct ushort2 { unsigned short x, y; };
 struct uchar4 { unsigned char x, y, z, w; };
 struct float2 { float x, y; };
@@ -47,6 +48,7 @@ struct double2 { double x, y; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
 static inline short2 make_short2(short a, short b) { return short2{a, b}; }
 
 typedef int hipError_t;
