@@ -1,0 +1,113 @@
+// orbf_frame.hip — the Frame-constructor steps between the extractor and the matcher ("callers either side
+// of the path"): Frame::UndistortKeyPoints (Frame.cc:874-925), Frame::ComputeImageBounds (:926-953) with the grid scalars of
+// Frame.cc:388-399, Frame::ComputeStereoFromRGBD (:1136-1157).  All three are per-keypoint maps: one thread per keypoint, HBM bound
+// (28 B in + 28 B out per keypoint), nothing to tile.
+//
+// cv::undistortPoints (OpenCV 3.x, un-vendored: restated from the published algorithm; parity unpinned against a
+// real OpenCV build): normalise with the camera matrix in double, 5 fixed-point iterations of the Brown-Conrady inverse, re-project
+// with the new camera matrix P = K, round to float.
+#include <hip/hip_runtime.h>
+
+#include "../../include/orbhip.h"
+
+static __device__ __host__ inline void undistort_point(const orbf_camera& c, const float xin, const float yin, float* xo, float* yo) {
+    const double fx = (double)c.fx, fy = (double)c.fy, cx = (double)c.cx, cy = (double)c.cy;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = (double)c.dist[0], k1 = (double)c.dist[1], p0 = (double)c.dist[2], p1 = (double)c.dist[3], k4 = (double)c.dist[4];
+    double x = (double)xin, y = (double)yin;
+    const double x0 = x = (x - cx) * ifx;
+    const double y0 = y = (y - cy) * ify;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        // k[5..7] (rational model) and k[8..11] (thin prism) are zero for the reference's 4/5-coefficient mDistCoef: the numerator of
+        // icdist is exactly 1 and the prism terms add exact zeros
+        const double icdist = 1. / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * p0 * x * y + p1 * (r2 + 2 * x * x);
+        const double deltaY = p0 * (r2 + 2 * y * y) + 2 * p1 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // RR = P * I with P = K: xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1/(0*x + 0*y + 1) = 1
+    *xo = (float)(fx * x + cx);
+    *yo = (float)(fy * y + cy);
+}
+
+static __global__ __launch_bounds__(256) void k_undistort(const orb_keypoint* kps, const int32_t* nkp, const int countStride, const int capK,
+                                                          const orbf_camera cam, orb_keypoint* out) {
+    const int b = blockIdx.y;
+    const int n = min(nkp[(size_t)b * countStride], capK);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    orb_keypoint kp = kps[(size_t)b * capK + i];
+    if (cam.dist[0] != 0.0f) undistort_point(cam, kp.x, kp.y, &kp.x, &kp.y);   // Frame.cc:879-883: k1 == 0 -> mvKeysUn = mvKeys
+    out[(size_t)b * capK + i] = kp;
+}
+
+static __global__ void k_bounds(const orbf_camera cam, const float w, const float h, float* out) {
+    const int t = threadIdx.x;
+    if (t >= 4) return;
+    const float px = (t & 1) ? w : 0.0f, py = (t & 2) ? h : 0.0f;
+    undistort_point(cam, px, py, &out[2 * t], &out[2 * t + 1]);
+}
+
+static __global__ __launch_bounds__(256) void k_rgbd(const orb_keypoint* kps, const orb_keypoint* kpsUn, const int32_t* nkp, const int countStride,
+                                                     const int capK, const float* depth, const size_t frameStride, const int rowStride,
+                                                     const float mbf, float* uRight, float* depthOut) {
+    const int b = blockIdx.y;
+    const int n = min(nkp[(size_t)b * countStride], capK);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= capK) return;
+    float ur = -1.0f, dz = -1.0f;
+    if (i < n) {
+        const orb_keypoint kp = kps[(size_t)b * capK + i];
+        // imDepth.at<float>(v, u) with float arguments: implicit float -> int conversion (truncation), Frame.cc:1146-1149
+        const int v = (int)kp.y, u = (int)kp.x;
+        const float d = depth[(size_t)b * frameStride + (size_t)v * rowStride + u];
+        if (d > 0) { dz = d; ur = kpsUn[(size_t)b * capK + i].x - mbf / d; }
+    }
+    uRight[(size_t)b * capK + i] = ur;
+    depthOut[(size_t)b * capK + i] = dz;
+}
+
+extern "C" int orbf_undistort_keypoints(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
+                                        const orbf_camera* cam, orb_keypoint* d_kps_un, void* stream) {
+    if (!d_kps || !d_nkp || !cam || !d_kps_un || cap_k <= 0 || batch < 0 || count_stride <= 0) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    hipLaunchKernelGGL(k_undistort, dim3((cap_k + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k, *cam, d_kps_un);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+extern "C" int orbf_image_bounds(const orbf_camera* cam, int width, int height, float bounds[4], orbm_grid_params* gp) {
+    if (!cam || !bounds || width <= 0 || height <= 0) return ORB_E_INVALID;
+    float c[8];
+    if (cam->dist[0] != 0.0f) {
+        float* d = nullptr;
+        if (hipMalloc(&d, sizeof(c)) != hipSuccess) return ORB_E_NOMEM;
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, 0, *cam, (float)width, (float)height, d);
+        const hipError_t e = hipMemcpy(c, d, sizeof(c), hipMemcpyDeviceToHost);
+        hipFree(d);
+        if (e != hipSuccess) return ORB_E_HIP;
+        // corners: 0 = (0,0), 1 = (w,0), 2 = (0,h), 3 = (w,h)   (Frame.cc:941-944)
+        bounds[0] = fminf(c[0], c[4]); bounds[1] = fmaxf(c[2], c[6]);
+        bounds[2] = fminf(c[1], c[3]); bounds[3] = fmaxf(c[5], c[7]);
+    } else {
+        bounds[0] = 0.0f; bounds[1] = (float)width; bounds[2] = 0.0f; bounds[3] = (float)height;
+    }
+    if (gp) {
+        gp->min_x = bounds[0]; gp->min_y = bounds[2];
+        gp->grid_w_inv = (float)ORBM_GRID_COLS / (float)(bounds[1] - bounds[0]);   // Frame.cc:394-397
+        gp->grid_h_inv = (float)ORBM_GRID_ROWS / (float)(bounds[3] - bounds[2]);
+    }
+    return ORB_OK;
+}
+
+extern "C" int orbf_stereo_from_rgbd(const orb_keypoint* d_kps, const orb_keypoint* d_kps_un, const int32_t* d_nkp, int count_stride, int cap_k,
+                                     int batch, const float* d_depth, size_t frame_stride, int row_stride, int width, int height, float mbf,
+                                     float* d_u_right, float* d_depth_out, void* stream) {
+    if (!d_kps || !d_kps_un || !d_nkp || !d_depth || !d_u_right || !d_depth_out || cap_k <= 0 || batch < 0 || count_stride <= 0 ||
+        width <= 0 || height <= 0 || row_stride < width) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    hipLaunchKernelGGL(k_rgbd, dim3((cap_k + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_kps, d_kps_un, d_nkp, count_stride, cap_k,
+                       d_depth, frame_stride, row_stride, mbf, d_u_right, d_depth_out);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}

@@ -201,20 +201,25 @@ def main():
         if not args.headline_only:
             m = orbhip.ORBmatcher(0.9, True)
             cap = out[0].shape[1]
-            q, nq, src = build_match_queries(out[0].cpu().numpy(), counts, ex.GetScaleFactors(), cap)
+            # the Frame constructor's steps between extractor and matcher (EuRoC calibration): UndistortKeyPoints -> AssignFeaturesToGrid
+            from orbhip.frame import Camera, FrameOps
+            fo = FrameOps(Camera.make(458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)), W, H)
+            un = fo.UndistortKeyPoints(out[0], out[2].view(-1), count_stride=2)
+            q, nq, src = build_match_queries(un.cpu().numpy(), counts, ex.GetScaleFactors(), cap)
             d_q = torch.from_numpy(q.view(np.uint8).reshape(B, cap, 28)).to(dev)
             d_nq = torch.from_numpy(nq).to(dev)
             d_qdesc = out[1][torch.from_numpy(src).to(dev)].contiguous()      # partner descriptors (prepared once, resident in HBM)
-            grid = (0.0, 0.0, float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H)))
+            grid = fo.grid
             work = torch.empty(m._L.orbm_search_workspace_bytes(B, cap), dtype=torch.uint8, device=dev)
             res = None
 
             def step_match():
-                nonlocal out, res
+                nonlocal out, res, un
                 out = ex.extract_batch(d_frames, (0, 1000), out=out)
                 cnt = out[2].view(-1)
-                gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
-                res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
+                un = fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=un)
+                gs, gi = m.grid_build(un, cnt, grid, count_stride=2)
+                res = m.SearchByProjection(un, out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
             for _ in range(2):
                 step_match()
             barrier()
@@ -226,8 +231,9 @@ def main():
                     out = ex.extract_batch(d_frames, (0, 1000), out=out)
                     ev0.record()
                     cnt = out[2].view(-1)
-                    gs, gi = m.grid_build(out[0], cnt, grid, count_stride=2)
-                    res = m.SearchByProjection(out[0], out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
+                    un = fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=un)
+                    gs, gi = m.grid_build(un, cnt, grid, count_stride=2)
+                    res = m.SearchByProjection(un, out[1], cnt, gs, gi, d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work)
                     ev1.record()
                 else:
                     step_match()
@@ -236,7 +242,7 @@ def main():
             nm = res[2].cpu().numpy()
             extra["extract_match"] = {"frames_per_s": round(B * msteps / dtm, 1), "ms_per_step": round(dtm / msteps * 1e3, 4),
                                       "match_only_ms": round(ev0.elapsed_time(ev1), 4), "mean_matches_per_frame": float(nm.mean()),
-                                      "queries_per_frame": float(nq.mean()), "search": "SearchByProjection motion model th=15, TH_HIGH, rot. histogram"}
+                                      "queries_per_frame": float(nq.mean()), "search": "UndistortKeyPoints (EuRoC k1,k2,p1,p2) + AssignFeaturesToGrid + SearchByProjection motion model th=15, TH_HIGH, rot. histogram"}
             # ---- extra leg 2: LocalBundleAdjustment linearisations (C5-size windows: 100 KF / 20k landmarks)
             from orbhip.lba import LbaWindows, synth_window
             nwin = args.lba_windows

@@ -139,6 +139,28 @@ typedef struct orbm_grid_params {
 int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
                     const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Frame constructor steps between the extractor and the matcher (reference src/Frame.cc)
+ * ------------------------------------------------------------------------------------------------------- */
+/* Pinhole intrinsics (Pinhole::toK) + mDistCoef = (k1, k2, p1, p2, k3) (Frame.h mDistCoef; k3 = 0 for 4-coefficient files) */
+typedef struct orbf_camera {
+    float fx, fy, cx, cy;
+    float dist[5];
+} orbf_camera;
+
+/* Frame::UndistortKeyPoints (Frame.cc:874-925): mvKeysUn = mvKeys with pt replaced by cv::undistortPoints(pt, K, mDistCoef, R = I, P = K);
+ * dist[0] == 0 copies (:879-883).  In place (d_kps_un == d_kps) is allowed. */
+int orbf_undistort_keypoints(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
+                             const orbf_camera* cam, orb_keypoint* d_kps_un, void* stream);
+/* Frame::ComputeImageBounds (Frame.cc:926-953) -> bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY} (host), and, if gp != NULL, the grid scalars
+ * mfGridElementWidthInv / HeightInv of Frame.cc:394-397 ready for orbm_grid_build.  Synchronous (runs once per calibration). */
+int orbf_image_bounds(const orbf_camera* cam, int width, int height, float bounds[4], orbm_grid_params* gp);
+/* Frame::ComputeStereoFromRGBD (Frame.cc:1136-1157): depth image(s) float32, frame b at d_depth + b*frame_stride, rows row_stride floats
+ * apart; mvDepth = d, mvuRight = kpU.x - mbf/d where d > 0, else -1.  Entries [n, cap_k) of the outputs are set to -1. */
+int orbf_stereo_from_rgbd(const orb_keypoint* d_kps, const orb_keypoint* d_kps_un, const int32_t* d_nkp, int count_stride, int cap_k,
+                          int batch, const float* d_depth, size_t frame_stride, int row_stride, int width, int height, float mbf,
+                          float* d_u_right, float* d_depth_out, void* stream);
+
 /* One projected map point = one query of a windowed search (the per-MapPoint values the reference computes before
  * calling Frame::GetFeaturesInArea: ORBmatcher.cc:88-103 for the local-map search, :2277-2309 for the motion model). */
 typedef struct orbm_query {

@@ -10,6 +10,7 @@
 #include "orbslam3_hip/ORBmatcher.h"
 #include "orbslam3_hip/Optimizer.h"
 #include "orbslam3_hip/ORBVocabulary.h"
+#include "orbslam3_hip/Frame.h"
 
 extern "C" {
 void* oro_create(int, float, int, int, int);
@@ -32,6 +33,9 @@ void obw_destroy(void*);
 int obw_transform(void*, const uint8_t*, int, int, int32_t*, int32_t*, double*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, double*);
 int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
                       const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
+void ofr_undistort_keypoints(const void*, int, const float*, void*);
+void ofr_image_bounds(const float*, int, int, float*);
+void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
 int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
@@ -296,6 +300,25 @@ int main() {
     for (size_t i = 0; i < pe.size(); i++) CHECK(outl[i] == (oout[i] != 0));
     for (int c = 0; c < 7; c++) CHECK(std::fabs(pp[c] - opp[c]) < 1e-7);
     CHECK(std::fabs(pp[0]) < 0.01 && std::fabs(pp[1]) < 0.01 && std::fabs(pp[2]) < 0.02);   // pulled back to identity
+    // ---- Frame constructor steps through FrameOps vs the oracle (EuRoC calibration, Examples/Monocular/EuRoC.yaml)
+    {
+        const float cam9[9] = {458.654f, 457.296f, 367.215f, 248.375f, -0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f, 0.0f};
+        orbslam3_hip::FrameOps FO(cam9[0], cam9[1], cam9[2], cam9[3], {cam9[4], cam9[5], cam9[6], cam9[7]}, 752, 480);
+        float ob[6];
+        ofr_image_bounds(cam9, 752, 480, ob);
+        CHECK(FO.mnMinX == ob[0] && FO.mnMaxX == ob[1] && FO.mnMinY == ob[2] && FO.mnMaxY == ob[3]);
+        CHECK(FO.mfGridElementWidthInv == ob[4] && FO.mfGridElementHeightInv == ob[5] && FO.mnMinX < -30.f);
+        std::vector<orb_keypoint> ks(500), un, oun(500);
+        for (auto& k : ks) { k = orb_keypoint{(float)(16 + rnd() % 720), (float)(16 + rnd() % 448), 31.f, (float)(rnd() % 360), (float)(rnd() % 200), (int)(rnd() % 8), -1}; }
+        FO.UndistortKeyPoints(ks, un);
+        ofr_undistort_keypoints(ks.data(), 500, cam9, oun.data());
+        CHECK(un.size() == 500 && std::memcmp(un.data(), oun.data(), 500 * sizeof(orb_keypoint)) == 0);
+        std::vector<float> depth((size_t)752 * 480), ur, dz, our(500), odz(500);
+        for (auto& d : depth) d = (rnd() % 5 == 0) ? 0.0f : (float)(rnd() % 6000) / 1000.0f;
+        FO.ComputeStereoFromRGBD(ks, un, depth.data(), 752, 40.0f, ur, dz);
+        ofr_stereo_from_rgbd(ks.data(), oun.data(), 500, depth.data(), 752, 40.0f, our.data(), odz.data());
+        CHECK(std::memcmp(ur.data(), our.data(), 500 * 4) == 0 && std::memcmp(dz.data(), odz.data(), 500 * 4) == 0);
+    }
     std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;
 }

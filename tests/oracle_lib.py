@@ -13,8 +13,8 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build_oracle(force=False):
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    # make is incremental: a no-op when liboracle.so is newer than every source
+    subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _SO
 
 
@@ -421,3 +421,32 @@ def search_by_projection_rig(kps, desc, nleft, link, queries, qdesc, grid, mode,
                                        _p(link) if link is not None else None, *[float(g) for g in grid], _p(queries), _p(qdesc), len(queries),
                                        mode, th_dist, nnratio, int(check_ori), _p(q_match), _p(kp_match))
     return q_match[:len(queries)], kp_match[:len(kps)], n
+
+
+# ---- Frame constructor steps (oracle/frame_oracle.cpp) ------------------------------------------------------------------------------
+def undistort_keypoints(kps, cam9):
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros_like(kps)
+    L = lib()
+    L.ofr_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    cam9 = np.ascontiguousarray(cam9, np.float32)
+    L.ofr_undistort_keypoints(_p(kps), len(kps), _p(cam9), _p(out))
+    return out
+
+
+def image_bounds(cam9, cols, rows):
+    out = np.zeros(6, np.float32)
+    L = lib()
+    L.ofr_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    cam9 = np.ascontiguousarray(cam9, np.float32)
+    L.ofr_image_bounds(_p(cam9), cols, rows, _p(out))
+    return out
+
+
+def stereo_from_rgbd(kps, kps_un, depth, mbf):
+    kps, kps_un, depth = np.ascontiguousarray(kps), np.ascontiguousarray(kps_un), np.ascontiguousarray(depth, np.float32)
+    ur, dz = np.zeros(len(kps), np.float32), np.zeros(len(kps), np.float32)
+    L = lib()
+    L.ofr_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.ofr_stereo_from_rgbd(_p(kps), _p(kps_un), len(kps), _p(depth), depth.shape[1], float(mbf), _p(ur), _p(dz))
+    return ur, dz
