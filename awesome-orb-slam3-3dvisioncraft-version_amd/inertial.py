@@ -1,0 +1,181 @@
+"""Host-side mirror of Optimizer::LocalInertialBA's optimisation (reference src/Optimizer.cc:4753-5365; vertices / edges of
+include/G2oTypes.h) above the C ABI (include/orbhip.h, "liba_*"): visual-inertial local bundle adjustment windows, batched.
+
+A window = key frames (ImuCamPose + velocity + gyro / acc bias, `KF_DTYPE`), the rig calibration (`Rig`), map points, visual edges
+(`EDGE_DTYPE` of orbhip.lba: kind 0 = EdgeMono, 1 = EdgeStereo, cam = camera index) and one `IMU_EDGE_DTYPE` record per preintegration
+(EdgeInertial + EdgeGyroRW + EdgeAccRW).  Arrays are torch CUDA tensors (product) or numpy (emulated test build)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OrbHipError
+from .lba import EDGE_DTYPE, EDGE_MONO, EDGE_STEREO, HUBER_MONO, HUBER_STEREO, _kb8_project, _rodrigues
+
+KF_DTYPE = np.dtype([("Rwb", "<f8", (9,)), ("twb", "<f8", (3,)), ("Rcw", "<f8", (2, 9)), ("tcw", "<f8", (2, 3)), ("v", "<f8", (3,)),
+                     ("bg", "<f8", (3,)), ("ba", "<f8", (3,)), ("pose_fixed", "<i4"), ("has_imu", "<i4"), ("imu_fixed", "<i4"), ("reserved", "<i4")])
+IMU_EDGE_DTYPE = np.dtype([("kf1", "<i4"), ("kf2", "<i4"), ("dR", "<f4", (9,)), ("dV", "<f4", (3,)), ("dP", "<f4", (3,)), ("JRg", "<f4", (9,)),
+                           ("JVg", "<f4", (9,)), ("JVa", "<f4", (9,)), ("JPg", "<f4", (9,)), ("JPa", "<f4", (9,)), ("b", "<f4", (6,)), ("dT", "<f4"),
+                           ("pad", "<f4"), ("huber", "<f8"), ("info", "<f8", (81,)), ("info_g", "<f8", (9,)), ("info_a", "<f8", (9,))])
+assert KF_DTYPE.itemsize == 376 and IMU_EDGE_DTYPE.itemsize == 1080
+HUBER_INERTIAL = float(np.sqrt(16.92))   # rki->setDelta(sqrt(16.92))  Optimizer.cc:5012
+GRAVITY_VALUE = 9.81                     # ImuTypes.h:40
+
+
+class Rig(C.Structure):
+    """Calibration members of ImuCamPose (G2oTypes.h:60-72): per camera Rcb, tcb, Rbc, tbc; bf; camera model + parameters."""
+    _fields_ = [("n_cams", C.c_int32), ("reserved", C.c_int32), ("Rcb", (C.c_double * 9) * 2), ("tcb", (C.c_double * 3) * 2),
+                ("Rbc", (C.c_double * 9) * 2), ("tbc", (C.c_double * 3) * 2), ("bf", C.c_double), ("model", C.c_int32 * 2), ("p", (C.c_double * 8) * 2)]
+
+
+def make_rig(Tcb_list, bf, models, params):
+    r = Rig()
+    r.n_cams = len(Tcb_list)
+    r.bf = float(bf)
+    for c, (Rcb, tcb) in enumerate(Tcb_list):
+        Rbc = Rcb.T
+        tbc = -Rbc @ tcb
+        for i in range(9):
+            r.Rcb[c][i] = float(Rcb.reshape(-1)[i]); r.Rbc[c][i] = float(Rbc.reshape(-1)[i])
+        for i in range(3):
+            r.tcb[c][i] = float(tcb[i]); r.tbc[c][i] = float(tbc[i])
+        r.model[c] = int(models[c])
+        for i in range(8):
+            r.p[c][i] = float(params[c][i]) if i < len(params[c]) else 0.0
+    return r
+
+
+def set_cam_poses(kf, rig):
+    """ImuCamPose constructor / Update tail: Rcw[i] = Rcb[i] * Rbw, tcw[i] = Rcb[i] * tbw + tcb[i] (G2oTypes.cc:213-220)."""
+    Rwb = kf["Rwb"].reshape(3, 3)
+    Rbw = Rwb.T
+    tbw = -Rbw @ kf["twb"]
+    for c in range(rig.n_cams):
+        Rcb = np.array(rig.Rcb[c]).reshape(3, 3)
+        kf["Rcw"][c] = (Rcb @ Rbw).reshape(-1)
+        kf["tcw"][c] = Rcb @ tbw + np.array(rig.tcb[c])
+
+
+def synth_inertial_window(seed=0, n_opt=8, n_fixed_vis=3, n_pts=500, max_obs=6, kind="mono", outliers=0.03, fx=458.654, fy=457.296, cx=367.215,
+                          cy=248.375, W=752, H=480, bf=47.906, dt=0.3):
+    """-> dict(kfs, rig, points, edges, imu).  kind: "mono" / "stereo" (EuRoC pinhole, one camera) or "fisheye" (two KB8 cameras, TUM-VI like).
+    Key frames in ascending id order: n_fixed_vis vision-only fixed KFs, the fixed IMU KF just before the temporal window, then n_opt optimisable
+    ones.  Preintegrations are the exact relative motion of the true trajectory plus noise; estimates start perturbed."""
+    rng = np.random.default_rng(seed)
+    g = np.array([0.0, 0.0, -GRAVITY_VALUE])
+    n_imu_kf = n_opt + 1
+    n_kf = n_fixed_vis + n_imu_kf
+    # rig
+    Rcb0 = _rodrigues(np.array([0.01, -0.02, 0.015])); tcb0 = np.array([0.05, -0.02, 0.01])
+    if kind == "fisheye":
+        pk = np.float32([190.978, 190.973, 254.932, 256.897, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673]).astype(np.float64)
+        Rrl = _rodrigues(np.array([0.002, -0.01, 0.003])); trl = np.array([-0.1, 0.001, 0.0005])
+        rig = make_rig([(Rcb0, tcb0), (Rrl @ Rcb0, Rrl @ tcb0 + trl)], 0.0, [1, 1], [pk, pk * np.array([1.001, 0.999, 1.002, 0.998, 1, 1, 1, 1])])
+    else:
+        rig = make_rig([(Rcb0, tcb0)], np.float32(bf), [0], [np.float32([fx, fy, cx, cy]).astype(np.float64)])
+    # true trajectory: an arc around the point cloud, cameras looking inwards; body = camera up to Tcb
+    Rwb_t = np.zeros((n_kf, 3, 3)); twb_t = np.zeros((n_kf, 3)); v_t = np.zeros((n_kf, 3))
+
+    def body_pose(t):      # t in seconds
+        a = 0.4 * t
+        c = np.array([9 * np.cos(a), 9 * np.sin(a), 0.3 * np.sin(2.0 * t)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross(np.array([0, 0, 1.0]), z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        Rwc = np.stack([x, y, z], 1)             # camera axes in world
+        Rwb = Rwc @ Rcb0                         # Rwc = Rwb * Rbc  ->  Rwb = Rwc * Rcb
+        twb = c - Rwb @ (-Rcb0.T @ tcb0)         # twc = twb + Rwb * tbc
+        return Rwb, twb
+    times = np.concatenate([-(np.arange(n_fixed_vis, 0, -1) * 0.9 + 0.6), np.arange(n_imu_kf) * dt])
+    for k in range(n_kf):
+        Rwb_t[k], twb_t[k] = body_pose(times[k])
+        e = 1e-5
+        v_t[k] = (body_pose(times[k] + e)[1] - body_pose(times[k] - e)[1]) / (2 * e)
+    # key-frame records (estimates = truth + perturbation for the optimisable ones); map values are float32 widened
+    kfs = np.zeros(n_kf, KF_DTYPE)
+    b0 = np.float32(rng.normal(0, [0.002] * 3 + [0.01] * 3))          # preintegration bias (bax bay baz bwx bwy bwz)
+    first_opt = n_fixed_vis + 1
+    for k in range(n_kf):
+        R, t, v = Rwb_t[k].copy(), twb_t[k].copy(), v_t[k].copy()
+        if k >= first_opt:
+            R = R @ _rodrigues(rng.normal(0, 0.004, 3)); t = t + rng.normal(0, 0.015, 3); v = v + rng.normal(0, 0.03, 3)
+        kfs[k]["Rwb"] = R.astype(np.float32).astype(np.float64).reshape(-1)
+        kfs[k]["twb"] = t.astype(np.float32)
+        kfs[k]["v"] = v.astype(np.float32)
+        kfs[k]["ba"] = (b0[:3] + np.float32(rng.normal(0, 0.003, 3))).astype(np.float32)
+        kfs[k]["bg"] = (b0[3:] + np.float32(rng.normal(0, 0.0005, 3))).astype(np.float32)
+        kfs[k]["pose_fixed"] = 0 if k >= first_opt else 1
+        kfs[k]["has_imu"] = 1 if k >= n_fixed_vis else 0
+        kfs[k]["imu_fixed"] = 0 if k >= first_opt else 1
+        set_cam_poses(kfs[k], rig)
+    # preintegrations, newest first like the loop of Optimizer.cc:4964-5062
+    imu = np.zeros(n_opt, IMU_EDGE_DTYPE)
+    for i in range(n_opt):
+        k2 = n_kf - 1 - i
+        k1 = k2 - 1
+        T = times[k2] - times[k1]
+        R1 = Rwb_t[k1]
+        E = imu[i]
+        E["kf1"], E["kf2"] = k1, k2
+        E["dT"] = np.float32(T)
+        Td = float(np.float32(T))
+        E["dR"] = (R1.T @ Rwb_t[k2] @ _rodrigues(rng.normal(0, 5e-4, 3))).reshape(-1)
+        vv1, vv2 = v_t[k1], v_t[k2]
+        E["dV"] = R1.T @ (vv2 - vv1 - g * Td) + rng.normal(0, 2e-3, 3)
+        E["dP"] = R1.T @ (twb_t[k2] - twb_t[k1] - vv1 * Td - 0.5 * g * Td * Td) + rng.normal(0, 2e-3, 3)
+        E["JRg"] = (-Td * np.eye(3) + rng.normal(0, 0.01, (3, 3))).reshape(-1)
+        E["JVg"] = rng.normal(0, 0.05, 9); E["JVa"] = (-Td * R1.T @ R1 + rng.normal(0, 0.01, (3, 3))).reshape(-1)
+        E["JPg"] = rng.normal(0, 0.01, 9); E["JPa"] = (-0.5 * Td * Td * np.eye(3) + rng.normal(0, 0.003, (3, 3))).reshape(-1)
+        E["b"] = b0
+        L = np.diag(np.sqrt([3e4] * 3 + [2e3] * 3 + [8e3] * 3)) @ (np.eye(9) + 0.05 * rng.normal(0, 1, (9, 9)))
+        info = (L @ L.T).astype(np.float32).astype(np.float64)
+        info = (info + info.T) / 2
+        if i == n_opt - 1:      # oldest edge: Huber + information * 1e-2 (Optimizer.cc:5005-5012)
+            info = info * 1e-2
+            E["huber"] = HUBER_INERTIAL
+        E["info"] = info.reshape(-1)
+        E["info_g"] = (np.eye(3) * 4e5 + 1e3 * rng.normal(0, 1, (3, 3))).astype(np.float32).reshape(-1)
+        E["info_a"] = (np.eye(3) * 2e3 + 10 * rng.normal(0, 1, (3, 3))).astype(np.float32).reshape(-1)
+    # map points and observations from the TRUE poses
+    pts = np.stack([rng.uniform(-4, 4, n_pts), rng.uniform(-4, 4, n_pts), rng.uniform(-1.5, 1.5, n_pts)], 1).astype(np.float32).astype(np.float64)
+    scale2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2
+    edges = []
+    true_kf = np.zeros(n_kf, KF_DTYPE)
+    for k in range(n_kf):
+        true_kf[k]["Rwb"] = Rwb_t[k].reshape(-1); true_kf[k]["twb"] = twb_t[k]
+        set_cam_poses(true_kf[k], rig)
+    for l in range(n_pts):
+        ks = rng.permutation(n_kf)
+        nob = 0
+        for k in ks:
+            if nob >= max_obs:
+                break
+            got = False
+            for c in range(rig.n_cams):
+                Xc = true_kf[k]["Rcw"][c].reshape(3, 3) @ pts[l] + true_kf[k]["tcw"][c]
+                if Xc[2] < 0.5:
+                    continue
+                if rig.model[c] == 0:
+                    u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+                    ok = 0 <= u < W and 0 <= v < H
+                else:
+                    uu, vv, th = _kb8_project(np.array(rig.p[c]), Xc[None, :])
+                    u, v = float(uu[0]), float(vv[0])
+                    ok = 0 <= u < 512 and 0 <= v < 512 and th[0] < 1.3
+                if not ok:
+                    continue
+                o = int(rng.integers(0, 8))
+                sg = float(np.sqrt(scale2[o]))
+                n2 = rng.normal(0, 1, 3) * sg
+                if rng.random() < outliers:
+                    n2[:2] = rng.normal(0, 25, 2)
+                stereo = kind == "stereo" and (l % 3 != 0)
+                obs = (u + n2[0], v + n2[1], (u + n2[0] - bf / Xc[2] + n2[2]) if stereo else 0.0)
+                edges.append((k, l, EDGE_STEREO if stereo else EDGE_MONO, c, obs, np.float32(1.0) / scale2[o]))
+                got = True
+            nob += got
+    ea = np.zeros(len(edges), EDGE_DTYPE)
+    for i, (k, l, kd, c, obs, s) in enumerate(edges):
+        ea[i]["pose"], ea[i]["point"], ea[i]["kind"], ea[i]["cam"], ea[i]["obs"], ea[i]["inv_sigma2"] = k, l, kd, c, np.float32(obs), s
+    ea = ea[np.argsort(ea["point"], kind="stable")]
+    return {"kfs": kfs, "rig": rig, "points": pts + rng.normal(0, 0.03, pts.shape), "edges": ea, "imu": imu}

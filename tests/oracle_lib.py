@@ -450,3 +450,62 @@ def stereo_from_rgbd(kps, kps_un, depth, mbf):
     L.ofr_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     L.ofr_stereo_from_rgbd(_p(kps), _p(kps_un), len(kps), _p(depth), depth.shape[1], float(mbf), _p(ur), _p(dz))
     return ur, dz
+
+
+# ---- visual-inertial local BA (oracle/inertial_oracle.cpp) ----------------------------------------------------------------------------
+def _ib(w):
+    return (np.ascontiguousarray(w["kfs"]), w["rig"], np.ascontiguousarray(w["points"], np.float64), np.ascontiguousarray(w["edges"]),
+            np.ascontiguousarray(w["imu"]))
+
+
+def inertial_imu_error(edge, kf1, kf2, rig, d=None):
+    e = np.zeros(9)
+    L = lib()
+    L.oib_imu_error.argtypes = [C.c_void_p] * 6
+    dd = None if d is None else np.ascontiguousarray(d, np.float64)
+    L.oib_imu_error(_p(np.ascontiguousarray(edge)), _p(np.ascontiguousarray(kf1)), _p(np.ascontiguousarray(kf2)), C.addressof(rig),
+                    None if dd is None else _p(dd), _p(e))
+    return e
+
+
+def inertial_imu_jacobian(edge, kf1, kf2):
+    J = np.zeros((9, 24))
+    L = lib()
+    L.oib_imu_jacobian.argtypes = [C.c_void_p] * 4
+    L.oib_imu_jacobian(_p(np.ascontiguousarray(edge)), _p(np.ascontiguousarray(kf1)), _p(np.ascontiguousarray(kf2)), _p(J))
+    return J
+
+
+def inertial_vis_error(edge, kf, rig, X, dpose=None, dpoint=None, jac=False):
+    e, A, B = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 6))
+    L = lib()
+    L.oib_vis_error.argtypes = [C.c_void_p] * 9
+    X = np.ascontiguousarray(X, np.float64)
+    dp = None if dpose is None else np.ascontiguousarray(dpose, np.float64)
+    dx = None if dpoint is None else np.ascontiguousarray(dpoint, np.float64)
+    L.oib_vis_error(_p(np.ascontiguousarray(edge)), _p(np.ascontiguousarray(kf)), C.addressof(rig), _p(X), None if dp is None else _p(dp),
+                    None if dx is None else _p(dx), _p(e), _p(A) if jac else None, _p(B) if jac else None)
+    return (e, A, B) if jac else e
+
+
+def inertial_errors(w, huber):
+    kfs, rig, pts, edges, imu = _ib(w)
+    vchi, vdp, ichi, rs = np.zeros(len(edges)), np.zeros(len(edges), np.uint8), np.zeros((len(imu), 3)), np.zeros(1)
+    L = lib()
+    L.oib_errors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oib_errors(_p(kfs), len(kfs), C.addressof(rig), _p(pts), len(pts), _p(edges), len(edges), _p(imu), len(imu), huber[0], huber[1],
+                 _p(vchi), _p(vdp), _p(ichi), _p(rs))
+    return {"vis_chi2": vchi, "vis_depth_pos": vdp, "imu_chi2": ichi, "robust_chi2_sum": rs[0]}
+
+
+def inertial_optimize(w, huber, lambda_init, iterations):
+    kfs, rig, pts, edges, imu = _ib(w)
+    kfs, pts = kfs.copy(), pts.copy()
+    stats = np.zeros(5)
+    L = lib()
+    L.oib_optimize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                               C.c_double, C.c_int, C.c_void_p]
+    L.oib_optimize(_p(kfs), len(kfs), C.addressof(rig), _p(pts), len(pts), _p(edges), len(edges), _p(imu), len(imu), huber[0], huber[1],
+                   float(lambda_init), iterations, _p(stats))
+    return kfs, pts, stats

@@ -1,0 +1,71 @@
+"""Visual-inertial local BA (Optimizer::LocalInertialBA, SURVEY N4 tail): oracle pins (central differences of every Jacobian through the
+vertices' own oplus, convergence) and HIP-vs-oracle parity of the optimised states."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from orbhip.inertial import HUBER_INERTIAL, synth_inertial_window
+from orbhip.lba import HUBER_MONO, HUBER_STEREO
+
+HUBER = (HUBER_MONO, HUBER_STEREO)
+_W = {}
+
+
+def window(kind, seed=0, **kw):
+    k = (kind, seed, tuple(sorted(kw.items())))
+    if k not in _W:
+        _W[k] = synth_inertial_window(seed, kind=kind, **kw)
+    return _W[k]
+
+
+@pytest.mark.parametrize("kind", ["mono", "stereo", "fisheye"])
+def test_oracle_inertial_jacobian_matches_central_differences(kind):
+    w = window(kind, n_pts=120)
+    kfs, rig, imu = w["kfs"], w["rig"], w["imu"]
+    for E in imu:
+        k1, k2 = kfs[E["kf1"]:E["kf1"] + 1], kfs[E["kf2"]:E["kf2"] + 1]
+        J = O.inertial_imu_jacobian(E, k1, k2)
+        e0 = O.inertial_imu_error(E, k1, k2, rig)
+        assert np.abs(e0).max() < 0.2          # the synthetic preintegration is consistent with the trajectory
+        Jn = np.zeros((9, 24))
+        # the error goes through float32 preintegration getters and a float-normalised ExpSO3 (rule R3): only float-smooth -> large step
+        h = 2e-3
+        for c in range(24):
+            d = np.zeros(24); d[c] = h
+            Jn[:, c] = (O.inertial_imu_error(E, k1, k2, rig, d) - O.inertial_imu_error(E, k1, k2, rig, -d)) / (2 * h)
+        assert np.abs(J - Jn).max() < 2e-3 * max(1.0, np.abs(J).max()), (np.abs(J - Jn).max(), np.unravel_index(np.abs(J - Jn).argmax(), J.shape))
+
+
+@pytest.mark.parametrize("kind", ["mono", "stereo", "fisheye"])
+def test_oracle_visual_jacobians_match_central_differences(kind):
+    w = window(kind, n_pts=120)
+    kfs, rig, pts, edges = w["kfs"], w["rig"], w["points"], w["edges"]
+    rng = np.random.default_rng(1)
+    for ei in rng.choice(len(edges), 10, replace=False):
+        E = edges[ei:ei + 1]
+        kf, X = kfs[E["pose"][0]:E["pose"][0] + 1], pts[E["point"][0]]
+        e0, A, B = O.inertial_vis_error(E, kf, rig, X, jac=True)
+        D = 3 if E["kind"][0] == 1 else 2
+        h = 2e-3 if rig.model[E["cam"][0]] == 1 else 1e-4     # KB8 rounds theta / psi through atan2f; pose oplus through a float ExpSO3
+        for c in range(6):
+            d = np.zeros(6); d[c] = h
+            n = (O.inertial_vis_error(E, kf, rig, X, dpose=d) - O.inertial_vis_error(E, kf, rig, X, dpose=-d)) / (2 * h)
+            assert np.abs(n[:D] - B[:D, c]).max() < 5e-3 * max(1.0, np.abs(B).max()), (ei, c)
+        hp = 2e-3 if rig.model[E["cam"][0]] == 1 else 1e-6
+        for c in range(3):
+            d = np.zeros(3); d[c] = hp
+            n = (O.inertial_vis_error(E, kf, rig, X, dpoint=d) - O.inertial_vis_error(E, kf, rig, X, dpoint=-d)) / (2 * hp)
+            assert np.abs(n[:D] - A[:D, c]).max() < (5e-3 if rig.model[E["cam"][0]] == 1 else 1e-5) * max(1.0, np.abs(A).max()), (ei, c)
+
+
+@pytest.mark.parametrize("kind,lam", [("mono", 1.0), ("stereo", 1e-2), ("fisheye", 1.0)])
+def test_oracle_inertial_ba_converges(kind, lam):
+    w = window(kind)
+    e0 = O.inertial_errors(w, HUBER)
+    kfs, pts, st = O.inertial_optimize(w, HUBER, lam, 10)
+    assert st[0] >= 3 and st[4] == pytest.approx(e0["robust_chi2_sum"]) and st[1] < 0.85 * st[4], st
+    fixed = w["kfs"]["pose_fixed"] == 1
+    assert np.array_equal(kfs[fixed], w["kfs"][fixed])
+    assert not np.array_equal(kfs[~fixed]["v"], w["kfs"][~fixed]["v"]) and not np.array_equal(kfs[~fixed]["bg"], w["kfs"][~fixed]["bg"])
+    assert (e0["imu_chi2"][:, 0] > 0).all() and e0["vis_depth_pos"].all()
+    assert w["imu"]["huber"][-1] == HUBER_INERTIAL
