@@ -805,124 +805,13 @@ static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const 
     }
 }
 
-// dense Cholesky (lower, column-major, in place) + forward / backward substitution; one workgroup per window.
-// Blocked right-looking: a panel of CH_NB columns is factored in LDS, then the trailing triangle gets ONE rank-CH_NB update
-// (both operands from the LDS panel, one global read-modify-write per element per panel instead of per column).
-#define CH_NB 16
-#define CH_LD (CH_NB + 1)    // padded panel row (17 doubles = 34 dwords: conflict-free 8-byte reads down a column)
+#include "dense_chol.inc"
 static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t* nfreeArr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
     if (!A.st[b].needTrial) return;
     const int n = nfreeArr[b] * 6, ld = A.np6;
-    double* pan = (double*)orb_smem;                    // [ld][CH_LD] panel rows kb.. (row r of the panel = matrix row kb + r)
-    double* red = pan + (size_t)ld * CH_LD;             // [256] reduction scratch
-    int* bad = (int*)(red + 256 + ld + CH_NB * CH_LD);
-    double* S = A.Hs + (size_t)b * ld * ld;
-    double* x = A.xp + (size_t)b * ld;
-    if (tid == 0) *bad = 0;
-    __syncthreads();
-    for (int kb = 0; kb < n; kb += CH_NB) {
-        const int nb = min(CH_NB, n - kb), m = n - kb;   // panel: m rows x nb columns
-        for (int c = wave; c < nb; c += 4)
-            for (int r = lane; r < m; r += 64) pan[r * CH_LD + c] = S[(size_t)(kb + c) * ld + kb + r];
-        __syncthreads();
-        for (int c = 0; c < nb; c++) {
-            const double dkk = pan[c * CH_LD + c];
-            if (!(dkk > 0) || !(dkk < 1.7e308)) { if (tid == 0) *bad = 1; break; }   // uniform
-            const double sq = sqrt(dkk);
-            __syncthreads();                              // pivot read by everyone before it is overwritten
-            for (int r = c + tid; r < m; r += 256) pan[r * CH_LD + c] = (r == c) ? sq : pan[r * CH_LD + c] / sq;
-            __syncthreads();
-            for (int c2 = c + 1 + wave; c2 < nb; c2 += 4) {
-                const double l2 = pan[c2 * CH_LD + c];
-                for (int r = c2 + lane; r < m; r += 64) pan[r * CH_LD + c2] -= pan[r * CH_LD + c] * l2;
-            }
-            __syncthreads();
-        }
-        if (*bad) break;
-        for (int c = wave; c < nb; c += 4)
-            for (int r = c + lane; r < m; r += 64) S[(size_t)(kb + c) * ld + kb + r] = pan[r * CH_LD + c];
-        // trailing update: S(i, j) -= sum_c L(i, kb+c) L(j, kb+c)  for j >= kb+nb, i >= j
-        for (int j = nb + wave; j < m; j += 4) {
-            double lj[CH_NB];
-#pragma unroll
-            for (int c = 0; c < CH_NB; c++) lj[c] = c < nb ? pan[j * CH_LD + c] : 0.0;
-            double* Sj = S + (size_t)(kb + j) * ld + kb;
-            for (int r = j + lane; r < m; r += 64) {
-                const double* pr = pan + r * CH_LD;
-                double acc = 0;
-#pragma unroll
-                for (int c = 0; c < CH_NB; c++) acc += pr[c] * lj[c];   // columns >= nb of the panel rows are never read with lj != 0
-                Sj[r] -= acc;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    __syncthreads();
-    if (*bad) { if (tid == 0) A.st[b].ok = 0; return; }
-    // L y = b, then L^T x = y, blocked by CH_NB: the right-hand side lives in LDS; per block step wave 0 solves the CH_NB x CH_NB
-    // triangle (staged in LDS) and all threads apply the block's columns to the remaining rows with coalesced column reads of L —
-    // two barriers per 16 unknowns instead of a global-memory round trip per unknown.
-    double* xs = red + 256;                               // [ld]
-    double* blk = xs + ld;                                // [CH_NB][CH_LD] diagonal block, blk[r][c] = L(kb+r, kb+c)
-    for (int i = tid; i < n; i += 256) xs[i] = x[i];
-    __syncthreads();
-    for (int kb = 0; kb < n; kb += CH_NB) {               // forward substitution
-        const int nb = min(CH_NB, n - kb);
-        if (tid < CH_NB * CH_NB) { const int r = tid & (CH_NB - 1), c = tid >> 4; blk[r * CH_LD + c] = (r < nb && c < nb && r >= c) ? S[(size_t)(kb + c) * ld + kb + r] : 0.0; }
-        __syncthreads();
-        if (wave == 0) {
-            double v = lane < nb ? xs[kb + lane] : 0.0;
-            for (int c = 0; c < nb; c++) {
-                const double xc = __shfl(v, c) / blk[c * CH_LD + c];
-                if (lane == c) v = xc;
-                else if (lane > c && lane < nb) v -= blk[lane * CH_LD + c] * xc;
-            }
-            if (lane < nb) xs[kb + lane] = v;
-        }
-        __syncthreads();
-        for (int i = kb + nb + tid; i < n; i += 256) {
-            double acc = xs[i];
-            for (int c = 0; c < nb; c++) acc -= S[(size_t)(kb + c) * ld + i] * xs[kb + c];
-            xs[i] = acc;
-        }
-        __syncthreads();
-    }
-    for (int kb = ((n - 1) / CH_NB) * CH_NB; kb >= 0; kb -= CH_NB) {   // backward substitution with L^T
-        const int nb = min(CH_NB, n - kb);
-        double part[CH_NB];
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++) part[c] = 0.0;
-        for (int i = kb + nb + tid; i < n; i += 256) {
-            const double xi = xs[i];
-#pragma unroll
-            for (int c = 0; c < CH_NB; c++)
-                if (c < nb) part[c] += S[(size_t)(kb + c) * ld + i] * xi;
-        }
-#pragma unroll
-        for (int c = 0; c < CH_NB; c++)
-            for (int off = 32; off > 0; off >>= 1) part[c] += __shfl_xor(part[c], off);
-        if (tid < CH_NB * CH_NB) { const int r = tid & (CH_NB - 1), c = tid >> 4; blk[r * CH_LD + c] = (r < nb && c < nb && r >= c) ? S[(size_t)(kb + c) * ld + kb + r] : 0.0; }
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < CH_NB; c++) red[wave * CH_NB + c] = part[c];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            double v = 0.0;
-            if (lane < nb) v = xs[kb + lane] - (((red[lane] + red[CH_NB + lane]) + red[2 * CH_NB + lane]) + red[3 * CH_NB + lane]);
-            for (int c = nb - 1; c >= 0; c--) {          // x_c = (v_c - sum_{r>c} L(r,c) x_r) / L(c,c): lane r > c holds x_r
-                double t = (lane > c && lane < nb) ? blk[lane * CH_LD + c] * v : 0.0;
-                for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                if (lane == c) v = (v - t) / blk[c * CH_LD + c];
-            }
-            if (lane < nb) xs[kb + lane] = v;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < n; i += 256) x[i] = xs[i];
+    if (!wg_chol_solve(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem) && threadIdx.x == 0) A.st[b].ok = 0;
 }
 
 static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {

@@ -85,7 +85,7 @@ extern "C" int orbf_image_bounds(const orbf_camera* cam, int width, int height, 
         if (hipMalloc(&d, sizeof(c)) != hipSuccess) return ORB_E_NOMEM;
         hipLaunchKernelGGL(k_bounds, dim3(1), dim3(64), 0, 0, *cam, (float)width, (float)height, d);
         const hipError_t e = hipMemcpy(c, d, sizeof(c), hipMemcpyDeviceToHost);
-        hipFree(d);
+        (void)hipFree(d);
         if (e != hipSuccess) return ORB_E_HIP;
         // corners: 0 = (0,0), 1 = (w,0), 2 = (0,h), 3 = (w,h)   (Frame.cc:941-944)
         bounds[0] = fminf(c[0], c[4]); bounds[1] = fmaxf(c[2], c[6]);

@@ -179,3 +179,103 @@ def synth_inertial_window(seed=0, n_opt=8, n_fixed_vis=3, n_pts=500, max_obs=6, 
         ea[i]["pose"], ea[i]["point"], ea[i]["kind"], ea[i]["cam"], ea[i]["obs"], ea[i]["inv_sigma2"] = k, l, kd, c, np.float32(obs), s
     ea = ea[np.argsort(ea["point"], kind="stable")]
     return {"kfs": kfs, "rig": rig, "points": pts + rng.normal(0, 0.03, pts.shape), "edges": ea, "imu": imu}
+
+
+# ---- device path ------------------------------------------------------------------------------------------------------------------------
+class LibaProblem(C.Structure):
+    _fields_ = [("kfs", C.c_void_p), ("n_kf", C.c_void_p), ("rigs", C.c_void_p), ("points", C.c_void_p), ("n_points", C.c_void_p),
+                ("edges", C.c_void_p), ("n_edges", C.c_void_p), ("imu", C.c_void_p), ("n_imu", C.c_void_p),
+                ("cap_kf", C.c_int32), ("cap_l", C.c_int32), ("cap_e", C.c_int32), ("cap_i", C.c_int32), ("rig_stride", C.c_int32),
+                ("max_free", C.c_int32), ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+def bind(lib):
+    vp, i32, sz, f64 = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+    protos = {
+        "liba_workspace_bytes": (sz, [C.POINTER(LibaProblem), i32]),
+        "liba_optimize": (i32, [C.POINTER(LibaProblem), i32, f64, i32, vp, vp, vp]),
+        "liba_compute_errors": (i32, [C.POINTER(LibaProblem), i32, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
+    assert a.is_contiguous()
+    return C.c_void_p(a.data_ptr())
+
+
+class InertialWindows:
+    """A batch of LocalInertialBA windows resident on the device.  `to_dev` maps a numpy array to device memory (torch.from_numpy(a).cuda()
+    for the product; identity for the emulated build).  Structured arrays travel as uint8 views."""
+
+    def __init__(self, windows, to_dev, *, lib=None, huber=(HUBER_MONO, HUBER_STEREO)):
+        self._L = bind(lib if lib is not None else _lib.load())
+        B = len(windows)
+        self.B = B
+        self.cap_kf = max(len(w["kfs"]) for w in windows)
+        self.cap_l = max(len(w["points"]) for w in windows)
+        self.cap_e = max(len(w["edges"]) for w in windows)
+        self.cap_i = max(1, max(len(w["imu"]) for w in windows))
+        self.max_free = max(int((w["kfs"]["pose_fixed"] == 0).sum()) for w in windows)
+        kfs = np.zeros((B, self.cap_kf), KF_DTYPE); pts = np.zeros((B, self.cap_l, 3)); edges = np.zeros((B, self.cap_e), EDGE_DTYPE)
+        imu = np.zeros((B, self.cap_i), IMU_EDGE_DTYPE)
+        n = np.zeros((4, B), np.int32)
+        rigs = (Rig * B)()
+        for b, w in enumerate(windows):
+            n[:, b] = len(w["kfs"]), len(w["points"]), len(w["edges"]), len(w["imu"])
+            kfs[b, :n[0, b]] = w["kfs"]; pts[b, :n[1, b]] = w["points"]; edges[b, :n[2, b]] = w["edges"]; imu[b, :n[3, b]] = w["imu"]
+            rigs[b] = w["rig"]
+        self.n = n
+        rig_bytes = np.frombuffer(bytes(rigs), np.uint8).copy()
+        self.d = {"kfs": to_dev(kfs.view(np.uint8).reshape(B, -1)), "points": to_dev(pts), "edges": to_dev(edges.view(np.uint8).reshape(B, -1)),
+                  "imu": to_dev(imu.view(np.uint8).reshape(B, -1)), "rigs": to_dev(rig_bytes),
+                  "n_kf": to_dev(n[0].copy()), "n_points": to_dev(n[1].copy()), "n_edges": to_dev(n[2].copy()), "n_imu": to_dev(n[3].copy())}
+        self._to_dev = to_dev
+        d = self.d
+        self.prob = LibaProblem(_ptr(d["kfs"]), _ptr(d["n_kf"]), _ptr(d["rigs"]), _ptr(d["points"]), _ptr(d["n_points"]), _ptr(d["edges"]), _ptr(d["n_edges"]),
+                                _ptr(d["imu"]), _ptr(d["n_imu"]), self.cap_kf, self.cap_l, self.cap_e, self.cap_i, 1, self.max_free, huber[0], huber[1])
+        self._work = None
+
+    def _stream(self):
+        a = self.d["points"]
+        if isinstance(a, np.ndarray):
+            return None
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+
+    def optimize(self, lambda_init, iterations):
+        """optimizer.optimize(iterations); key frames / points updated in place on the device.  -> stats [B, 5] (device array)."""
+        if self._work is None:
+            nbytes = self._L.liba_workspace_bytes(C.byref(self.prob), self.B)
+            self._work = self._to_dev(np.zeros(nbytes, np.uint8))
+        stats = self._to_dev(np.zeros((self.B, 5)))
+        rc = self._L.liba_optimize(C.byref(self.prob), self.B, float(lambda_init), int(iterations), _ptr(self._work), _ptr(stats), self._stream())
+        if rc != 0:
+            raise OrbHipError(rc, "liba_optimize failed")
+        return stats
+
+    def compute_errors(self):
+        vchi = self._to_dev(np.zeros((self.B, self.cap_e))); vdp = self._to_dev(np.zeros((self.B, self.cap_e), np.uint8))
+        ichi = self._to_dev(np.zeros((self.B, self.cap_i, 3))); rs = self._to_dev(np.zeros(self.B))
+        rc = self._L.liba_compute_errors(C.byref(self.prob), self.B, _ptr(vchi), _ptr(vdp), _ptr(ichi), _ptr(rs), self._stream())
+        if rc != 0:
+            raise OrbHipError(rc, "liba_compute_errors failed")
+        return {"vis_chi2": vchi, "vis_depth_pos": vdp, "imu_chi2": ichi, "robust_chi2_sum": rs}
+
+    def keyframes(self):
+        a = self.d["kfs"]
+        a = a if isinstance(a, np.ndarray) else a.cpu().numpy()
+        return a.reshape(self.B, -1).view(KF_DTYPE).reshape(self.B, self.cap_kf)
+
+    def points(self):
+        a = self.d["points"]
+        return a if isinstance(a, np.ndarray) else a.cpu().numpy()

@@ -423,6 +423,63 @@ int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int3
                   const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
                   void* stream);
 
+/* SURVEY.md N4 (tail) — Optimizer::LocalInertialBA (reference src/Optimizer.cc:4753-5365): the visual-inertial local BA of the
+ * inertial modes.  Graph (include/G2oTypes.h, src/G2oTypes.cc): VertexPose (ImuCamPose, 6 dof, body-frame right perturbation
+ * G2oTypes.cc:196-221), VertexVelocity / VertexGyroBias / VertexAccBias (3 dof each, additive), VertexSBAPointXYZ (marginalised);
+ * EdgeInertial (9-dim, six vertices, G2oTypes.cc:706-800), EdgeGyroRW / EdgeAccRW (G2oTypes.h:633-700), EdgeMono / EdgeStereo
+ * (G2oTypes.h:337-437, G2oTypes.cc:352-418; pinhole or KannalaBrandt8, camera index 0/1 of the rig).  Solver: g2o Levenberg-Marquardt
+ * with setUserLambdaInit (Optimizer.cc:4884-4896), Schur complement of the landmarks, dense Cholesky of the reduced system.
+ * One workgroup runs the whole optimize(iterations) of one window in a single launch; windows are batched. */
+typedef struct liba_keyframe {      /* ImuCamPose + the V / G / A vertex estimates of one key frame; row-major 3x3 */
+    double Rwb[9], twb[3];          /* body pose (pKF->GetImuRotation / GetImuPosition) */
+    double Rcw[2][9], tcw[2][3];    /* per camera, as the ImuCamPose constructor sets them (G2oTypes.cc:43-66); rewritten by every update */
+    double v[3], bg[3], ba[3];      /* VertexVelocity, VertexGyroBias, VertexAccBias estimates */
+    int32_t pose_fixed;             /* VP->setFixed */
+    int32_t has_imu;                /* V / G / A vertices exist (pKFi->bImu) */
+    int32_t imu_fixed;              /* V / G / A fixed (the key frame just before the temporal window) */
+    int32_t reserved;
+} liba_keyframe;                    /* 376 bytes; key frames in ascending mnId order (= g2o's Hessian block order) */
+typedef struct liba_rig {           /* calibration members of ImuCamPose (G2oTypes.h:60-72) */
+    int32_t n_cams, reserved;
+    double Rcb[2][9], tcb[2][3], Rbc[2][9], tbc[2][3];
+    double bf;
+    int32_t model[2];               /* LBA_CAM_PINHOLE / LBA_CAM_KB8 */
+    double p[2][8];                 /* mvParameters widened */
+} liba_rig;
+typedef struct liba_imu_edge {      /* one IMU::Preintegrated between consecutive key frames: EdgeInertial + EdgeGyroRW + EdgeAccRW */
+    int32_t kf1, kf2;               /* previous / current key frame (indices into the window's key frames) */
+    float dR[9], dV[3], dP[3];      /* Preintegrated::dR, dV, dP (CV_32F) */
+    float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9];
+    float b[6];                     /* Preintegrated::b = bax bay baz bwx bwy bwz (the bias the measurements were integrated with) */
+    float dT, pad;
+    double huber;                   /* 0 = no robust kernel; sqrt(16.92) for i == N-1 or bRecInit (Optimizer.cc:5005-5012) */
+    double info[81];                /* EdgeInertial::information() as the reference leaves it (constructor clean-up, x1e-2 for i == N-1) */
+    double info_g[9], info_a[9];    /* EdgeGyroRW / EdgeAccRW information (Optimizer.cc:5024-5043) */
+} liba_imu_edge;                    /* 1080 bytes */
+#define LIBA_MAX_FREE 32            /* optimisable key frames per window (maxOpt is 10, or 25 for bLarge: Optimizer.cc:4758-4764) */
+typedef struct liba_problem {
+    liba_keyframe* kfs;             /* [batch][cap_kf]  UPDATED IN PLACE */
+    const int32_t* n_kf;            /* [batch] */
+    const liba_rig* rigs;           /* window b uses rigs[b * rig_stride] (rig_stride 0 = one shared rig) */
+    double* points;                 /* [batch][cap_l][3]  UPDATED IN PLACE */
+    const int32_t* n_points;        /* [batch] */
+    const lba_edge* edges;          /* [batch][cap_e]  landmark-major; pose = key-frame index, kind = LBA_EDGE_MONO / LBA_EDGE_STEREO, cam = camera of the rig */
+    const int32_t* n_edges;         /* [batch] */
+    const liba_imu_edge* imu;       /* [batch][cap_i]  in the reference's insertion order (newest first) */
+    const int32_t* n_imu;           /* [batch] */
+    int32_t cap_kf, cap_l, cap_e, cap_i, rig_stride;
+    int32_t max_free;               /* upper bound of optimisable key frames in any window (<= LIBA_MAX_FREE): sizes the reduced system */
+    double huber_mono, huber_stereo;   /* thHuberMono / thHuberStereo (Optimizer.cc:5071-5073) */
+} liba_problem;
+size_t liba_workspace_bytes(const liba_problem* prob, int batch);
+/* optimizer.optimize(iterations) (Optimizer.cc:5225).  d_stats: [batch][5] device doubles = {iterations run (-1: invalid window), final
+ * activeRobustChi2 (err_end), final lambda, lambda trials, initial activeRobustChi2 (err)}.  Asynchronous on `stream`. */
+int liba_optimize(const liba_problem* prob, int batch, double lambda_init, int iterations, void* d_workspace, double* d_stats, void* stream);
+/* computeActiveErrors: per visual edge chi2 and isDepthPositive (the outlier pass of Optimizer.cc:5237-5275 reads both), per preintegration
+ * {EdgeInertial, EdgeGyroRW, EdgeAccRW} chi2, and activeRobustChi2 per window.  Any output may be NULL. */
+int liba_compute_errors(const liba_problem* prob, int batch, double* d_vis_chi2, uint8_t* d_vis_depth_pos, double* d_imu_chi2,
+                        double* d_robust_sum, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device-memory helpers so that adapters written against this header need no HIP headers.
  * ------------------------------------------------------------------------------------------------------- */

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "orbhip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:orbx|orbm|orbf|lba|orb|pose|bow)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:orbx|orbm|orbf|lba|liba|orb|pose|bow)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_declares_entry_points():
