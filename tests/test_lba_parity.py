@@ -130,7 +130,7 @@ def test_hip_lba_c5_size_window(hip_lib):
 
 
 # ---- the LM loop (Schur complement + Cholesky + rho test) ------------------------------------------------------------
-def check_optimize(lib, backend, kinds, iterations, huber=HUBER):
+def check_optimize(lib, backend, kinds, iterations, huber=HUBER, pose_tol=1e-7):
     ws, cams = [], None
     for i, kind in enumerate(kinds):
         w, cams = window(kind, seed=10 + i, n_kf=10 + i, n_pts=200 + 31 * i)
@@ -144,8 +144,8 @@ def check_optimize(lib, backend, kinds, iterations, huber=HUBER):
         assert stats[b, 0] == ost[0] and stats[b, 3] == ost[3], (stats[b], ost)          # same iterations / lambda trials
         assert abs(stats[b, 1] - ost[1]) < 1e-6 * ost[1]
         # north_star bar: 1e-4 on BA poses; double arithmetic in both, different summation orders
-        assert np.abs(poses[b, :npz] - op).max() < 1e-7, np.abs(poses[b, :npz] - op).max()
-        assert np.abs(points[b, :nl] - ox).max() < 1e-6
+        assert np.abs(poses[b, :npz] - op).max() < pose_tol, np.abs(poses[b, :npz] - op).max()
+        assert np.abs(points[b, :nl] - ox).max() < 10 * pose_tol
         assert ost[1] < 0.9 * O.lba_build_system(w, cams, huber)["robust_chi2_sum"][0]                                # it really optimised
         assert np.abs(poses[b, :npz][w["pose_hidx"] < 0] - w["poses"][w["pose_hidx"] < 0]).max() == 0    # fixed KFs untouched
 
@@ -180,4 +180,6 @@ def test_emu_global_ba_parameterisation(emu_lib):
 
 @pytest.mark.gpu
 def test_hip_global_ba_parameterisation(hip_lib):
-    check_optimize(hip_lib, "hip", ("mono", "stereo", "body"), 10, huber=(0.0, 0.0))
+    # without the Huber kernel the 5 % gross outliers of the synthetic windows pull hard: 10 iterations amplify the summation-order
+    # difference to ~2e-7 (measured 1.8e-7 on MI355X); the bar is 1e-4
+    check_optimize(hip_lib, "hip", ("mono", "stereo", "body"), 10, huber=(0.0, 0.0), pose_tol=1e-6)
