@@ -315,6 +315,36 @@ def main():
                 for b in range(16):
                     O.pose_optimize(pf["poses"][b], pf["edges"][b, :pf["n_edges"][b]], pf["cameras"])
                 extra["pose_optimization"]["cpu_port_frames_per_s_1core"] = round(16 / (time.perf_counter() - tc), 1)
+            # ---- extra leg 3b (SURVEY N4 tail): Optimizer::LocalInertialBA windows, one workgroup per window, optimize(10) in a single launch
+            try:
+                from orbhip.inertial import InertialWindows, synth_inertial_window
+                iw = [synth_inertial_window(60 + i + 10 * rank, n_opt=10, n_fixed_vis=6, n_pts=1200, max_obs=8, kind="stereo") for i in range(2)]
+                IB = 512
+                td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                IWn = InertialWindows([iw[i % 2] for i in range(IB)], td)
+                kf0, pt0 = IWn.d["kfs"].clone(), IWn.d["points"].clone()
+                IWn.optimize(1.0, 10)
+                barrier()
+                t4b = time.perf_counter()
+                for _ in range(2):
+                    IWn.d["kfs"].copy_(kf0); IWn.d["points"].copy_(pt0)
+                    ist = IWn.optimize(1.0, 10)
+                barrier()
+                dti = (time.perf_counter() - t4b) / 2
+                ist = ist.cpu().numpy()
+                extra["inertial_ba"] = {"windows_per_s": round(IB / dti, 1), "lm_iterations_per_s": round(float(ist[:, 0].sum()) / dti, 1),
+                                        "ms_per_batch": round(dti * 1e3, 3), "windows_per_batch": IB, "edges_per_window": float(np.mean([len(w["edges"]) for w in iw])),
+                                        "opt_keyframes": 10, "points_per_window": 1200, "chi2_drop": float((ist[:, 1] / ist[:, 4]).mean()),
+                                        "what": "Optimizer::LocalInertialBA optimize(10): EdgeInertial/GyroRW/AccRW + EdgeMono/EdgeStereo, LM + Schur + Cholesky"}
+                if world == 1 and not args.no_cpu_baseline:
+                    import oracle_lib as O
+                    from orbhip.lba import HUBER_MONO, HUBER_STEREO
+                    tc = time.perf_counter()
+                    _, _, ost = O.inertial_optimize(iw[0], (HUBER_MONO, HUBER_STEREO), 1.0, 10)
+                    extra["inertial_ba"]["cpu_port_windows_per_s_1core"] = round(1.0 / (time.perf_counter() - tc), 2)
+            except Exception as err:   # noqa: BLE001
+                extra["inertial_ba_error"] = "%s: %s" % (type(err).__name__, err)
+                sys.stderr.write(traceback.format_exc())
             # ---- extra leg 4 (SURVEY N2 + M6, BASELINE configs[2] shape): Frame::ComputeBoW on a k=10, L=6 vocabulary (the stock ORBvoc shape,
             #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
             from orbhip.bow import ORBVocabulary, synth_vocabulary_fast

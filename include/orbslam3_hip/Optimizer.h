@@ -195,5 +195,82 @@ private:
     detail::DevBuf e_, c_, p_, n_, o_, f_, g_;
 };
 
+// Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, bool bLarge, bool bRecInit) (reference include/Optimizer.h:97, src/Optimizer.cc:4753-5365)
+// over liba_optimize().  The caller keeps the reference's graph-building walk and calls, in the same order:
+//   setRig(...)                    once (ImuCamPose calibration members, G2oTypes.cc:43-66)
+//   addKeyFrame(...)               in ascending mnId order: VertexPose (+ VertexVelocity / GyroBias / AccBias when bImu), Optimizer.cc:4899-4960
+//   addInertial(...)               per preintegration, newest first (Optimizer.cc:4964-5062); `info` = EdgeInertial::information() as built by the
+//                                  reference's constructor (G2oTypes.cc:706-725) and scaled at :5009, infoG / infoA = Optimizer.cc:5024-5043
+//   addPoint / addMono / addStereo per map point and observation (Optimizer.cc:5078-5215); observations of one point are contiguous
+//   optimize(lambdaInit, its)      lambdaInit = 1e-2 (bLarge) / 1e0, its = opt_it (Optimizer.cc:4884-4896, :5225)
+// and then reads keyFrame(i) / point(i) / visualChi2 / depthPositive for the outlier pass and the write-back (Optimizer.cc:5237-5360).
+class InertialBA {
+public:
+    void setRig(const liba_rig& rig) { rig_ = rig; }
+    // Rwb / twb: pKF->GetImuRotation / GetImuPosition; Rcw / tcw of camera 0: pKF->GetRotation / GetTranslation (row-major doubles widened from
+    // the float cv::Mat); camera 1 (if any) is derived like G2oTypes.cc:55-63 by the caller and passed in Rcw1 / tcw1 (may be null)
+    int addKeyFrame(const double Rwb[9], const double twb[3], const double Rcw0[9], const double tcw0[3], const double* Rcw1, const double* tcw1,
+                    const double v[3], const double bg[3], const double ba[3], bool poseFixed, bool hasImu, bool imuFixed) {
+        liba_keyframe k{};
+        for (int i = 0; i < 9; i++) { k.Rwb[i] = Rwb[i]; k.Rcw[0][i] = Rcw0[i]; if (Rcw1) k.Rcw[1][i] = Rcw1[i]; }
+        for (int i = 0; i < 3; i++) { k.twb[i] = twb[i]; k.tcw[0][i] = tcw0[i]; if (tcw1) k.tcw[1][i] = tcw1[i]; k.v[i] = v ? v[i] : 0; k.bg[i] = bg ? bg[i] : 0; k.ba[i] = ba ? ba[i] : 0; }
+        k.pose_fixed = poseFixed; k.has_imu = hasImu; k.imu_fixed = imuFixed;
+        kfs_.push_back(k);
+        return (int)kfs_.size() - 1;
+    }
+    void addInertial(const liba_imu_edge& e) { imu_.push_back(e); }
+    int addPoint(const float Xw[3]) { pts_.push_back(Xw[0]); pts_.push_back(Xw[1]); pts_.push_back(Xw[2]); return (int)pts_.size() / 3 - 1; }
+    void addMono(int kf, int point, float u, float v, float invSigma2, int camIdx = 0) { edges_.push_back(lba_edge{kf, point, LBA_EDGE_MONO, (int16_t)camIdx, {u, v, 0.f}, invSigma2}); }
+    void addStereo(int kf, int point, float u, float v, float uR, float invSigma2) { edges_.push_back(lba_edge{kf, point, LBA_EDGE_STEREO, 0, {u, v, uR}, invSigma2}); }
+
+    // returns the iterations run (-1: the window was rejected: unsorted edges, > LIBA_MAX_FREE optimisable key frames, bad indices)
+    int optimize(double lambdaInit, int iterations, double* err = nullptr, double* errEnd = nullptr) {
+        const int nk = (int)kfs_.size(), nl = (int)pts_.size() / 3, ne = (int)edges_.size(), ni = (int)imu_.size();
+        if (!nk || !nl || !ne) return 0;
+        int nfree = 0;
+        for (auto& k : kfs_) nfree += !k.pose_fixed;
+        if (nfree == 0 || nfree > LIBA_MAX_FREE) return -1;
+        liba_problem P{};
+        P.kfs = dk_.upload(kfs_.data(), nk); P.points = dp_.upload(pts_.data(), pts_.size()); P.edges = de_.upload(edges_.data(), ne);
+        P.imu = di_.upload(imu_.data(), ni ? ni : 0); P.rigs = dr_.upload(&rig_, 1);
+        const int32_t n4[4] = {nk, nl, ne, ni};
+        const int32_t* dn = dn_.upload(n4, 4);
+        P.n_kf = dn; P.n_points = dn + 1; P.n_edges = dn + 2; P.n_imu = dn + 3;
+        P.cap_kf = nk; P.cap_l = nl; P.cap_e = ne; P.cap_i = ni > 0 ? ni : 1; P.rig_stride = 0; P.max_free = nfree;
+        P.huber_mono = (double)std::sqrt(5.991f); P.huber_stereo = (double)std::sqrt(7.815f);   // const float thHuberMono = sqrt(5.991) (Optimizer.cc:5071)
+        void* work = dw_.ensure(liba_workspace_bytes(&P, 1));
+        double* dst = (double*)ds_.ensure(5 * 8 + (size_t)ne * 9 + 64);
+        uint8_t* ddp = (uint8_t*)(dst + 5 + ne);
+        if (liba_optimize(&P, 1, lambdaInit, iterations, work, dst, nullptr) != ORB_OK) throw std::runtime_error("liba_optimize");
+        if (liba_compute_errors(&P, 1, dst + 5, ddp, nullptr, nullptr, nullptr) != ORB_OK) throw std::runtime_error("liba_compute_errors");
+        double st[5];
+        chi2_.resize(ne); depth_.resize(ne);
+        orb_memcpy_d2h(st, dst, sizeof(st), nullptr);
+        orb_memcpy_d2h(chi2_.data(), dst + 5, (size_t)ne * 8, nullptr);
+        orb_memcpy_d2h(depth_.data(), ddp, (size_t)ne, nullptr);
+        orb_memcpy_d2h(kfs_.data(), P.kfs, (size_t)nk * sizeof(liba_keyframe), nullptr);
+        orb_memcpy_d2h(pts_.data(), P.points, pts_.size() * 8, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        if (err) *err = st[4];
+        if (errEnd) *errEnd = st[1];
+        return (int)st[0];
+    }
+    const liba_keyframe& keyFrame(int i) const { return kfs_[i]; }
+    const double* point(int i) const { return &pts_[(size_t)i * 3]; }
+    double visualChi2(int edge) const { return chi2_[edge]; }          // e->chi2() after the optimisation (Optimizer.cc:5247,5264)
+    bool depthPositive(int edge) const { return depth_[edge] != 0; }   // e->isDepthPositive()
+
+private:
+    liba_rig rig_{};
+    std::vector<liba_keyframe> kfs_;
+    std::vector<double> pts_;
+    std::vector<lba_edge> edges_;
+    std::vector<liba_imu_edge> imu_;
+    std::vector<double> chi2_;
+    std::vector<uint8_t> depth_;
+    detail::DevBuf dk_, dp_, de_, di_, dr_, dn_, dw_, ds_;
+};
+
+
 }  // namespace orbslam3_hip
 #endif

@@ -36,6 +36,7 @@ int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_
 void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
 void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
+void oib_optimize(void*, int, const void*, double*, int, const void*, int, const void*, int, double, double, double, int, double*);
 int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
@@ -318,6 +319,75 @@ int main() {
         FO.ComputeStereoFromRGBD(ks, un, depth.data(), 752, 40.0f, ur, dz);
         ofr_stereo_from_rgbd(ks.data(), oun.data(), 500, depth.data(), 752, 40.0f, our.data(), odz.data());
         CHECK(std::memcmp(ur.data(), our.data(), 500 * 4) == 0 && std::memcmp(dz.data(), odz.data(), 500 * 4) == 0);
+    }
+    // ---- N4 tail: Optimizer::LocalInertialBA through InertialBA vs the oracle
+    {
+        orbslam3_hip::InertialBA IB;
+        liba_rig rig{};
+        rig.n_cams = 1; rig.bf = 47.906;
+        const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int i = 0; i < 9; i++) { rig.Rcb[0][i] = I9[i]; rig.Rbc[0][i] = I9[i]; }
+        rig.tcb[0][0] = 0.05; rig.tbc[0][0] = -0.05;
+        rig.model[0] = LBA_CAM_PINHOLE;
+        const double fxd = 458.654, fyd = 457.296, cxd = 367.215, cyd = 248.375;
+        rig.p[0][0] = fxd; rig.p[0][1] = fyd; rig.p[0][2] = cxd; rig.p[0][3] = cyd;
+        IB.setRig(rig);
+        const int NK = 6;
+        const double dtk = 0.3;
+        auto nz = [&](double s) { return s * ((int)(rnd() % 2001) - 1000) / 1000.0; };
+        std::vector<liba_keyframe> okf;
+        for (int k = 0; k < NK; k++) {
+            const bool fixed = k == 0;
+            double twb[3] = {0.3 * k + (fixed ? 0 : nz(0.02)), fixed ? 0 : nz(0.02), fixed ? 0 : nz(0.02)};
+            double v[3] = {1.0 + (fixed ? 0 : nz(0.05)), fixed ? 0 : nz(0.05), fixed ? 0 : nz(0.05)};
+            double bg[3] = {nz(0.001), nz(0.001), nz(0.001)}, ba[3] = {nz(0.01), nz(0.01), nz(0.01)};
+            double tcw[3] = {-twb[0] + rig.tcb[0][0], -twb[1], -twb[2]};   // Rcw = Rcb * Rbw = I; tcw = Rcb * (-Rbw twb) + tcb
+            IB.addKeyFrame(I9, twb, I9, tcw, nullptr, nullptr, v, bg, ba, fixed, true, fixed);
+            okf.push_back(IB.keyFrame(k));
+        }
+        std::vector<liba_imu_edge> oimu;
+        for (int i = 0; i < NK - 1; i++) {     // newest first
+            liba_imu_edge e{};
+            e.kf2 = NK - 1 - i; e.kf1 = e.kf2 - 1;
+            e.dT = (float)dtk;
+            for (int q = 0; q < 9; q++) { e.dR[q] = (float)I9[q]; e.JRg[q] = (float)(-dtk * I9[q]); e.JVa[q] = (float)(-dtk * I9[q]); e.JPa[q] = (float)(-0.5 * dtk * dtk * I9[q]); }
+            e.dV[2] = (float)(9.81 * dtk); e.dP[2] = (float)(0.5 * 9.81 * dtk * dtk);      // exact deltas of the constant-velocity truth
+            for (int q = 0; q < 9; q++) { e.info[q * 10] = q < 3 ? 3e4 : (q < 6 ? 2e3 : 8e3); }
+            for (int q = 0; q < 3; q++) { e.info_g[q * 4] = 4e5; e.info_a[q * 4] = 2e3; }
+            if (i == NK - 2) { e.huber = std::sqrt(16.92); for (int q = 0; q < 81; q++) e.info[q] *= 1e-2; }
+            IB.addInertial(e);
+            oimu.push_back(e);
+        }
+        std::vector<double> opts;
+        std::vector<lba_edge> oedges;
+        for (int l = 0; l < 80; l++) {
+            const float X[3] = {(float)(0.75 + nz(3.0)), (float)nz(2.0), (float)(6.0 + nz(2.0))};
+            const int pi = IB.addPoint(X);
+            for (int c = 0; c < 3; c++) opts.push_back((double)X[c]);
+            for (int k = 0; k < NK; k++) {
+                const double xc = X[0] - 0.3 * k + 0.05, yc = X[1], zc = X[2];   // truth: twb = (0.3k, 0, 0)
+                const float u = (float)(fxd * xc / zc + cxd + nz(0.7)), v = (float)(fyd * yc / zc + cyd + nz(0.7));
+                if (u < 0 || u >= 752 || v < 0 || v >= 480) continue;
+                if (l % 2) { IB.addStereo(k, pi, u, v, (float)(u - 47.906 / zc), 1.0f); oedges.push_back(lba_edge{k, pi, LBA_EDGE_STEREO, 0, {u, v, (float)(u - 47.906 / zc)}, 1.0f}); }
+                else { IB.addMono(k, pi, u, v, 1.0f); oedges.push_back(lba_edge{k, pi, LBA_EDGE_MONO, 0, {u, v, 0.f}, 1.0f}); }
+            }
+        }
+        double ostats[5], err = 0, errEnd = 0;
+        oib_optimize(okf.data(), NK, &rig, opts.data(), 80, oedges.data(), (int)oedges.size(), oimu.data(), (int)oimu.size(), (double)std::sqrt(5.991f),
+                     (double)std::sqrt(7.815f), 1.0, 10, ostats);
+        const int its2 = IB.optimize(1.0, 10, &err, &errEnd);
+        CHECK(its2 == (int)ostats[0] && its2 >= 3);
+        CHECK(std::fabs(err - ostats[4]) < 1e-9 * ostats[4] && std::fabs(errEnd - ostats[1]) < 1e-6 * ostats[1] && errEnd < 0.5 * err);
+        for (int k = 0; k < NK; k++)
+            for (int c = 0; c < 3; c++) {
+                CHECK(std::fabs(IB.keyFrame(k).twb[c] - okf[k].twb[c]) < 1e-6 && std::fabs(IB.keyFrame(k).v[c] - okf[k].v[c]) < 1e-6);
+                CHECK(std::fabs(IB.keyFrame(k).bg[c] - okf[k].bg[c]) < 1e-6 && std::fabs(IB.keyFrame(k).ba[c] - okf[k].ba[c]) < 1e-6);
+            }
+        CHECK(std::fabs(IB.keyFrame(0).twb[0]) == 0.0 && std::fabs(IB.keyFrame(3).twb[0] - 0.9) < 0.02);   // fixed KF untouched, others pulled to the truth
+        for (int l = 0; l < 80; l++) for (int c = 0; c < 3; c++) CHECK(std::fabs(IB.point(l)[c] - opts[(size_t)l * 3 + c]) < 1e-5);
+        int nout = 0;
+        for (size_t e = 0; e < oedges.size(); e++) { CHECK(IB.depthPositive((int)e)); nout += IB.visualChi2((int)e) > 5.991; }
+        CHECK(nout < (int)oedges.size() / 10);
     }
     std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;

@@ -127,3 +127,20 @@ def test_emu_inertial_ba_matches_oracle(emu_lib, kinds, lam, its):
 @pytest.mark.parametrize("kinds,lam,its", [(("mono", "stereo", "mono"), 1.0, 10), (("fisheye", "stereo"), 1e-2, 4)], ids=["mono+stereo", "fisheye"])
 def test_hip_inertial_ba_matches_oracle(hip_lib, kinds, lam, its):
     check_inertial(hip_lib, "hip", kinds, lam, its)
+
+
+@pytest.mark.gpu
+def test_hip_inertial_ba_is_deterministic_and_rejects_bad_windows(hip_lib):
+    ws = [window("stereo", seed=31, n_opt=10, n_pts=600, max_obs=8), window("mono", seed=32, n_opt=5, n_pts=300)]
+    runs = []
+    for _ in range(2):
+        IW = InertialWindows(ws, to_dev("hip"), lib=hip_lib, huber=HUBER)
+        st = to_host(IW.optimize(1.0, 6))
+        runs.append((st.copy(), IW.keyframes().copy(), IW.points().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    # unsorted (not landmark-major) edges -> the window is refused (stats[0] = -1) and nothing is touched
+    bad = dict(ws[1]); bad["edges"] = ws[1]["edges"][::-1].copy()
+    IW = InertialWindows([ws[0], bad], to_dev("hip"), lib=hip_lib, huber=HUBER)
+    st = to_host(IW.optimize(1.0, 3))
+    assert st[0, 0] >= 1 and st[1, 0] == -1
+    assert np.array_equal(IW.keyframes()[1, :len(bad["kfs"])], bad["kfs"])
