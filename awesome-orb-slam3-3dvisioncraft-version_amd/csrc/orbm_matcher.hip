@@ -1057,3 +1057,26 @@ extern "C" int orbm_search_for_triangulation(const orbm_tri_side* kf1, const orb
     hipLaunchKernelGGL(k_tri, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
     return launch_status();
 }
+
+// ---- SearchBySim3's agreement pass (ORBmatcher.cc:2203-2219): vpMatches12[i1] = idx2 iff vnMatch1[i1] == idx2 and vnMatch2[idx2] == i1
+static __global__ __launch_bounds__(256) void k_mutual(const int32_t* m12, const int32_t* m21, const int32_t* n1p, const int32_t* n2p, const int cap1,
+                                                        const int cap2, int32_t* out12, int32_t* nfound) {
+    const int b = blockIdx.y, i1 = blockIdx.x * 256 + threadIdx.x;
+    const int n1 = min(n1p[b], cap1), n2 = min(n2p[b], cap2);
+    bool ok = false;
+    if (i1 < cap1) {
+        int idx2 = -1;
+        if (i1 < n1) { idx2 = m12[(size_t)b * cap1 + i1]; ok = idx2 >= 0 && idx2 < n2 && m21[(size_t)b * cap2 + idx2] == i1; }
+        out12[(size_t)b * cap1 + i1] = ok ? idx2 : -1;
+    }
+    const int c = __popcll(__ballot(ok));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&nfound[b], c);
+}
+extern "C" int orbm_mutual_matches(const int32_t* d_match12, const int32_t* d_match21, const int32_t* d_n1, const int32_t* d_n2, int cap1, int cap2,
+                                   int batch, int32_t* d_out12, int32_t* d_nfound, void* stream) {
+    if (!d_match12 || !d_match21 || !d_n1 || !d_n2 || !d_out12 || !d_nfound || cap1 <= 0 || cap2 <= 0 || batch < 0) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    if (hipMemsetAsync(d_nfound, 0, (size_t)batch * 4, (hipStream_t)stream) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_mutual, dim3((cap1 + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_match12, d_match21, d_n1, d_n2, cap1, cap2, d_out12, d_nfound);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}

@@ -89,6 +89,7 @@ def bind(lib):
                                                 vp, vp, vp, vp, vp]),
         "orbm_fuse": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(FuseParams), vp, vp, vp, vp]),
         "orbm_search_for_triangulation": (i32, [C.POINTER(TriSide), C.POINTER(TriSide), vp, i32, i32, i32, i32, vp, vp, vp]),
+        "orbm_mutual_matches": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)
@@ -232,6 +233,20 @@ class ORBmatcher:
                                       _ptr(queries), _ptr(qdesc), _ptr(nq), cap_q, B, C.byref(prm), _ptr(q_match), _ptr(q_dist), _ptr(nfused),
                                       _stream(kps)))
         return q_match, q_dist, nfused
+
+    # -- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:2008-2220)
+    def SearchBySim3(self, kf1, kf2, q12, q12desc, q21, q21desc):
+        """kf1 / kf2: dict(kps [B,cap,7], desc, counts [B], grid_start, grid_idx, grid).  q12[b][i1] = map point of key frame 1's keypoint i1
+        projected into key frame 2 (VALID iff it exists, is not already matched and passed the gates of :2044-2080); q21 likewise the other
+        way.  One query slot per keypoint (cap_q = cap_k).  -> (vpMatches12 as indices into key frame 2 or -1 [B,cap1], nFound [B])"""
+        n1, n2 = kf1["counts"], kf2["counts"]
+        m12, _, _ = self.Fuse(kf2["kps"], kf2["desc"], n2, kf2["grid_start"], kf2["grid_idx"], q12, q12desc, n1, kf2["grid"], th_dist=TH_HIGH)
+        m21, _, _ = self.Fuse(kf1["kps"], kf1["desc"], n1, kf1["grid_start"], kf1["grid_idx"], q21, q21desc, n2, kf1["grid"], th_dist=TH_HIGH)
+        B, cap1, cap2 = m12.shape[0], m12.shape[1], m21.shape[1]
+        out = _like(m12, (B, cap1), np.int32)
+        nfound = _like(m12, (B,), np.int32)
+        self._check(self._L.orbm_mutual_matches(_ptr(m12), _ptr(m21), _ptr(n1), _ptr(n2), cap1, cap2, B, _ptr(out), _ptr(nfound), _stream(m12)))
+        return out, nfound
 
     # -- SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:1138-1428), pinhole / one camera
     def SearchForTriangulation(self, kf1, kf2, pairs, bOnlyStereo=False, bCoarse=False):

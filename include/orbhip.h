@@ -213,6 +213,12 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
                               const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
                               void* d_work, void* stream);
 
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:2008-2220) = orbm_fuse in both directions (each map point
+ * keeps its own best candidate in [L-1, L] with bestDist <= TH_HIGH and no chi2 gate: vnMatch1 / vnMatch2, :2044-2119 and :2122-2201) followed by
+ * this agreement pass (:2203-2219): out12[b][i1] = idx2 iff match12[b][i1] == idx2 and match21[b][idx2] == i1, else -1; nfound[b] = the return value. */
+int orbm_mutual_matches(const int32_t* d_match12, const int32_t* d_match21, const int32_t* d_n1, const int32_t* d_n2, int cap1, int cap2,
+                        int batch, int32_t* d_out12, int32_t* d_nfound, void* stream);
+
 /* Fisheye-rig (F.Nleft != -1) variants.  Keypoints / descriptors are the concatenation [mvKeys | mvKeysRight] like the reference's
  * N-sized arrays; d_nleft[b] = Nleft.  The grid has 2 x 64 x 48 cells per frame (second half = mGridRight, entries are global indices):
  * grid_start [batch][2*64*48+1].  d_kp_link[b][i] = global index of keypoint i's stereo partner (mvLeftToRightMatch[i] + Nleft, or

@@ -165,6 +165,49 @@ public:
         return nFused;
     }
 
+    // ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.h:79, ORBmatcher.cc:2008-2220).  q12[i1] = the values the
+    // reference computes for key frame 1's map point i1 before pKF2->GetFeaturesInArea (:2044-2080: VALID iff it exists, is not in vpMatches12
+    // already, is not bad and passed the depth / image / distance gates; u, v, radius = th*mvScaleFactors[nPredictedLevel], max_level =
+    // nPredictedLevel), q21[i2] likewise for key frame 2 (:2122-2158); the descriptors are pMP->GetDescriptor().  matches12[i1] = index into key
+    // frame 2 of the agreed match or -1 (the caller sets vpMatches12[i1] = vpMapPoints2[idx2]); returns nFound.
+    int SearchBySim3(const FrameView& KF1, const FrameView& KF2, const std::vector<orbm_query>& q12, const std::vector<uint8_t>& q12desc,
+                     const std::vector<orbm_query>& q21, const std::vector<uint8_t>& q21desc, std::vector<int>& matches12) {
+        const int n1 = KF1.N, n2 = KF2.N;
+        matches12.assign(n1, -1);
+        if (n1 == 0 || n2 == 0 || (int)q12.size() != n1 || (int)q21.size() != n2) return 0;
+        const int32_t counts[2] = {n1, n2};
+        const int32_t* dc = cnt_.upload(counts, 2);
+        int32_t* vn1 = (int32_t*)qm_.ensure((size_t)n1 * 4);
+        int32_t* vn2 = (int32_t*)km_.ensure((size_t)n2 * 4);
+        int32_t* dist = (int32_t*)work_.ensure((size_t)std::max(n1, n2) * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(8);
+        orbm_fuse_params prm{};
+        prm.th_dist = TH_HIGH; prm.chi2_gate = 0;
+        for (int dir = 0; dir < 2; dir++) {      // dir 0: key frame 1's points searched in key frame 2
+            const FrameView& T = dir == 0 ? KF2 : KF1;
+            const std::vector<orbm_query>& q = dir == 0 ? q12 : q21;
+            const std::vector<uint8_t>& qd = dir == 0 ? q12desc : q21desc;
+            const orb_keypoint* dk = kps_.upload(T.keysUn, T.N);
+            const uint8_t* dd = desc_.upload(T.descriptors, (size_t)T.N * 32);
+            const orbm_query* dq = q_.upload(q.data(), q.size());
+            const uint8_t* dqd = qd_.upload(qd.data(), qd.size());
+            int32_t* gs = (int32_t*)gs_.ensure((ORBM_GRID_COLS * ORBM_GRID_ROWS + 1) * 4);
+            int32_t* gi = (int32_t*)gi_.ensure((size_t)T.N * 4);
+            prm.grid = T.grid;
+            if (orbm_grid_build(dk, dc + (dir == 0 ? 1 : 0), 1, T.N, 1, &T.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build");
+            if (orbm_fuse(dk, dd, nullptr, dc + (dir == 0 ? 1 : 0), 1, T.N, gs, gi, dq, dqd, dc + (dir == 0 ? 0 : 1), (int)q.size(), 1, &prm,
+                          dir == 0 ? vn1 : vn2, dist, dnm, nullptr) != ORB_OK) throw std::runtime_error("orbm_fuse");
+            if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");   // the upload buffers are reused by the second direction
+        }
+        int32_t* out = (int32_t*)ur_.ensure((size_t)n1 * 4);
+        if (orbm_mutual_matches(vn1, vn2, dc, dc + 1, n1, n2, 1, out, dnm + 1, nullptr) != ORB_OK) throw std::runtime_error("orbm_mutual_matches");
+        int nFound = 0;
+        orb_memcpy_d2h(matches12.data(), out, (size_t)n1 * 4, nullptr);
+        orb_memcpy_d2h(&nFound, dnm + 1, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        return nFound;
+    }
+
     // One key frame as SearchForTriangulation reads it: mvKeysUn, mDescriptors, mvuRight, GetMapPoint(i) != NULL, and mFeatVec as CSR
     // (node ids ascending = std::map order; featIdx = the concatenated per-node index vectors).
     struct KeyFrameView {

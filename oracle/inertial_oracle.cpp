@@ -431,7 +431,7 @@ void oib_optimize(void* kfs_, int n_kf, const void* rig_, double* points, int n_
                   double huberMono, double huberStereo, double lambda_init, int iterations, double* stats) {
     Problem P{(Kf*)kfs_, n_kf, (const Rig*)rig_, points, n_points, (const VisEdge*)vis_, n_vis, (const ImuEdge*)imu_, n_imu, huberMono, huberStereo};
     P.index();
-    const int DR = P.DR, np6 = P.np6;
+    const int DR = P.DR;
     std::vector<int> lmStart(n_points + 1, 0);
     for (int e = 0; e < n_vis; e++) lmStart[P.vis[e].point + 1]++;
     for (int l = 0; l < n_points; l++) lmStart[l + 1] += lmStart[l];

@@ -519,6 +519,66 @@ int omo_fuse(const void* kps, const uint8_t* desc, const float* uRight, int n, f
     return nFused;
 }
 
+// ORBmatcher::SearchBySim3 (ORBmatcher.cc:2008-2220).  q12[i1] / q21[i2]: the per-map-point values computed before KeyFrame::GetFeaturesInArea
+// (:2044-2080, :2122-2158; VALID iff the point exists, is not already matched and passed the gates; max_level = nPredictedLevel).
+int omo_search_by_sim3(const void* kps1, const uint8_t* desc1, int n1, float minX1, float minY1, float gwInv1, float ghInv1,
+                       const void* kps2, const uint8_t* desc2, int n2, float minX2, float minY2, float gwInv2, float ghInv2,
+                       const void* q12_, const uint8_t* q12desc, const void* q21_, const uint8_t* q21desc, int32_t* matches12) {
+    FrameView K1{n1, (const KeyPoint*)kps1, desc1, nullptr, minX1, minY1, gwInv1, ghInv1};
+    FrameView K2{n2, (const KeyPoint*)kps2, desc2, nullptr, minX2, minY2, gwInv2, ghInv2};
+    K1.AssignFeaturesToGrid(); K2.AssignFeaturesToGrid();
+    const Query* Q12 = (const Query*)q12_;
+    const Query* Q21 = (const Query*)q21_;
+    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1);
+    // Transform from KF1 to KF2 and search (:2044-2120)
+    for (int i1 = 0; i1 < n1; i1++) {
+        const Query& q = Q12[i1];
+        if (!(q.flags & Q_VALID)) continue;
+        const int nPredictedLevel = q.max_level;
+        const std::vector<size_t> vIndices = K2.GetFeaturesInArea(q.u, q.v, q.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = q12desc + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            const size_t idx = *vit;
+            const KeyPoint& kp = K2.kps[idx];
+            if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+            const int dist = DescriptorDistance(dMP, K2.desc + idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch1[i1] = bestIdx;
+    }
+    // Transform from KF2 to KF1 and search (:2122-2201)
+    for (int i2 = 0; i2 < n2; i2++) {
+        const Query& q = Q21[i2];
+        if (!(q.flags & Q_VALID)) continue;
+        const int nPredictedLevel = q.max_level;
+        const std::vector<size_t> vIndices = K1.GetFeaturesInArea(q.u, q.v, q.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = q21desc + (size_t)i2 * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            const size_t idx = *vit;
+            const KeyPoint& kp = K1.kps[idx];
+            if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+            const int dist = DescriptorDistance(dMP, K1.desc + idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if (bestDist <= TH_HIGH) vnMatch2[i2] = bestIdx;
+    }
+    // Check agreement (:2203-2219)
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}
+
 // M12 ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)  ORBmatcher.cc:1138-1428, for pinhole
 // key frames without a second camera (mpCamera2 == NULL).  The epipolar gate is Pinhole::epipolarConstrain (Pinhole.cpp:155-177) with
 // its fundamental matrix F12 = K1^-T [t12]x R12 K2^-1 passed in (it is a constant of the key-frame pair; the reference recomputes it

@@ -37,6 +37,8 @@ void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
 void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
 void oib_optimize(void*, int, const void*, double*, int, const void*, int, const void*, int, double, double, double, int, double*);
+int omo_search_by_sim3(const void*, const uint8_t*, int, float, float, float, float, const void*, const uint8_t*, int, float, float, float, float, const void*,
+                       const uint8_t*, const void*, const uint8_t*, int32_t*);
 int omo_search_for_triangulation(const void*, const void*, const float*, const float*, const float*, const float*, int, int, int, int32_t*);
 }
 
@@ -131,6 +133,25 @@ int main() {
                                  obi.data(), obd.data());
         CHECK(nf == onf && nf > 20);
         CHECK(std::memcmp(obi.data(), bi.data(), obi.size() * 4) == 0 && std::memcmp(obd.data(), bd.data(), obd.size() * 4) == 0);
+        // SearchBySim3: frame A's points searched in B (the fuse queries, no gate) and B's in A, then the agreement pass
+        {
+            std::vector<orbm_query> q21(kB.size());
+            for (size_t i = 0; i < kB.size(); i++) {
+                q21[i] = orbm_query{};
+                q21[i].u = kB[i].x - (fq[0].u - kA[0].x); q21[i].v = kB[i].y - (fq[0].v - kA[0].y);
+                q21[i].radius = 7.5f * sf[kB[i].octave]; q21[i].min_level = (int16_t)(kB[i].octave - 1); q21[i].max_level = (int16_t)kB[i].octave;
+                q21[i].flags = (i % 7) ? ORBM_Q_VALID : 0;
+            }
+            std::vector<orbm_query> q12 = fq;
+            for (auto& e : q12) e.radius *= 2.5f;
+            std::vector<int> s12;
+            const int ns = m.SearchBySim3(FA, F, q12, dA, q21, dB, s12);
+            std::vector<int32_t> os12(kA.size());
+            const int ons = omo_search_by_sim3(kA.data(), dA.data(), FA.N, 0.f, 0.f, 64.f / W, 48.f / H, kB.data(), dB.data(), F.N, 0.f, 0.f, 64.f / W, 48.f / H,
+                                               q12.data(), dA.data(), q21.data(), dB.data(), os12.data());
+            CHECK(ns == ons && ns > 20);
+            CHECK(std::memcmp(os12.data(), s12.data(), os12.size() * 4) == 0);
+        }
         // SearchForTriangulation: vocabulary node = a hash of descriptor bits; pure image-plane translation geometry
         orbslam3_hip::ORBmatcher::KeyFrameView K1, K2;
         std::vector<uint8_t> mp1(kA.size(), 0), mp2(kB.size(), 0);

@@ -509,3 +509,16 @@ def inertial_optimize(w, huber, lambda_init, iterations):
     L.oib_optimize(_p(kfs), len(kfs), C.addressof(rig), _p(pts), len(pts), _p(edges), len(edges), _p(imu), len(imu), huber[0], huber[1],
                    float(lambda_init), iterations, _p(stats))
     return kfs, pts, stats
+
+
+def search_by_sim3(k1, d1, grid1, k2, d2, grid2, q12, q12desc, q21, q21desc):
+    L = lib()
+    k1, k2 = np.ascontiguousarray(k1), np.ascontiguousarray(k2)
+    out = np.zeros(max(len(k1), 1), np.int32)
+    f = C.c_float
+    L.omo_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f, f, f, f, C.c_void_p, C.c_void_p, C.c_int, f, f, f, f,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.omo_search_by_sim3(_p(k1), _p(np.ascontiguousarray(d1)), len(k1), *[float(g) for g in grid1], _p(k2), _p(np.ascontiguousarray(d2)), len(k2),
+                             *[float(g) for g in grid2], _p(np.ascontiguousarray(q12)), _p(np.ascontiguousarray(q12desc)),
+                             _p(np.ascontiguousarray(q21)), _p(np.ascontiguousarray(q21desc)), _p(out))
+    return out[:len(k1)], n

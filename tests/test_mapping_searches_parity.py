@@ -178,3 +178,50 @@ def test_oracle_triangulation_epipolar_gate_is_selective():
     _, n_good = O.search_for_triangulation(sides[0], sides[1], good, ep, sig2, S["scale"], False, False, False)
     _, n_bad = O.search_for_triangulation(sides[0], sides[1], bad, ep, sig2, S["scale"], False, False, False)
     assert n_good > 60 and n_bad < 0.25 * n_good
+
+
+# ---- SearchBySim3 (ORBmatcher.cc:2008-2220): fuse-style search in both directions + agreement -----------------------------------------
+def _sim3_case(lib, backend, th, seed=0):
+    S = scene()
+    ka, da, kb, db = S["ka"], S["da"], S["kb"], S["db"]
+    rng = np.random.default_rng(seed)
+
+    def queries(src, sgn):
+        q = np.zeros(len(src), QUERY_DTYPE)
+        q["u"] = src["x"] + np.float32(sgn * S["shift"][0]) + rng.normal(0, 0.7, len(src)).astype(np.float32)
+        q["v"] = src["y"] + np.float32(sgn * S["shift"][1]) + rng.normal(0, 0.7, len(src)).astype(np.float32)
+        lvl = np.clip(src["octave"] + rng.integers(-1, 2, len(src)), 0, 7)
+        q["radius"] = np.float32(th) * S["scale"][lvl]
+        q["min_level"] = lvl - 1; q["max_level"] = lvl
+        q["flags"] = np.where(rng.random(len(src)) < 0.8, Q_VALID, 0)     # no map point / already matched / failed a gate
+        return q
+    q12, q21 = queries(ka, +1), queries(kb, -1)
+    om, on = O.search_by_sim3(ka, da, S["grid"], kb, db, S["grid"], q12, da, q21, db)
+    B, c1, c2 = 2, len(ka) + 5, len(kb) + 9
+    m = orbhip.ORBmatcher(lib=lib)
+    d = lambda a: to_dev(a, backend)
+    sides = []
+    for k, dsc, c in ((ka, da, c1), (kb, db, c2)):
+        kps, n = d(_slab(kp_f32(k), c, B)), d(np.full(B, len(k), np.int32))
+        gs, gi = m.grid_build(kps, n, S["grid"])
+        sides.append(dict(kps=kps, desc=d(_slab(dsc, c, B)), counts=n, grid_start=gs, grid_idx=gi, grid=S["grid"]))
+    dq = lambda q, c: d(_slab(q, c, B).view(np.uint8).reshape(B, c, 28))
+    out, nf = m.SearchBySim3(sides[0], sides[1], dq(q12, c1), d(_slab(da, c1, B)), dq(q21, c2), d(_slab(db, c2, B)))
+    out, nf = to_host(out), to_host(nf)
+    for b in range(B):
+        assert nf[b] == on and np.array_equal(out[b, :len(ka)], om) and (out[b, len(ka):] == -1).all()
+    assert on > 60
+    # the agreement pass really rejects one-directional matches
+    one_way, _, _ = O.fuse(kb, db, q12, da, S["grid"], 100, None, None)
+    assert (one_way >= 0).sum() > on
+
+
+@pytest.mark.parametrize("th", [7.5])
+def test_emu_search_by_sim3(emu_lib, th):
+    _sim3_case(emu_lib, "emu", th)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("th", [7.5, 3.0, 15.0])
+def test_hip_search_by_sim3(hip_lib, th):
+    _sim3_case(hip_lib, "hip", th)
