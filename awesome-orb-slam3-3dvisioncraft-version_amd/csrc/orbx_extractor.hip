@@ -270,6 +270,7 @@ struct FastParams {
     int* candCount; int nlevels;        // [frame][nlevels]
     int iniTh, minTh;
     int imgBytes;                       // LDS bytes reserved for the image tile (== score-map bytes)
+    int nTiles, batch;                  // tiles per frame, frames: the XCD-aware 1-D grid
 };
 
 // circular 16-bit mask has a run of >= 9 ones
@@ -318,9 +319,27 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
 #ifndef FAST_Q2CAP
 #define FAST_Q2CAP 2048   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
 #endif
+#ifndef FAST_XCD
+#define FAST_XCD 0   // 1: frame-per-XCD mapping (xcd_frame_unit) for k_fast too.  Measured on MI355X: 1.162 ms vs 1.137 ms with the plain (tile, frame)
+                     // grid at batch 512, equal at batch 64 — k_fast's staging is not L2-fill bound (tiles overlap by 6 px only), while k_describe's
+                     // 43x48-byte patches overlap heavily and gain 2-3 % from it.  Kept switchable.
+#endif
 #define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
 #define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)   // 16 rows: each of the 4 waves owns 8 rows x 64 columns = FAST_QCAP/4 pixels
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice: one chunk's survivors + up to 63 carried over from the previous chunk
+
+// XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2.  With a
+// (unit, frame) grid the units of ONE frame are spread over all eight XCDs, so every XCD pulls the same frame's pyramid (1.1 MB) through
+// its own L2: up to 8x the fill traffic, and these kernels' load phases run at several TB/s.  Instead the grid is 1-D and XCD x takes the
+// frames f with f % 8 == x, walking a frame's units in order: a frame's pyramid is fetched once and stays L2-resident while it is worked on.
+// grid = units_per_frame * 8 * ceil(batch / 8); returns false for the padding workgroups of a batch that is not a multiple of 8.
+static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, const int batch, int* frame, int* unit) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int fr = (slot / unitsPerFrame) * 8 + xcd;
+    *frame = fr;
+    *unit = slot - (slot / unitsPerFrame) * unitsPerFrame;
+    return fr < batch;
+}
 
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
@@ -337,8 +356,14 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+#if FAST_XCD
+    int frame, tileIdx;
+    if (!xcd_frame_unit(P.nTiles, P.batch, &frame, &tileIdx)) return;
+    const FastTile T = P.tiles[tileIdx];
+#else
     const FastTile T = P.tiles[blockIdx.x];
     const int frame = blockIdx.y;
+#endif
     const FastLevel& L = P.lv[T.level];
 
     const int iniY = ORBX_MINB + T.cellRow * L.hCell;
@@ -998,6 +1023,7 @@ struct DescParams {
     const uint32_t* sel; const uint32_t* selAux; int selFrame;
     const int* selCount; const int* lapCount; int nlevels;
     orb_keypoint* kps; uint8_t* desc; int cap; int32_t* counts;
+    int groups, batch;   // workgroups (4 keypoints each) per frame, frames: the XCD-aware 1-D grid
 };
 
 static __device__ __forceinline__ int reflect101(int p, int len) {
@@ -1076,8 +1102,9 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int frame = blockIdx.y;
-    const int g = blockIdx.x * 4 + wave;
+    int frame, grp;
+    if (!xcd_frame_unit(P.groups, P.batch, &frame, &grp)) return;
+    const int g = grp * 4 + wave;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
     uint8_t* blur = patch;   // the source patch is dead after IC_Angle + the row pass
@@ -1763,7 +1790,12 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         F.tiles = h->d_tiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
         F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
         F.imgBytes = h->fastImgBytes;
+        F.nTiles = h->nTiles; F.batch = batch;
+#if FAST_XCD
+        hipLaunchKernelGGL(k_fast, dim3(h->nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
+#else
         hipLaunchKernelGGL(k_fast, dim3(h->nTiles, batch), dim3(256), h->fastSmem, st, F);
+#endif
     }
     HIPCHK(h, hipEventRecord(h->ev[2], st));
     // E3 octree
@@ -1794,7 +1826,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
         D.sel = h->d_sel; D.selAux = h->d_selAux; D.selFrame = h->selFrame; D.selCount = h->d_selCount; D.lapCount = h->d_lapCount;
         D.nlevels = nl; D.kps = d_kps; D.desc = d_desc; D.cap = cap_per_frame; D.counts = d_counts;
-        hipLaunchKernelGGL(k_describe, dim3((h->maxKp + 3) / 4, batch), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
+        D.groups = (h->maxKp + 3) / 4; D.batch = batch;
+        hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
     }
     HIPCHK(h, hipEventRecord(h->ev[4], st));
     h->timed = true;
