@@ -1099,7 +1099,11 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 #define DBP 40           // blurred pitch
 #define DESC_WAVE_STRIDE 5648   // 43*52 (patch; reused for the 37x40 blurred tile once the row pass is done) + 37*46*2 (row pass) + pad to 16
 
-static __global__ __launch_bounds__(256) void k_describe(DescParams P) {
+#ifndef DESC_WAVES
+#define DESC_WAVES 7   // waves per SIMD the register allocator must leave room for: 72 VGPRs (12 B of scratch) instead of 76 -> 7 workgroups per CU,
+                      // which is also what the LDS footprint allows; the kernel's load phase is latency bound (0.850 -> 0.792 ms on MI355X)
+#endif
+static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int frame, grp;
