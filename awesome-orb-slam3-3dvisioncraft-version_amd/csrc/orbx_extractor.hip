@@ -1017,6 +1017,7 @@ static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
 struct DescLevel {
     const uint8_t* base; size_t frameStride; int rowStride;
     int w, h; int selOff; float scale; float size;   // size = (float)(int)(31*scale)
+    int selCap;
 };
 struct DescParams {
     DescLevel lv[ORBX_MAX_LEVELS];
@@ -1024,6 +1025,7 @@ struct DescParams {
     const int* selCount; const int* lapCount; int nlevels;
     orb_keypoint* kps; uint8_t* desc; int cap; int32_t* counts;
     int groups, batch;   // workgroups (4 keypoints each) per frame, frames: the XCD-aware 1-D grid
+    int unitStart[ORBX_MAX_LEVELS + 1];   // workgroup u of a frame serves level l with unitStart[l] <= u < unitStart[l+1] (ceil(selCap_l / 4) each)
 };
 
 static __device__ __forceinline__ int reflect101(int p, int len) {
@@ -1108,33 +1110,35 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int frame, grp;
     if (!xcd_frame_unit(P.groups, P.batch, &frame, &grp)) return;
-    const int g = grp * 4 + wave;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
     uint8_t* blur = patch;   // the source patch is dead after IC_Angle + the row pass
 
-    // locate keypoint g of this frame: level, position inside the level's octree list, output slot
-    const int* sc = P.selCount + (size_t)frame * P.nlevels;
-    const int* lc = P.lapCount + (size_t)frame * P.nlevels;
-    int level = -1, pos = 0, nTotal = 0, monoBase = 0, lapBase = 0, monoTotal = 0;
-    {
-        int acc = 0;
-        for (int l = 0; l < P.nlevels; l++) {
-            const int n = sc[l], nl = lc[l];
-            if (level < 0 && g < acc + n) { level = l; pos = g - acc; monoBase = monoTotal; lapBase = nTotal - monoTotal; }
-            acc += n;
-            nTotal += n;
-            monoTotal += n - nl;
-        }
-    }
-    if (g == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
-    const bool valid = level >= 0;
-    const DescLevel& L = P.lv[valid ? level : 0];
+    // The workgroup's level and position follow from its index alone (a constant table), so the keypoint record is fetched in the FIRST
+    // global round trip, together with the per-level counts that are only needed for `valid` and, at the very end, for the output slot;
+    // the patch rows are the second round trip.  (Locating keypoint g through the prefix sums of the counts first cost a third one, and
+    // this kernel's load phase is latency bound.)
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if (grp >= P.unitStart[l]) level = l;
+    const int pos = (grp - P.unitStart[level]) * 4 + wave;
+    const DescLevel& L = P.lv[level];
+    const bool inSlab = pos < L.selCap;
     uint32_t key = 0, aux = 0;
-    if (valid) {
+    if (inSlab) {
         key = P.sel[(size_t)frame * P.selFrame + L.selOff + pos];
         aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
     }
+    const int* sc = P.selCount + (size_t)frame * P.nlevels;
+    const int* lc = P.lapCount + (size_t)frame * P.nlevels;
+    int nTotal = 0, monoBase = 0, lapBase = 0, monoTotal = 0, nLevel = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        const int n = sc[l], nl = lc[l];
+        if (l == level) { nLevel = n; monoBase = monoTotal; lapBase = nTotal - monoTotal; }
+        nTotal += n;
+        monoTotal += n - nl;
+    }
+    if (grp == 0 && wave == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
+    const bool valid = inSlab && pos < nLevel;
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
     int ox = 0;   // column of the patch's first pixel inside the LDS rows
     if (valid) {
@@ -1826,11 +1830,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         for (int l = 0; l < nl; l++) {
             DescLevel& dl = D.lv[l]; const LevelHost& L = h->lv[l];
             level_view(h, l, dl.base, dl.frameStride, dl.rowStride);
-            dl.w = L.w; dl.h = L.h; dl.selOff = L.selOff; dl.scale = h->scale[l]; dl.size = (float)(int)(31 * h->scale[l]);
+            dl.w = L.w; dl.h = L.h; dl.selOff = L.selOff; dl.selCap = L.selCap; dl.scale = h->scale[l]; dl.size = (float)(int)(31 * h->scale[l]);
         }
         D.sel = h->d_sel; D.selAux = h->d_selAux; D.selFrame = h->selFrame; D.selCount = h->d_selCount; D.lapCount = h->d_lapCount;
         D.nlevels = nl; D.kps = d_kps; D.desc = d_desc; D.cap = cap_per_frame; D.counts = d_counts;
-        D.groups = (h->maxKp + 3) / 4; D.batch = batch;
+        D.unitStart[0] = 0;
+        for (int l = 0; l < nl; l++) D.unitStart[l + 1] = D.unitStart[l] + (h->lv[l].selCap + 3) / 4;
+        D.groups = D.unitStart[nl]; D.batch = batch;
         hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
     }
     HIPCHK(h, hipEventRecord(h->ev[4], st));
