@@ -1099,11 +1099,26 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 #define DB 37            // blurred edge (radius 18)
 #define DRP 46           // row-pass buffer: 37 columns x 46 rows of u16 (transposed; 23 dwords per column, odd)
 #define DBP 40           // blurred pitch
+#ifndef DESC_ALIAS
+#define DESC_ALIAS 1
+#endif
+#if DESC_ALIAS
+// LDS per keypoint: [ region A: the 43x52 source patch, overwritten IN PLACE by the 37x46 u16 row-pass buffer (3404 B) | 37x40 blurred tile ].
+// A lane reads its whole patch row into registers before any lane of the wave writes a row-pass value (same wave, program order, fenced),
+// so the two can share storage: 4896 B per wave instead of 5648 -> 8 workgroups per CU instead of 7.
+#define DESC_ROWP_OFF 0
+#define DESC_BLUR_OFF 3408
+#define DESC_WAVE_STRIDE 4896
+#else
+#define DESC_ROWP_OFF (DP * DPP)
+#define DESC_BLUR_OFF 0
 #define DESC_WAVE_STRIDE 5648   // 43*52 (patch; reused for the 37x40 blurred tile once the row pass is done) + 37*46*2 (row pass) + pad to 16
+#endif
 
 #ifndef DESC_WAVES
-#define DESC_WAVES 7   // waves per SIMD the register allocator must leave room for: 72 VGPRs (12 B of scratch) instead of 76 -> 7 workgroups per CU,
-                      // which is also what the LDS footprint allows; the kernel's load phase is latency bound (0.850 -> 0.792 ms on MI355X)
+#define DESC_WAVES 8   // waves per SIMD the register allocator leaves room for.  The kernel's load phase is latency bound, so residency matters:
+                      // 76 VGPRs / 5648 B of LDS per wave gave 6 workgroups per CU (0.850 ms on MI355X), 72 VGPRs 7 (0.792 ms); with the row-pass
+                      // buffer aliased onto the patch (DESC_ALIAS) it is 57 VGPRs, 4896 B and 8 workgroups (0.759 ms)
 #endif
 static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
@@ -1111,8 +1126,8 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
     int frame, grp;
     if (!xcd_frame_unit(P.groups, P.batch, &frame, &grp)) return;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
-    uint16_t* rowp = (uint16_t*)(patch + DP * DPP);
-    uint8_t* blur = patch;   // the source patch is dead after IC_Angle + the row pass
+    uint16_t* rowp = (uint16_t*)(patch + DESC_ROWP_OFF);
+    uint8_t* blur = patch + DESC_BLUR_OFF;
 
     // The workgroup's level and position follow from its index alone (a constant table), so the keypoint record is fetched in the FIRST
     // global round trip, together with the per-level counts that are only needed for `valid` and, at the very end, for the output slot;
@@ -1180,9 +1195,10 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
         // e[k] = patch bytes 4k..4k+3; both IC_Angle (rows 6..36) and the Gaussian row pass (all 43 rows) run on packed bytes
         // with v_dot4_u32_u8
         int m10 = 0, m01 = 0;
+        uint32_t e[11];   // e[k] = bytes 4k..4k+3 of this lane's patch row
         if (lane < DP) {
             const uint32_t* rw = (const uint32_t*)(patch + lane * DPP);
-            uint32_t d[12], e[11];
+            uint32_t d[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) d[k] = rw[k];
 #pragma unroll
@@ -1206,6 +1222,13 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
                 m10 = (int)sw - 15 * (int)s1;
                 m01 = v * (int)s1;
             }
+        }
+        // (DESC_ALIAS: the row-pass buffer overwrites the patch; every lane's patch row is in registers by now — the wave-level fence keeps
+        // the LDS reads above the writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < DP) {
             // Gaussian row pass: k = cvRound(256*g) = {18,34,49,55,49,34,18}; out(c) = dot4(bytes c..c+3, k[0..3]) + dot4(bytes c+4..c+7,
             // {k[4..6],0}); sums <= 255*257 fit u16
             const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
@@ -1234,8 +1257,8 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
         const int half = rem >= DB ? 1 : 0, col = rem - half * DB;
         if (!vflag[w]) continue;
         const int r0 = half ? 18 : 0;
-        const uint32_t* cp = (const uint32_t*)((const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DP * DPP) + col * DRP + r0);
-        uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE + r0 * DBP + col;
+        const uint32_t* cp = (const uint32_t*)((const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DESC_ROWP_OFF) + col * DRP + r0);
+        uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE + DESC_BLUR_OFF + r0 * DBP + col;
         typedef unsigned short u16x2 __attribute__((vector_size(4)));
         uint32_t E[13], O[12];   // E[k] = rows (r0+2k, r0+2k+1), O[k] = rows (r0+2k+1, r0+2k+2)
 #pragma unroll
