@@ -45,6 +45,21 @@ def main():
     o = O.lba_build_system(w, cams, (HUBER_MONO, HUBER_STEREO))
     np.savez_compressed(os.path.join(HERE, "lba_mixed_12kf.npz"), n_edges=len(w["edges"]), Hpp=o["Hpp"], bp=o["bp"], Hll_sum=o["Hll"].sum(0),
                         bl_sum=o["bl"].sum(0), Hpl_sum=o["Hpl"].sum(0), chi2=o["chi2"], robust=o["robust_chi2_sum"])
+    # Frame glue: cv::undistortPoints restatement on a grid of pixel positions, EuRoC calibration (Examples/Monocular/EuRoC.yaml:9-17)
+    from orbhip.frame import Camera
+    cam = Camera.make(458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)).as_array()
+    gx, gy = np.meshgrid(np.arange(0, 752, 47, dtype=np.float32), np.arange(0, 480, 43, dtype=np.float32))
+    k = np.zeros(gx.size, O.KP_DTYPE); k["x"], k["y"] = gx.ravel(), gy.ravel()
+    u = O.undistort_keypoints(k, cam)
+    np.savez_compressed(os.path.join(HERE, "undistort_euroc.npz"), cam=cam, xy=np.stack([k["x"], k["y"]], 1), xy_un=np.stack([u["x"], u["y"]], 1),
+                        bounds=O.image_bounds(cam, 752, 480))
+    # visual-inertial local BA: seed-7 stereo window, optimize(1.0, 6): statistics + final states
+    from orbhip.inertial import synth_inertial_window
+    iw = synth_inertial_window(7, n_opt=6, n_fixed_vis=2, n_pts=250, max_obs=6, kind="stereo")
+    kf, pts, st = O.inertial_optimize(iw, (HUBER_MONO, HUBER_STEREO), 1.0, 6)
+    e0 = O.inertial_errors(iw, (HUBER_MONO, HUBER_STEREO))
+    np.savez_compressed(os.path.join(HERE, "inertial_stereo_6kf.npz"), n_edges=len(iw["edges"]), stats=st, twb=kf["twb"], Rwb=kf["Rwb"], v=kf["v"], bg=kf["bg"],
+                        ba=kf["ba"], points_sum=pts.sum(0), imu_chi2_0=e0["imu_chi2"], robust0=e0["robust_chi2_sum"])
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
