@@ -144,3 +144,21 @@ def test_hip_inertial_ba_is_deterministic_and_rejects_bad_windows(hip_lib):
     st = to_host(IW.optimize(1.0, 3))
     assert st[0, 0] >= 1 and st[1, 0] == -1
     assert np.array_equal(IW.keyframes()[1, :len(bad["kfs"])], bad["kfs"])
+
+
+@pytest.mark.gpu
+def test_hip_inertial_ba_large_window(hip_lib):
+    """bLarge (Optimizer.cc:4760-4764): 25 optimisable key frames (375 reduced unknowns), lambda 1e-2, optimize(4)."""
+    w = window("stereo", seed=41, n_opt=25, n_fixed_vis=8, n_pts=900, max_obs=10, dt=0.12)
+    IW = InertialWindows([w], to_dev("hip"), lib=hip_lib, huber=HUBER)
+    st = to_host(IW.optimize(1e-2, 4))[0]
+    okf, opts, ost = O.inertial_optimize(w, HUBER, 1e-2, 4)
+    kf = IW.keyframes()[0, :len(w["kfs"])]
+    assert st[0] == ost[0] and st[3] == ost[3] and abs(st[1] - ost[1]) < 1e-7 * ost[1], (st, ost)
+    for f in ("Rwb", "twb", "v", "bg", "ba"):
+        assert np.abs(kf[f] - okf[f]).max() < 2e-6, f
+    assert np.abs(IW.points()[0, :len(w["points"])] - opts).max() < 2e-5 and ost[1] < 0.9 * ost[4]
+    # more optimisable key frames than LIBA_MAX_FREE: refused by the wrapper's max_free check (ORB_E_INVALID)
+    big = window("mono", seed=42, n_opt=33, n_fixed_vis=1, n_pts=200, dt=0.1)
+    with pytest.raises(Exception):
+        InertialWindows([big], to_dev("hip"), lib=hip_lib, huber=HUBER).optimize(1.0, 2)
