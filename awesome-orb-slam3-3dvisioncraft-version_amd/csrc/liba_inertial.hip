@@ -17,7 +17,7 @@
 #include "dense_chol.inc"
 
 #define LIBA_T 256
-#define LIBA_IMULIN (216 + 216 + 9)   // per inertial edge: J (9x24), rho1*Omega*J (9x24), -rho1*Omega*e (9)
+#define LIBA_IMULIN (216 + 216 + 9 + 10)   // per inertial edge: J (9x24), rho1*Omega*J (9x24), -rho1*Omega*e (9), e (9), rho1
 #define LIBA_KFD (sizeof(liba_keyframe) / 8)
 
 struct LibaArgs {
@@ -34,14 +34,14 @@ struct LibaArgs {
 struct Win {
     liba_keyframe* kfs; int nKf; const liba_rig* rig; double* pts; int nPts; const lba_edge* edges; int nE; const liba_imu_edge* imu; int nImu;
     double *Hpl, *Hll, *bl, *Dinv, *xl, *ptBak, *H, *S, *bv, *xp, *imuLin, *kfBak;
-    int *lmStart, *kfEdges;
+    int *lmStart, *kfEdges, *obsTab;
     double huberMono, huberStereo;
 };
 
 static inline size_t liba_window_bytes(const liba_problem& P, int DRmax) {
     size_t d = (size_t)P.cap_e * 18 + (size_t)P.cap_l * (9 + 3 + 9 + 3 + 3) + (size_t)DRmax * DRmax * 2 + (size_t)DRmax * 2 + (size_t)P.cap_i * LIBA_IMULIN +
                (size_t)P.cap_kf * LIBA_KFD;
-    size_t i = (size_t)P.cap_l + 1 + P.cap_e + 3;
+    size_t i = (size_t)P.cap_l + 1 + P.cap_e + 3 + (size_t)P.cap_l * P.max_free;
     return (d * 8 + i * 4 + 255) & ~(size_t)255;
 }
 static __device__ __host__ inline void liba_carve(const liba_problem& P, int DRmax, unsigned char* base, Win& w) {
@@ -60,7 +60,9 @@ static __device__ __host__ inline void liba_carve(const liba_problem& P, int DRm
     w.kfBak = d; d += (size_t)P.cap_kf * LIBA_KFD;
     int* i = (int*)d;
     w.lmStart = i; i += P.cap_l + 1;
-    w.kfEdges = i;
+    w.kfEdges = i; i += P.cap_e;
+    w.obsTab = i;      // [cap_l][max_free]: first edge of landmark l on optimisable pose slot s, as e * 4 + n (n = 1 or 2 consecutive edges;
+                       // 3 = more, or not consecutive: scan the landmark's list), -1 = not observed
 }
 
 // ---- 3x3 helpers, row-major ----
@@ -465,7 +467,11 @@ static __device__ __forceinline__ int imu_col_offset(const liba_imu_edge& E, con
     return hi[E.kf2] < 0 ? -1 : hi[E.kf2] + (c - 21);
 }
 
-static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
+#ifndef LIBA_WAVES
+#define LIBA_WAVES 2   // 2 workgroups per CU: the kernel is a chain of dependent global loads (latency bound), +36 % windows/s on MI355X
+                       // although the allocator then spills ~1 KB per lane to scratch
+#endif
+static __global__ __launch_bounds__(LIBA_T, LIBA_WAVES) void k_liba_optimize(LibaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const liba_problem& P = A.P;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -544,13 +550,28 @@ static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
         __threadfence_block();
         __syncthreads();
     }
+    const int mf = P.max_free;
+    for (int l = tid; l < w.nPts; l += LIBA_T) {
+        int* tab = w.obsTab + (size_t)l * mf;
+        for (int s2 = 0; s2 < nfp; s2++) tab[s2] = -1;
+        for (int e = w.lmStart[l]; e < w.lmStart[l + 1]; e++) {
+            const int h = hp[w.edges[e].pose];
+            if (h < 0) continue;
+            const int cur = tab[h / 6];
+            if (cur < 0) tab[h / 6] = e * 4 + 1;
+            else tab[h / 6] = ((cur & 3) == 1 && (cur >> 2) + 1 == e) ? (cur >> 2) * 4 + 2 : (cur >> 2) * 4 + 3;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
 
     double lambda = A.lambdaInit, ni = 2;
     int nBad = 0, it = 0, trialsTotal = 0;
-    double currentChi = 0;
     const double chi0 = robust_chi(w, hp, hi, scratch);
+    // g2o recomputes the active errors at the top of every iteration; the state there is the one the last accepted trial (or the pop after a
+    // rejected one) left, whose robust chi2 this kernel already holds: same function, same data, same bits
+    double currentChi = chi0;
     for (it = 0; it < A.iterations; it++) {
-        currentChi = robust_chi(w, hp, hi, scratch);
         double tempChi = currentChi;
         const double iniChi = currentChi;
         // ================= buildSystem =================
@@ -621,18 +642,35 @@ static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
             const liba_imu_edge& E = w.imu[i];
             if (!imu_active(E, hp, hi)) continue;
             double* J = w.imuLin + (size_t)i * LIBA_IMULIN;
-            double* OJ = J + 216;
-            double* Oe = OJ + 216;
             double e9[9], eR[9], c3[3], r0, r1;
             inertial_error(E, w.kfs[E.kf1], w.kfs[E.kf2], e9, eR);
             inertial_jacobian(E, w.kfs[E.kf1], w.kfs[E.kf2], e9, eR, J);
             imu_chi(E, w.kfs[E.kf1], w.kfs[E.kf2], e9, c3);
             huber(c3[0], E.huber, &r0, &r1);
-            for (int r = 0; r < 9; r++) {
-                for (int c = 0; c < 24; c++) { double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * J[q * 24 + c]; OJ[r * 24 + c] = r1 * s; }
-                double s = 0;
-                for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * e9[q];
-                Oe[r] = -r1 * s;
+            for (int r = 0; r < 9; r++) J[441 + r] = e9[r];
+            J[450] = r1;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // rho1 * Omega * J and -rho1 * Omega * e, entries spread over the workgroup
+        for (int t = tid; t < w.nImu * 225; t += LIBA_T) {
+            const int i = t / 225, k = t - i * 225;
+            const liba_imu_edge& E = w.imu[i];
+            if (!imu_active(E, hp, hi)) continue;
+            double* J = w.imuLin + (size_t)i * LIBA_IMULIN;
+            const double r1 = J[450];
+            if (k < 216) {
+                const int r = k / 24, c = k - r * 24;
+                double sacc = 0;
+#pragma unroll
+                for (int q = 0; q < 9; q++) sacc += E.info[r * 9 + q] * J[q * 24 + c];
+                J[216 + k] = r1 * sacc;
+            } else {
+                const int r = k - 216;
+                double sacc = 0;
+#pragma unroll
+                for (int q = 0; q < 9; q++) sacc += E.info[r * 9 + q] * J[441 + q];
+                J[432 + r] = -r1 * sacc;
             }
         }
         __threadfence_block();
@@ -724,6 +762,8 @@ static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
                 for (int i = 0; i < 42; i++) acc[i] = 0.0;
                 for (int q = kfStart[pi] + lane; q < kfStart[pi + 1]; q += 64) {
                     const int e1 = w.kfEdges[q], l = w.edges[e1].point;
+                    const int tv = w.obsTab[(size_t)l * mf + pj];
+                    if (tv < 0) continue;             // pose pj does not observe this landmark
                     const double* Wi = w.Hpl + (size_t)e1 * 18;
                     const double* Di = w.Dinv + (size_t)l * 9;
                     double Y[18];
@@ -731,13 +771,17 @@ static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
                     for (int c = 0; c < 3; c++)
 #pragma unroll
                         for (int r = 0; r < 6; r++) Y[c * 6 + r] = Wi[r] * Di[c * 3] + Wi[6 + r] * Di[c * 3 + 1] + Wi[12 + r] * Di[c * 3 + 2];
-                    for (int e2 = w.lmStart[l]; e2 < w.lmStart[l + 1]; e2++) {
-                        if (w.edges[e2].pose != kj) continue;
-                        const double* Wj = w.Hpl + (size_t)e2 * 18;
+                    {
+                        const int n2 = tv & 3;
+                        const int eb = n2 == 3 ? w.lmStart[l] : (tv >> 2), ee = n2 == 3 ? w.lmStart[l + 1] : (tv >> 2) + n2;
+                        for (int e2 = eb; e2 < ee; e2++) {
+                            if (n2 == 3 && w.edges[e2].pose != kj) continue;
+                            const double* Wj = w.Hpl + (size_t)e2 * 18;
 #pragma unroll
-                        for (int c = 0; c < 6; c++)
+                            for (int c = 0; c < 6; c++)
 #pragma unroll
-                            for (int r = 0; r < 6; r++) acc[c * 6 + r] += Y[r] * Wj[c] + Y[6 + r] * Wj[6 + c] + Y[12 + r] * Wj[12 + c];
+                                for (int r = 0; r < 6; r++) acc[c * 6 + r] += Y[r] * Wj[c] + Y[6 + r] * Wj[6 + c] + Y[12 + r] * Wj[12 + c];
+                        }
                     }
                     if (pi == pj) {   // _bschur: b_p - Hpl Dinv bl
                         const double* bl = w.bl + (size_t)l * 3;
@@ -825,7 +869,7 @@ static __global__ __launch_bounds__(LIBA_T) void k_liba_optimize(LibaArgs A) {
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) { it++; break; }
     }
-    const double chiEnd = robust_chi(w, hp, hi, scratch);
+    const double chiEnd = currentChi;
     if (tid == 0) { stats[0] = it; stats[1] = chiEnd; stats[2] = lambda; stats[3] = trialsTotal; stats[4] = chi0; }
     (void)np6;
 }
