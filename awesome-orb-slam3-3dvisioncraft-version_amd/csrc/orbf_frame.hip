@@ -8,6 +8,8 @@
 // with the new camera matrix P = K, round to float.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../../include/orbhip.h"
 
 static __device__ __host__ inline void undistort_point(const orbf_camera& c, const float xin, const float yin, float* xo, float* yo) {
@@ -109,5 +111,169 @@ extern "C" int orbf_stereo_from_rgbd(const orb_keypoint* d_kps, const orb_keypoi
     if (batch == 0) return ORB_OK;
     hipLaunchKernelGGL(k_rgbd, dim3((cap_k + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, d_kps, d_kps_un, d_nkp, count_stride, cap_k,
                        d_depth, frame_stride, row_stride, mbf, d_u_right, d_depth_out);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+// ---- Frame::ComputeStereoFishEyeMatches (Frame.cc:1281-1325) + KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:334-400) -----------------
+// One thread per left-camera keypoint of the lapping area: brute-force 2-NN over the right camera's lapping keypoints (all lanes read the same
+// train descriptor: broadcast loads), ratio test, triangulation, gates.  Float32 cv::Mat arithmetic / libm float calls / cv::SVD of the reference
+// follow rule R4 (the same rule oracle/frame_oracle.cpp states): transcendental functions in double on the float argument,
+// rounded to float; float products as double-accumulated sums rounded once; the null vector of the 4x4 system by cyclic Jacobi on A^T A in double.
+static __device__ void kb8_unproject(const float* p, const float u, const float v, float* ray) {   // KannalaBrandt8.cpp:101-124
+    const float pwx = (u - p[2]) / p[0], pwy = (v - p[3]) / p[1];
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf(-(float)(3.14159265358979323846 / 2.0), theta_d), (float)(3.14159265358979323846 / 2.0));
+    if (theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = p[4] * theta2, k1_theta4 = p[5] * theta4, k2_theta6 = p[6] * theta6, k3_theta8 = p[7] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < 1e-6f) break;
+        }
+        scale = (float)tan((double)theta) / theta_d;
+    }
+    ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
+}
+static __device__ void kb8_project_f(const float* p, const float* X, float* uv) {   // KannalaBrandt8.cpp:28-42
+    const float x2_plus_y2 = X[0] * X[0] + X[1] * X[1];
+    const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)X[2]);
+    const float psi = (float)atan2((double)X[1], (double)X[0]);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
+    uv[0] = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
+    uv[1] = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
+}
+static __device__ void null_vector4(const float* A, float* v4) {
+    double M[16], V[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += (double)A[k * 4 + i] * (double)A[k * 4 + j];
+            M[i * 4 + j] = s; V[i * 4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 8; sweep++)
+        for (int pI = 0; pI < 3; pI++)
+            for (int q = pI + 1; q < 4; q++) {
+                const double apq = M[pI * 4 + q];
+                if (apq == 0.0) continue;
+                const double th = (M[q * 4 + q] - M[pI * 4 + pI]) / (2.0 * apq);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 4; k++) { const double a = M[k * 4 + pI], b = M[k * 4 + q]; M[k * 4 + pI] = c * a - sn * b; M[k * 4 + q] = sn * a + c * b; }
+                for (int k = 0; k < 4; k++) { const double a = M[pI * 4 + k], b = M[q * 4 + k]; M[pI * 4 + k] = c * a - sn * b; M[q * 4 + k] = sn * a + c * b; }
+                for (int k = 0; k < 4; k++) { const double a = V[k * 4 + pI], b = V[k * 4 + q]; V[k * 4 + pI] = c * a - sn * b; V[k * 4 + q] = sn * a + c * b; }
+            }
+    int m = 0;
+    for (int i = 1; i < 4; i++) if (M[i * 4 + i] < M[m * 4 + m]) m = i;
+    for (int k = 0; k < 4; k++) v4[k] = (float)V[k * 4 + m];
+}
+static __device__ __forceinline__ float fdot3(const float* a, const float* b) { return (float)((double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]); }
+static __device__ float triangulate_matches(const orbf_fisheye_rig& G, const orb_keypoint& kp1, const orb_keypoint& kp2, const float sigmaLevel, const float unc,
+                                            float* x3D) {
+    float r1[3], r2[3], r21[3];
+    kb8_unproject(G.k_left, kp1.x, kp1.y, r1);
+    kb8_unproject(G.k_right, kp2.x, kp2.y, r2);
+    for (int i = 0; i < 3; i++) r21[i] = fdot3(G.R_lr + 3 * i, r2);
+    const double n1 = sqrt((double)r1[0] * r1[0] + (double)r1[1] * r1[1] + (double)r1[2] * r1[2]);
+    const double n2 = sqrt((double)r21[0] * r21[0] + (double)r21[1] * r21[1] + (double)r21[2] * r21[2]);
+    const double dotp = (double)r1[0] * r21[0] + (double)r1[1] * r21[1] + (double)r1[2] * r21[2];
+    const float cosParallaxRays = (float)(dotp / (n1 * n2));
+    if (cosParallaxRays > 0.9998) return -1;
+    float R21[9], t21[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R21[i * 3 + j] = G.R_lr[j * 3 + i];
+    for (int i = 0; i < 3; i++) t21[i] = -fdot3(R21 + 3 * i, G.t_lr);
+    float A[16];
+    for (int c = 0; c < 4; c++) {
+        const float T1r0 = c == 0 ? 1.f : 0.f, T1r1 = c == 1 ? 1.f : 0.f, T1r2 = c == 2 ? 1.f : 0.f;
+        const float T2r0 = c < 3 ? R21[c] : t21[0], T2r1 = c < 3 ? R21[3 + c] : t21[1], T2r2 = c < 3 ? R21[6 + c] : t21[2];
+        A[c] = r1[0] * T1r2 - T1r0;
+        A[4 + c] = r1[1] * T1r2 - T1r1;
+        A[8 + c] = r2[0] * T2r2 - T2r0;
+        A[12 + c] = r2[1] * T2r2 - T2r1;
+    }
+    float v4[4];
+    null_vector4(A, v4);
+    for (int i = 0; i < 3; i++) x3D[i] = v4[i] / v4[3];
+    const float z1 = x3D[2];
+    if (z1 <= 0) return -1;
+    const float z2 = fdot3(R21 + 6, x3D) + t21[2];
+    if (z2 <= 0) return -1;
+    float uv1[2];
+    kb8_project_f(G.k_left, x3D, uv1);
+    const float errX1 = uv1[0] - kp1.x, errY1 = uv1[1] - kp1.y;
+    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -1;
+    float x3D2[3], uv2[2];
+    for (int i = 0; i < 3; i++) x3D2[i] = fdot3(R21 + 3 * i, x3D) + t21[i];
+    kb8_project_f(G.k_right, x3D2, uv2);
+    const float errX2 = uv2[0] - kp2.x, errY2 = uv2[1] - kp2.y;
+    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -1;
+    return z1;
+}
+
+struct FishArgs {
+    const orb_keypoint* kl; const uint8_t* dl; const int32_t* nl; const int32_t* ml;
+    const orb_keypoint* kr; const uint8_t* dr; const int32_t* nr; const int32_t* mr;
+    int capL, capR, cstride;
+    orbf_fisheye_rig rig;
+    int32_t* l2r; int32_t* r2l; float* depth; float* p3d; int32_t* nmatches;
+};
+static __global__ __launch_bounds__(256) void k_fisheye_init(FishArgs A) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < A.capL) { A.l2r[(size_t)b * A.capL + i] = -1; A.depth[(size_t)b * A.capL + i] = -1.0f; for (int c = 0; c < 3; c++) A.p3d[((size_t)b * A.capL + i) * 3 + c] = 0.f; }
+    if (i < A.capR) A.r2l[(size_t)b * A.capR + i] = -1;
+    if (i == 0) A.nmatches[b] = 0;
+}
+static __global__ __launch_bounds__(256) void k_fisheye_match(FishArgs A) {
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const int nleft = min(A.nl[(size_t)b * A.cstride], A.capL), nright = min(A.nr[(size_t)b * A.cstride], A.capR);
+    const int monoL = min(max(A.ml[(size_t)b * A.cstride], 0), nleft), monoR = min(max(A.mr[(size_t)b * A.cstride], 0), nright);
+    const int nq = nleft - monoL, nt = nright - monoR;
+    const bool act = q < nq;
+    const int iq = min(monoL + q, max(nleft - 1, 0));
+    const uint32_t* dq = (const uint32_t*)(A.dl + ((size_t)b * A.capL + iq) * 32);
+    uint32_t Q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) Q[k] = (act || nleft > 0) ? dq[k] : 0u;
+    // BFMatcher(NORM_HAMMING).knnMatch(k = 2): ascending train scan, strict '<' (the rule of orbm_knn2)
+    int d0 = 256, d1 = 256, i0 = -1, i1 = -1;
+    const uint32_t* dt = (const uint32_t*)(A.dr + ((size_t)b * A.capR + monoR) * 32);
+    for (int j = 0; j < nt; j++) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __popc(Q[k] ^ dt[(size_t)j * 8 + k]);
+        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+        else if (d < d1) { d1 = d; i1 = j; }
+    }
+    if (!act || i1 < 0) return;
+    if (!((double)(float)d0 < (double)(float)d1 * 0.7)) return;
+    const orb_keypoint k1 = A.kl[(size_t)b * A.capL + monoL + q];
+    const orb_keypoint k2 = A.kr[(size_t)b * A.capR + monoR + i0];
+    float x3D[3];
+    const float dep = triangulate_matches(A.rig, k1, k2, A.rig.level_sigma2[min(max(k1.octave, 0), 15)], A.rig.level_sigma2[min(max(k2.octave, 0), 15)], x3D);
+    if (dep > 0.0001f) {
+        const int gl = monoL + q, gr = monoR + i0;
+        A.l2r[(size_t)b * A.capL + gl] = gr;
+        atomicMax(&A.r2l[(size_t)b * A.capR + gr], gl);     // the serial loop's last writer = the largest left index
+        A.depth[(size_t)b * A.capL + gl] = dep;
+        for (int c = 0; c < 3; c++) A.p3d[((size_t)b * A.capL + gl) * 3 + c] = x3D[c];
+        atomicAdd(&A.nmatches[b], 1);
+    }
+}
+
+extern "C" int orbf_stereo_fisheye_matches(const orb_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l, const int32_t* d_mono_l,
+                                           const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, const int32_t* d_mono_r, int cap_l,
+                                           int cap_r, int count_stride, int batch, const orbf_fisheye_rig* rig, int32_t* d_left_to_right,
+                                           int32_t* d_right_to_left, float* d_depth, float* d_p3d, int32_t* d_nmatches, void* stream) {
+    if (!d_kps_l || !d_desc_l || !d_n_l || !d_mono_l || !d_kps_r || !d_desc_r || !d_n_r || !d_mono_r || !rig || !d_left_to_right || !d_right_to_left ||
+        !d_depth || !d_p3d || !d_nmatches || cap_l <= 0 || cap_r <= 0 || count_stride <= 0 || batch < 0) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    FishArgs A{d_kps_l, d_desc_l, d_n_l, d_mono_l, d_kps_r, d_desc_r, d_n_r, d_mono_r, cap_l, cap_r, count_stride, *rig,
+               d_left_to_right, d_right_to_left, d_depth, d_p3d, d_nmatches};
+    hipLaunchKernelGGL(k_fisheye_init, dim3((std::max(cap_l, cap_r) + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_fisheye_match, dim3((cap_l + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }

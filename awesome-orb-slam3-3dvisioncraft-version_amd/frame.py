@@ -65,3 +65,35 @@ class FrameOps:
         self._check(self._L.orbf_stereo_from_rgbd(_ptr(kps), _ptr(kps_un), _ptr(counts), count_stride, cap, B, _ptr(depth), H * W, W, W, H,
                                                   float(mbf), _ptr(ur), _ptr(dz), _stream(kps)))
         return ur, dz
+
+
+class FisheyeRig(C.Structure):
+    """KannalaBrandt8 parameters of mpCamera / mpCamera2, mRlr / mtlr (Frame.cc:1242-1243), mvLevelSigma2"""
+    _fields_ = [("k_left", C.c_float * 8), ("k_right", C.c_float * 8), ("R_lr", C.c_float * 9), ("t_lr", C.c_float * 3), ("level_sigma2", C.c_float * 16)]
+
+    @classmethod
+    def make(cls, k_left, k_right, R_lr, t_lr, level_sigma2):
+        ls = list(level_sigma2) + [0.0] * (16 - len(level_sigma2))
+        return cls((C.c_float * 8)(*[float(v) for v in k_left]), (C.c_float * 8)(*[float(v) for v in k_right]),
+                   (C.c_float * 9)(*[float(v) for v in np.asarray(R_lr).reshape(-1)]), (C.c_float * 3)(*[float(v) for v in t_lr]), (C.c_float * 16)(*ls))
+
+    def as_array(self):
+        return np.array(list(self.k_left) + list(self.k_right) + list(self.R_lr) + list(self.t_lr), np.float32)
+
+
+def ComputeStereoFishEyeMatches(kps_l, desc_l, n_l, mono_l, kps_r, desc_r, n_r, mono_r, rig, *, lib=None, count_stride=1):
+    """Frame::ComputeStereoFishEyeMatches for a batch of fisheye stereo frames -> (mvLeftToRightMatch [B,capL], mvRightToLeftMatch [B,capR],
+    mvDepth [B,capL], mvStereo3Dpoints [B,capL,3], nMatches [B])"""
+    L = lib if lib is not None else _lib.load()
+    fn = L.orbf_stereo_fisheye_matches
+    vp, i32 = C.c_void_p, C.c_int
+    fn.restype = i32
+    fn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(FisheyeRig), vp, vp, vp, vp, vp, vp]
+    B, capL, capR = kps_l.shape[0], kps_l.shape[1], kps_r.shape[1]
+    l2r, r2l = _like(kps_l, (B, capL), np.int32), _like(kps_l, (B, capR), np.int32)
+    depth, p3d, nm = _like(kps_l, (B, capL), np.float32), _like(kps_l, (B, capL, 3), np.float32), _like(kps_l, (B,), np.int32)
+    rc = fn(_ptr(kps_l), _ptr(desc_l), _ptr(n_l), _ptr(mono_l), _ptr(kps_r), _ptr(desc_r), _ptr(n_r), _ptr(mono_r), capL, capR, count_stride, B,
+            C.byref(rig), _ptr(l2r), _ptr(r2l), _ptr(depth), _ptr(p3d), _ptr(nm), _stream(kps_l))
+    if rc != 0:
+        raise OrbHipError(rc, "orbf_stereo_fisheye_matches failed")
+    return l2r, r2l, depth, p3d, nm

@@ -161,6 +161,21 @@ int orbf_stereo_from_rgbd(const orb_keypoint* d_kps, const orb_keypoint* d_kps_u
                           int batch, const float* d_depth, size_t frame_stride, int row_stride, int width, int height, float mbf,
                           float* d_u_right, float* d_depth_out, void* stream);
 
+/* Frame::ComputeStereoFishEyeMatches (Frame.cc:1281-1325) with KannalaBrandt8::TriangulateMatches (KannalaBrandt8.cpp:334-400) for two fisheye
+ * cameras.  Left / right keypoints and descriptors as the two extractors wrote them; d_n_* = Nleft / Nright, d_mono_* = monoLeft / monoRight (the
+ * extractors' return values: keypoints [mono, N) lie in the lapping area), element stride count_stride (2 for orbx_extract_batch_dev counts:
+ * pass d_counts and d_counts + 1).  Outputs: mvLeftToRightMatch [batch][cap_l], mvRightToLeftMatch [batch][cap_r] (indices into the own camera's
+ * arrays, -1 = none), mvDepth [batch][cap_l] (-1), mvStereo3Dpoints [batch][cap_l][3] (left-camera frame; zeros where none), nMatches [batch]. */
+typedef struct orbf_fisheye_rig {
+    float k_left[8], k_right[8];   /* KannalaBrandt8 mvParameters fx fy cx cy k1..k4 of mpCamera / mpCamera2 */
+    float R_lr[9], t_lr[3];        /* mRlr (row-major), mtlr = the rotation / translation of mTlr (Frame.cc:1242-1243) */
+    float level_sigma2[16];        /* mvLevelSigma2 */
+} orbf_fisheye_rig;
+int orbf_stereo_fisheye_matches(const orb_keypoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l, const int32_t* d_mono_l,
+                                const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, const int32_t* d_mono_r, int cap_l,
+                                int cap_r, int count_stride, int batch, const orbf_fisheye_rig* rig, int32_t* d_left_to_right,
+                                int32_t* d_right_to_left, float* d_depth, float* d_p3d, int32_t* d_nmatches, void* stream);
+
 /* One projected map point = one query of a windowed search (the per-MapPoint values the reference computes before
  * calling Frame::GetFeaturesInArea: ORBmatcher.cc:88-103 for the local-map search, :2277-2309 for the motion model). */
 typedef struct orbm_query {

@@ -1,6 +1,6 @@
 // orbslam3_hip/Frame.h — adapter for the ORB_SLAM3::Frame constructor steps that sit between ORBextractor and ORBmatcher
 // (reference src/Frame.cc: UndistortKeyPoints :874-925, ComputeImageBounds :926-953 with the grid scalars :394-397,
-// ComputeStereoFromRGBD :1136-1157) over liborbhip.so (include/orbhip.h, "Frame constructor steps").
+// ComputeStereoFromRGBD :1136-1157, ComputeStereoFishEyeMatches :1281-1325) over liborbhip.so (include/orbhip.h, "Frame constructor steps").
 //
 // Host-vector form for a drop-in Frame; a device-resident pipeline calls orbf_* directly on the extractor's output slabs.
 #ifndef ORBSLAM3_HIP_FRAME_H
@@ -64,6 +64,47 @@ private:
     orbm_grid_params grid_{};
     int cols_, rows_;
     detail::DevBuf kps_, kpsUn_, cnt_, depth_, out_;
+};
+
+// Frame::ComputeStereoFishEyeMatches (Frame.cc:1281-1325) for a KannalaBrandt8 stereo rig, host-vector form.  mvKeys / mvKeysRight, mDescriptors /
+// mDescriptorsRight and monoLeft / monoRight as the two extractors returned them; rig = camera parameters, mRlr / mtlr, mvLevelSigma2.
+// mvStereo3Dpoints comes back as 3 floats per left keypoint (valid where mvLeftToRightMatch[i] >= 0).  Returns nMatches.
+class FisheyeStereoMatcher {
+public:
+    explicit FisheyeStereoMatcher(const orbf_fisheye_rig& rig) : rig_(rig) {}
+    int ComputeStereoFishEyeMatches(const std::vector<orb_keypoint>& mvKeys, const uint8_t* mDescriptors, int monoLeft,
+                                    const std::vector<orb_keypoint>& mvKeysRight, const uint8_t* mDescriptorsRight, int monoRight,
+                                    std::vector<int>& mvLeftToRightMatch, std::vector<int>& mvRightToLeftMatch, std::vector<float>& mvDepth,
+                                    std::vector<float>& mvStereo3Dpoints) {
+        const int nl = (int)mvKeys.size(), nr = (int)mvKeysRight.size();
+        mvLeftToRightMatch.assign(nl, -1); mvRightToLeftMatch.assign(nr, -1); mvDepth.assign(nl, -1.0f); mvStereo3Dpoints.assign((size_t)nl * 3, 0.0f);
+        if (nl == 0 || nr == 0) return 0;
+        const orb_keypoint* dkl = kl_.upload(mvKeys.data(), nl);
+        const orb_keypoint* dkr = kr_.upload(mvKeysRight.data(), nr);
+        const uint8_t* ddl = dl_.upload(mDescriptors, (size_t)nl * 32);
+        const uint8_t* ddr = dr_.upload(mDescriptorsRight, (size_t)nr * 32);
+        const int32_t c[4] = {nl, monoLeft, nr, monoRight};
+        const int32_t* dc = cnt_.upload(c, 4);
+        int32_t* l2r = (int32_t*)o1_.ensure((size_t)nl * 4);
+        int32_t* r2l = (int32_t*)o2_.ensure((size_t)nr * 4);
+        float* dep = (float*)o3_.ensure((size_t)nl * 4);
+        float* p3d = (float*)o4_.ensure((size_t)nl * 12);
+        int32_t* dn = (int32_t*)o5_.ensure(16);
+        if (orbf_stereo_fisheye_matches(dkl, ddl, dc, dc + 1, dkr, ddr, dc + 2, dc + 3, nl, nr, 1, 1, &rig_, l2r, r2l, dep, p3d, dn, nullptr) != ORB_OK)
+            throw std::runtime_error("orbf_stereo_fisheye_matches failed");
+        int n = 0;
+        orb_memcpy_d2h(mvLeftToRightMatch.data(), l2r, (size_t)nl * 4, nullptr);
+        orb_memcpy_d2h(mvRightToLeftMatch.data(), r2l, (size_t)nr * 4, nullptr);
+        orb_memcpy_d2h(mvDepth.data(), dep, (size_t)nl * 4, nullptr);
+        orb_memcpy_d2h(mvStereo3Dpoints.data(), p3d, (size_t)nl * 12, nullptr);
+        orb_memcpy_d2h(&n, dn, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        return n;
+    }
+
+private:
+    orbf_fisheye_rig rig_;
+    detail::DevBuf kl_, kr_, dl_, dr_, cnt_, o1_, o2_, o3_, o4_, o5_;
 };
 
 }  // namespace orbslam3_hip

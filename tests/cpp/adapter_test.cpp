@@ -35,6 +35,7 @@ int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_
                       const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
 void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
+int ofr_stereo_fisheye(const void*, const uint8_t*, int, int, const void*, const uint8_t*, int, int, const float*, const float*, int32_t*, int32_t*, float*, float*);
 void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
 void oib_optimize(void*, int, const void*, double*, int, const void*, int, const void*, int, double, double, double, int, double*);
 int omo_search_by_sim3(const void*, const uint8_t*, int, float, float, float, float, const void*, const uint8_t*, int, float, float, float, float, const void*,
@@ -340,6 +341,50 @@ int main() {
         FO.ComputeStereoFromRGBD(ks, un, depth.data(), 752, 40.0f, ur, dz);
         ofr_stereo_from_rgbd(ks.data(), oun.data(), 500, depth.data(), 752, 40.0f, our.data(), odz.data());
         CHECK(std::memcmp(ur.data(), our.data(), 500 * 4) == 0 && std::memcmp(dz.data(), odz.data(), 500 * 4) == 0);
+    }
+    // ---- Frame::ComputeStereoFishEyeMatches through FisheyeStereoMatcher vs the oracle (two KB8 cameras 10 cm apart, planted correspondences)
+    {
+        orbf_fisheye_rig rg{};
+        const float kb[8] = {190.978f, 190.973f, 254.932f, 256.897f, 0.0034823894f, 0.0007150348f, -0.0020532361f, 0.00020293673f};
+        for (int i = 0; i < 8; i++) { rg.k_left[i] = kb[i]; rg.k_right[i] = kb[i]; }
+        const float I9f[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int i = 0; i < 9; i++) rg.R_lr[i] = I9f[i];
+        rg.t_lr[0] = 0.1f;
+        for (int l = 0; l < 8; l++) rg.level_sigma2[l] = std::pow(1.44f, (float)l);
+        auto kbproj = [&](double X, double Y, double Z, float& u, float& v) {
+            const double r = std::sqrt(X * X + Y * Y), th = std::atan2(r, Z), psi = std::atan2(Y, X);
+            const double th2 = th * th, rd = th * (1 + kb[4] * th2 + kb[5] * th2 * th2 + kb[6] * th2 * th2 * th2 + kb[7] * th2 * th2 * th2 * th2);
+            u = (float)(kb[0] * rd * std::cos(psi) + kb[2]); v = (float)(kb[1] * rd * std::sin(psi) + kb[3]);
+        };
+        const int NS = 90, ML = 7, MR = 4;
+        std::vector<orb_keypoint> fl(ML + NS), fr(MR + NS);
+        std::vector<uint8_t> fdl((ML + NS) * 32), fdr((MR + NS) * 32);
+        for (auto& b8 : fdl) b8 = (uint8_t)rnd();
+        for (auto& b8 : fdr) b8 = (uint8_t)rnd();
+        for (int i = 0; i < ML; i++) fl[i] = orb_keypoint{(float)(30 + rnd() % 400), (float)(30 + rnd() % 400), 31.f, 0.f, 50.f, (int)(rnd() % 8), -1};
+        for (int i = 0; i < MR; i++) fr[i] = orb_keypoint{(float)(30 + rnd() % 400), (float)(30 + rnd() % 400), 31.f, 0.f, 50.f, (int)(rnd() % 8), -1};
+        for (int i = 0; i < NS; i++) {
+            const double X = ((int)(rnd() % 4000) - 2000) / 1000.0, Y = ((int)(rnd() % 3000) - 1500) / 1000.0, Z = 1.2 + (rnd() % 3000) / 1000.0;
+            float u, v;
+            kbproj(X, Y, Z, u, v);       fl[ML + i] = orb_keypoint{u, v, 31.f, 0.f, 50.f, (int)(rnd() % 8), -1};
+            kbproj(X - 0.1, Y, Z, u, v); fr[MR + (i * 7) % NS] = orb_keypoint{u, v, 31.f, 0.f, 50.f, (int)(rnd() % 8), -1};
+            std::memcpy(&fdr[(size_t)(MR + (i * 7) % NS) * 32], &fdl[(size_t)(ML + i) * 32], 32);
+            fdr[(size_t)(MR + (i * 7) % NS) * 32 + (i % 32)] ^= (uint8_t)(1u << (i % 8));
+        }
+        orbslam3_hip::FisheyeStereoMatcher FM(rg);
+        std::vector<int> l2r, r2l; std::vector<float> dep, p3;
+        const int nm2 = FM.ComputeStereoFishEyeMatches(fl, fdl.data(), ML, fr, fdr.data(), MR, l2r, r2l, dep, p3);
+        std::vector<int32_t> ol2r(fl.size()), or2l(fr.size()); std::vector<float> odep(fl.size()), op3(fl.size() * 3);
+        float rigarr[28];
+        for (int i = 0; i < 8; i++) { rigarr[i] = rg.k_left[i]; rigarr[8 + i] = rg.k_right[i]; }
+        for (int i = 0; i < 9; i++) rigarr[16 + i] = rg.R_lr[i];
+        for (int i = 0; i < 3; i++) rigarr[25 + i] = rg.t_lr[i];
+        const int onm2 = ofr_stereo_fisheye(fl.data(), fdl.data(), (int)fl.size(), ML, fr.data(), fdr.data(), (int)fr.size(), MR, rigarr, rg.level_sigma2, ol2r.data(),
+                                            or2l.data(), odep.data(), op3.data());
+        CHECK(nm2 == onm2 && nm2 > 60);
+        for (size_t i = 0; i < fl.size(); i++) { CHECK(l2r[i] == ol2r[i]); CHECK(std::fabs(dep[i] - odep[i]) <= 2e-6f * std::fabs(odep[i])); }
+        for (size_t i = 0; i < fr.size(); i++) CHECK(r2l[i] == or2l[i]);
+        for (int i = 0; i < ML; i++) CHECK(l2r[i] == -1);
     }
     // ---- N4 tail: Optimizer::LocalInertialBA through InertialBA vs the oracle
     {

@@ -522,3 +522,17 @@ def search_by_sim3(k1, d1, grid1, k2, d2, grid2, q12, q12desc, q21, q21desc):
                              *[float(g) for g in grid2], _p(np.ascontiguousarray(q12)), _p(np.ascontiguousarray(q12desc)),
                              _p(np.ascontiguousarray(q21)), _p(np.ascontiguousarray(q21desc)), _p(out))
     return out[:len(k1)], n
+
+
+def stereo_fisheye(kl, dl, mono_l, kr, dr, mono_r, rig_arr, level_sigma2):
+    kl, kr = np.ascontiguousarray(kl), np.ascontiguousarray(kr)
+    nl, nr = len(kl), len(kr)
+    l2r, r2l = np.zeros(max(nl, 1), np.int32), np.zeros(max(nr, 1), np.int32)
+    depth, p3d = np.zeros(max(nl, 1), np.float32), np.zeros((max(nl, 1), 3), np.float32)
+    L = lib()
+    L.ofr_stereo_fisheye.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rg, ls = np.ascontiguousarray(rig_arr, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    n = L.ofr_stereo_fisheye(_p(kl), _p(np.ascontiguousarray(dl)), nl, int(mono_l), _p(kr), _p(np.ascontiguousarray(dr)), nr, int(mono_r), _p(rg), _p(ls),
+                             _p(l2r), _p(r2l), _p(depth), _p(p3d))
+    return l2r[:nl], r2l[:nr], depth[:nl], p3d[:nl], n

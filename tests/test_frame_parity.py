@@ -114,3 +114,81 @@ def test_emu_frame_ops_match_oracle(emu_lib, cam, size):
                          ids=["euroc", "tum1_k3", "no_distortion"])
 def test_hip_frame_ops_match_oracle(hip_lib, cam, size):
     check_frame_ops(hip_lib, "hip", cam, *size)
+
+
+# ---- Frame::ComputeStereoFishEyeMatches (two KannalaBrandt8 cameras) ------------------------------------------------------------------
+from orbhip.frame import ComputeStereoFishEyeMatches, FisheyeRig  # noqa: E402
+from orbhip.lba import _kb8_project, _rodrigues  # noqa: E402
+
+KB_L = np.float32([190.978, 190.973, 254.932, 256.897, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673])   # TUM_512.yaml-like
+KB_R = np.float32([190.442, 190.434, 252.597, 254.917, 0.0034003171, 0.0017662670, -0.0026630025, 0.00032995968])
+
+
+def fisheye_frame(seed, n_stereo=260, n_mono_l=90, n_mono_r=70):
+    """One fisheye stereo frame: 3-D points seen by both cameras (lapping area) + monocular-only keypoints in front of them in the arrays."""
+    rng = np.random.default_rng(seed)
+    R_lr = _rodrigues(np.array([0.004, -0.012, 0.003])).astype(np.float32); t_lr = np.float32([0.101, -0.0011, 0.0006])   # x_l = R_lr x_r + t_lr
+    X = np.stack([rng.uniform(-3, 3, n_stereo), rng.uniform(-2, 2, n_stereo), rng.uniform(1.2, 9, n_stereo)], 1)     # left-camera frame
+    Xr = (X - t_lr) @ R_lr.astype(np.float64)                                                                        # R_lr^T (x - t)
+    ul, vl, _ = _kb8_project(KB_L.astype(np.float64), X); ur, vr, _ = _kb8_project(KB_R.astype(np.float64), Xr)
+
+    def cam(u, v, n_mono):
+        n = n_mono + len(u)
+        k = np.zeros(n, KP_DTYPE)
+        k["x"][:n_mono] = rng.uniform(20, 490, n_mono); k["y"][:n_mono] = rng.uniform(20, 490, n_mono)
+        k["x"][n_mono:] = u + rng.normal(0, 0.4, len(u)); k["y"][n_mono:] = v + rng.normal(0, 0.4, len(u))
+        k["octave"] = rng.integers(0, 8, n); k["size"], k["angle"], k["response"], k["class_id"] = 31, rng.uniform(0, 360, n), 50, -1
+        return k
+    kl, kr = cam(ul, vl, n_mono_l), cam(ur, vr, n_mono_r)
+    base = rng.integers(0, 256, (n_stereo, 32), dtype=np.uint8)
+    dl = np.concatenate([rng.integers(0, 256, (n_mono_l, 32), dtype=np.uint8), base])
+    flips = np.zeros((n_stereo, 256), np.uint8)
+    for i in range(n_stereo):
+        flips[i, rng.choice(256, int(rng.integers(0, 40)), replace=False)] = 1
+    dr = np.concatenate([rng.integers(0, 256, (n_mono_r, 32), dtype=np.uint8), base ^ np.packbits(flips, axis=1, bitorder="little")])
+    # a few gross geometric outliers (wrong right position) and near-duplicate descriptors (fail the ratio test)
+    nb = min(25, n_stereo // 4)
+    bad = rng.choice(n_stereo, nb, replace=False)
+    kr["x"][n_mono_r + bad[:nb // 2]] += rng.uniform(15, 60, nb // 2)
+    dr[n_mono_r + bad[nb // 2:]] = dr[n_mono_r + (bad[nb // 2:] + 1) % n_stereo]
+    perm = rng.permutation(n_stereo)                       # right-camera order is unrelated to the left one
+    kr[n_mono_r:] = kr[n_mono_r:][perm]; dr[n_mono_r:] = dr[n_mono_r:][perm]
+    sig2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2
+    return kl, dl, n_mono_l, kr, dr, n_mono_r, FisheyeRig.make(KB_L, KB_R, R_lr, t_lr, sig2), sig2
+
+
+def check_fisheye(lib, backend):
+    dev = to_dev(backend)
+    frames = [fisheye_frame(50), fisheye_frame(51, n_stereo=120, n_mono_l=0, n_mono_r=200), fisheye_frame(52, n_stereo=1, n_mono_l=5, n_mono_r=5)]
+    rig = frames[0][6]
+    B, capL, capR = len(frames), max(len(f[0]) for f in frames) + 3, max(len(f[3]) for f in frames) + 7
+    kl = np.zeros((B, capL), KP_DTYPE); kr = np.zeros((B, capR), KP_DTYPE); dl = np.zeros((B, capL, 32), np.uint8); dr = np.zeros((B, capR, 32), np.uint8)
+    n = np.zeros((4, B), np.int32)
+    for b, f in enumerate(frames):
+        kl[b, :len(f[0])], dl[b, :len(f[0])], kr[b, :len(f[3])], dr[b, :len(f[3])] = f[0], f[1], f[3], f[4]
+        n[:, b] = len(f[0]), f[2], len(f[3]), f[5]
+    v7 = lambda k: k.view(np.float32).reshape(B, -1, 7)
+    out = ComputeStereoFishEyeMatches(dev(v7(kl)), dev(dl), dev(n[0].copy()), dev(n[1].copy()), dev(v7(kr)), dev(dr), dev(n[2].copy()), dev(n[3].copy()), rig, lib=lib)
+    l2r, r2l, depth, p3d, nm = [to_host(o) for o in out]
+    for b, f in enumerate(frames):
+        ol2r, or2l, od, op, on = O.stereo_fisheye(f[0], f[1], f[2], f[3], f[4], f[5], rig.as_array(), f[7])
+        nl, nr = len(f[0]), len(f[3])
+        assert nm[b] == on and np.array_equal(l2r[b, :nl], ol2r) and np.array_equal(r2l[b, :nr], or2l), b
+        # rule R4 leaves libm's double atan2 / tan / cos as the only platform dependence: identical decisions, floats to ~1 ulp
+        assert np.allclose(depth[b, :nl], od, rtol=2e-6, atol=0) and np.allclose(p3d[b, :nl], op, rtol=2e-6, atol=1e-7), b
+        assert (l2r[b, nl:] == -1).all() and (depth[b, nl:] == -1).all()
+    ol2r, _, od, op, on = O.stereo_fisheye(*frames[0][:6], rig.as_array(), frames[0][7])
+    # planted pairs nearer than ~5 m are recovered (baseline 0.1 m: beyond that the cos-parallax gate 0.9998 refuses them); the displaced and
+    # the ambiguous ones are rejected; monocular keypoints never match
+    assert 60 < on < 200 and (ol2r[:frames[0][2]] == -1).all()
+    m = ol2r >= 0
+    assert np.median(np.abs(od[m] - op[m, 2])) == 0 and od[m].min() > 1.0 and od[m].max() < 5.5
+
+
+def test_emu_stereo_fisheye_matches(emu_lib):
+    check_fisheye(emu_lib, "emu")
+
+
+@pytest.mark.gpu
+def test_hip_stereo_fisheye_matches(hip_lib):
+    check_fisheye(hip_lib, "hip")
