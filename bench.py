@@ -13,6 +13,7 @@ import argparse
 import json
 import os
 import sys
+import traceback
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -408,6 +409,48 @@ def main():
             extra["stereo"] = {"compute_stereo_matches_ms_per_batch": round(dtsm * 1e3, 3), "stereo_frames_per_s": round(B / dtst, 1),
                                "mean_stereo_points_per_frame": round(nst, 1),
                                "what": "2 x ORBextractor + Frame::ComputeStereoMatches per stereo frame (bf = 47.9, baseline 0.11 m)"}
+        # ---- extra leg 6 (BASELINE configs[3] shape: fisheye stereo, 1280x720, nFeatures = 1500): two extractors with lapping areas +
+        #      Frame::ComputeStereoFishEyeMatches (2-NN, ratio test, KannalaBrandt8::TriangulateMatches); images are synthetic, so the
+        #      triangulation gates see arbitrary geometry — the leg measures the arithmetic, not a calibration
+        if not args.headline_only:
+            try:
+                from orbhip.frame import ComputeStereoFishEyeMatches, FisheyeRig
+                FB, FW, FH, FN = 128, 1280, 720, 1500
+                from orbhip.synth import synth_image
+                base = [torch.from_numpy(synth_image(900 + i + 16 * rank, FW, FH)).to(dev) for i in range(8)]
+                fL = torch.stack([base[i % 8] for i in range(FB)]).contiguous()
+                fR = torch.stack([torch.roll(base[i % 8], shifts=-(8 + 2 * (i % 8)), dims=1) for i in range(FB)]).contiguous()
+                eL = orbhip.ORBextractor(FN, 1.2, 8, 20, 7, device=local_rank, max_batch=FB)
+                eR = orbhip.ORBextractor(FN, 1.2, 8, 20, 7, device=local_rank, max_batch=FB)
+                lap = (300, 980)
+                kbp = [190.978 * 2.5, 190.973 * 2.5, FW / 2.0, FH / 2.0, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673]
+                rigF = FisheyeRig.make(kbp, kbp, np.eye(3), [0.1, 0.0, 0.0], [float(v) for v in (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2])
+                oL, oR = eL.extract_batch(fL, lap), eR.extract_batch(fR, lap)
+
+                def fish():
+                    cl, cr = oL[2].view(-1), oR[2].view(-1)
+                    return ComputeStereoFishEyeMatches(oL[0], oL[1], cl, cl[1:], oR[0], oR[1], cr, cr[1:], rigF, count_stride=2)
+                fm = fish()
+                barrier()
+                t9 = time.perf_counter()
+                for _ in range(3):
+                    fm = fish()
+                barrier()
+                dtf = (time.perf_counter() - t9) / 3
+                t10 = time.perf_counter()
+                for _ in range(3):
+                    oL = eL.extract_batch(fL, lap, out=oL); oR = eR.extract_batch(fR, lap, out=oR)
+                    fm = fish()
+                barrier()
+                dtff = (time.perf_counter() - t10) / 3
+                cn = oL[2].cpu().numpy()
+                extra["fisheye_stereo"] = {"stereo_frames_per_s": round(FB / dtff, 1), "compute_stereo_fisheye_matches_ms_per_batch": round(dtf * 1e3, 3),
+                                           "frames_per_batch": FB, "size": "%dx%d" % (FW, FH), "nfeatures": FN, "mean_keypoints_left": float(cn[:, 0].mean()),
+                                           "mean_lapping_keypoints_left": float((cn[:, 0] - cn[:, 1]).mean()), "mean_matches": float(fm[4].float().mean().item()),
+                                           "what": "2 x ORBextractor (lapping area 300..980) + Frame::ComputeStereoFishEyeMatches per fisheye stereo frame"}
+            except Exception as err:   # noqa: BLE001
+                extra["fisheye_stereo_error"] = "%s: %s" % (type(err).__name__, err)
+                sys.stderr.write(traceback.format_exc())
     except Exception as err:   # an extra leg must never cost the headline line
         import traceback
         extra["error"] = "%s: %s" % (type(err).__name__, err)
