@@ -951,3 +951,256 @@ extern "C" int liba_compute_errors(const liba_problem* prob, int batch, double* 
     hipLaunchKernelGGL(k_liba_errors, dim3(batch), dim3(LIBA_T), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
+
+// ================================================================================================================================================
+// Optimizer::PoseInertialOptimizationLastKeyFrame (reference src/Optimizer.cc:7665-8067): the per-frame optimisation of the inertial tracking
+// modes.  One wave per frame runs the whole schedule in a single launch: 4 rounds x 10 Gauss-Newton iterations (OptimizationAlgorithmGaussNewton +
+// LinearSolverDense, :7669-7672) over the frame's pose / velocity / biases (15 unknowns) with EdgeMonoOnlyPose / EdgeStereoOnlyPose, EdgeInertial,
+// EdgeGyroRW, EdgeAccRW; chi2 re-classification between rounds (bClose rule, Huber dropped for the last round); the < 30 inliers recovery pass; the
+// 15x15 Hessian of the final state for the next frame's prior.  Lanes stride over the reprojection edges (butterfly sums in a fixed order); the 9x9
+// inertial block, the random-walk blocks and the dense Cholesky are spread over the lanes through LDS.
+// ================================================================================================================================================
+struct PoseInertialArgs {
+    liba_keyframe* frames; const liba_keyframe* keyframes; const liba_rig* rigs; int rigStride;
+    const pose_edge* edges; const int32_t* nEdges; int capE; const liba_imu_edge* imu; int recInit;
+    uint8_t* outlier; double* H; int32_t* nGood;
+};
+#define PIK_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+template <bool JAC>
+static __device__ __forceinline__ void pose_edge_linearize(const pose_edge& E, const liba_keyframe& kf, const liba_rig& rig, VLin& L) {
+    lba_edge V;
+    V.pose = 0; V.point = 0; V.kind = (int16_t)(E.kind & 0xFF); V.cam = E.cam; V.obs[0] = E.obs[0]; V.obs[1] = E.obs[1]; V.obs[2] = E.obs[2]; V.inv_sigma2 = E.inv_sigma2;
+    const double X[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
+    vis_linearize<JAC>(V, kf, rig, X, 0.0, 0.0, L);
+}
+
+static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int ne = min(A.nEdges[b], A.capE);
+    // LDS: F (liba_keyframe) | Hs[225] | bs[15] | xs[15] | J9[81] | OJ[81] | e9[9] | Oe[9] | chiLast[capE] | level[capE] u8 | outl[capE] u8 | dep[capE] u8
+    liba_keyframe& F = *(liba_keyframe*)orb_smem;
+    double* Hs = (double*)(orb_smem + ((sizeof(liba_keyframe) + 15) & ~(size_t)15));
+    double* bs = Hs + 225;
+    double* xs = bs + 15;
+    double* J9 = xs + 15;
+    double* OJ = J9 + 81;
+    double* e9s = OJ + 81;
+    double* Oes = e9s + 9;
+    double* chiLast = Oes + 9;
+    uint8_t* level = (uint8_t*)(chiLast + A.capE);
+    uint8_t* outl = level + A.capE;
+    uint8_t* dep = outl + A.capE;
+    const liba_keyframe& K = A.keyframes[b];
+    const liba_rig& rig = A.rigs[(size_t)b * A.rigStride];
+    const liba_imu_edge& E = A.imu[b];
+    const pose_edge* edges = A.edges + (size_t)b * A.capE;
+    for (int t = lane; t < (int)LIBA_KFD; t += 64) ((double*)&F)[t] = ((const double*)&A.frames[b])[t];
+    for (int e = lane; e < ne; e += 64) { chiLast[e] = 0.0; level[e] = 0; outl[e] = 0; dep[e] = 1; }
+    PIK_WAVE_SYNC()
+    const double thMono = (double)sqrtf(5.991f), thStereo = (double)sqrtf(7.815f);
+    const float chi2Mono[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    int nBad = 0, nInliers = 0;
+    bool robust = true;
+    VLin L;
+    // the 9x9 block J^T Omega J of EdgeInertial over the frame's (pose, velocity) columns, left in OJ-free storage: Hs[a*15+c] gets it added
+    auto inertial_blocks = [&](const bool withRhs) {
+        if (lane == 0) {
+            double e9[9], eR[9], J[216];
+            inertial_error(E, K, F, e9, eR);
+            inertial_jacobian(E, K, F, e9, eR, J);
+            for (int r = 0; r < 9; r++) { for (int c = 0; c < 9; c++) J9[r * 9 + c] = J[r * 24 + 15 + c]; e9s[r] = e9[r]; }
+        }
+        PIK_WAVE_SYNC()
+        for (int t = lane; t < 90; t += 64) {
+            if (t < 81) { const int r = t / 9, c = t - r * 9; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * J9[q * 9 + c]; OJ[t] = s; }
+            else if (withRhs) { const int r = t - 81; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * e9s[q]; Oes[r] = s; }
+        }
+        PIK_WAVE_SYNC()
+    };
+    for (int it = 0; it < 4; it++) {
+        for (int gn = 0; gn < 10; gn++) {
+            // ---- reprojection edges of level 0: H_pose (21 unique) + b_pose (6), fixed-order butterfly
+            double acc[27];
+#pragma unroll
+            for (int i = 0; i < 27; i++) acc[i] = 0.0;
+            for (int e = lane; e < ne; e += 64) {
+                if (level[e]) continue;
+                const pose_edge PE = edges[e];
+                pose_edge_linearize<true>(PE, F, rig, L);
+                chiLast[e] = L.chi2;
+                double rho1 = 1.0;
+                if (robust) { const double d = (PE.kind & 0xFF) == LBA_EDGE_STEREO ? thStereo : thMono; if (L.chi2 > d * d) rho1 = d / sqrt(L.chi2); }
+                const double wt = rho1 * (double)PE.inv_sigma2;
+                int idx = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int r = c; r < 6; r++) acc[idx++] += wt * (L.B[r] * L.B[c] + L.B[6 + r] * L.B[6 + c] + L.B[12 + r] * L.B[12 + c]);
+#pragma unroll
+                for (int r = 0; r < 6; r++) acc[21 + r] += -wt * (L.B[r] * L.e[0] + L.B[6 + r] * L.e[1] + L.B[12 + r] * L.e[2]);
+            }
+#pragma unroll
+            for (int i = 0; i < 27; i++)
+                for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
+            inertial_blocks(true);
+            // ---- assemble H (column-major 15x15, full) and b
+            for (int t = lane; t < 225; t += 64) {
+                const int c = t / 15, r = t - c * 15;
+                double v = 0.0;
+                if (r < 6 && c < 6) {
+                    const int lo = r < c ? r : c, hi = r < c ? c : r;   // acc is packed by columns of the lower triangle: (c, r >= c)
+                    int idx = 0;
+                    for (int cc = 0; cc < lo; cc++) idx += 6 - cc;
+                    idx += hi - lo;
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 21; k++) if (k == idx) a = acc[k];
+                    v = a;
+                }
+                if (r < 9 && c < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + r] * OJ[q * 9 + c]; v += s; }
+                if (r >= 9 && c >= 9 && (r - 9) / 3 == (c - 9) / 3) { const double* Om = r < 12 ? E.info_g : E.info_a; v += Om[((r - 9) % 3) * 3 + (c - 9) % 3]; }
+                Hs[t] = v;
+            }
+            if (lane < 15) {
+                double v = 0.0;
+                if (lane < 6) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) if (k == lane) v = acc[21 + k];
+                }
+                if (lane < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + lane] * Oes[q]; v += -s; }
+                else {
+                    const int w2 = (lane - 9) / 3, r = (lane - 9) % 3;
+                    const double* Om = w2 == 0 ? E.info_g : E.info_a;
+                    double oe = 0;
+                    for (int q = 0; q < 3; q++) oe += Om[r * 3 + q] * (w2 == 0 ? F.bg[q] - K.bg[q] : F.ba[q] - K.ba[q]);
+                    v = -oe;
+                }
+                bs[lane] = v; xs[lane] = v;
+            }
+            PIK_WAVE_SYNC()
+            // ---- dense Cholesky of the 15x15 system (lower triangle of the column-major Hs), columns spread over the lanes
+            bool ok = true;
+            for (int k = 0; k < 15; k++) {
+                const double dkk = Hs[k * 15 + k];
+                if (!(dkk > 0) || !(dkk < 1.7e308)) { ok = false; break; }   // uniform
+                const double sq = sqrt(dkk);
+                PIK_WAVE_SYNC()
+                if (lane >= k && lane < 15) Hs[k * 15 + lane] = lane == k ? sq : Hs[k * 15 + lane] / sq;
+                PIK_WAVE_SYNC()
+                for (int t = lane; t < 225; t += 64) {
+                    const int j = t / 15, i = t - j * 15;
+                    if (j > k && i >= j) Hs[j * 15 + i] -= Hs[k * 15 + i] * Hs[k * 15 + j];
+                }
+                PIK_WAVE_SYNC()
+            }
+            if (!ok) break;
+            if (lane == 0) {
+                for (int i = 0; i < 15; i++) { double v = xs[i]; for (int k = 0; k < i; k++) v -= Hs[k * 15 + i] * xs[k]; xs[i] = v / Hs[i * 15 + i]; }
+                for (int i = 14; i >= 0; i--) { double v = xs[i]; for (int k = i + 1; k < 15; k++) v -= Hs[i * 15 + k] * xs[k]; xs[i] = v / Hs[i * 15 + i]; }
+                double x[15];
+                for (int i = 0; i < 15; i++) x[i] = xs[i];
+                pose_update(F, rig, x);
+                for (int i = 0; i < 3; i++) { F.v[i] += x[6 + i]; F.bg[i] += x[9 + i]; F.ba[i] += x[12 + i]; }
+            }
+            PIK_WAVE_SYNC()
+        }
+        // ---- classification (:7838-7896): chi2() of an edge that was optimised is the value of the last computeActiveErrors (state before the final
+        //      update); outlier edges are re-evaluated at the current state; isDepthPositive() always reads the current state
+        const float chi2close = 1.5f * chi2Mono[it];
+        int bad = 0, good = 0;
+        for (int e0 = 0; e0 < ne; e0 += 64) {
+            const int e = e0 + lane;
+            bool isBad = false, act = e < ne;
+            if (act) {
+                const pose_edge PE = edges[e];
+                pose_edge_linearize<false>(PE, F, rig, L);
+                if (outl[e]) chiLast[e] = L.chi2;
+                const float chi2 = (float)chiLast[e];
+                if ((PE.kind & 0xFF) != LBA_EDGE_STEREO) {
+                    const bool bClose = (PE.kind & 0x100) != 0;
+                    isBad = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !L.depthPositive;
+                } else isBad = chi2 > chi2Stereo[it];
+                outl[e] = isBad; level[e] = isBad;
+            }
+            bad += __popcll(__ballot(act && isBad));
+            good += __popcll(__ballot(act && !isBad));
+        }
+        nBad = bad; nInliers = good;
+        if (it == 2) robust = false;
+        PIK_WAVE_SYNC()
+        if (ne + 3 < 10) break;
+    }
+    if (nInliers < 30 && !A.recInit) {   // :7904-7934
+        int bad = 0;
+        for (int e0 = 0; e0 < ne; e0 += 64) {
+            const int e = e0 + lane;
+            bool stillBad = false;
+            if (e < ne) {
+                const pose_edge PE = edges[e];
+                pose_edge_linearize<false>(PE, F, rig, L);
+                if ((float)L.chi2 < ((PE.kind & 0xFF) == LBA_EDGE_STEREO ? 24.f : 18.f)) outl[e] = 0; else stillBad = true;
+            }
+            bad += __popcll(__ballot(stillBad));
+        }
+        nBad = bad;
+        PIK_WAVE_SYNC()
+    }
+    // ---- outputs: state, outlier flags, the Hessian of the final state (:8040-8062)
+    {
+        double acc[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc[i] = 0.0;
+        for (int e = lane; e < ne; e += 64) {
+            if (outl[e]) continue;
+            const pose_edge PE = edges[e];
+            pose_edge_linearize<true>(PE, F, rig, L);
+            const double wt = (double)PE.inv_sigma2;
+            int idx = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int r = c; r < 6; r++) acc[idx++] += wt * (L.B[r] * L.B[c] + L.B[6 + r] * L.B[6 + c] + L.B[12 + r] * L.B[12 + c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++)
+            for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
+        inertial_blocks(false);
+        double* Hout = A.H + (size_t)b * 225;
+        for (int t = lane; t < 225; t += 64) {
+            const int r = t / 15, c = t - r * 15;   // row-major output
+            double v = 0.0;
+            if (r < 6 && c < 6) {
+                const int lo = r < c ? r : c, hi = r < c ? c : r;
+                int idx = 0;
+                for (int cc = 0; cc < lo; cc++) idx += 6 - cc;
+                idx += hi - lo;
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < 21; k++) if (k == idx) a = acc[k];
+                v = a;
+            }
+            if (r < 9 && c < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + r] * OJ[q * 9 + c]; v += s; }
+            if (r >= 9 && c >= 9 && (r - 9) / 3 == (c - 9) / 3) { const double* Om = r < 12 ? E.info_g : E.info_a; v += Om[((r - 9) % 3) * 3 + (c - 9) % 3]; }
+            Hout[t] = v;
+        }
+    }
+    for (int t = lane; t < (int)LIBA_KFD; t += 64) ((double*)&A.frames[b])[t] = ((const double*)&F)[t];
+    for (int e = lane; e < A.capE; e += 64) A.outlier[(size_t)b * A.capE + e] = e < ne ? outl[e] : 0;
+    if (lane == 0) A.nGood[b] = ne - nBad;
+}
+
+extern "C" int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyframe* d_keyframes, const liba_rig* d_rigs, int rig_stride, const pose_edge* d_edges,
+                                     const int32_t* d_n_edges, int cap_e, const liba_imu_edge* d_imu, int batch, int rec_init, uint8_t* d_outlier,
+                                     double* d_H, int32_t* d_n_good, void* stream) {
+    if (!d_frames || !d_keyframes || !d_rigs || !d_edges || !d_n_edges || !d_imu || !d_outlier || !d_H || !d_n_good || cap_e <= 0 || batch < 0 || rig_stride < 0)
+        return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    PoseInertialArgs A{d_frames, d_keyframes, d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, rec_init, d_outlier, d_H, d_n_good};
+    const size_t smem = ((sizeof(liba_keyframe) + 15) & ~(size_t)15) + (size_t)(225 + 15 + 15 + 81 + 81 + 9 + 9 + cap_e) * 8 + (size_t)3 * cap_e + 16;
+    if (smem > 160 * 1024) return ORB_E_INVALID;
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial_kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_pose_inertial_kf, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}

@@ -279,3 +279,54 @@ class InertialWindows:
     def points(self):
         a = self.d["points"]
         return a if isinstance(a, np.ndarray) else a.cpu().numpy()
+
+
+# ---- Optimizer::PoseInertialOptimizationLastKeyFrame (tracking, inertial modes) -------------------------------------------------------
+from .lba import POSE_EDGE_DTYPE  # noqa: E402
+
+EDGE_CLOSE = 0x100   # pose_edge.kind flag: pFrame->mvpMapPoints[idx]->mTrackDepth < 10.f (Optimizer.cc:7852)
+
+
+def synth_inertial_frame(seed=0, n_pts=300, kind="mono", outliers=0.08):
+    """-> dict(frame, keyframe, rig, edges, imu): one tracked frame, its last key frame (fixed) and the preintegration between them."""
+    w = synth_inertial_window(seed, n_opt=1, n_fixed_vis=0, n_pts=n_pts, max_obs=2, kind=kind, outliers=outliers)
+    rng = np.random.default_rng(seed + 991)
+    e = w["edges"][w["edges"]["pose"] == 1]
+    pe = np.zeros(len(e), POSE_EDGE_DTYPE)
+    pe["xw"] = w["points"][e["point"]].astype(np.float32)
+    pe["obs"], pe["inv_sigma2"], pe["cam"] = e["obs"], e["inv_sigma2"], e["cam"]
+    pe["kind"] = e["kind"] | np.where(rng.random(len(e)) < 0.6, EDGE_CLOSE, 0).astype(np.int16)
+    imu = w["imu"][:1].copy()
+    imu["huber"] = 0.0
+    imu["info"] = imu["info"] * 1e2     # synth_inertial_window scaled the oldest edge's information by 1e-2
+    return {"frame": w["kfs"][1:2].copy(), "keyframe": w["kfs"][0:1].copy(), "rig": w["rig"], "edges": pe, "imu": imu}
+
+
+def pose_inertial_optimization_last_keyframe(frames, keyframes, rigs, edges, n_edges, imu, to_dev, *, rec_init=False, lib=None):
+    """Batched Optimizer::PoseInertialOptimizationLastKeyFrame.  frames / keyframes: KF_DTYPE [B]; rigs: list of Rig (len B) or one Rig;
+    edges: POSE_EDGE_DTYPE [B, cap_e]; n_edges int32 [B]; imu: IMU_EDGE_DTYPE [B].  -> (frames' [B] KF_DTYPE, outlier [B, cap_e] u8, H [B,15,15], n_good [B])"""
+    L = lib if lib is not None else _lib.load()
+    fn = L.liba_pose_inertial_kf
+    vp, i32 = C.c_void_p, C.c_int
+    fn.restype = i32
+    fn.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
+    B, cap_e = edges.shape[0], edges.shape[1]
+    rl = rigs if isinstance(rigs, (list, tuple)) else [rigs]
+    rig_bytes = np.frombuffer(b"".join(bytes(r) for r in rl), np.uint8).copy()
+    d_f = to_dev(np.ascontiguousarray(frames).view(np.uint8).reshape(B, -1).copy())
+    d_k = to_dev(np.ascontiguousarray(keyframes).view(np.uint8).reshape(B, -1))
+    d_r = to_dev(rig_bytes)
+    d_e = to_dev(np.ascontiguousarray(edges).view(np.uint8).reshape(B, -1))
+    d_n = to_dev(np.ascontiguousarray(n_edges, np.int32))
+    d_i = to_dev(np.ascontiguousarray(imu).view(np.uint8).reshape(B, -1))
+    d_o, d_H, d_g = to_dev(np.zeros((B, cap_e), np.uint8)), to_dev(np.zeros((B, 225))), to_dev(np.zeros(B, np.int32))
+    stream = None
+    if not isinstance(d_f, np.ndarray):
+        import torch
+        stream = C.c_void_p(torch.cuda.current_stream(d_f.device).cuda_stream)
+    rc = fn(_ptr(d_f), _ptr(d_k), _ptr(d_r), 1 if len(rl) > 1 else 0, _ptr(d_e), _ptr(d_n), cap_e, _ptr(d_i), B, int(rec_init), _ptr(d_o), _ptr(d_H), _ptr(d_g),
+            stream)
+    if rc != 0:
+        raise OrbHipError(rc, "liba_pose_inertial_kf failed")
+    host = lambda a: a if isinstance(a, np.ndarray) else a.cpu().numpy()
+    return host(d_f).reshape(B, -1).view(KF_DTYPE).reshape(B), host(d_o), host(d_H).reshape(B, 15, 15), host(d_g)

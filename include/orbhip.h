@@ -501,6 +501,19 @@ int liba_optimize(const liba_problem* prob, int batch, double lambda_init, int i
 int liba_compute_errors(const liba_problem* prob, int batch, double* d_vis_chi2, uint8_t* d_vis_depth_pos, double* d_imu_chi2,
                         double* d_robust_sum, void* stream);
 
+/* Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool bRecInit) (reference src/Optimizer.cc:7665-8067): the per-frame optimisation of
+ * the inertial tracking modes (Tracking.cc: after TrackLocalMap's matching when the map was updated).  Frame pose / velocity / gyro bias / acc bias free
+ * (15 unknowns), the last key frame's vertices fixed; EdgeMonoOnlyPose / EdgeStereoOnlyPose (G2oTypes.h:387-421, 463-491) as pose_edge records
+ * (kind = LBA_EDGE_MONO / LBA_EDGE_STEREO, cam = camera of the rig, kind |= LIBA_EDGE_CLOSE iff mTrackDepth < 10), one EdgeInertial + EdgeGyroRW +
+ * EdgeAccRW (liba_imu_edge with kf1 = key frame, kf2 = frame; huber ignored).  4 rounds x optimize(10) of g2o's Gauss-Newton with the dense solver,
+ * chi2 re-classification {12, 7.5, 5.991, 5.991} / {15.6, 9.8, 7.815, 7.815} with the 1.5x bClose rule, Huber dropped for the last round, the
+ * < 30 inliers recovery pass.  One wave per frame, single launch.  Outputs: d_frames updated in place (SetImuPoseVelocity + mImuBias), mvbOutlier per
+ * edge, the 15x15 row-major Hessian of the final state (ConstraintPoseImu::H, :8040-8062), and the return value nInitialCorrespondences - nBad. */
+#define LIBA_EDGE_CLOSE 0x100
+int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyframe* d_keyframes, const liba_rig* d_rigs, int rig_stride, const pose_edge* d_edges,
+                          const int32_t* d_n_edges, int cap_e, const liba_imu_edge* d_imu, int batch, int rec_init, uint8_t* d_outlier, double* d_H,
+                          int32_t* d_n_good, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device-memory helpers so that adapters written against this header need no HIP headers.
  * ------------------------------------------------------------------------------------------------------- */

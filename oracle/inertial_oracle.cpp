@@ -590,3 +590,145 @@ void oib_optimize(void* kfs_, int n_kf, const void* rig_, double* points, int n_
     if (stats) { stats[0] = it; stats[1] = P.robustChi(); stats[2] = lambda; stats[3] = trialsTotal; stats[4] = chi0; }
 }
 }  // extern "C"
+
+// ---- Optimizer::PoseInertialOptimizationLastKeyFrame (reference src/Optimizer.cc:7665-8067) --------------------------------------------
+// One frame: VertexPose / Velocity / GyroBias / AccBias free, the last key frame's four vertices fixed; EdgeMonoOnlyPose / EdgeStereoOnlyPose
+// (G2oTypes.h:387-421, 463-491; G2oTypes.cc:371-389, 420-441), EdgeInertial, EdgeGyroRW, EdgeAccRW; OptimizationAlgorithmGaussNewton with
+// LinearSolverDense (:7669-7672); 4 rounds x optimize(10), chi2 re-classification with the bClose rule, Huber dropped for the last round,
+// the < 30 inliers recovery pass, and the 15x15 Hessian of the final state handed to the next frame (ConstraintPoseImu, :8040-8062).
+namespace {
+struct PEdge { float xw[3]; float obs[3]; float inv_sigma2; int16_t kind, cam; };   // == pose_edge; kind bit 8 (0x100) = bClose (mTrackDepth < 10)
+struct PLin { int D; double e[3], B[18], chi2; bool depthPositive; };
+void poseEdgeLinearize(const PEdge& E, const Kf& kf, const Rig& rig, bool jac, PLin& L) {
+    VisEdge V; V.kf = 0; V.point = 0; V.kind = (int16_t)(E.kind & 0xFF); V.cam = E.cam; V.obs[0] = E.obs[0]; V.obs[1] = E.obs[1]; V.obs[2] = E.obs[2]; V.inv_sigma2 = E.inv_sigma2;
+    const double X[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
+    VLin T;
+    visLinearize(V, kf, rig, X, 0, 0, jac, T);
+    L.D = T.D; memcpy(L.e, T.e, sizeof(L.e)); memcpy(L.B, T.B, sizeof(L.B)); L.chi2 = T.chi2; L.depthPositive = T.depthPositive;
+}
+bool cholSolve15(double* S, int n, double* x) {   // LinearSolverDense: dense Cholesky of the (here 15x15) system; column-major lower
+    for (int k = 0; k < n; k++) {
+        double dkk = S[k * n + k];
+        if (!(dkk > 0) || !std::isfinite(dkk)) return false;
+        dkk = std::sqrt(dkk);
+        S[k * n + k] = dkk;
+        for (int i = k + 1; i < n; i++) S[k * n + i] /= dkk;
+        for (int j = k + 1; j < n; j++) { const double ljk = S[k * n + j]; for (int i = j; i < n; i++) S[j * n + i] -= S[k * n + i] * ljk; }
+    }
+    for (int i = 0; i < n; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= S[k * n + i] * x[k]; x[i] = v / S[i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < n; k++) v -= S[i * n + k] * x[k]; x[i] = v / S[i * n + i]; }
+    return true;
+}
+}  // namespace
+
+extern "C" int oib_pose_inertial_kf(void* frame_, const void* keyframe_, const void* rig_, const void* edges_, int n_edges, const void* imu_, int rec_init,
+                                    uint8_t* outlier, double* H15) {
+    Kf& F = *(Kf*)frame_;
+    const Kf& K = *(const Kf*)keyframe_;
+    const Rig& rig = *(const Rig*)rig_;
+    const PEdge* edges = (const PEdge*)edges_;
+    const ImuEdge& E = *(const ImuEdge*)imu_;
+    const double thMono = (double)std::sqrt(5.991f), thStereo = (double)std::sqrt(7.815f);   // const float thHuberMono = sqrt(5.991)
+    std::vector<double> chiLast(n_edges, 0.0);
+    std::vector<char> level(n_edges, 0), depthOk(n_edges, 1);
+    for (int i = 0; i < n_edges; i++) outlier[i] = 0;
+    const float chi2Mono[4] = {12, 7.5, 5.991, 5.991}, chi2Stereo[4] = {15.6, 9.8, 7.815, 7.815};
+    int nBad = 0, nInliers = 0;
+    bool robust = true;
+    PLin L;
+    for (int it = 0; it < 4; it++) {
+        for (int gn = 0; gn < 10; gn++) {   // optimizer.optimize(its[it]): Gauss-Newton, no step control
+            double H[225] = {0}, b[15] = {0};
+            for (int i = 0; i < n_edges; i++) {
+                if (level[i]) continue;
+                poseEdgeLinearize(edges[i], F, rig, true, L);
+                chiLast[i] = L.chi2;
+                double rho1 = 1.0;
+                if (robust) { const double d = (edges[i].kind & 0xFF) == 1 ? thStereo : thMono, dsqr = d * d; if (L.chi2 > dsqr) rho1 = d / std::sqrt(L.chi2); }
+                const double w = rho1 * (double)edges[i].inv_sigma2;
+                for (int r = 0; r < 6; r++) {
+                    double s = 0; for (int d = 0; d < L.D; d++) s += L.B[d * 6 + r] * L.e[d];
+                    b[r] += -w * s;
+                    for (int c = 0; c < 6; c++) { double t = 0; for (int d = 0; d < L.D; d++) t += L.B[d * 6 + r] * L.B[d * 6 + c]; H[c * 15 + r] += w * t; }
+                }
+            }
+            {   // EdgeInertial (vertices 4, 5 = this frame's pose and velocity are free), no robust kernel (:7797-7804)
+                double e9[9], J[9 * 24];
+                inertialError(E, K, F, e9);
+                inertialJacobian(E, K, F, J);
+                for (int a = 0; a < 9; a++) {
+                    double s = 0;
+                    for (int r = 0; r < 9; r++) { double oe = 0; for (int q = 0; q < 9; q++) oe += E.info[r * 9 + q] * e9[q]; s += J[r * 24 + 15 + a] * oe; }
+                    b[a] += -s;
+                    for (int c = 0; c < 9; c++) {
+                        double t = 0;
+                        for (int r = 0; r < 9; r++) { double oj = 0; for (int q = 0; q < 9; q++) oj += E.info[r * 9 + q] * J[q * 24 + 15 + c]; t += J[r * 24 + 15 + a] * oj; }
+                        H[c * 15 + a] += t;
+                    }
+                }
+                for (int w2 = 0; w2 < 2; w2++) {   // EdgeGyroRW / EdgeAccRW: e = b_frame - b_kf, J = I on the free vertex
+                    const double* Om = w2 == 0 ? E.info_g : E.info_a;
+                    const int o = 9 + 3 * w2;
+                    double er[3];
+                    for (int k = 0; k < 3; k++) er[k] = w2 == 0 ? F.bg[k] - K.bg[k] : F.ba[k] - K.ba[k];
+                    for (int r = 0; r < 3; r++) {
+                        double oe = 0; for (int q = 0; q < 3; q++) oe += Om[r * 3 + q] * er[q];
+                        b[o + r] += -oe;
+                        for (int c = 0; c < 3; c++) H[(o + c) * 15 + o + r] += Om[r * 3 + c];
+                    }
+                }
+            }
+            double x[15];
+            memcpy(x, b, sizeof(x));
+            if (!cholSolve15(H, 15, x)) break;   // cannot happen with positive definite inertial / random-walk information; mirrors `ok` ending the loop
+            poseUpdate(F, rig, x);
+            for (int i = 0; i < 3; i++) { F.v[i] += x[6 + i]; F.bg[i] += x[9 + i]; F.ba[i] += x[12 + i]; }
+        }
+        // classification (:7838-7896).  e->chi2() of an edge that took part in the optimisation is the value of the LAST computeActiveErrors,
+        // i.e. at the state before the final update (Gauss-Newton does not re-evaluate); outlier edges are recomputed at the current state
+        nBad = 0; nInliers = 0;
+        const float chi2close = 1.5 * chi2Mono[it];
+        for (int pass = 0; pass < 2; pass++)
+            for (int i = 0; i < n_edges; i++) {
+                const bool stereo = (edges[i].kind & 0xFF) == 1;
+                if ((int)stereo != pass) continue;          // the reference walks vpEdgesMono first, then vpEdgesStereo
+                poseEdgeLinearize(edges[i], F, rig, false, L);      // isDepthPositive() always reads the current estimate
+                depthOk[i] = L.depthPositive;
+                if (outlier[i]) chiLast[i] = L.chi2;
+                const float chi2 = (float)chiLast[i];
+                bool bad;
+                if (!stereo) { const bool bClose = (edges[i].kind & 0x100) != 0; bad = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !depthOk[i]; }
+                else bad = chi2 > chi2Stereo[it];
+                outlier[i] = bad; level[i] = bad;
+                if (bad) nBad++; else nInliers++;
+            }
+        if (it == 2) robust = false;
+        if (n_edges + 3 < 10) break;
+    }
+    if (nInliers < 30 && !rec_init) {   // :7904-7934
+        nBad = 0;
+        for (int i = 0; i < n_edges; i++) {
+            poseEdgeLinearize(edges[i], F, rig, false, L);
+            const bool stereo = (edges[i].kind & 0xFF) == 1;
+            if ((float)L.chi2 < (stereo ? 24.f : 18.f)) outlier[i] = 0; else nBad++;
+        }
+    }
+    // H of the final state (:8040-8060): EdgeInertial::GetHessian2 (columns of vertices 4, 5), the random-walk blocks, the inlier reprojection edges
+    for (int i = 0; i < 225; i++) H15[i] = 0;
+    {
+        double J[9 * 24];
+        inertialJacobian(E, K, F, J);
+        for (int a = 0; a < 9; a++) for (int c = 0; c < 9; c++) {
+            double t = 0;
+            for (int r = 0; r < 9; r++) { double oj = 0; for (int q = 0; q < 9; q++) oj += E.info[r * 9 + q] * J[q * 24 + 15 + c]; t += J[r * 24 + 15 + a] * oj; }
+            H15[a * 15 + c] += t;   // row-major 15x15
+        }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { H15[(9 + r) * 15 + 9 + c] += E.info_g[r * 3 + c]; H15[(12 + r) * 15 + 12 + c] += E.info_a[r * 3 + c]; }
+    }
+    for (int i = 0; i < n_edges; i++) {
+        if (outlier[i]) continue;
+        poseEdgeLinearize(edges[i], F, rig, true, L);
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double t = 0; for (int d = 0; d < L.D; d++) t += L.B[d * 6 + r] * L.B[d * 6 + c]; H15[r * 15 + c] += (double)edges[i].inv_sigma2 * t; }
+    }
+    return n_edges - nBad;
+}

@@ -536,3 +536,19 @@ def stereo_fisheye(kl, dl, mono_l, kr, dr, mono_r, rig_arr, level_sigma2):
     n = L.ofr_stereo_fisheye(_p(kl), _p(np.ascontiguousarray(dl)), nl, int(mono_l), _p(kr), _p(np.ascontiguousarray(dr)), nr, int(mono_r), _p(rg), _p(ls),
                              _p(l2r), _p(r2l), _p(depth), _p(p3d))
     return l2r[:nl], r2l[:nr], depth[:nl], p3d[:nl], n
+
+
+POSE_EDGE_DTYPE_I = np.dtype([("xw", "<f4", (3,)), ("obs", "<f4", (3,)), ("inv_sigma2", "<f4"), ("kind", "<i2"), ("cam", "<i2")])
+
+
+def pose_inertial_kf(frame, keyframe, rig, edges, imu, rec_init=False):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame restated -> (frame state, outlier flags, H 15x15, return value)"""
+    f = np.ascontiguousarray(frame).copy()
+    edges = np.ascontiguousarray(edges)
+    outl = np.zeros(max(len(edges), 1), np.uint8)
+    H = np.zeros((15, 15))
+    L = lib()
+    L.oib_pose_inertial_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    n = L.oib_pose_inertial_kf(_p(f), _p(np.ascontiguousarray(keyframe)), C.addressof(rig), _p(edges), len(edges), _p(np.ascontiguousarray(imu)), int(rec_init),
+                               _p(outl), _p(H))
+    return f, outl[:len(edges)], H, n

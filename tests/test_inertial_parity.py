@@ -162,3 +162,56 @@ def test_hip_inertial_ba_large_window(hip_lib):
     big = window("mono", seed=42, n_opt=33, n_fixed_vis=1, n_pts=200, dt=0.1)
     with pytest.raises(Exception):
         InertialWindows([big], to_dev("hip"), lib=hip_lib, huber=HUBER).optimize(1.0, 2)
+
+
+# ---- Optimizer::PoseInertialOptimizationLastKeyFrame ----------------------------------------------------------------------------------
+from orbhip.inertial import pose_inertial_optimization_last_keyframe, synth_inertial_frame  # noqa: E402
+from orbhip.lba import POSE_EDGE_DTYPE  # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["mono", "stereo", "fisheye"])
+def test_oracle_pose_inertial_recovers_the_frame(kind):
+    f = synth_inertial_frame(5, 320, kind)
+    fr, outl, H, n = O.pose_inertial_kf(f["frame"], f["keyframe"], f["rig"], f["edges"], f["imu"])
+    assert n == len(f["edges"]) - int(outl.sum()) and 0.5 * len(f["edges"]) < n < len(f["edges"])
+    # the frame started 1.5 cm / 0.4 deg off the trajectory the observations and the preintegration were generated from
+    truth = synth_inertial_frame(5, 320, kind, outliers=0.0)
+    assert np.abs(fr["twb"] - f["frame"]["twb"]).max() > 1e-3
+    Hs = (H + H.T) / 2
+    assert np.linalg.eigvalsh(Hs).min() > 0 and np.abs(H[:9, :9] - H[:9, :9].T).max() < 1e-6 * np.abs(H).max()
+    assert truth["frame"].dtype == fr.dtype
+
+
+def check_pose_inertial(lib, backend, kinds, rec_init=False, n_pts=300):
+    fs = [synth_inertial_frame(70 + i, n_pts + 40 * i, k) for i, k in enumerate(kinds)]
+    B, cap = len(fs), max(len(f["edges"]) for f in fs) + 5
+    edges = np.zeros((B, cap), POSE_EDGE_DTYPE)
+    n = np.zeros(B, np.int32)
+    for b, f in enumerate(fs):
+        edges[b, :len(f["edges"])] = f["edges"]; n[b] = len(f["edges"])
+    frames = np.concatenate([f["frame"] for f in fs]); kfs = np.concatenate([f["keyframe"] for f in fs]); imu = np.concatenate([f["imu"] for f in fs])
+    fr, outl, H, good = pose_inertial_optimization_last_keyframe(frames, kfs, [f["rig"] for f in fs], edges, n, imu, to_dev(backend), rec_init=rec_init, lib=lib)
+    for b, f in enumerate(fs):
+        ofr, ooutl, oH, on = O.pose_inertial_kf(f["frame"], f["keyframe"], f["rig"], f["edges"], f["imu"], rec_init)
+        kb8 = f["rig"].model[0] == 1
+        assert good[b] == on and np.array_equal(outl[b, :n[b]], ooutl) and (outl[b, n[b]:] == 0).all(), (b, good[b], on)
+        tol = 2e-5 if kb8 else 2e-6
+        for fld in ("Rwb", "twb", "v", "bg", "ba", "Rcw", "tcw"):
+            assert np.abs(fr[b][fld] - ofr[0][fld]).max() < tol, (b, fld, np.abs(fr[b][fld] - ofr[0][fld]).max())
+        assert np.abs(H[b] - oH).max() <= (1e-3 if kb8 else 1e-6) * np.abs(oH).max(), b
+
+
+def test_emu_pose_inertial_matches_oracle(emu_lib):
+    check_pose_inertial(emu_lib, "emu", ("mono", "stereo", "fisheye"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", [False, True])
+def test_hip_pose_inertial_matches_oracle(hip_lib, rec):
+    check_pose_inertial(hip_lib, "hip", ("mono", "stereo", "fisheye", "mono"), rec_init=rec)
+
+
+@pytest.mark.gpu
+def test_hip_pose_inertial_few_inliers_recovery(hip_lib):
+    """< 30 inliers and !bRecInit: the recovery pass (Optimizer.cc:7904-7934) re-admits edges below chi2 18 / 24."""
+    check_pose_inertial(hip_lib, "hip", ("mono", "stereo"), n_pts=24)
