@@ -350,6 +350,40 @@ def main():
             except Exception as err:   # noqa: BLE001
                 extra["inertial_ba_error"] = "%s: %s" % (type(err).__name__, err)
                 sys.stderr.write(traceback.format_exc())
+            # ---- extra leg 3c: Optimizer::PoseInertialOptimizationLastKeyFrame, one wave per frame, 4 x 10 Gauss-Newton in a single launch
+            try:
+                from orbhip.inertial import pose_inertial_optimization_last_keyframe, synth_inertial_frame
+                from orbhip.lba import POSE_EDGE_DTYPE
+                pfs = [synth_inertial_frame(80 + i + 8 * rank, 300, "stereo") for i in range(8)]
+                PIB = 4096
+                capE = max(len(f["edges"]) for f in pfs)
+                pe = np.zeros((PIB, capE), POSE_EDGE_DTYPE); pn = np.zeros(PIB, np.int32)
+                for b2 in range(PIB):
+                    f = pfs[b2 % 8]
+                    pe[b2, :len(f["edges"])] = f["edges"]; pn[b2] = len(f["edges"])
+                pfr = np.concatenate([pfs[b2 % 8]["frame"] for b2 in range(PIB)]); pkf = np.concatenate([pfs[b2 % 8]["keyframe"] for b2 in range(PIB)])
+                pim = np.concatenate([pfs[b2 % 8]["imu"] for b2 in range(PIB)])
+                tdv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                pose_inertial_optimization_last_keyframe(pfr, pkf, pfs[0]["rig"], pe, pn, pim, tdv)
+                barrier()
+                t4c = time.perf_counter()
+                for _ in range(2):
+                    pres = pose_inertial_optimization_last_keyframe(pfr, pkf, pfs[0]["rig"], pe, pn, pim, tdv)
+                barrier()
+                dtpi = (time.perf_counter() - t4c) / 2
+                extra["pose_inertial"] = {"frames_per_s_incl_h2d_d2h": round(PIB / dtpi, 1), "ms_per_batch": round(dtpi * 1e3, 3), "frames_per_batch": PIB,
+                                          "edges_per_frame": float(pn.mean()), "mean_inliers": float(pres[3].mean()),
+                                          "what": "Optimizer::PoseInertialOptimizationLastKeyFrame (4 x 10 Gauss-Newton over pose/velocity/biases, re-classification, 15x15 prior) "
+                                                  "per frame; this leg's timing includes the wrapper's host<->device copies of the batch"}
+                if world == 1 and not args.no_cpu_baseline:
+                    import oracle_lib as O
+                    tc = time.perf_counter()
+                    for b2 in range(8):
+                        O.pose_inertial_kf(pfs[b2]["frame"], pfs[b2]["keyframe"], pfs[b2]["rig"], pfs[b2]["edges"], pfs[b2]["imu"])
+                    extra["pose_inertial"]["cpu_port_frames_per_s_1core"] = round(8 / (time.perf_counter() - tc), 1)
+            except Exception as err:   # noqa: BLE001
+                extra["pose_inertial_error"] = "%s: %s" % (type(err).__name__, err)
+                sys.stderr.write(traceback.format_exc())
             # ---- extra leg 4 (SURVEY N2 + M6, BASELINE configs[2] shape): Frame::ComputeBoW on a k=10, L=6 vocabulary (the stock ORBvoc shape,
             #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
             from orbhip.bow import ORBVocabulary, synth_vocabulary_fast

@@ -272,5 +272,53 @@ private:
 };
 
 
+// Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool bRecInit) (reference include/Optimizer.h:70, src/Optimizer.cc:7665-8067) over
+// liba_pose_inertial_kf().  The caller walks pFrame->mvpMapPoints like :7706-7790 (addMono / addStereo, bClose = pMP->mTrackDepth < 10.f), passes the
+// frame's and the last key frame's ImuCamPose / velocity / biases and the preintegration record (kf1 = key frame, kf2 = frame; `info` from the
+// reference's EdgeInertial constructor), and reads back the state (-> SetImuPoseVelocity, mImuBias), mvbOutlier, H (-> new ConstraintPoseImu) and
+// the return value.
+class PoseInertialOptimizer {
+public:
+    void setRig(const liba_rig& rig) { rig_ = rig; }
+    void clear() { edges_.clear(); }
+    void addMono(const float Xw[3], float u, float v, float invSigma2, bool bClose, int camIdx = 0) {
+        edges_.push_back(pose_edge{{Xw[0], Xw[1], Xw[2]}, {u, v, 0.f}, invSigma2, (int16_t)(LBA_EDGE_MONO | (bClose ? LIBA_EDGE_CLOSE : 0)), (int16_t)camIdx});
+    }
+    void addStereo(const float Xw[3], float u, float v, float uR, float invSigma2) {
+        edges_.push_back(pose_edge{{Xw[0], Xw[1], Xw[2]}, {u, v, uR}, invSigma2, (int16_t)LBA_EDGE_STEREO, 0});
+    }
+    int size() const { return (int)edges_.size(); }
+    // frame is updated in place; H15 = row-major 15x15 (pose 6, velocity 3, gyro bias 3, acc bias 3)
+    int optimize(liba_keyframe& frame, const liba_keyframe& lastKeyFrame, const liba_imu_edge& preint, bool bRecInit, std::vector<bool>& mvbOutlier, double H15[225]) {
+        const int ne = (int)edges_.size();
+        mvbOutlier.assign(ne, false);
+        if (ne == 0) return 0;
+        liba_keyframe* dF = f_.upload(&frame, 1);
+        const liba_keyframe* dK = k_.upload(&lastKeyFrame, 1);
+        const liba_rig* dR = r_.upload(&rig_, 1);
+        const pose_edge* dE = e_.upload(edges_.data(), ne);
+        const liba_imu_edge* dI = i_.upload(&preint, 1);
+        const int32_t* dN = n_.upload(&ne, 1);
+        uint8_t* dO = (uint8_t*)o_.ensure((size_t)ne + 16);
+        double* dH = (double*)h_.ensure(225 * 8);
+        int32_t* dG = (int32_t*)g_.ensure(16);
+        if (liba_pose_inertial_kf(dF, dK, dR, 0, dE, dN, ne, dI, 1, bRecInit ? 1 : 0, dO, dH, dG, nullptr) != ORB_OK) throw std::runtime_error("liba_pose_inertial_kf");
+        std::vector<uint8_t> fl(ne);
+        int32_t good = 0;
+        orb_memcpy_d2h(&frame, dF, sizeof(frame), nullptr);
+        orb_memcpy_d2h(fl.data(), dO, ne, nullptr);
+        orb_memcpy_d2h(H15, dH, 225 * 8, nullptr);
+        orb_memcpy_d2h(&good, dG, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        for (int i = 0; i < ne; i++) mvbOutlier[i] = fl[i] != 0;
+        return good;
+    }
+
+private:
+    liba_rig rig_{};
+    std::vector<pose_edge> edges_;
+    detail::DevBuf f_, k_, r_, e_, i_, n_, o_, h_, g_;
+};
+
 }  // namespace orbslam3_hip
 #endif

@@ -37,6 +37,7 @@ void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
 int ofr_stereo_fisheye(const void*, const uint8_t*, int, int, const void*, const uint8_t*, int, int, const float*, const float*, int32_t*, int32_t*, float*, float*);
 void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
+int oib_pose_inertial_kf(void*, const void*, const void*, const void*, int, const void*, int, uint8_t*, double*);
 void oib_optimize(void*, int, const void*, double*, int, const void*, int, const void*, int, double, double, double, int, double*);
 int omo_search_by_sim3(const void*, const uint8_t*, int, float, float, float, float, const void*, const uint8_t*, int, float, float, float, float, const void*,
                        const uint8_t*, const void*, const uint8_t*, int32_t*);
@@ -454,6 +455,51 @@ int main() {
         int nout = 0;
         for (size_t e = 0; e < oedges.size(); e++) { CHECK(IB.depthPositive((int)e)); nout += IB.visualChi2((int)e) > 5.991; }
         CHECK(nout < (int)oedges.size() / 10);
+    }
+    // ---- Optimizer::PoseInertialOptimizationLastKeyFrame through PoseInertialOptimizer vs the oracle
+    {
+        liba_rig rig{};
+        rig.n_cams = 1; rig.bf = 47.906;
+        const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int i = 0; i < 9; i++) { rig.Rcb[0][i] = I9[i]; rig.Rbc[0][i] = I9[i]; }
+        rig.model[0] = LBA_CAM_PINHOLE;
+        rig.p[0][0] = 458.654; rig.p[0][1] = 457.296; rig.p[0][2] = 367.215; rig.p[0][3] = 248.375;
+        auto nz = [&](double s2) { return s2 * ((int)(rnd() % 2001) - 1000) / 1000.0; };
+        liba_keyframe kf{}, fr{};
+        for (int i = 0; i < 9; i++) { kf.Rwb[i] = I9[i]; kf.Rcw[0][i] = I9[i]; fr.Rwb[i] = I9[i]; fr.Rcw[0][i] = I9[i]; }
+        kf.v[0] = 1.0; kf.has_imu = 1; kf.pose_fixed = 1; kf.imu_fixed = 1;
+        fr.twb[0] = 0.3 + 0.02; fr.twb[1] = -0.015; fr.twb[2] = 0.01; fr.v[0] = 1.03; fr.v[1] = -0.02; fr.has_imu = 1;
+        for (int i = 0; i < 3; i++) { fr.tcw[0][i] = -fr.twb[i]; fr.bg[i] = nz(0.001); fr.ba[i] = nz(0.01); kf.bg[i] = nz(0.001); kf.ba[i] = nz(0.01); }
+        liba_imu_edge pe2{};
+        pe2.kf1 = 0; pe2.kf2 = 1; pe2.dT = 0.3f;
+        for (int q = 0; q < 9; q++) { pe2.dR[q] = (float)I9[q]; pe2.JRg[q] = (float)(-0.3 * I9[q]); pe2.JVa[q] = (float)(-0.3 * I9[q]); pe2.JPa[q] = (float)(-0.045 * I9[q]); }
+        pe2.dV[2] = (float)(9.81 * 0.3); pe2.dP[2] = (float)(0.5 * 9.81 * 0.09);
+        for (int q = 0; q < 9; q++) pe2.info[q * 10] = q < 3 ? 3e4 : (q < 6 ? 2e3 : 8e3);
+        for (int q = 0; q < 3; q++) { pe2.info_g[q * 4] = 4e5; pe2.info_a[q * 4] = 2e3; }
+        orbslam3_hip::PoseInertialOptimizer PIO;
+        PIO.setRig(rig);
+        std::vector<pose_edge> oe;
+        for (int l = 0; l < 150; l++) {
+            const float X[3] = {(float)(0.3 + nz(3.0)), (float)nz(2.0), (float)(5.0 + nz(2.0))};
+            float u = (float)(458.654 * (X[0] - 0.3) / X[2] + 367.215 + nz(0.8)), v = (float)(457.296 * X[1] / X[2] + 248.375 + nz(0.8));   // truth: twb = (0.3, 0, 0)
+            if (l % 13 == 0) { u += 30.f; v -= 18.f; }
+            const bool close = l % 3 != 0;
+            if (l % 2) { PIO.addStereo(X, u, v, (float)(u - 47.906 / X[2]), 1.0f); oe.push_back(pose_edge{{X[0], X[1], X[2]}, {u, v, (float)(u - 47.906 / X[2])}, 1.0f, LBA_EDGE_STEREO, 0}); }
+            else { PIO.addMono(X, u, v, 1.0f, close); oe.push_back(pose_edge{{X[0], X[1], X[2]}, {u, v, 0.f}, 1.0f, (int16_t)(LBA_EDGE_MONO | (close ? LIBA_EDGE_CLOSE : 0)), 0}); }
+        }
+        liba_keyframe ofr = fr;
+        std::vector<uint8_t> oout(oe.size());
+        double oH[225], H15[225];
+        const int ogood = oib_pose_inertial_kf(&ofr, &kf, &rig, oe.data(), (int)oe.size(), &pe2, 0, oout.data(), oH);
+        std::vector<bool> outl2;
+        const int good2 = PIO.optimize(fr, kf, pe2, false, outl2, H15);
+        CHECK(good2 == ogood && good2 > 120 && good2 < 150);
+        for (size_t i = 0; i < oe.size(); i++) CHECK(outl2[i] == (oout[i] != 0));
+        for (int c = 0; c < 3; c++) { CHECK(std::fabs(fr.twb[c] - ofr.twb[c]) < 1e-6 && std::fabs(fr.v[c] - ofr.v[c]) < 1e-6 && std::fabs(fr.bg[c] - ofr.bg[c]) < 1e-6); }
+        CHECK(std::fabs(fr.twb[0] - 0.3) < 0.01 && std::fabs(fr.twb[1]) < 0.01);
+        double hmax = 0;
+        for (int i = 0; i < 225; i++) hmax = std::max(hmax, std::fabs(oH[i]));
+        for (int i = 0; i < 225; i++) CHECK(std::fabs(H15[i] - oH[i]) <= 1e-6 * hmax);
     }
     std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;
