@@ -445,13 +445,22 @@ int main() {
         const int its2 = IB.optimize(1.0, 10, &err, &errEnd);
         CHECK(its2 == (int)ostats[0] && its2 >= 3);
         CHECK(std::fabs(err - ostats[4]) < 1e-9 * ostats[4] && std::fabs(errEnd - ostats[1]) < 1e-6 * ostats[1] && errEnd < 0.5 * err);
+        {
+            double dt_ = 0, dv_ = 0, dbg_ = 0, dba_ = 0;
+            for (int k = 0; k < NK; k++) for (int c = 0; c < 3; c++) {
+                dt_ = std::max(dt_, std::fabs(IB.keyFrame(k).twb[c] - okf[k].twb[c])); dv_ = std::max(dv_, std::fabs(IB.keyFrame(k).v[c] - okf[k].v[c]));
+                dbg_ = std::max(dbg_, std::fabs(IB.keyFrame(k).bg[c] - okf[k].bg[c])); dba_ = std::max(dba_, std::fabs(IB.keyFrame(k).ba[c] - okf[k].ba[c]));
+            }
+            std::printf("adapter inertial BA: its %d, max |d twb| %.3g, |d v| %.3g, |d bg| %.3g, |d ba| %.3g\n", its2, dt_, dv_, dbg_, dba_);
+        }
         for (int k = 0; k < NK; k++)
             for (int c = 0; c < 3; c++) {
-                CHECK(std::fabs(IB.keyFrame(k).twb[c] - okf[k].twb[c]) < 1e-6 && std::fabs(IB.keyFrame(k).v[c] - okf[k].v[c]) < 1e-6);
-                CHECK(std::fabs(IB.keyFrame(k).bg[c] - okf[k].bg[c]) < 1e-6 && std::fabs(IB.keyFrame(k).ba[c] - okf[k].ba[c]) < 1e-6);
+                // float-rounded ExpSO3 (rule R3) + device libm: a few 1e-6 after 10 LM iterations on this small window (bar: 1e-4)
+                CHECK(std::fabs(IB.keyFrame(k).twb[c] - okf[k].twb[c]) < 5e-6 && std::fabs(IB.keyFrame(k).v[c] - okf[k].v[c]) < 5e-6);
+                CHECK(std::fabs(IB.keyFrame(k).bg[c] - okf[k].bg[c]) < 5e-6 && std::fabs(IB.keyFrame(k).ba[c] - okf[k].ba[c]) < 5e-6);
             }
         CHECK(std::fabs(IB.keyFrame(0).twb[0]) == 0.0 && std::fabs(IB.keyFrame(3).twb[0] - 0.9) < 0.02);   // fixed KF untouched, others pulled to the truth
-        for (int l = 0; l < 80; l++) for (int c = 0; c < 3; c++) CHECK(std::fabs(IB.point(l)[c] - opts[(size_t)l * 3 + c]) < 1e-5);
+        for (int l = 0; l < 80; l++) for (int c = 0; c < 3; c++) CHECK(std::fabs(IB.point(l)[c] - opts[(size_t)l * 3 + c]) < 5e-5);
         int nout = 0;
         for (size_t e = 0; e < oedges.size(); e++) { CHECK(IB.depthPositive((int)e)); nout += IB.visualChi2((int)e) > 5.991; }
         CHECK(nout < (int)oedges.size() / 10);
@@ -495,7 +504,7 @@ int main() {
         const int good2 = PIO.optimize(fr, kf, pe2, false, outl2, H15);
         CHECK(good2 == ogood && good2 > 120 && good2 < 150);
         for (size_t i = 0; i < oe.size(); i++) CHECK(outl2[i] == (oout[i] != 0));
-        for (int c = 0; c < 3; c++) { CHECK(std::fabs(fr.twb[c] - ofr.twb[c]) < 1e-6 && std::fabs(fr.v[c] - ofr.v[c]) < 1e-6 && std::fabs(fr.bg[c] - ofr.bg[c]) < 1e-6); }
+        for (int c = 0; c < 3; c++) { CHECK(std::fabs(fr.twb[c] - ofr.twb[c]) < 5e-6 && std::fabs(fr.v[c] - ofr.v[c]) < 5e-6 && std::fabs(fr.bg[c] - ofr.bg[c]) < 5e-6); }
         CHECK(std::fabs(fr.twb[0] - 0.3) < 0.01 && std::fabs(fr.twb[1]) < 0.01);
         double hmax = 0;
         for (int i = 0; i < 225; i++) hmax = std::max(hmax, std::fabs(oH[i]));

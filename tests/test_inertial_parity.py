@@ -109,7 +109,7 @@ def check_inertial(lib, backend, kinds, lam, its, **kw):
         assert abs(stats[b, 1] - ost[1]) <= (1e-4 if kb8 else 1e-7) * ost[1] and abs(stats[b, 4] - ost[4]) <= (1e-4 if kb8 else 1e-9) * ost[4]
         # north_star bar: 1e-4 on BA states.  Pinhole: double arithmetic on both sides, different summation order + float-rounded ExpSO3
         # (rule R3) -> ~1e-7; KB8 adds the atan2f tolerance
-        tol = 2e-5 if kb8 else 2e-6
+        tol = 2e-5 if kb8 else 5e-6
         for f in ("Rwb", "twb", "v", "bg", "ba", "Rcw", "tcw"):
             assert np.abs(kf[b, :nk][f] - okf[f]).max() < tol, (f, np.abs(kf[b, :nk][f] - okf[f]).max())
         assert np.abs(pts[b, :nl] - opts).max() < 10 * tol
@@ -156,8 +156,8 @@ def test_hip_inertial_ba_large_window(hip_lib):
     kf = IW.keyframes()[0, :len(w["kfs"])]
     assert st[0] == ost[0] and st[3] == ost[3] and abs(st[1] - ost[1]) < 1e-7 * ost[1], (st, ost)
     for f in ("Rwb", "twb", "v", "bg", "ba"):
-        assert np.abs(kf[f] - okf[f]).max() < 2e-6, f
-    assert np.abs(IW.points()[0, :len(w["points"])] - opts).max() < 2e-5 and ost[1] < 0.9 * ost[4]
+        assert np.abs(kf[f] - okf[f]).max() < 5e-6, f
+    assert np.abs(IW.points()[0, :len(w["points"])] - opts).max() < 5e-5 and ost[1] < 0.9 * ost[4]
     # more optimisable key frames than LIBA_MAX_FREE: refused by the wrapper's max_free check (ORB_E_INVALID)
     big = window("mono", seed=42, n_opt=33, n_fixed_vis=1, n_pts=200, dt=0.1)
     with pytest.raises(Exception):
@@ -195,7 +195,7 @@ def check_pose_inertial(lib, backend, kinds, rec_init=False, n_pts=300):
         ofr, ooutl, oH, on = O.pose_inertial_kf(f["frame"], f["keyframe"], f["rig"], f["edges"], f["imu"], rec_init)
         kb8 = f["rig"].model[0] == 1
         assert good[b] == on and np.array_equal(outl[b, :n[b]], ooutl) and (outl[b, n[b]:] == 0).all(), (b, good[b], on)
-        tol = 2e-5 if kb8 else 2e-6
+        tol = 2e-5 if kb8 else 5e-6
         for fld in ("Rwb", "twb", "v", "bg", "ba", "Rcw", "tcw"):
             assert np.abs(fr[b][fld] - ofr[0][fld]).max() < tol, (b, fld, np.abs(fr[b][fld] - ofr[0][fld]).max())
         assert np.abs(H[b] - oH).max() <= (1e-3 if kb8 else 1e-6) * np.abs(oH).max(), b
