@@ -953,16 +953,21 @@ extern "C" int liba_compute_errors(const liba_problem* prob, int batch, double* 
 }
 
 // ================================================================================================================================================
-// Optimizer::PoseInertialOptimizationLastKeyFrame (reference src/Optimizer.cc:7665-8067): the per-frame optimisation of the inertial tracking
-// modes.  One wave per frame runs the whole schedule in a single launch: 4 rounds x 10 Gauss-Newton iterations (OptimizationAlgorithmGaussNewton +
-// LinearSolverDense, :7669-7672) over the frame's pose / velocity / biases (15 unknowns) with EdgeMonoOnlyPose / EdgeStereoOnlyPose, EdgeInertial,
-// EdgeGyroRW, EdgeAccRW; chi2 re-classification between rounds (bClose rule, Huber dropped for the last round); the < 30 inliers recovery pass; the
-// 15x15 Hessian of the final state for the next frame's prior.  Lanes stride over the reprojection edges (butterfly sums in a fixed order); the 9x9
-// inertial block, the random-walk blocks and the dense Cholesky are spread over the lanes through LDS.
+// Optimizer::PoseInertialOptimizationLastKeyFrame / ...LastFrame (reference src/Optimizer.cc:7665-8067, :8068-8415): the per-frame optimisation of the
+// inertial tracking modes.  One wave per frame runs the whole schedule in a single launch: 4 rounds x 10 Gauss-Newton iterations
+// (OptimizationAlgorithmGaussNewton + LinearSolverDense, :7669-7672) with EdgeMonoOnlyPose / EdgeStereoOnlyPose, EdgeInertial, EdgeGyroRW, EdgeAccRW;
+// chi2 re-classification between rounds (bClose rule, Huber dropped for the last round); the < 30 inliers recovery pass; the Hessian of the final state
+// for the next frame's prior.
+//   LASTF = false: frame pose / velocity / biases free (15 unknowns), the last key frame fixed; output H = the 15x15 Hessian.
+//   LASTF = true : the previous frame's four vertices are free too (30 unknowns, [frame | previous]) and tied down by EdgePriorPoseImu (Huber 5);
+//                  chi2Mono = 5.991 in every round; output H = the 30x30 Hessian marginalised over the previous frame (Optimizer::Marginalize,
+//                  :5366-5450: JacobiSVD pseudo-inverse with singular values <= 1e-6 dropped; here a one-sided Jacobi SVD spread over the lanes).
+// Lanes stride over the reprojection edges (butterfly sums in a fixed order); the inertial / prior blocks and the dense Cholesky are spread over the lanes
+// through LDS.
 // ================================================================================================================================================
 struct PoseInertialArgs {
-    liba_keyframe* frames; const liba_keyframe* keyframes; const liba_rig* rigs; int rigStride;
-    const pose_edge* edges; const int32_t* nEdges; int capE; const liba_imu_edge* imu; int recInit;
+    liba_keyframe* frames; liba_keyframe* prevs; const liba_rig* rigs; int rigStride;
+    const pose_edge* edges; const int32_t* nEdges; int capE; const liba_imu_edge* imu; const liba_prior* priors; int recInit;
     uint8_t* outlier; double* H; int32_t* nGood;
 };
 #define PIK_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -974,50 +979,115 @@ static __device__ __forceinline__ void pose_edge_linearize(const pose_edge& E, c
     const double X[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
     vis_linearize<JAC>(V, kf, rig, X, 0.0, 0.0, L);
 }
+// EdgePriorPoseImu::computeError / linearizeOplus (G2oTypes.cc:935-968): e[15], J 15x15 row-major over the previous frame's [pose 6 | v 3 | bg 3 | ba 3]
+static __device__ void prior_linearize(const liba_prior& C, const liba_keyframe& P, double* e, double* J) {
+    double M[9], er[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i * 3 + j] = C.Rwb[i] * P.Rwb[j] + C.Rwb[3 + i] * P.Rwb[3 + j] + C.Rwb[6 + i] * P.Rwb[6 + j];
+    log_so3(M, er);
+    const double d[3] = {P.twb[0] - C.twb[0], P.twb[1] - C.twb[1], P.twb[2] - C.twb[2]};
+    double et[3];
+    mulT31(C.Rwb, d, et);
+    for (int i = 0; i < 3; i++) { e[i] = er[i]; e[3 + i] = et[i]; e[6 + i] = P.v[i] - C.vwb[i]; e[9 + i] = P.bg[i] - C.bg[i]; e[12 + i] = P.ba[i] - C.ba[i]; }
+    for (int i = 0; i < 225; i++) J[i] = 0.0;
+    double iJ[9];
+    inv_right_jacobian_so3(er, iJ);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { J[r * 15 + c] = iJ[r * 3 + c]; J[(3 + r) * 15 + 3 + c] = M[r * 3 + c]; }
+    for (int k = 6; k < 15; k++) J[k * 15 + k] = 1.0;
+}
 
-static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs A) {
+template <bool LASTF>
+static __global__ __launch_bounds__(64) void k_pose_inertial(PoseInertialArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    constexpr int N = LASTF ? 30 : 15;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int ne = min(A.nEdges[b], A.capE);
-    // LDS: F (liba_keyframe) | Hs[225] | bs[15] | xs[15] | J9[81] | OJ[81] | e9[9] | Oe[9] | chiLast[capE] | level[capE] u8 | outl[capE] u8 | dep[capE] u8
+    // LDS: F | Pv (liba_keyframe) | Hs[N*N] | xs[N] | J24[216] | OJ[216] | e9[9] | Oe[9] | Jp[225] | HJp[225] | ep[15] | Hep[15] | ctl[2] |
+    //      chiLast[capE] | level[capE] u8 | outl[capE] u8
+    const size_t kfb = (sizeof(liba_keyframe) + 15) & ~(size_t)15;
     liba_keyframe& F = *(liba_keyframe*)orb_smem;
-    double* Hs = (double*)(orb_smem + ((sizeof(liba_keyframe) + 15) & ~(size_t)15));
-    double* bs = Hs + 225;
-    double* xs = bs + 15;
-    double* J9 = xs + 15;
-    double* OJ = J9 + 81;
-    double* e9s = OJ + 81;
+    liba_keyframe& Pv = *(liba_keyframe*)(orb_smem + kfb);
+    double* Hs = (double*)(orb_smem + 2 * kfb);
+    double* xs = Hs + N * N;
+    double* J24 = xs + N;
+    double* OJ = J24 + 216;
+    double* e9s = OJ + 216;
     double* Oes = e9s + 9;
-    double* chiLast = Oes + 9;
+    double* Jp = Oes + 9;
+    double* HJp = Jp + 225;
+    double* eps = HJp + 225;
+    double* Heps = eps + 15;
+    double* ctl = Heps + 15;
+    double* chiLast = ctl + 2;
     uint8_t* level = (uint8_t*)(chiLast + A.capE);
     uint8_t* outl = level + A.capE;
-    uint8_t* dep = outl + A.capE;
-    const liba_keyframe& K = A.keyframes[b];
     const liba_rig& rig = A.rigs[(size_t)b * A.rigStride];
     const liba_imu_edge& E = A.imu[b];
     const pose_edge* edges = A.edges + (size_t)b * A.capE;
-    for (int t = lane; t < (int)LIBA_KFD; t += 64) ((double*)&F)[t] = ((const double*)&A.frames[b])[t];
-    for (int e = lane; e < ne; e += 64) { chiLast[e] = 0.0; level[e] = 0; outl[e] = 0; dep[e] = 1; }
+    for (int t = lane; t < (int)LIBA_KFD; t += 64) { ((double*)&F)[t] = ((const double*)&A.frames[b])[t]; ((double*)&Pv)[t] = ((const double*)&A.prevs[b])[t]; }
+    for (int e = lane; e < ne; e += 64) { chiLast[e] = 0.0; level[e] = 0; outl[e] = 0; }
     PIK_WAVE_SYNC()
     const double thMono = (double)sqrtf(5.991f), thStereo = (double)sqrtf(7.815f);
-    const float chi2Mono[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    const float chi2MonoKF[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
     int nBad = 0, nInliers = 0;
     bool robust = true;
     VLin L;
-    // the 9x9 block J^T Omega J of EdgeInertial over the frame's (pose, velocity) columns, left in OJ-free storage: Hs[a*15+c] gets it added
-    auto inertial_blocks = [&](const bool withRhs) {
+    // unknown index -> column of the EdgeInertial Jacobian ([VP1 6 | VV1 3 | VG1 3 | VA1 3 | VP2 6 | VV2 3], vertex 1 = key frame / previous frame) or -1
+    auto icol = [](const int u) -> int { return u < 9 ? 15 + u : (LASTF && u >= 15 ? u - 15 : -1); };
+    // J of EdgeInertial, Omega*J, Omega*e in LDS; (LASTF) J of the prior edge, H_prior*J, H_prior*e and its Huber weight in ctl[0]
+    auto edge_blocks = [&](const bool weighted) {
         if (lane == 0) {
-            double e9[9], eR[9], J[216];
-            inertial_error(E, K, F, e9, eR);
-            inertial_jacobian(E, K, F, e9, eR, J);
-            for (int r = 0; r < 9; r++) { for (int c = 0; c < 9; c++) J9[r * 9 + c] = J[r * 24 + 15 + c]; e9s[r] = e9[r]; }
+            double e9[9], eR[9];
+            inertial_error(E, Pv, F, e9, eR);
+            inertial_jacobian(E, Pv, F, e9, eR, J24);
+            for (int r = 0; r < 9; r++) e9s[r] = e9[r];
+        }
+        if (LASTF && lane == 1) prior_linearize(A.priors[b], Pv, eps, Jp);
+        PIK_WAVE_SYNC()
+        for (int t = lane; t < 225; t += 64) {
+            if (t < 216) { const int r = t / 24, c = t - r * 24; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * J24[q * 24 + c]; OJ[t] = s; }
+            else { const int r = t - 216; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * e9s[q]; Oes[r] = s; }
+        }
+        if (LASTF) {
+            const double* Hp = A.priors[b].H;
+            for (int t = lane; t < 240; t += 64) {
+                if (t < 225) { const int r = t / 15, c = t - r * 15; double s = 0; for (int q = 0; q < 15; q++) s += Hp[r * 15 + q] * Jp[q * 15 + c]; HJp[t] = s; }
+                else { const int r = t - 225; double s = 0; for (int q = 0; q < 15; q++) s += Hp[r * 15 + q] * eps[q]; Heps[r] = s; }
+            }
+            PIK_WAVE_SYNC()
+            if (lane == 0) {
+                double chi = 0;
+                for (int r = 0; r < 15; r++) chi += eps[r] * Heps[r];
+                ctl[0] = (weighted && chi > 25.0) ? 5.0 / sqrt(chi) : 1.0;   // RobustKernelHuber, delta 5 (:8251)
+            }
         }
         PIK_WAVE_SYNC()
-        for (int t = lane; t < 90; t += 64) {
-            if (t < 81) { const int r = t / 9, c = t - r * 9; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * J9[q * 9 + c]; OJ[t] = s; }
-            else if (withRhs) { const int r = t - 81; double s = 0; for (int q = 0; q < 9; q++) s += E.info[r * 9 + q] * e9s[q]; Oes[r] = s; }
+    };
+    // entry (r, c) of the system matrix without the reprojection part
+    auto h_entry = [&](const int r, const int c) -> double {
+        double v = 0.0;
+        const int ar = icol(r), ac = icol(c);
+        if (ar >= 0 && ac >= 0) { double s = 0; for (int q = 0; q < 9; q++) s += J24[q * 24 + ar] * OJ[q * 24 + ac]; v += s; }
+        // random walks: e = b_frame - b_other, J_frame = +I (unknowns 9..14), J_other = -I (unknowns 24..29, LASTF only)
+        const int fr = (r >= 9 && r < 15) ? r - 9 : ((LASTF && r >= 24) ? r - 24 : -1), fc = (c >= 9 && c < 15) ? c - 9 : ((LASTF && c >= 24) ? c - 24 : -1);
+        if (fr >= 0 && fc >= 0 && fr / 3 == fc / 3) {
+            const double* Om = fr < 3 ? E.info_g : E.info_a;
+            const bool rF = r < 15, cF = c < 15;
+            if (rF == cF) v += Om[(fr % 3) * 3 + fc % 3];
+            else if (rF) v += -Om[(fr % 3) * 3 + fc % 3];          // (frame, other) block = -Omega
+            else v += -Om[(fc % 3) * 3 + fr % 3];                  // (other, frame) block = -Omega^T
         }
-        PIK_WAVE_SYNC()
+        if (LASTF && r >= 15 && c >= 15) { double s = 0; for (int q = 0; q < 15; q++) s += Jp[q * 15 + r - 15] * HJp[q * 15 + c - 15]; v += ctl[0] * s; }
+        return v;
+    };
+    auto pose_acc = [&](const double (&acc)[27], const int r, const int c) -> double {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;   // acc is packed by columns of the lower triangle: (c, r >= c)
+        int idx = 0;
+        for (int cc = 0; cc < lo; cc++) idx += 6 - cc;
+        idx += hi - lo;
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 21; k++) if (k == idx) a = acc[k];
+        return a;
     };
     for (int it = 0; it < 4; it++) {
         for (int gn = 0; gn < 10; gn++) {
@@ -1044,75 +1114,76 @@ static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs
 #pragma unroll
             for (int i = 0; i < 27; i++)
                 for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
-            inertial_blocks(true);
-            // ---- assemble H (column-major 15x15, full) and b
-            for (int t = lane; t < 225; t += 64) {
-                const int c = t / 15, r = t - c * 15;
-                double v = 0.0;
-                if (r < 6 && c < 6) {
-                    const int lo = r < c ? r : c, hi = r < c ? c : r;   // acc is packed by columns of the lower triangle: (c, r >= c)
-                    int idx = 0;
-                    for (int cc = 0; cc < lo; cc++) idx += 6 - cc;
-                    idx += hi - lo;
-                    double a = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 21; k++) if (k == idx) a = acc[k];
-                    v = a;
-                }
-                if (r < 9 && c < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + r] * OJ[q * 9 + c]; v += s; }
-                if (r >= 9 && c >= 9 && (r - 9) / 3 == (c - 9) / 3) { const double* Om = r < 12 ? E.info_g : E.info_a; v += Om[((r - 9) % 3) * 3 + (c - 9) % 3]; }
-                Hs[t] = v;
+            edge_blocks(true);
+            // ---- assemble H (column-major N x N, full) and b
+            for (int t = lane; t < N * N; t += 64) {
+                const int c = t / N, r = t - c * N;
+                Hs[t] = h_entry(r, c) + ((r < 6 && c < 6) ? pose_acc(acc, r, c) : 0.0);
             }
-            if (lane < 15) {
+            if (lane < N) {
+                const int u = lane;
                 double v = 0.0;
-                if (lane < 6) {
+                if (u < 6) {
 #pragma unroll
-                    for (int k = 0; k < 6; k++) if (k == lane) v = acc[21 + k];
+                    for (int k = 0; k < 6; k++) if (k == u) v = acc[21 + k];
                 }
-                if (lane < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + lane] * Oes[q]; v += -s; }
-                else {
-                    const int w2 = (lane - 9) / 3, r = (lane - 9) % 3;
-                    const double* Om = w2 == 0 ? E.info_g : E.info_a;
+                const int au = icol(u);
+                if (au >= 0) { double s = 0; for (int q = 0; q < 9; q++) s += J24[q * 24 + au] * Oes[q]; v += -s; }
+                const int fu = (u >= 9 && u < 15) ? u - 9 : ((LASTF && u >= 24) ? u - 24 : -1);
+                if (fu >= 0) {
+                    const double* Om = fu < 3 ? E.info_g : E.info_a;
                     double oe = 0;
-                    for (int q = 0; q < 3; q++) oe += Om[r * 3 + q] * (w2 == 0 ? F.bg[q] - K.bg[q] : F.ba[q] - K.ba[q]);
-                    v = -oe;
+                    for (int q = 0; q < 3; q++) oe += Om[(fu % 3) * 3 + q] * (fu < 3 ? F.bg[q] - Pv.bg[q] : F.ba[q] - Pv.ba[q]);
+                    v += u < 15 ? -oe : oe;
                 }
-                bs[lane] = v; xs[lane] = v;
+                if (LASTF && u >= 15) { double s = 0; for (int q = 0; q < 15; q++) s += Jp[q * 15 + u - 15] * Heps[q]; v += -ctl[0] * s; }
+                xs[u] = v;
             }
             PIK_WAVE_SYNC()
-            // ---- dense Cholesky of the 15x15 system (lower triangle of the column-major Hs), columns spread over the lanes
+            // ---- dense Cholesky (lower triangle of the column-major Hs), columns spread over the lanes
             bool ok = true;
-            for (int k = 0; k < 15; k++) {
-                const double dkk = Hs[k * 15 + k];
+            for (int k = 0; k < N; k++) {
+                const double dkk = Hs[k * N + k];
                 if (!(dkk > 0) || !(dkk < 1.7e308)) { ok = false; break; }   // uniform
                 const double sq = sqrt(dkk);
                 PIK_WAVE_SYNC()
-                if (lane >= k && lane < 15) Hs[k * 15 + lane] = lane == k ? sq : Hs[k * 15 + lane] / sq;
+                if (lane >= k && lane < N) Hs[k * N + lane] = lane == k ? sq : Hs[k * N + lane] / sq;
                 PIK_WAVE_SYNC()
-                for (int t = lane; t < 225; t += 64) {
-                    const int j = t / 15, i = t - j * 15;
-                    if (j > k && i >= j) Hs[j * 15 + i] -= Hs[k * 15 + i] * Hs[k * 15 + j];
+                for (int t = lane; t < N * N; t += 64) {
+                    const int j = t / N, i = t - j * N;
+                    if (j > k && i >= j) Hs[j * N + i] -= Hs[k * N + i] * Hs[k * N + j];
                 }
                 PIK_WAVE_SYNC()
             }
             if (!ok) break;
             if (lane == 0) {
-                for (int i = 0; i < 15; i++) { double v = xs[i]; for (int k = 0; k < i; k++) v -= Hs[k * 15 + i] * xs[k]; xs[i] = v / Hs[i * 15 + i]; }
-                for (int i = 14; i >= 0; i--) { double v = xs[i]; for (int k = i + 1; k < 15; k++) v -= Hs[i * 15 + k] * xs[k]; xs[i] = v / Hs[i * 15 + i]; }
+                for (int i = 0; i < N; i++) { double v = xs[i]; for (int k = 0; k < i; k++) v -= Hs[k * N + i] * xs[k]; xs[i] = v / Hs[i * N + i]; }
+                for (int i = N - 1; i >= 0; i--) { double v = xs[i]; for (int k = i + 1; k < N; k++) v -= Hs[i * N + k] * xs[k]; xs[i] = v / Hs[i * N + i]; }
+            }
+            PIK_WAVE_SYNC()
+            if (lane == 0) {
                 double x[15];
                 for (int i = 0; i < 15; i++) x[i] = xs[i];
                 pose_update(F, rig, x);
                 for (int i = 0; i < 3; i++) { F.v[i] += x[6 + i]; F.bg[i] += x[9 + i]; F.ba[i] += x[12 + i]; }
             }
+            if (LASTF && lane == 1) {
+                double x[15];
+                for (int i = 0; i < 15; i++) x[i] = xs[15 + i];
+                pose_update(Pv, rig, x);
+                for (int i = 0; i < 3; i++) { Pv.v[i] += x[6 + i]; Pv.bg[i] += x[9 + i]; Pv.ba[i] += x[12 + i]; }
+            }
             PIK_WAVE_SYNC()
         }
-        // ---- classification (:7838-7896): chi2() of an edge that was optimised is the value of the last computeActiveErrors (state before the final
-        //      update); outlier edges are re-evaluated at the current state; isDepthPositive() always reads the current state
-        const float chi2close = 1.5f * chi2Mono[it];
+        // ---- classification (:7838-7896 / :8267-8330): chi2() of an edge that was optimised is the value of the last computeActiveErrors (state before the
+        //      final update); outlier edges are re-evaluated at the current state; isDepthPositive() always reads the current state
+        const float chi2Mono = LASTF ? 5.991f : chi2MonoKF[it];
+        const float chi2close = 1.5f * chi2Mono;
         int bad = 0, good = 0;
         for (int e0 = 0; e0 < ne; e0 += 64) {
             const int e = e0 + lane;
-            bool isBad = false, act = e < ne;
+            bool isBad = false;
+            const bool act = e < ne;
             if (act) {
                 const pose_edge PE = edges[e];
                 pose_edge_linearize<false>(PE, F, rig, L);
@@ -1120,7 +1191,7 @@ static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs
                 const float chi2 = (float)chiLast[e];
                 if ((PE.kind & 0xFF) != LBA_EDGE_STEREO) {
                     const bool bClose = (PE.kind & 0x100) != 0;
-                    isBad = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !L.depthPositive;
+                    isBad = (chi2 > chi2Mono && !bClose) || (bClose && chi2 > chi2close) || !L.depthPositive;
                 } else isBad = chi2 > chi2Stereo[it];
                 outl[e] = isBad; level[e] = isBad;
             }
@@ -1130,9 +1201,9 @@ static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs
         nBad = bad; nInliers = good;
         if (it == 2) robust = false;
         PIK_WAVE_SYNC()
-        if (ne + 3 < 10) break;
+        if (ne + (LASTF ? 4 : 3) < 10) break;
     }
-    if (nInliers < 30 && !A.recInit) {   // :7904-7934
+    if (nInliers < 30 && !A.recInit) {   // :7904-7934 / :8332-8362
         int bad = 0;
         for (int e0 = 0; e0 < ne; e0 += 64) {
             const int e = e0 + lane;
@@ -1147,11 +1218,11 @@ static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs
         nBad = bad;
         PIK_WAVE_SYNC()
     }
-    // ---- outputs: state, outlier flags, the Hessian of the final state (:8040-8062)
+    // ---- the Hessian of the final state: information() without robust weights, inlier reprojection edges only (:8040-8062 / :8366-8400)
     {
-        double acc[21];
+        double acc[27];
 #pragma unroll
-        for (int i = 0; i < 21; i++) acc[i] = 0.0;
+        for (int i = 0; i < 27; i++) acc[i] = 0.0;
         for (int e = lane; e < ne; e += 64) {
             if (outl[e]) continue;
             const pose_edge PE = edges[e];
@@ -1166,29 +1237,73 @@ static __global__ __launch_bounds__(64) void k_pose_inertial_kf(PoseInertialArgs
 #pragma unroll
         for (int i = 0; i < 21; i++)
             for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
-        inertial_blocks(false);
+        edge_blocks(false);
         double* Hout = A.H + (size_t)b * 225;
-        for (int t = lane; t < 225; t += 64) {
-            const int r = t / 15, c = t - r * 15;   // row-major output
-            double v = 0.0;
-            if (r < 6 && c < 6) {
-                const int lo = r < c ? r : c, hi = r < c ? c : r;
-                int idx = 0;
-                for (int cc = 0; cc < lo; cc++) idx += 6 - cc;
-                idx += hi - lo;
-                double a = 0.0;
-#pragma unroll
-                for (int k = 0; k < 21; k++) if (k == idx) a = acc[k];
-                v = a;
+        if (!LASTF) {
+            for (int t = lane; t < 225; t += 64) {
+                const int r = t / 15, c = t - r * 15;   // row-major output
+                Hout[t] = h_entry(r, c) + ((r < 6 && c < 6) ? pose_acc(acc, r, c) : 0.0);
             }
-            if (r < 9 && c < 9) { double s = 0; for (int q = 0; q < 9; q++) s += J9[q * 9 + r] * OJ[q * 9 + c]; v += s; }
-            if (r >= 9 && c >= 9 && (r - 9) / 3 == (c - 9) / 3) { const double* Om = r < 12 ? E.info_g : E.info_a; v += Om[((r - 9) % 3) * 3 + (c - 9) % 3]; }
-            Hout[t] = v;
+        } else {
+            for (int t = lane; t < N * N; t += 64) {
+                const int c = t / N, r = t - c * N;
+                Hs[t] = h_entry(r, c) + ((r < 6 && c < 6) ? pose_acc(acc, r, c) : 0.0);
+            }
+            PIK_WAVE_SYNC()
+            // Optimizer::Marginalize(H, 0, 14): H_ff - H_fp * pinv(H_pp) * H_pf.  pinv by a one-sided Jacobi SVD of H_pp: lane k < 15 owns row k of U
+            // (columns converge to u_i * sigma_i) and of V; the (p, q) rotations run in a fixed order, <= 30 sweeps, stop when every column pair is orthogonal
+            double* U = Jp;      // 15 x 15 row-major (the prior blocks are dead now)
+            double* V = HJp;
+            for (int t = lane; t < 225; t += 64) { const int r = t / 15, c = t - r * 15; U[t] = Hs[(15 + c) * N + 15 + r]; V[t] = r == c ? 1.0 : 0.0; }
+            PIK_WAVE_SYNC()
+            for (int sweep = 0; sweep < 30; sweep++) {
+                double off = 0.0;
+                for (int p = 0; p < 14; p++)
+                    for (int q = p + 1; q < 15; q++) {
+                        double al = 0, be = 0, ga = 0;
+                        if (lane < 15) { const double up = U[lane * 15 + p], uq = U[lane * 15 + q]; al = up * up; be = uq * uq; ga = up * uq; }
+                        // fixed-order sum over rows 0..14 (the oracle adds them in the same order)
+                        double sal = 0, sbe = 0, sga = 0;
+                        for (int k = 0; k < 15; k++) { sal += __shfl(al, k); sbe += __shfl(be, k); sga += __shfl(ga, k); }
+                        if (sga == 0.0) continue;
+                        off = fmax(off, fabs(sga) / sqrt(sal * sbe + 1e-300));
+                        const double zeta = (sbe - sal) / (2.0 * sga);
+                        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                        if (lane < 15) {
+                            const double up = U[lane * 15 + p], uq = U[lane * 15 + q]; U[lane * 15 + p] = cs * up - sn * uq; U[lane * 15 + q] = sn * up + cs * uq;
+                            const double vp = V[lane * 15 + p], vq = V[lane * 15 + q]; V[lane * 15 + p] = cs * vp - sn * vq; V[lane * 15 + q] = sn * vp + cs * vq;
+                        }
+                    }
+                if (off < 1e-15) break;
+            }
+            PIK_WAVE_SYNC()
+            // s_i^2 = |U[:, i]|^2 ; pinv = sum_i V[:, i] U[:, i]^T / s_i^2 over s_i > 1e-6 ; T = pinv * H_pf ; out = H_ff - H_fp * T
+            if (lane < 15) { double s2 = 0; for (int k = 0; k < 15; k++) s2 += U[k * 15 + lane] * U[k * 15 + lane]; eps[lane] = s2; }
+            PIK_WAVE_SYNC()
+            double* inv = J24;   // 225 doubles over J24 | OJ (contiguous, dead now)
+            for (int t = lane; t < 225; t += 64) {
+                const int r = t / 15, c = t - r * 15;
+                double s = 0;
+                for (int i = 0; i < 15; i++) { const double s2 = eps[i]; if (sqrt(s2) > 1e-6) s += V[r * 15 + i] * U[c * 15 + i] / s2; }
+                inv[t] = s;
+            }
+            PIK_WAVE_SYNC()
+            for (int t = lane; t < 225; t += 64) {
+                const int r = t / 15, c = t - r * 15;
+                double s = 0;
+                for (int k = 0; k < 15; k++) { double tk = 0; for (int m = 0; m < 15; m++) tk += inv[k * 15 + m] * Hs[c * N + 15 + m]; s += Hs[(15 + k) * N + r] * tk; }
+                Hout[t] = Hs[c * N + r] - s;
+            }
         }
     }
-    for (int t = lane; t < (int)LIBA_KFD; t += 64) ((double*)&A.frames[b])[t] = ((const double*)&F)[t];
+    for (int t = lane; t < (int)LIBA_KFD; t += 64) { ((double*)&A.frames[b])[t] = ((const double*)&F)[t]; if (LASTF) ((double*)&A.prevs[b])[t] = ((const double*)&Pv)[t]; }
     for (int e = lane; e < A.capE; e += 64) A.outlier[(size_t)b * A.capE + e] = e < ne ? outl[e] : 0;
     if (lane == 0) A.nGood[b] = ne - nBad;
+}
+
+static size_t pose_inertial_smem(int cap_e, int N) {
+    return 2 * ((sizeof(liba_keyframe) + 15) & ~(size_t)15) + (size_t)(N * N + N + 216 + 216 + 9 + 9 + 225 + 225 + 15 + 15 + 2 + cap_e) * 8 + (size_t)2 * cap_e + 16;
 }
 
 extern "C" int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyframe* d_keyframes, const liba_rig* d_rigs, int rig_stride, const pose_edge* d_edges,
@@ -1197,10 +1312,24 @@ extern "C" int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyfram
     if (!d_frames || !d_keyframes || !d_rigs || !d_edges || !d_n_edges || !d_imu || !d_outlier || !d_H || !d_n_good || cap_e <= 0 || batch < 0 || rig_stride < 0)
         return ORB_E_INVALID;
     if (batch == 0) return ORB_OK;
-    PoseInertialArgs A{d_frames, d_keyframes, d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, rec_init, d_outlier, d_H, d_n_good};
-    const size_t smem = ((sizeof(liba_keyframe) + 15) & ~(size_t)15) + (size_t)(225 + 15 + 15 + 81 + 81 + 9 + 9 + cap_e) * 8 + (size_t)3 * cap_e + 16;
+    PoseInertialArgs A{d_frames, const_cast<liba_keyframe*>(d_keyframes), d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, nullptr, rec_init, d_outlier, d_H, d_n_good};
+    const size_t smem = pose_inertial_smem(cap_e, 15);
     if (smem > 160 * 1024) return ORB_E_INVALID;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial_kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
-    hipLaunchKernelGGL(k_pose_inertial_kf, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_pose_inertial<false>, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
+    return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+extern "C" int liba_pose_inertial_lastframe(liba_keyframe* d_frames, liba_keyframe* d_prev_frames, const liba_rig* d_rigs, int rig_stride, const pose_edge* d_edges,
+                                            const int32_t* d_n_edges, int cap_e, const liba_imu_edge* d_imu, const liba_prior* d_priors, int batch, int rec_init,
+                                            uint8_t* d_outlier, double* d_H, int32_t* d_n_good, void* stream) {
+    if (!d_frames || !d_prev_frames || !d_rigs || !d_edges || !d_n_edges || !d_imu || !d_priors || !d_outlier || !d_H || !d_n_good || cap_e <= 0 || batch < 0 ||
+        rig_stride < 0) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    PoseInertialArgs A{d_frames, d_prev_frames, d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, d_priors, rec_init, d_outlier, d_H, d_n_good};
+    const size_t smem = pose_inertial_smem(cap_e, 30);
+    if (smem > 160 * 1024) return ORB_E_INVALID;
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_pose_inertial<true>, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }

@@ -330,3 +330,47 @@ def pose_inertial_optimization_last_keyframe(frames, keyframes, rigs, edges, n_e
         raise OrbHipError(rc, "liba_pose_inertial_kf failed")
     host = lambda a: a if isinstance(a, np.ndarray) else a.cpu().numpy()
     return host(d_f).reshape(B, -1).view(KF_DTYPE).reshape(B), host(d_o), host(d_H).reshape(B, 15, 15), host(d_g)
+
+
+PRIOR_DTYPE = np.dtype([("Rwb", "<f8", (9,)), ("twb", "<f8", (3,)), ("vwb", "<f8", (3,)), ("bg", "<f8", (3,)), ("ba", "<f8", (3,)), ("H", "<f8", (225,))])
+assert PRIOR_DTYPE.itemsize == 246 * 8
+
+
+def synth_prior(prev, seed=0):
+    """A ConstraintPoseImu for key-frame record `prev`: linearisation point near the state, H = a positive definite 15x15 of realistic scale."""
+    rng = np.random.default_rng(seed + 4242)
+    c = np.zeros(1, PRIOR_DTYPE)
+    c["Rwb"] = (prev["Rwb"].reshape(3, 3) @ _rodrigues(rng.normal(0, 1e-3, 3))).reshape(-1)
+    c["twb"] = prev["twb"] + rng.normal(0, 5e-3, 3); c["vwb"] = prev["v"] + rng.normal(0, 1e-2, 3)
+    c["bg"] = prev["bg"] + rng.normal(0, 1e-4, 3); c["ba"] = prev["ba"] + rng.normal(0, 1e-3, 3)
+    Lm = np.diag(np.sqrt([2e4] * 3 + [5e3] * 3 + [1e3] * 3 + [3e5] * 3 + [2e3] * 3)) @ (np.eye(15) + 0.05 * rng.normal(0, 1, (15, 15)))
+    H = Lm @ Lm.T
+    c["H"] = ((H + H.T) / 2).reshape(-1)
+    return c
+
+
+def pose_inertial_optimization_last_frame(frames, prevs, rigs, edges, n_edges, imu, priors, to_dev, *, rec_init=False, lib=None):
+    """Batched Optimizer::PoseInertialOptimizationLastFrame.  -> (frames', prevs', outlier [B, cap_e], H [B,15,15] (the marginalised prior), n_good [B])"""
+    L = lib if lib is not None else _lib.load()
+    fn = L.liba_pose_inertial_lastframe
+    vp, i32 = C.c_void_p, C.c_int
+    fn.restype = i32
+    fn.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]
+    B, cap_e = edges.shape[0], edges.shape[1]
+    rl = rigs if isinstance(rigs, (list, tuple)) else [rigs]
+    rig_bytes = np.frombuffer(b"".join(bytes(r) for r in rl), np.uint8).copy()
+    u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(B, -1)
+    d_f, d_p = to_dev(u8(frames).copy()), to_dev(u8(prevs).copy())
+    d_r, d_e, d_n, d_i, d_c = to_dev(rig_bytes), to_dev(u8(edges)), to_dev(np.ascontiguousarray(n_edges, np.int32)), to_dev(u8(imu)), to_dev(u8(priors))
+    d_o, d_H, d_g = to_dev(np.zeros((B, cap_e), np.uint8)), to_dev(np.zeros((B, 225))), to_dev(np.zeros(B, np.int32))
+    stream = None
+    if not isinstance(d_f, np.ndarray):
+        import torch
+        stream = C.c_void_p(torch.cuda.current_stream(d_f.device).cuda_stream)
+    rc = fn(_ptr(d_f), _ptr(d_p), _ptr(d_r), 1 if len(rl) > 1 else 0, _ptr(d_e), _ptr(d_n), cap_e, _ptr(d_i), _ptr(d_c), B, int(rec_init), _ptr(d_o), _ptr(d_H),
+            _ptr(d_g), stream)
+    if rc != 0:
+        raise OrbHipError(rc, "liba_pose_inertial_lastframe failed")
+    host = lambda a: a if isinstance(a, np.ndarray) else a.cpu().numpy()
+    kfv = lambda a: host(a).reshape(B, -1).view(KF_DTYPE).reshape(B)
+    return kfv(d_f), kfv(d_p), host(d_o), host(d_H).reshape(B, 15, 15), host(d_g)

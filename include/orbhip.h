@@ -514,6 +514,19 @@ int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyframe* d_keyfra
                           const int32_t* d_n_edges, int cap_e, const liba_imu_edge* d_imu, int batch, int rec_init, uint8_t* d_outlier, double* d_H,
                           int32_t* d_n_good, void* stream);
 
+/* Optimizer::PoseInertialOptimizationLastFrame(Frame*, bool bRecInit) (reference src/Optimizer.cc:8068-8415): as liba_pose_inertial_kf, but the previous
+ * FRAME's pose / velocity / biases are free too (30 unknowns) and tied down by EdgePriorPoseImu (G2oTypes.h:737-784; Huber delta 5) built from the
+ * ConstraintPoseImu the previous call left (liba_prior: its members after the constructor's eigenvalue clean-up, H row-major); the preintegration is
+ * mpImuPreintegratedFrame (kf1 = previous frame, kf2 = frame); chi2Mono = 5.991 in every round.  d_prev_frames is updated in place as well.  d_H =
+ * the final 30x30 Hessian marginalised over the previous frame (Optimizer::Marginalize, :5366-5450) = the 15x15 block handed to the new ConstraintPoseImu. */
+typedef struct liba_prior {
+    double Rwb[9], twb[3], vwb[3], bg[3], ba[3];   /* ConstraintPoseImu linearisation point */
+    double H[225];                                 /* ConstraintPoseImu::H, row-major */
+} liba_prior;
+int liba_pose_inertial_lastframe(liba_keyframe* d_frames, liba_keyframe* d_prev_frames, const liba_rig* d_rigs, int rig_stride, const pose_edge* d_edges,
+                                 const int32_t* d_n_edges, int cap_e, const liba_imu_edge* d_imu, const liba_prior* d_priors, int batch, int rec_init,
+                                 uint8_t* d_outlier, double* d_H, int32_t* d_n_good, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device-memory helpers so that adapters written against this header need no HIP headers.
  * ------------------------------------------------------------------------------------------------------- */

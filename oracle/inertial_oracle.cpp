@@ -732,3 +732,188 @@ extern "C" int oib_pose_inertial_kf(void* frame_, const void* keyframe_, const v
     }
     return n_edges - nBad;
 }
+
+// ---- Optimizer::PoseInertialOptimizationLastFrame (reference src/Optimizer.cc:8068-8415) ----------------------------------------------------
+// As above, but the previous FRAME's four vertices are free too (30 unknowns) and tied down by EdgePriorPoseImu (G2oTypes.h:737-784, G2oTypes.cc:935-
+// 968; Huber delta 5) built from the ConstraintPoseImu the previous call left; chi2Mono is 5.991 in all rounds; the final 30x30 Hessian is marginalised
+// over the previous frame (Optimizer::Marginalize, :5366-5450: JacobiSVD pseudo-inverse, singular values <= 1e-6 dropped) into the next prior.
+namespace {
+struct Prior { double Rwb[9], twb[3], vwb[3], bg[3], ba[3], H[225]; };   // == liba_prior: ConstraintPoseImu (H row-major, as its constructor leaves it)
+// EdgePriorPoseImu::computeError / linearizeOplus on key-frame state P (the previous frame): e[15], J 15x15 row-major over [pose 6 | v 3 | bg 3 | ba 3]
+void priorLinearize(const Prior& C, const Kf& P, double* e, double* J) {
+    double M[9], er[3];
+    mulT33(C.Rwb, P.Rwb, M);              // Rwb^T * VP->estimate().Rwb
+    logSO3(M, er);
+    double d[3] = {P.twb[0] - C.twb[0], P.twb[1] - C.twb[1], P.twb[2] - C.twb[2]}, et[3];
+    mulT31(C.Rwb, d, et);
+    for (int i = 0; i < 3; i++) { e[i] = er[i]; e[3 + i] = et[i]; e[6 + i] = P.v[i] - C.vwb[i]; e[9 + i] = P.bg[i] - C.bg[i]; e[12 + i] = P.ba[i] - C.ba[i]; }
+    if (J) {
+        for (int i = 0; i < 225; i++) J[i] = 0.0;
+        double iJ[9];
+        invRightJacobianSO3(er, iJ);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { J[r * 15 + c] = iJ[r * 3 + c]; J[(3 + r) * 15 + 3 + c] = M[r * 3 + c]; }
+        for (int k = 6; k < 15; k++) J[k * 15 + k] = 1.0;
+    }
+}
+// pseudo-inverse of an n x n matrix by one-sided (Hestenes) Jacobi SVD in double; singular values <= 1e-6 dropped (Optimizer.cc:5406-5414)
+void pinvJacobi(const double* Ain, int n, double* out) {
+    std::vector<double> U(Ain, Ain + n * n), V(n * n, 0.0);   // row-major; columns of U converge to u_i * sigma_i
+    for (int i = 0; i < n; i++) V[i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < n; k++) { alpha += U[k * n + p] * U[k * n + p]; beta += U[k * n + q] * U[k * n + q]; gamma += U[k * n + p] * U[k * n + q]; }
+                if (gamma == 0.0) continue;
+                off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta + 1e-300));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < n; k++) {
+                    const double up = U[k * n + p], uq = U[k * n + q]; U[k * n + p] = c * up - sn * uq; U[k * n + q] = sn * up + c * uq;
+                    const double vp = V[k * n + p], vq = V[k * n + q]; V[k * n + p] = c * vp - sn * vq; V[k * n + q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    // A = U' S V^T with U'[:,i] = U[:,i] / s_i  ->  pinv = V S^-1 U'^T = sum_i V[:,i] U[:,i]^T / s_i^2
+    for (int i = 0; i < n * n; i++) out[i] = 0.0;
+    for (int i = 0; i < n; i++) {
+        double s2 = 0;
+        for (int k = 0; k < n; k++) s2 += U[k * n + i] * U[k * n + i];
+        const double sv = std::sqrt(s2);
+        if (!(sv > 1e-6)) continue;
+        for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) out[r * n + c] += V[r * n + i] * U[c * n + i] / s2;
+    }
+}
+const int kImuCol30[24] = {15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 0, 1, 2, 3, 4, 5, 6, 7, 8};   // EdgeInertial column -> unknown ([frame 15 | previous 15])
+}  // namespace
+
+extern "C" int oib_pose_inertial_lastframe(void* frame_, void* prev_, const void* rig_, const void* edges_, int n_edges, const void* imu_, const void* prior_,
+                                           int rec_init, uint8_t* outlier, double* H15) {
+    Kf& F = *(Kf*)frame_;
+    Kf& Pv = *(Kf*)prev_;
+    const Rig& rig = *(const Rig*)rig_;
+    const PEdge* edges = (const PEdge*)edges_;
+    const ImuEdge& E = *(const ImuEdge*)imu_;
+    const Prior& C = *(const Prior*)prior_;
+    const double thMono = (double)std::sqrt(5.991f), thStereo = (double)std::sqrt(7.815f);
+    std::vector<double> chiLast(n_edges, 0.0);
+    std::vector<char> level(n_edges, 0), depthOk(n_edges, 1);
+    for (int i = 0; i < n_edges; i++) outlier[i] = 0;
+    const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    int nBad = 0, nInliers = 0;
+    bool robust = true;
+    PLin L;
+    const int N = 30;
+    auto addInertialAndPrior = [&](double* H, double* b, bool weighted) {   // H column-major N x N
+        double e9[9], J[9 * 24];
+        inertialError(E, Pv, F, e9);
+        inertialJacobian(E, Pv, F, J);
+        for (int a = 0; a < 24; a++) {
+            if (b) { double s = 0; for (int r = 0; r < 9; r++) { double oe = 0; for (int q = 0; q < 9; q++) oe += E.info[r * 9 + q] * e9[q]; s += J[r * 24 + a] * oe; } b[kImuCol30[a]] += -s; }
+            for (int c = 0; c < 24; c++) {
+                double t = 0;
+                for (int r = 0; r < 9; r++) { double oj = 0; for (int q = 0; q < 9; q++) oj += E.info[r * 9 + q] * J[q * 24 + c]; t += J[r * 24 + a] * oj; }
+                H[kImuCol30[c] * N + kImuCol30[a]] += t;
+            }
+        }
+        for (int w2 = 0; w2 < 2; w2++) {   // EdgeGyroRW / EdgeAccRW(previous, frame): e = b_frame - b_prev, J_prev = -I, J_frame = +I
+            const double* Om = w2 == 0 ? E.info_g : E.info_a;
+            const int of = 9 + 3 * w2, op = 24 + 3 * w2;
+            double er[3];
+            for (int k = 0; k < 3; k++) er[k] = w2 == 0 ? F.bg[k] - Pv.bg[k] : F.ba[k] - Pv.ba[k];
+            for (int r = 0; r < 3; r++) {
+                double oe = 0; for (int q = 0; q < 3; q++) oe += Om[r * 3 + q] * er[q];
+                if (b) { b[of + r] += -oe; b[op + r] += oe; }
+                for (int c = 0; c < 3; c++) {
+                    H[(of + c) * N + of + r] += Om[r * 3 + c]; H[(op + c) * N + op + r] += Om[r * 3 + c];
+                    H[(op + c) * N + of + r] += -Om[r * 3 + c]; H[(of + c) * N + op + r] += -Om[c * 3 + r];
+                }
+            }
+        }
+        {   // EdgePriorPoseImu on the previous frame, Huber delta 5 (:8244-8252)
+            double e[15], J15[225], He[15];
+            priorLinearize(C, Pv, e, J15);
+            double chi = 0;
+            for (int r = 0; r < 15; r++) { double s = 0; for (int q = 0; q < 15; q++) s += C.H[r * 15 + q] * e[q]; He[r] = s; chi += e[r] * s; }
+            double rho1 = 1.0;
+            if (weighted && chi > 25.0) rho1 = 5.0 / std::sqrt(chi);
+            for (int a = 0; a < 15; a++) {
+                if (b) { double s = 0; for (int r = 0; r < 15; r++) s += J15[r * 15 + a] * He[r]; b[15 + a] += -rho1 * s; }
+                for (int c = 0; c < 15; c++) {
+                    double t = 0;
+                    for (int r = 0; r < 15; r++) { double hj = 0; for (int q = 0; q < 15; q++) hj += C.H[r * 15 + q] * J15[q * 15 + c]; t += J15[r * 15 + a] * hj; }
+                    H[(15 + c) * N + 15 + a] += rho1 * t;
+                }
+            }
+        }
+    };
+    for (int it = 0; it < 4; it++) {
+        for (int gn = 0; gn < 10; gn++) {
+            std::vector<double> H(N * N, 0.0), b(N, 0.0);
+            for (int i = 0; i < n_edges; i++) {
+                if (level[i]) continue;
+                poseEdgeLinearize(edges[i], F, rig, true, L);
+                chiLast[i] = L.chi2;
+                double rho1 = 1.0;
+                if (robust) { const double d = (edges[i].kind & 0xFF) == 1 ? thStereo : thMono, dsqr = d * d; if (L.chi2 > dsqr) rho1 = d / std::sqrt(L.chi2); }
+                const double w = rho1 * (double)edges[i].inv_sigma2;
+                for (int r = 0; r < 6; r++) {
+                    double s = 0; for (int d = 0; d < L.D; d++) s += L.B[d * 6 + r] * L.e[d];
+                    b[r] += -w * s;
+                    for (int c = 0; c < 6; c++) { double t = 0; for (int d = 0; d < L.D; d++) t += L.B[d * 6 + r] * L.B[d * 6 + c]; H[c * N + r] += w * t; }
+                }
+            }
+            addInertialAndPrior(H.data(), b.data(), true);
+            std::vector<double> x = b;
+            if (!cholSolve15(H.data(), N, x.data())) break;
+            poseUpdate(F, rig, &x[0]);
+            poseUpdate(Pv, rig, &x[15]);
+            for (int i = 0; i < 3; i++) { F.v[i] += x[6 + i]; F.bg[i] += x[9 + i]; F.ba[i] += x[12 + i]; Pv.v[i] += x[21 + i]; Pv.bg[i] += x[24 + i]; Pv.ba[i] += x[27 + i]; }
+        }
+        nBad = 0; nInliers = 0;
+        const float chi2close = 1.5 * chi2Mono[it];
+        for (int i = 0; i < n_edges; i++) {
+            const bool stereo = (edges[i].kind & 0xFF) == 1;
+            poseEdgeLinearize(edges[i], F, rig, false, L);
+            depthOk[i] = L.depthPositive;
+            if (outlier[i]) chiLast[i] = L.chi2;
+            const float chi2 = (float)chiLast[i];
+            bool bad;
+            if (!stereo) { const bool bClose = (edges[i].kind & 0x100) != 0; bad = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !depthOk[i]; }
+            else bad = chi2 > chi2Stereo[it];
+            outlier[i] = bad; level[i] = bad;
+            if (bad) nBad++; else nInliers++;
+        }
+        if (it == 2) robust = false;
+        if (n_edges + 4 < 10) break;
+    }
+    if (nInliers < 30 && !rec_init) {
+        nBad = 0;
+        for (int i = 0; i < n_edges; i++) {
+            poseEdgeLinearize(edges[i], F, rig, false, L);
+            const bool stereo = (edges[i].kind & 0xFF) == 1;
+            if ((float)L.chi2 < (stereo ? 24.f : 18.f)) outlier[i] = 0; else nBad++;
+        }
+    }
+    // 30x30 Hessian of the final state (:8366-8400), marginalised over the previous frame (:8402) -> the frame's 15x15 prior
+    std::vector<double> H(N * N, 0.0);
+    addInertialAndPrior(H.data(), nullptr, false);
+    for (int i = 0; i < n_edges; i++) {
+        if (outlier[i]) continue;
+        poseEdgeLinearize(edges[i], F, rig, true, L);
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double t = 0; for (int d = 0; d < L.D; d++) t += L.B[d * 6 + r] * L.B[d * 6 + c]; H[c * N + r] += (double)edges[i].inv_sigma2 * t; }
+    }
+    double Hpp[225], inv[225];
+    for (int r = 0; r < 15; r++) for (int c = 0; c < 15; c++) Hpp[r * 15 + c] = H[(15 + c) * N + 15 + r];
+    pinvJacobi(Hpp, 15, inv);
+    for (int r = 0; r < 15; r++)
+        for (int c = 0; c < 15; c++) {
+            double s = 0;
+            for (int k = 0; k < 15; k++) { double t = 0; for (int m = 0; m < 15; m++) t += inv[k * 15 + m] * H[c * N + 15 + m]; s += H[(15 + k) * N + r] * t; }   // H_fp * inv * H_pf
+            H15[r * 15 + c] = H[c * N + r] - s;
+        }
+    return n_edges - nBad;
+}

@@ -552,3 +552,15 @@ def pose_inertial_kf(frame, keyframe, rig, edges, imu, rec_init=False):
     n = L.oib_pose_inertial_kf(_p(f), _p(np.ascontiguousarray(keyframe)), C.addressof(rig), _p(edges), len(edges), _p(np.ascontiguousarray(imu)), int(rec_init),
                                _p(outl), _p(H))
     return f, outl[:len(edges)], H, n
+
+
+def pose_inertial_lastframe(frame, prev, rig, edges, imu, prior, rec_init=False):
+    f, pv = np.ascontiguousarray(frame).copy(), np.ascontiguousarray(prev).copy()
+    edges = np.ascontiguousarray(edges)
+    outl = np.zeros(max(len(edges), 1), np.uint8)
+    H = np.zeros((15, 15))
+    L = lib()
+    L.oib_pose_inertial_lastframe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    n = L.oib_pose_inertial_lastframe(_p(f), _p(pv), C.addressof(rig), _p(edges), len(edges), _p(np.ascontiguousarray(imu)), _p(np.ascontiguousarray(prior)),
+                                      int(rec_init), _p(outl), _p(H))
+    return f, pv, outl[:len(edges)], H, n

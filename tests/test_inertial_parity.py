@@ -215,3 +215,47 @@ def test_hip_pose_inertial_matches_oracle(hip_lib, rec):
 def test_hip_pose_inertial_few_inliers_recovery(hip_lib):
     """< 30 inliers and !bRecInit: the recovery pass (Optimizer.cc:7904-7934) re-admits edges below chi2 18 / 24."""
     check_pose_inertial(hip_lib, "hip", ("mono", "stereo"), n_pts=24)
+
+
+# ---- Optimizer::PoseInertialOptimizationLastFrame -------------------------------------------------------------------------------------
+from orbhip.inertial import PRIOR_DTYPE, pose_inertial_optimization_last_frame, synth_prior  # noqa: E402
+
+
+def test_oracle_pose_inertial_lastframe_prior_is_psd_and_marginal():
+    f = synth_inertial_frame(6, 300, "stereo")
+    pr = synth_prior(f["keyframe"][0], 2)
+    fr, pv, outl, H, n = O.pose_inertial_lastframe(f["frame"], f["keyframe"], f["rig"], f["edges"], f["imu"], pr)
+    assert n == len(f["edges"]) - int(outl.sum()) and n > 150
+    assert np.linalg.eigvalsh((H + H.T) / 2).min() > 0 and np.abs(pv["twb"] - f["keyframe"]["twb"]).max() > 1e-4    # the previous frame moved too
+    assert np.abs(H - H.T).max() < 1e-3 * np.abs(H).max()      # symmetric up to the slightly non-symmetric random-walk information matrices
+
+
+def check_pose_inertial_lastframe(lib, backend, kinds, rec_init=False, n_pts=300):
+    fs = [synth_inertial_frame(90 + i, n_pts + 40 * i, k) for i, k in enumerate(kinds)]
+    B, cap = len(fs), max(len(f["edges"]) for f in fs) + 5
+    edges = np.zeros((B, cap), POSE_EDGE_DTYPE)
+    n = np.zeros(B, np.int32)
+    for b, f in enumerate(fs):
+        edges[b, :len(f["edges"])] = f["edges"]; n[b] = len(f["edges"])
+    frames = np.concatenate([f["frame"] for f in fs]); prevs = np.concatenate([f["keyframe"] for f in fs]); imu = np.concatenate([f["imu"] for f in fs])
+    priors = np.concatenate([synth_prior(f["keyframe"][0], b) for b, f in enumerate(fs)])
+    fr, pv, outl, H, good = pose_inertial_optimization_last_frame(frames, prevs, [f["rig"] for f in fs], edges, n, imu, priors, to_dev(backend), rec_init=rec_init,
+                                                                  lib=lib)
+    for b, f in enumerate(fs):
+        ofr, opv, ooutl, oH, on = O.pose_inertial_lastframe(f["frame"], f["keyframe"], f["rig"], f["edges"], f["imu"], priors[b:b + 1], rec_init)
+        kb8 = f["rig"].model[0] == 1
+        assert good[b] == on and np.array_equal(outl[b, :n[b]], ooutl), (b, good[b], on)
+        tol = 2e-5 if kb8 else 5e-6
+        for fld in ("Rwb", "twb", "v", "bg", "ba", "Rcw", "tcw"):
+            assert np.abs(fr[b][fld] - ofr[0][fld]).max() < tol and np.abs(pv[b][fld] - opv[0][fld]).max() < tol, (b, fld)
+        assert np.abs(H[b] - oH).max() <= (1e-3 if kb8 else 1e-5) * np.abs(oH).max(), (b, np.abs(H[b] - oH).max() / np.abs(oH).max())
+
+
+def test_emu_pose_inertial_lastframe_matches_oracle(emu_lib):
+    check_pose_inertial_lastframe(emu_lib, "emu", ("mono", "stereo"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", [False, True])
+def test_hip_pose_inertial_lastframe_matches_oracle(hip_lib, rec):
+    check_pose_inertial_lastframe(hip_lib, "hip", ("mono", "stereo", "fisheye", "stereo"), rec_init=rec)
