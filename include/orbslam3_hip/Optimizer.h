@@ -314,10 +314,41 @@ public:
         return good;
     }
 
+    // Optimizer::PoseInertialOptimizationLastFrame (include/Optimizer.h:71, src/Optimizer.cc:8068-8415): prevFrame (pFrame->mpPrevFrame's state) is free too
+    // and updated in place; prior = pFp->mpcpi's members (after the ConstraintPoseImu constructor); preint = mpImuPreintegratedFrame (kf1 = previous frame);
+    // H15 = H.block<15,15>(15,15) of the marginalised Hessian -> new ConstraintPoseImu(...).
+    int optimizeLastFrame(liba_keyframe& frame, liba_keyframe& prevFrame, const liba_prior& prior, const liba_imu_edge& preint, bool bRecInit,
+                          std::vector<bool>& mvbOutlier, double H15[225]) {
+        const int ne = (int)edges_.size();
+        mvbOutlier.assign(ne, false);
+        if (ne == 0) return 0;
+        liba_keyframe* dF = f_.upload(&frame, 1);
+        liba_keyframe* dK = k_.upload(&prevFrame, 1);
+        const liba_rig* dR = r_.upload(&rig_, 1);
+        const pose_edge* dE = e_.upload(edges_.data(), ne);
+        const liba_imu_edge* dI = i_.upload(&preint, 1);
+        const liba_prior* dC = c_.upload(&prior, 1);
+        const int32_t* dN = n_.upload(&ne, 1);
+        uint8_t* dO = (uint8_t*)o_.ensure((size_t)ne + 16);
+        double* dH = (double*)h_.ensure(225 * 8);
+        int32_t* dG = (int32_t*)g_.ensure(16);
+        if (liba_pose_inertial_lastframe(dF, dK, dR, 0, dE, dN, ne, dI, dC, 1, bRecInit ? 1 : 0, dO, dH, dG, nullptr) != ORB_OK) throw std::runtime_error("liba_pose_inertial_lastframe");
+        std::vector<uint8_t> fl(ne);
+        int32_t good = 0;
+        orb_memcpy_d2h(&frame, dF, sizeof(frame), nullptr);
+        orb_memcpy_d2h(&prevFrame, dK, sizeof(prevFrame), nullptr);
+        orb_memcpy_d2h(fl.data(), dO, ne, nullptr);
+        orb_memcpy_d2h(H15, dH, 225 * 8, nullptr);
+        orb_memcpy_d2h(&good, dG, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        for (int i = 0; i < ne; i++) mvbOutlier[i] = fl[i] != 0;
+        return good;
+    }
+
 private:
     liba_rig rig_{};
     std::vector<pose_edge> edges_;
-    detail::DevBuf f_, k_, r_, e_, i_, n_, o_, h_, g_;
+    detail::DevBuf f_, k_, r_, e_, i_, n_, o_, h_, g_, c_;
 };
 
 }  // namespace orbslam3_hip

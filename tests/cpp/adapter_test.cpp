@@ -37,6 +37,7 @@ void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
 int ofr_stereo_fisheye(const void*, const uint8_t*, int, int, const void*, const uint8_t*, int, int, const float*, const float*, int32_t*, int32_t*, float*, float*);
 void ofr_stereo_from_rgbd(const void*, const void*, int, const float*, int, float, float*, float*);
+int oib_pose_inertial_lastframe(void*, void*, const void*, const void*, int, const void*, const void*, int, uint8_t*, double*);
 int oib_pose_inertial_kf(void*, const void*, const void*, const void*, int, const void*, int, uint8_t*, double*);
 void oib_optimize(void*, int, const void*, double*, int, const void*, int, const void*, int, double, double, double, int, double*);
 int omo_search_by_sim3(const void*, const uint8_t*, int, float, float, float, float, const void*, const uint8_t*, int, float, float, float, float, const void*,
@@ -509,6 +510,21 @@ int main() {
         double hmax = 0;
         for (int i = 0; i < 225; i++) hmax = std::max(hmax, std::fabs(oH[i]));
         for (int i = 0; i < 225; i++) CHECK(std::fabs(H15[i] - oH[i]) <= 1e-6 * hmax);
+        // ... and PoseInertialOptimizationLastFrame: the key frame plays the previous frame, with a diagonal prior at its state
+        liba_prior pr{};
+        for (int i = 0; i < 9; i++) pr.Rwb[i] = kf.Rwb[i];
+        for (int i = 0; i < 3; i++) { pr.twb[i] = kf.twb[i] + 0.002 * (i + 1); pr.vwb[i] = kf.v[i] - 0.004; pr.bg[i] = kf.bg[i]; pr.ba[i] = kf.ba[i] + 0.001; }
+        for (int i = 0; i < 15; i++) pr.H[i * 16] = i < 3 ? 2e4 : (i < 6 ? 5e3 : (i < 9 ? 1e3 : (i < 12 ? 3e5 : 2e3)));
+        liba_keyframe f2 = ofr, p2 = kf, of2 = ofr, op2 = kf;
+        f2.twb[0] += 0.01; of2.twb[0] += 0.01;
+        const int og2 = oib_pose_inertial_lastframe(&of2, &op2, &rig, oe.data(), (int)oe.size(), &pe2, &pr, 0, oout.data(), oH);
+        const int g2 = PIO.optimizeLastFrame(f2, p2, pr, pe2, false, outl2, H15);
+        CHECK(g2 == og2 && g2 > 100);
+        for (size_t i = 0; i < oe.size(); i++) CHECK(outl2[i] == (oout[i] != 0));
+        for (int c = 0; c < 3; c++) { CHECK(std::fabs(f2.twb[c] - of2.twb[c]) < 5e-6 && std::fabs(p2.twb[c] - op2.twb[c]) < 5e-6 && std::fabs(p2.v[c] - op2.v[c]) < 5e-6); }
+        hmax = 0;
+        for (int i = 0; i < 225; i++) hmax = std::max(hmax, std::fabs(oH[i]));
+        for (int i = 0; i < 225; i++) CHECK(std::fabs(H15[i] - oH[i]) <= 1e-5 * hmax);
     }
     std::printf("adapter_test OK: %d keypoints, %d matches, %d LBA edges, LM chi2 %.1f -> %.1f\n", n, nm, ne, rs, chiFinal);
     return 0;
