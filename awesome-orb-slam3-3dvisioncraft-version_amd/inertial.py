@@ -374,3 +374,45 @@ def pose_inertial_optimization_last_frame(frames, prevs, rigs, edges, n_edges, i
     host = lambda a: a if isinstance(a, np.ndarray) else a.cpu().numpy()
     kfv = lambda a: host(a).reshape(B, -1).view(KF_DTYPE).reshape(B)
     return kfv(d_f), kfv(d_p), host(d_o), host(d_H).reshape(B, 15, 15), host(d_g)
+
+
+class PoseInertialBatch:
+    """Device-resident batch for liba_pose_inertial_kf / liba_pose_inertial_lastframe: upload once, run many times (bench / pipelines)."""
+
+    def __init__(self, frames, others, rigs, edges, n_edges, imu, to_dev, priors=None, lib=None):
+        self._L = lib if lib is not None else _lib.load()
+        B, self.cap_e = edges.shape[0], edges.shape[1]
+        self.B = B
+        rl = rigs if isinstance(rigs, (list, tuple)) else [rigs]
+        self.rig_stride = 1 if len(rl) > 1 else 0
+        u8 = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(B, -1)
+        self.f0, self.o0 = to_dev(u8(frames).copy()), to_dev(u8(others).copy())
+        self.f, self.o = to_dev(u8(frames).copy()), to_dev(u8(others).copy())
+        self.r, self.e, self.n, self.i = to_dev(np.frombuffer(b"".join(bytes(r) for r in rl), np.uint8).copy()), to_dev(u8(edges)), to_dev(np.ascontiguousarray(n_edges, np.int32)), to_dev(u8(imu))
+        self.c = None if priors is None else to_dev(u8(priors))
+        self.out, self.H, self.g = to_dev(np.zeros((B, self.cap_e), np.uint8)), to_dev(np.zeros((B, 225))), to_dev(np.zeros(B, np.int32))
+
+    def run(self, rec_init=False):
+        vp, i32 = C.c_void_p, C.c_int
+        if not isinstance(self.f, np.ndarray):
+            import torch
+            self.f.copy_(self.f0); self.o.copy_(self.o0)
+            stream = C.c_void_p(torch.cuda.current_stream(self.f.device).cuda_stream)
+        else:
+            self.f[...] = self.f0; self.o[...] = self.o0
+            stream = None
+        if self.c is None:
+            fn = self._L.liba_pose_inertial_kf
+            fn.restype = i32
+            fn.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp]
+            rc = fn(_ptr(self.f), _ptr(self.o), _ptr(self.r), self.rig_stride, _ptr(self.e), _ptr(self.n), self.cap_e, _ptr(self.i), self.B, int(rec_init), _ptr(self.out),
+                    _ptr(self.H), _ptr(self.g), stream)
+        else:
+            fn = self._L.liba_pose_inertial_lastframe
+            fn.restype = i32
+            fn.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]
+            rc = fn(_ptr(self.f), _ptr(self.o), _ptr(self.r), self.rig_stride, _ptr(self.e), _ptr(self.n), self.cap_e, _ptr(self.i), _ptr(self.c), self.B, int(rec_init),
+                    _ptr(self.out), _ptr(self.H), _ptr(self.g), stream)
+        if rc != 0:
+            raise OrbHipError(rc, "liba_pose_inertial_* failed")
+        return self.g

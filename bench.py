@@ -364,17 +364,21 @@ def main():
                 pfr = np.concatenate([pfs[b2 % 8]["frame"] for b2 in range(PIB)]); pkf = np.concatenate([pfs[b2 % 8]["keyframe"] for b2 in range(PIB)])
                 pim = np.concatenate([pfs[b2 % 8]["imu"] for b2 in range(PIB)])
                 tdv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-                pose_inertial_optimization_last_keyframe(pfr, pkf, pfs[0]["rig"], pe, pn, pim, tdv)
-                barrier()
-                t4c = time.perf_counter()
-                for _ in range(2):
-                    pres = pose_inertial_optimization_last_keyframe(pfr, pkf, pfs[0]["rig"], pe, pn, pim, tdv)
-                barrier()
-                dtpi = (time.perf_counter() - t4c) / 2
-                extra["pose_inertial"] = {"frames_per_s_incl_h2d_d2h": round(PIB / dtpi, 1), "ms_per_batch": round(dtpi * 1e3, 3), "frames_per_batch": PIB,
-                                          "edges_per_frame": float(pn.mean()), "mean_inliers": float(pres[3].mean()),
-                                          "what": "Optimizer::PoseInertialOptimizationLastKeyFrame (4 x 10 Gauss-Newton over pose/velocity/biases, re-classification, 15x15 prior) "
-                                                  "per frame; this leg's timing includes the wrapper's host<->device copies of the batch"}
+                from orbhip.inertial import PoseInertialBatch, synth_prior
+                rates = {}
+                for name, pri in (("last_keyframe", None), ("last_frame", np.concatenate([synth_prior(pfs[b2 % 8]["keyframe"][0], b2 % 8) for b2 in range(PIB)]))):
+                    PBt = PoseInertialBatch(pfr, pkf, pfs[0]["rig"], pe, pn, pim, tdv, priors=pri)
+                    PBt.run()
+                    barrier()
+                    t4c = time.perf_counter()
+                    for _ in range(3):
+                        pg = PBt.run()
+                    barrier()
+                    rates[name] = (PIB / ((time.perf_counter() - t4c) / 3), float(pg.float().mean().item()))
+                extra["pose_inertial"] = {"last_keyframe_frames_per_s": round(rates["last_keyframe"][0], 1), "last_frame_frames_per_s": round(rates["last_frame"][0], 1),
+                                          "frames_per_batch": PIB, "edges_per_frame": float(pn.mean()), "mean_inliers": rates["last_keyframe"][1],
+                                          "what": "Optimizer::PoseInertialOptimizationLastKeyFrame / ...LastFrame (4 x 10 Gauss-Newton over 15 / 30 unknowns, re-classification, "
+                                                  "prior Hessian / marginalisation) per frame, device resident"}
                 if world == 1 and not args.no_cpu_baseline:
                     import oracle_lib as O
                     tc = time.perf_counter()
