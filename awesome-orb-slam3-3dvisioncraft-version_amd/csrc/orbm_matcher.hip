@@ -542,6 +542,55 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
             const uint32_t e = valid ? sEnt[(i + g) * SBP_STAGE + sl] : 0u;
             const int cidx = (int)(e & 0xFFFF);
             bool unb = valid && occ[cidx] == 0;
+            // Optimistic parallel resolution: all queries of the batch decide at once against the occupancy at the batch start.  That equals the
+            // serial result unless an earlier query of the batch accepts a keypoint that also sits in a later query's candidate list (then the later
+            // one would have seen it blocked, or would overwrite its holder): the batch is committed up to the first such query and the next batch
+            // starts there.  Rig twins, whose `continue` rules chain, take the serial loop below.  (~75 dependent scalar instructions per query in the serial form; the resolver is one wave per frame.)
+            if (link == nullptr && !(__ballot(g < nb && ((cwl >> 28) & 1)))) {
+                const uint32_t um = (uint32_t)((__ballot(unb) >> (8 * g)) & 0xFFull);
+                const bool have1 = um != 0u;
+                const uint32_t um2 = um & (um - 1u);
+                const bool have2 = um2 != 0u;
+                const uint32_t eb1 = (uint32_t)__shfl((int)e, 8 * g + (have1 ? __ffs((int)um) - 1 : 0));
+                const uint32_t eb2 = (uint32_t)__shfl((int)e, 8 * g + (have2 ? __ffs((int)um2) - 1 : 0));
+                bool accept = false, skipAfter = false;
+                if (g < nb) {
+                    if (mode == ORBM_MODE_BEST_ONLY && !((cwl >> 29) & 1)) skipAfter = true;   // left window empty (no twins here: rightCam == 0)
+                    if (have1) {
+                        const int bestDist = (int)((eb1 >> 16) & 0x1FF);
+                        if (bestDist <= th) {
+                            if (mode == ORBM_MODE_LOCAL_MAP) {
+                                const int bestLevel = (int)((eb1 >> 25) & 0x3F);
+                                const int bestDist2 = have2 ? (int)((eb2 >> 16) & 0x1FF) : 256;
+                                const int bestLevel2 = have2 ? (int)((eb2 >> 25) & 0x3F) : -1;
+                                if (bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2) skipAfter = true;
+                                else accept = bestLevel != bestLevel2 || (float)bestDist <= ratio * (float)bestDist2;
+                            } else accept = true;
+                        }
+                    }
+                }
+                const int aidx = accept ? (int)(eb1 & 0xFFFF) : -1;
+                bool clash = false;
+                for (int k = 0; k + 1 < nb; k++) {
+                    const int bi = __builtin_amdgcn_readlane(aidx, 8 * k);
+                    if (bi >= 0 && g > k && valid && cidx == bi) clash = true;
+                }
+                // commit the longest clash-free prefix of the batch (group 0 never clashes) and go on from the first clashing query
+                const unsigned long long cm = __ballot(clash);
+                const int np = cm ? (__ffsll((long long)cm) - 1) >> 3 : nb;
+                const bool lead = sl == 0 && accept && g < np;
+                if (lead) {
+                    const int q = q0 + i + g;
+                    occ[aidx] = (uint8_t)((cwl >> 30) & 1);
+                    kp_match[aidx] = q;
+                    q_match[q] = aidx;
+                }
+                nmatches += __popcll(__ballot(lead));
+                skipTwin = __builtin_amdgcn_readlane((int)skipAfter, 8 * (np - 1)) != 0;
+                __syncthreads();
+                i += np;
+                continue;
+            }
             for (int j = 0; j < nb; j++) {
                 const int q = q0 + i + j;
                 const int cw = __builtin_amdgcn_readlane(cwl, j * 8);
