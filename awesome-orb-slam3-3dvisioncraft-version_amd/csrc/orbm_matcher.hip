@@ -231,10 +231,11 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
     int incl = ce - cs;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
+        if (off >= ncol) break;   // wave-uniform: lanes >= ncol hold zero lengths, the scan only has to cover the window's columns
         const int t = __shfl_up(incl, off);
         if (lane >= off) incl += t;
     }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int total = __builtin_amdgcn_readlane(incl, ncol - 1);
     const int excl = incl - (ce - cs);
     for (int base = 0; base < total; base += 64) {
         const int t = base + lane;
@@ -311,14 +312,18 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
             __builtin_amdgcn_wave_barrier();
             unsigned long long key = ~0ull;
             if (lane < count) { const uint32_t e = w[2 + lane]; key = ((unsigned long long)((((e >> 16) & 0x1FFu) << 6) | (uint32_t)lane) << 32) | e; }
+            // the network only has to cover the first 2^m >= count lanes (the others hold ~0 and would stay at the end anyway): a typical list of
+            // <= 8 entries takes 6 of the 21 compare-exchange steps, each a dependent cross-lane shuffle in a latency-bound kernel
 #pragma unroll
-            for (int k = 2; k <= 64; k <<= 1)
+            for (int k = 2; k <= 64; k <<= 1) {
+                if ((k >> 1) >= count) break;   // wave-uniform
 #pragma unroll
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     const unsigned long long other = __shfl_xor(key, j);
                     const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
                     key = keepMin ? (key < other ? key : other) : (key > other ? key : other);
                 }
+            }
             __builtin_amdgcn_wave_barrier();
             if (lane < count) w[2 + lane] = (uint32_t)key;
         }
