@@ -285,6 +285,8 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
 }
 
 static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    uint32_t* lst = (uint32_t*)orb_smem + (threadIdx.x >> 6) * SBP_CAPC;   // this wave's compacted list: sorted in LDS, written to the workspace once
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nq = min(A.nq[b], A.cap_q);
@@ -300,18 +302,21 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
             const unsigned long long m = __ballot(pass);
             if (pass) {
                 const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < SBP_CAPC) w[2 + pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+                if (pos < SBP_CAPC) lst[pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
             }
             count += __popcll(m);
             anyArea |= __ballot(area) != 0ull;
         });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nl = min(count, SBP_CAPC);
+        uint32_t ent = lane < nl ? lst[lane] : 0u;
         if (count > 1 && count <= SBP_CAPC) {
             // sort the cached list by (distance, enumeration position): the resolver then takes "first unblocked" instead of min-reducing.
-            // Wave-wide bitonic sort of (dist << 6 | pos) << 32 | entry; the wave re-reads its own just-written list.
-            __threadfence_block();   // the list was written by other lanes of this wave (global memory): workgroup-scope release/acquire
-            __builtin_amdgcn_wave_barrier();
+            // Wave-wide bitonic sort of (dist << 6 | pos) << 32 | entry.
             unsigned long long key = ~0ull;
-            if (lane < count) { const uint32_t e = w[2 + lane]; key = ((unsigned long long)((((e >> 16) & 0x1FFu) << 6) | (uint32_t)lane) << 32) | e; }
+            if (lane < count) key = ((unsigned long long)((((ent >> 16) & 0x1FFu) << 6) | (uint32_t)lane) << 32) | ent;
             // the network only has to cover the first 2^m >= count lanes (the others hold ~0 and would stay at the end anyway): a typical list of
             // <= 8 entries takes 6 of the 21 compare-exchange steps, each a dependent cross-lane shuffle in a latency-bound kernel
 #pragma unroll
@@ -324,9 +329,9 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
                     key = keepMin ? (key < other ? key : other) : (key > other ? key : other);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < count) w[2 + lane] = (uint32_t)key;
+            ent = (uint32_t)key;
         }
+        if (lane < nl) w[2 + lane] = ent;
     }
     if (lane == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
 }
@@ -1041,7 +1046,7 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     A.cells = cells; A.kp_link = d_kp_link;
     A.chi2_gate = 0; A.q_dist = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
-    hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return launch_status();
 }
