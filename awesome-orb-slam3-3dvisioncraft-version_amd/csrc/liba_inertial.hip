@@ -503,10 +503,10 @@ static __global__ __launch_bounds__(LIBA_T, LIBA_WAVES) void k_liba_optimize(Lib
     if (tid < 16) ictl[tid] = 0;
     __syncthreads();
     if (tid == 0) {
-        int o = 0, nfp = 0, nfi = 0;
+        int o = 0, nfp = 0;
         for (int k = 0; k < w.nKf; k++) if (hp[k] == 0) { hp[k] = o; o += 6; if (nfp < LIBA_MAX_FREE) freeKf[nfp] = k; nfp++; }
         ictl[0] = o;
-        for (int k = 0; k < w.nKf; k++) if (hi[k] == 0) { hi[k] = o; o += 9; nfi++; }
+        for (int k = 0; k < w.nKf; k++) if (hi[k] == 0) { hi[k] = o; o += 9; }
         ictl[1] = o; ictl[2] = nfp;
         if (nfp > LIBA_MAX_FREE || o > A.DRmax || o == 0) ictl[3] = 1;
     }
