@@ -229,7 +229,6 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
     int cs = 0, ce = 0;
     if (lane < ncol) { cs = gs[(nMinCellX + lane) * ORBM_GRID_ROWS + nMinCellY]; ce = gs[(nMinCellX + lane) * ORBM_GRID_ROWS + nMaxCellY + 1]; }
     int incl = ce - cs;
-#pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         if (off >= ncol) break;   // wave-uniform: lanes >= ncol hold zero lengths, the scan only has to cover the window's columns
         const int t = __shfl_up(incl, off);
