@@ -37,11 +37,25 @@ static __constant__ uint32_t c_icmask[16][12];   // [|v|][dword k of the patch r
 // ============================================================================================================
 // E1  pyramid level:  dst(level l) = cv::resize(src(level l-1), INTER_LINEAR)  — 11-bit fixed point
 // ============================================================================================================
+// XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2.  With a
+// (unit, frame) grid the units of ONE frame are spread over all eight XCDs, so every XCD pulls the same frame's pyramid (1.1 MB) through
+// its own L2: up to 8x the fill traffic, and these kernels' load phases run at several TB/s.  Instead the grid is 1-D and XCD x takes the
+// frames f with f % 8 == x, walking a frame's units in order: a frame's pyramid is fetched once and stays L2-resident while it is worked on.
+// grid = units_per_frame * 8 * ceil(batch / 8); returns false for the padding workgroups of a batch that is not a multiple of 8.
+static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, const int batch, int* frame, int* unit) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int fr = (slot / unitsPerFrame) * 8 + xcd;
+    *frame = fr;
+    *unit = slot - (slot / unitsPerFrame) * unitsPerFrame;
+    return fr < batch;
+}
+
 struct ResizeParams {
     const uint8_t* src; size_t sFrame; int sStride, sw, sh;
     uint8_t* dst; size_t dFrame; int dStride, dw, dh;
     double scale_x, scale_y;   // 1 / ((double)dw / sw), 1 / ((double)dh / sh)  — cv::resize's scale_x / scale_y
     const int* coef;           // k_resize2: per-level tables xs[dw] | xw[dw] | ys[dh] | yw[dh] (resize_coef of every column / row)
+    int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
 };
 
 // cv::resize coefficient of one destination coordinate, computed in-kernel with the same IEEE
@@ -148,6 +162,9 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 // (t = p0*a0 + p1*a1 as one v_dot2_u32_u16 on a byte pair picked by v_perm from an 8-byte window; cv::resize's ">> 4" applied,
 // stored << 9 so that the V pass is one v_mul_hi_u32_u24 per tap: ((b << 7) * ((t >> 4) << 9)) >> 32 == (b * (t >> 4)) >> 16).
 // V pass: 4 adjacent pixels per thread from two 16-byte LDS reads.
+#ifndef R2_XCD
+#define R2_XCD 1
+#endif
 #define R2_TH 32
 #define R2_ROWS 46        // 32 * 1.3 + 2 taps + 2 slack (estimated footprint)
 #define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks, 16-byte aligned)
@@ -161,8 +178,16 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     uint32_t* hbuf = (uint32_t*)(rowt + R2_TH);   // [R2_ROWS][R2_HP]  ((p0*a0 + p1*a1) >> 4) << 9
     uint8_t* tile = (uint8_t*)(hbuf + R2_ROWS * R2_HP);   // [R2_ROWS][RS_PITCH]
     const int tid = threadIdx.x;
+#if R2_XCD
+    int frameZ, tileI;
+    if (!xcd_frame_unit(P.tilesX * P.tilesY, P.batch, &frameZ, &tileI)) return;
+    const int tyI = tileI / P.tilesX, txI = tileI - tyI * P.tilesX;
+    const int bx0 = txI * RS_TW, by0 = tyI * R2_TH;
+#else
+    const int frameZ = blockIdx.z;
     const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * R2_TH;
-    const uint8_t* S = P.src + (size_t)blockIdx.z * P.sFrame;
+#endif
+    const uint8_t* S = P.src + (size_t)frameZ * P.sFrame;
     const int* xs = P.coef; const int* xw = xs + P.dw; const int* ys = xw + P.dw; const int* yw = ys + P.dh;
     // Source footprint of the tile from a float estimate of the first / last coefficient, widened by one column / row on each
     // side (the exact indices come from the double-precision tables and can differ by one): the staging loads then do not wait
@@ -231,7 +256,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     const int xg = tid & 15;
     const int dx0 = bx0 + xg * 4;
     if (dx0 >= P.dw) return;
-    uint8_t* D = P.dst + (size_t)blockIdx.z * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
+    uint8_t* D = P.dst + (size_t)frameZ * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int ty = (tid >> 4) + 16 * k;
@@ -327,19 +352,6 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
 #define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
 #define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)   // 16 rows: each of the 4 waves owns 8 rows x 64 columns = FAST_QCAP/4 pixels
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice: one chunk's survivors + up to 63 carried over from the previous chunk
-
-// XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2.  With a
-// (unit, frame) grid the units of ONE frame are spread over all eight XCDs, so every XCD pulls the same frame's pyramid (1.1 MB) through
-// its own L2: up to 8x the fill traffic, and these kernels' load phases run at several TB/s.  Instead the grid is 1-D and XCD x takes the
-// frames f with f % 8 == x, walking a frame's units in order: a frame's pyramid is fetched once and stays L2-resident while it is worked on.
-// grid = units_per_frame * 8 * ceil(batch / 8); returns false for the padding workgroups of a batch that is not a multiple of 8.
-static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, const int batch, int* frame, int* unit) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int fr = (slot / unitsPerFrame) * 8 + xcd;
-    *frame = fr;
-    *unit = slot - (slot / unitsPerFrame) * unitsPerFrame;
-    return fr < batch;
-}
 
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
@@ -1800,8 +1812,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
         R.coef = h->d_coef + h->coefOff[l];
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
-            dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + R2_TH - 1) / R2_TH, batch);
+            R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
+#if R2_XCD
+            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * R.tilesY * 8 * ((batch + 7) / 8)), dim3(256), R2_SMEM, st, R);
+#else
+            dim3 grid(R.tilesX, R.tilesY, batch);
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
+#endif
         } else {
             dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
             hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
