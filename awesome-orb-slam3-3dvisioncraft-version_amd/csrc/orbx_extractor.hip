@@ -1591,6 +1591,10 @@ struct orbx_extractor {
     // last call (debug taps / pyramid views)
     const uint8_t* lastImages = nullptr; size_t lastFrameStride = 0; int lastRowStride = 0, lastBatch = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed = false;
+    // single-frame entry point: the launch sequence of one call is captured once into a HIP graph (per lapping window) and replayed —
+    // a frame is ~11 kernels + 2 memsets of a few tens of microseconds each, i.e. launch bound
+    hipGraphExec_t graphExec = nullptr; int graphLap0 = 0, graphLap1 = 0; int graphState = 0;   // 0 = not tried, 1 = usable, -1 = capture unsupported
+    bool capturing = false;
     std::string err;
 };
 
@@ -1620,6 +1624,7 @@ static void orbx_free(orbx_extractor* h) {
                     h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1800,7 +1805,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     HIPCHK(h, hipSetDevice(h->device));
     const int nl = h->cfg.nlevels;
     h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
-    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     // E1 pyramid
     for (int l = 1; l < nl; l++) {
@@ -1824,7 +1829,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
         }
     }
-    HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[1], st));
     // E2 FAST
     {
         FastParams F;
@@ -1845,7 +1850,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         hipLaunchKernelGGL(k_fast, dim3(h->nTiles, batch), dim3(256), h->fastSmem, st, F);
 #endif
     }
-    HIPCHK(h, hipEventRecord(h->ev[2], st));
+    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[2], st));
     // E3 octree
     {
         OctParams O;
@@ -1862,7 +1867,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
         hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
-    HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly
     {
         DescParams D;
@@ -1879,8 +1884,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         D.groups = D.unitStart[nl]; D.batch = batch;
         hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
     }
-    HIPCHK(h, hipEventRecord(h->ev[4], st));
-    h->timed = true;
+    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
+    if (!h->capturing) h->timed = true;
     HIPCHK(h, hipGetLastError());
     return ORB_OK;
 }
@@ -1894,9 +1899,32 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
     if (width != h->W || height != h->H || stride < width) return orbx_fail(h, ORB_E_INVALID, "image size differs from the handle's");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->imgStride, image, stride, width, height, hipMemcpyHostToDevice, h->stream));
-    int rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1,
-                                    h->maxKp, h->d_counts1, h->stream);
-    if (rc != ORB_OK) return rc;
+    int rc = ORB_OK;
+    if (h->graphState >= 0 && (!h->graphExec || h->graphLap0 != lap0 || h->graphLap1 != lap1)) {
+        if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            h->capturing = true;
+            rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp,
+                                        h->d_counts1, h->stream);
+            h->capturing = false;
+            hipGraph_t g = nullptr;
+            const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+            if (rc == ORB_OK && ec == hipSuccess && g && hipGraphInstantiate(&h->graphExec, g, nullptr, nullptr, 0) == hipSuccess) {
+                h->graphLap0 = lap0; h->graphLap1 = lap1; h->graphState = 1;
+            } else { h->graphExec = nullptr; h->graphState = -1; }
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            rc = ORB_OK;
+        } else { h->graphState = -1; (void)hipGetLastError(); }
+    }
+    if (h->graphExec) {
+        h->timed = false;   // per-kernel events are not part of the graph
+        HIPCHK(h, hipGraphLaunch(h->graphExec, h->stream));
+    } else {
+        rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp,
+                                    h->d_counts1, h->stream);
+        if (rc != ORB_OK) return rc;
+    }
     int32_t counts[2];
     HIPCHK(h, hipMemcpyAsync(counts, h->d_counts1, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
