@@ -63,6 +63,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OrbHipError(ORB_E_INVALID, "%s not found: build it with tools/build_lib.sh (hipcc, gfx950); "
                               "there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64; if liborbhip.so is dlopen'ed first it binds the system copy
+        # and torch later loads a second runtime whose device pointers the first one rejects (every launch fails with ORB_E_HIP).  Importing torch
+        # first makes the library's libamdhip64 dependency resolve to the copy that is already mapped.
+        try:
+            import torch  # noqa: F401
+        except Exception:   # noqa: BLE001  (the library itself does not need torch)
+            pass
         _lib = bind(C.CDLL(LIB_PATH))
     return _lib
 
