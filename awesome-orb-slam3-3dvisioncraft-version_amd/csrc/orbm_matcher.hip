@@ -193,6 +193,47 @@ struct SbpArgs {
     int32_t* q_dist;
 };
 
+// One entry of the window's enumeration (position p of the frame's grid-index list, or -1): the tests of GetFeaturesInArea and the candidate filters
+// that do not depend on matches made during the call.
+static __device__ __forceinline__ void window_entry(const SbpArgs& A, const orbm_query& Q, const Desc& qd, const int n, const int p, const float r,
+                                                    const int minLevel, const int maxLevel, const bool bCheckLevels, const orb_keypoint* kps,
+                                                    const uint8_t* desc, const float* ur, const uint8_t* occ0, const int32_t* gi, bool& pass, bool& area,
+                                                    int& idx, int& dist, int& oct) {
+        if (p >= 0) {
+            idx = gi[p];
+            if (idx >= 0 && idx < n) {
+                const orb_keypoint kp = kps[idx];
+                oct = kp.octave;
+                pass = true;
+                if (bCheckLevels) {
+                    if (oct < minLevel) pass = false;
+                    if (maxLevel >= 0 && oct > maxLevel) pass = false;
+                }
+                const float distx = kp.x - Q.u, disty = kp.y - Q.v;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
+                area = pass;
+                if (pass && occ0 && occ0[idx]) pass = false;
+                if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
+                    const float uR = ur[idx];
+                    if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
+                }
+                if (pass && A.chi2_gate) {   // ORBmatcher.cc:1791-1815 (float e2 * float sigma, compared as double)
+                    const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                    const float s2 = A.inv_sigma2[oct & 15];
+                    if (ur && ur[idx] >= 0) {
+                        const float er = Q.u_right - ur[idx];
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * s2) > 7.8) pass = false;
+                    } else {
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * s2) > 5.99) pass = false;
+                    }
+                }
+                if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
+            }
+        }
+}
+
 // Wave-level enumeration of Frame::GetFeaturesInArea(u, v, radius, minLevel, maxLevel) in the reference's order
 // (ix outer, iy inner, insertion order inside a cell == CSR order inside one grid column segment), with the
 // candidate filters that do not depend on matches made during the call.  sink(pass, idx, dist, octave, inArea) is called
@@ -246,40 +287,180 @@ static __device__ __forceinline__ void enumerate_window(const SbpArgs& A, int b,
         }
         bool pass = false, area = false;   // area: returned by GetFeaturesInArea (level + box); pass: also survives the call-constant filters
         int idx = 0, dist = 256, oct = 0;
-        if (p >= 0) {
-            idx = gi[p];
-            if (idx >= 0 && idx < n) {
-                const orb_keypoint kp = kps[idx];
-                oct = kp.octave;
-                pass = true;
-                if (bCheckLevels) {
-                    if (oct < minLevel) pass = false;
-                    if (maxLevel >= 0 && oct > maxLevel) pass = false;
-                }
-                const float distx = kp.x - Q.u, disty = kp.y - Q.v;
-                if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
-                area = pass;
-                if (pass && occ0 && occ0[idx]) pass = false;
-                if (pass && (Q.flags & ORBM_Q_STEREO) && ur) {
-                    const float uR = ur[idx];
-                    if (uR > 0 && fabsf(Q.u_right - uR) > r) pass = false;
-                }
-                if (pass && A.chi2_gate) {   // ORBmatcher.cc:1791-1815 (float e2 * float sigma, compared as double)
-                    const float ex = Q.u - kp.x, ey = Q.v - kp.y;
-                    const float s2 = A.inv_sigma2[oct & 15];
-                    if (ur && ur[idx] >= 0) {
-                        const float er = Q.u_right - ur[idx];
-                        const float e2 = ex * ex + ey * ey + er * er;
-                        if ((double)(e2 * s2) > 7.8) pass = false;
-                    } else {
-                        const float e2 = ex * ex + ey * ey;
-                        if ((double)(e2 * s2) > 5.99) pass = false;
-                    }
-                }
-                if (pass) dist = hamming(qd, load_desc(desc + (size_t)idx * 32));
+        window_entry(A, Q, qd, n, p, r, minLevel, maxLevel, bCheckLevels, kps, desc, ur, occ0, gi, pass, area, idx, dist, oct);
+        sink(pass, idx, dist, oct, area);
+    }
+}
+
+#ifndef SBP_HALF
+#define SBP_HALF 1
+#endif
+// Two queries per wave (32 lanes each).  A search window holds 10-30 grid entries, so a wave per query is mostly idle lanes on a chain of dependent
+// global loads; halving the number of waves halves the kernel when it is latency bound.  Windows wider than 32 grid columns (any half of the wave) send
+// the whole wave down the one-query-at-a-time path of k_sbp_candidates.
+static __device__ __forceinline__ void sort_and_store_list(uint32_t* lst, uint32_t* w, const int count, const bool anyArea, const int lane) {
+    // full-wave form (one query): sort the <= 64 cached entries by (distance, enumeration position) and write them out once
+    const int nl = min(count, SBP_CAPC);
+    uint32_t ent = lane < nl ? lst[lane] : 0u;
+    if (count > 1 && count <= SBP_CAPC) {
+        unsigned long long key = ~0ull;
+        if (lane < count) key = ((unsigned long long)((((ent >> 16) & 0x1FFu) << 6) | (uint32_t)lane) << 32) | ent;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+            if ((k >> 1) >= count) break;   // wave-uniform
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j);
+                const bool keepMin = ((lane & j) == 0) == ((lane & k) == 0);
+                key = keepMin ? (key < other ? key : other) : (key > other ? key : other);
             }
         }
-        sink(pass, idx, dist, oct, area);
+        ent = (uint32_t)key;
+    }
+    if (lane < nl) w[2 + lane] = ent;
+    if (lane == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
+}
+
+static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int half = lane >> 5, hl = lane & 31;
+    uint32_t* lst2 = (uint32_t*)orb_smem + wv * 2 * SBP_CAPC;       // two lists of SBP_CAPC entries per wave
+    const int nq = min(A.nq[b], A.cap_q);
+    const int q0 = (blockIdx.x * 4 + wv) * 2;
+    if (q0 >= nq) return;
+    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+    const int q = q0 + half;
+    const bool live = q < nq;
+    const orbm_query Q = A.queries[(size_t)b * A.cap_q + min(q, nq - 1)];
+    const bool valid = live && (Q.flags & ORBM_Q_VALID);
+    // window geometry (Frame.cc:779-806), per half
+    const orbm_grid_params& g = A.prm.grid;
+    const float r = Q.radius;
+    const int nMinCellX = max(0, (int)floorf((Q.u - g.min_x - r) * g.grid_w_inv));
+    const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((Q.u - g.min_x + r) * g.grid_w_inv));
+    const int nMinCellY = max(0, (int)floorf((Q.v - g.min_y - r) * g.grid_h_inv));
+    const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf((Q.v - g.min_y + r) * g.grid_h_inv));
+    const bool window = valid && nMinCellX < ORBM_GRID_COLS && nMaxCellX >= 0 && nMinCellY < ORBM_GRID_ROWS && nMaxCellY >= 0 && nMaxCellY >= nMinCellY &&
+                        nMaxCellX >= nMinCellX;
+    const int ncol = window ? nMaxCellX - nMinCellX + 1 : 0;
+    if (__ballot(ncol > 32)) {
+        // rare: a window wider than half a wave.  Both queries take the one-query path, one after the other (wave-uniform)
+        for (int hsel = 0; hsel < 2; hsel++) {
+            const int qq = q0 + hsel;
+            if (qq >= nq) break;
+            const orbm_query QQ = A.queries[(size_t)b * A.cap_q + qq];
+            uint32_t* w = A.work + ((size_t)b * A.cap_q + qq) * SBP_WORK_PER_Q;
+            uint32_t* lst = lst2;
+            int count = 0;
+            bool anyArea = false;
+            if (QQ.flags & ORBM_Q_VALID) {
+                const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + qq) * 32);
+                enumerate_window(A, b, QQ, qd, n, [&](bool pass, int idx, int dist, int oct, bool area) {
+                    const unsigned long long m = __ballot(pass);
+                    if (pass) {
+                        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < SBP_CAPC) lst[pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+                    }
+                    count += __popcll(m);
+                    anyArea |= __ballot(area) != 0ull;
+                });
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sort_and_store_list(lst, w, count, anyArea, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
+    uint32_t* lst = lst2 + half * SBP_CAPC;
+    uint32_t* w = A.work + ((size_t)b * A.cap_q + min(q, nq - 1)) * SBP_WORK_PER_Q;
+    const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + min(q, nq - 1)) * 32);
+    const int minLevel = Q.min_level, maxLevel = Q.max_level;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
+    const uint8_t* desc = A.desc + (size_t)b * A.cap_k * 32;
+    const float* ur = A.u_right ? A.u_right + (size_t)b * A.cap_k : nullptr;
+    const uint8_t* occ0 = (A.occupied0 && !A.kp_link) ? A.occupied0 + (size_t)b * A.cap_k : nullptr;
+    const int32_t* gs = A.grid_start + (size_t)b * (A.cells + 1) + ((Q.flags & ORBM_Q_RIGHT) ? GRID_CELLS : 0);
+    const int32_t* gi = A.grid_idx + (size_t)b * A.cap_k;
+    // column ranges of the window (lane hl = column), prefix scan inside the half
+    int cs = 0, ce = 0;
+    if (hl < ncol) { cs = gs[(nMinCellX + hl) * ORBM_GRID_ROWS + nMinCellY]; ce = gs[(nMinCellX + hl) * ORBM_GRID_ROWS + nMaxCellY + 1]; }
+    int incl = ce - cs;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (hl >= off) incl += t;
+    }
+    const int excl = incl - (ce - cs);
+    const int total = __shfl(incl, half * 32 + 31);     // lanes >= ncol carry the last column's inclusive sum
+    int count = 0;
+    bool anyArea = false;
+    for (int base = 0; __ballot(base < total); base += 32) {
+        const int t = base + hl;
+        // column of entry t: the first column whose inclusive sum exceeds t (binary search over the half's 32 lanes, 5 cross-lane reads)
+        int lo = 0, hi = 31;
+#pragma unroll
+        for (int st = 0; st < 5; st++) {
+            const int mid = (lo + hi) >> 1;
+            const int v = __shfl(incl, half * 32 + mid);
+            if (v > t) hi = mid; else lo = mid + 1;
+        }
+        const int sc = __shfl(cs, half * 32 + lo), xc = __shfl(excl, half * 32 + lo);
+        const int p = (t < total) ? sc + (t - xc) : -1;
+        bool pass = false, area = false;
+        int idx = 0, dist = 256, oct = 0;
+        window_entry(A, Q, qd, n, p, r, minLevel, maxLevel, bCheckLevels, kps, desc, ur, occ0, gi, pass, area, idx, dist, oct);
+        const unsigned long long m = __ballot(pass);
+        const uint32_t hm = (uint32_t)(m >> (32 * half));
+        if (pass) {
+            const int pos = count + __popc(hm & ((1u << hl) - 1u));
+            if (pos < SBP_CAPC) lst[pos] = (uint32_t)idx | ((uint32_t)dist << 16) | ((uint32_t)(oct & 0x3F) << 25);
+        }
+        count += __popc(hm);
+        anyArea |= ((uint32_t)(__ballot(area) >> (32 * half))) != 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (__ballot(count > 32 && count <= SBP_CAPC)) {
+        // rare: a list longer than half a wave needs the 64-lane network: the halves take turns
+        for (int hsel = 0; hsel < 2; hsel++) {
+            const int ch = __shfl(count, hsel * 32);
+            const int aa = __shfl((int)anyArea, hsel * 32);
+            const int qq = q0 + hsel;
+            if (qq < nq) sort_and_store_list(lst2 + hsel * SBP_CAPC, A.work + ((size_t)b * A.cap_q + qq) * SBP_WORK_PER_Q, ch, aa != 0, lane);
+        }
+        return;
+    }
+    // half-wave sort of (dist << 6 | pos) << 32 | entry; lists longer than SBP_CAPC are left unsorted (the resolver re-enumerates those queries)
+    const int nl = min(count, SBP_CAPC);
+    uint32_t ent = hl < nl ? lst[hl] : 0u;
+    uint32_t ent2 = (hl + 32 < nl) ? lst[hl + 32] : 0u;      // only when count > SBP_CAPC (unsorted copy-out)
+    {
+        const bool needSort = count > 1 && count <= 32;
+        unsigned long long key = ~0ull;
+        if (needSort && hl < count) key = ((unsigned long long)((((ent >> 16) & 0x1FFu) << 6) | (uint32_t)hl) << 32) | ent;
+#pragma unroll
+        for (int k = 2; k <= 32; k <<= 1) {
+            if (!__ballot(needSort && (k >> 1) < count)) break;   // wave-uniform: neither half needs this stage
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j);
+                const bool keepMin = ((hl & j) == 0) == ((hl & k) == 0);
+                key = keepMin ? (key < other ? key : other) : (key > other ? key : other);
+            }
+        }
+        if (needSort) ent = (uint32_t)key;
+    }
+    if (live) {
+        if (hl < nl) w[2 + hl] = ent;
+        if (hl + 32 < nl) w[2 + hl + 32] = ent2;
+        if (hl == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
     }
 }
 
@@ -1045,7 +1226,11 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     A.cells = cells; A.kp_link = d_kp_link;
     A.chi2_gate = 0; A.q_dist = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
+#if SBP_HALF
+    hipLaunchKernelGGL(k_sbp_candidates2, dim3((cap_q + 7) / 8, batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
+#else
     hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
+#endif
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return launch_status();
 }
