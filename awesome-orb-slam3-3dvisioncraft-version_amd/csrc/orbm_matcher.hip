@@ -558,7 +558,8 @@ static __global__ __launch_bounds__(256) void k_fuse(SbpArgs A) {
 // reference's accept rules against the live occupancy; distances come from k_sbp_candidates.
 // The serial chain touches LDS only: queries are staged 64 at a time (count, HAS_OBS flag and the first SBP_STAGE candidates
 // of each, loaded lane-parallel), and the rotation-histogram bins are computed after the loop (they do not feed back).
-#define SBP_STAGE 8
+#define SBP_STAGE 16
+struct __attribute__((packed, aligned(4))) SbpRow4 { uint32_t a, b, c, d; };   // 4 list entries; rows of the work buffer are 8-byte aligned
 static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -599,8 +600,14 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                 obs = (qf & ORBM_Q_HAS_OBS) ? 1 : 0;
                 // bit 29: GetFeaturesInArea returned something; bit 28: right-camera twin of the previous query; bit 27: right camera
                 fl = (int)((w[0] >> 31) << 29) | ((qf & ORBM_Q_TWIN) ? 1 << 28 : 0) | ((qf & ORBM_Q_RIGHT) ? 1 << 27 : 0);
+                // up to SBP_STAGE entries, four 16-byte loads in flight (entries past the count are never read back)
                 const int m = min(c, SBP_STAGE);
-                for (int k = 0; k < m; k++) sEnt[lane * SBP_STAGE + k] = w[2 + k];
+                SbpRow4 v[SBP_STAGE / 4];
+#pragma unroll
+                for (int u = 0; u < SBP_STAGE / 4; u++) v[u] = (4 * u < m) ? *(const SbpRow4*)(w + 2 + 4 * u) : SbpRow4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int u = 0; u < SBP_STAGE / 4; u++)
+                    if (4 * u < m) *(uint4*)&sEnt[lane * SBP_STAGE + 4 * u] = make_uint4(v[u].a, v[u].b, v[u].c, v[u].d);
             }
             sCnt[lane] = c | (obs << 30) | fl;
         }
@@ -716,35 +723,62 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
             }
                 };
         for (int i = 0; i < qend;) {
-            // Batched fast path (occupancy modes): up to 8 consecutive queries with <= SBP_STAGE cached candidates each are laid out over
-            // the wave, 8 lanes per query; ONE read of the occupancy serves all of them, the queries are then decided in order with
-            // scalar work only (ballot byte -> first / second unblocked lane), and an accepted keypoint is broadcast to the later queries'
-            // lanes in registers (`unb` update) instead of through LDS.
-            int nb = 0;
+            // Batched fast path (occupancy modes): up to 8 consecutive queries with <= SBP_STAGE cached candidates each are packed over the wave by
+            // their list lengths (a query of c candidates takes max(c, 1) lanes, 64 lanes in all); ONE read of the occupancy serves all of them.
+            // stk[k] = first lane of query k of the batch (scalar registers), stk[k] = total for k >= nb.
+            int nb = 0, wq = 65;
+            int stk[9];
+            stk[0] = 0;
             if (!initMode) {
-                const int cq = (lane < 8 && i + lane < qend) ? (sCnt[i + lane] & 0x07FFFFFF) : SBP_STAGE + 1;
-                nb = min(__ffsll((long long)__ballot(cq > SBP_STAGE)) - 1, 8);
+                if (lane < 8 && i + lane < qend) { const int cq = sCnt[i + lane] & 0x07FFFFFF; wq = cq > SBP_STAGE ? 65 : max(cq, 1); }
+                bool open = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int end = stk[k] + __builtin_amdgcn_readlane(wq, k);
+                    open = open && end <= 64;
+                    stk[k + 1] = open ? end : stk[k];
+                    nb += open ? 1 : 0;
+                }
             }
             if (nb < 2) { resolve_one(i); i++; continue; }
-            const int g = lane >> 3, sl = lane & 7;
-            const int cwl = g < nb ? sCnt[i + g] : 0;
-            const bool valid = g < nb && sl < (cwl & 0x07FFFFFF);
+            const int total = stk[8];
+            int g = 0, myst = 0, myend = total;
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                if (lane >= stk[k]) { g++; myst = stk[k]; }
+                if (lane < stk[8 - k]) myend = stk[8 - k];
+            }
+            g = min(g, nb - 1);
+            const bool inb = lane < total;
+            const int sl = lane - myst;
+            const int cwl = inb ? sCnt[i + g] : 0;
+            const bool valid = inb && sl < (cwl & 0x07FFFFFF);
             const uint32_t e = valid ? sEnt[(i + g) * SBP_STAGE + sl] : 0u;
             const int cidx = (int)(e & 0xFFFF);
             bool unb = valid && occ[cidx] == 0;
-            // Optimistic parallel resolution: all queries of the batch decide at once against the occupancy at the batch start.  That equals the
-            // serial result unless an earlier query of the batch accepts a keypoint that also sits in a later query's candidate list (then the later
-            // one would have seen it blocked, or would overwrite its holder): the batch is committed up to the first such query and the next batch
-            // starts there.  Rig twins, whose `continue` rules chain, take the serial loop below.  (~75 dependent scalar instructions per query in the serial form; the resolver is one wave per frame.)
-            if (link == nullptr && !(__ballot(g < nb && ((cwl >> 28) & 1)))) {
-                const uint32_t um = (uint32_t)((__ballot(unb) >> (8 * g)) & 0xFFull);
-                const bool have1 = um != 0u;
-                const uint32_t um2 = um & (um - 1u);
-                const bool have2 = um2 != 0u;
-                const uint32_t eb1 = (uint32_t)__shfl((int)e, 8 * g + (have1 ? __ffs((int)um) - 1 : 0));
-                const uint32_t eb2 = (uint32_t)__shfl((int)e, 8 * g + (have2 ? __ffs((int)um2) - 1 : 0));
+            // Optimistic parallel resolution: all queries of the batch decide at once against the occupancy at the batch start.  A committed accept
+            // changes a later query's decision only through that query's best / second-best unblocked candidate (the list is sorted: blocking
+            // anything behind them changes nothing), or when both accept the same keypoint (store order).  Such a (k < g) pair is a clash: the
+            // batch is committed up to the first clashing query and the next batch starts there.  The 8 x 8 (k, g) pairs are tested one per lane.
+            // Rig twins, whose `continue` rules chain, take the serial loop below.
+            if (link == nullptr && !(__ballot(inb && ((cwl >> 28) & 1)))) {
+                const int width = myend - myst;
+                const unsigned long long wmask = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+                const bool head = inb && sl == 0;
+                // pair lane L = 8 g2 + k2: first lanes of queries k2 and g2 (independent of the decisions: issued before them)
+                const int k2 = lane & 7, g2 = lane >> 3;
+                int sk = 0, sg = 0;
+#pragma unroll
+                for (int k = 1; k < 8; k++) { sk = k2 == k ? stk[k] : sk; sg = g2 == k ? stk[k] : sg; }
+                const bool pairOn = k2 < g2 && g2 < nb;
+                const unsigned long long um = (__ballot(unb) >> myst) & wmask;
+                const bool have1 = um != 0ull;
+                const unsigned long long um2 = um & (um - 1ull);
+                const bool have2 = um2 != 0ull;
+                const uint32_t eb1 = (uint32_t)__shfl((int)e, myst + (have1 ? __ffsll((long long)um) - 1 : 0));
+                const uint32_t eb2 = (uint32_t)__shfl((int)e, myst + (have2 ? __ffsll((long long)um2) - 1 : 0));
                 bool accept = false, skipAfter = false;
-                if (g < nb) {
+                if (inb) {
                     if (mode == ORBM_MODE_BEST_ONLY && !((cwl >> 29) & 1)) skipAfter = true;   // left window empty (no twins here: rightCam == 0)
                     if (have1) {
                         const int bestDist = (int)((eb1 >> 16) & 0x1FF);
@@ -760,15 +794,11 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     }
                 }
                 const int aidx = accept ? (int)(eb1 & 0xFFFF) : -1;
-                bool clash = false;
-                for (int k = 0; k + 1 < nb; k++) {
-                    const int bi = __builtin_amdgcn_readlane(aidx, 8 * k);
-                    if (bi >= 0 && g > k && valid && cidx == bi) clash = true;
-                }
-                // commit the longest clash-free prefix of the batch (group 0 never clashes) and go on from the first clashing query
-                const unsigned long long cm = __ballot(clash);
-                const int np = cm ? (__ffsll((long long)cm) - 1) >> 3 : nb;
-                const bool lead = sl == 0 && accept && g < np;
+                const int bi1 = have1 ? (int)(eb1 & 0xFFFF) : -2, bi2 = have2 ? (int)(eb2 & 0xFFFF) : -2;
+                const int ak = __shfl(aidx, sk & 63), b1 = __shfl(bi1, sg & 63), b2 = __shfl(bi2, sg & 63);
+                const unsigned long long cm = __ballot(pairOn && ak >= 0 && (ak == b1 || ak == b2));
+                const int np = cm ? (__ffsll((long long)cm) - 1) >> 3 : nb;   // pair lanes are ordered by g2; query 0 never clashes
+                const bool lead = head && accept && g < np;
                 if (lead) {
                     const int q = q0 + i + g;
                     occ[aidx] = (uint8_t)((cwl >> 30) & 1);
@@ -776,24 +806,25 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
                     q_match[q] = aidx;
                 }
                 nmatches += __popcll(__ballot(lead));
-                skipTwin = __builtin_amdgcn_readlane((int)skipAfter, 8 * (np - 1)) != 0;
+                skipTwin = __ballot(head && g == np - 1 && skipAfter) != 0ull;
                 __syncthreads();
                 i += np;
                 continue;
             }
-            for (int j = 0; j < nb; j++) {
+            for (int j = 0, stj = 0, wj = 0; j < nb; j++, stj += wj) {
+                wj = __builtin_amdgcn_readlane(wq, j);
                 const int q = q0 + i + j;
-                const int cw = __builtin_amdgcn_readlane(cwl, j * 8);
+                const int cw = __builtin_amdgcn_readlane(cwl, stj);
                 const bool twin = (cw >> 28) & 1, rightCam = (cw >> 27) & 1;
                 if (!twin) skipTwin = false;
                 if (twin && skipTwin) continue;
                 if (mode == ORBM_MODE_BEST_ONLY && !rightCam && !((cw >> 29) & 1)) skipTwin = true;
-                const uint32_t um = (uint32_t)((__ballot(unb) >> (8 * j)) & 0xFFull);
-                if (um == 0u) continue;   // no candidates, or every candidate already holds an observed point
-                const uint32_t eb1 = (uint32_t)__builtin_amdgcn_readlane((int)e, 8 * j + __ffs((int)um) - 1);
-                const uint32_t um2 = um & (um - 1u);
-                const bool have2 = um2 != 0u;
-                const uint32_t eb2 = have2 ? (uint32_t)__builtin_amdgcn_readlane((int)e, 8 * j + __ffs((int)um2) - 1) : 0u;
+                const unsigned long long um = (__ballot(unb) >> stj) & (wj >= 64 ? ~0ull : ((1ull << wj) - 1ull));
+                if (um == 0ull) continue;   // no candidates, or every candidate already holds an observed point
+                const uint32_t eb1 = (uint32_t)__builtin_amdgcn_readlane((int)e, stj + __ffsll((long long)um) - 1);
+                const unsigned long long um2 = um & (um - 1ull);
+                const bool have2 = um2 != 0ull;
+                const uint32_t eb2 = have2 ? (uint32_t)__builtin_amdgcn_readlane((int)e, stj + __ffsll((long long)um2) - 1) : 0u;
                 if (!decide(eb1, have2, eb2, rightCam)) continue;
                 const int bestIdx = (int)(eb1 & 0xFFFF), obs = (cw >> 30) & 1;
                 nmatches++;
@@ -1217,7 +1248,7 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
         return ORB_E_INVALID;
     if (params->mode != ORBM_MODE_LOCAL_MAP && params->mode != ORBM_MODE_BEST_ONLY && params->mode != ORBM_MODE_INIT) return ORB_E_INVALID;
     if (params->mode == ORBM_MODE_INIT && (cap_q > 65534 || cells != GRID_CELLS)) return ORB_E_INVALID;
-    const size_t smem = (32 + 8 + 64 * 8 + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15) + (params->mode == ORBM_MODE_INIT ? (size_t)cap_k * 4 : 0);
+    const size_t smem = (32 + 8 + 64 * SBP_STAGE + 64) * 4 + (((size_t)cap_k + 15) & ~(size_t)15) + (params->mode == ORBM_MODE_INIT ? (size_t)cap_k * 4 : 0);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     SbpArgs A;
     A.kps = d_kps; A.desc = d_desc; A.u_right = d_u_right; A.occupied0 = d_occupied0; A.nkp = d_nkp; A.cstride = count_stride; A.cap_k = cap_k;

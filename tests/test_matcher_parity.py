@@ -170,6 +170,34 @@ def test_hip_search_by_projection_candidate_overflow(hip_lib):
     _overflow_case(hip_lib, "hip")
 
 
+def _mixed_window_case(lib, backend, max_queries=None, seed=11):
+    """Window radii log-uniform in 4..320 px, level filter on for half of the queries: neighbouring queries of one wave land on different paths of
+    the two-queries-per-wave candidates kernel (half-wave lists, > 32-entry lists, > 32-column windows, > 64-entry overflow)."""
+    S = scene()
+    rng = np.random.default_rng(seed)
+    q = make_queries(S, MODE_LOCAL_MAP, 5, rng)
+    if max_queries:
+        q = q[:max_queries].copy()
+        S = dict(S); S["da"] = S["da"][:max_queries]
+    q["radius"] = np.exp(rng.uniform(np.log(4.0), np.log(320.0), len(q))).astype(np.float32)
+    nolevel = rng.random(len(q)) < 0.5
+    q["min_level"][nolevel] = -1; q["max_level"][nolevel] = -1
+    oq, ok, on = O.search_by_projection(S["kb"], S["db"], q, S["da"], S["grid"], MODE_LOCAL_MAP, TH_HIGH, 0.8, True)
+    _, _, qm, km, nm = run_sbp(lib, backend, S, q, MODE_LOCAL_MAP, TH_HIGH, 0.8, True)
+    assert nm[0] == on and np.array_equal(km[0, :len(S["kb"])], ok) and np.array_equal(qm[0, :len(q)], oq)
+    assert on > 20
+
+
+def test_emu_search_by_projection_mixed_windows(emu_lib):
+    _mixed_window_case(emu_lib, "emu", max_queries=90)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_hip_search_by_projection_mixed_windows(hip_lib, seed):
+    _mixed_window_case(hip_lib, "hip", seed=seed)
+
+
 def test_descriptor_distance_kats():
     # bit-hack popcount == popcount; known answers
     z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
