@@ -4,7 +4,8 @@
 //   k_hamming        M1   ORBmatcher::DescriptorDistance for a Q x T tile            ORBmatcher.cc:2700-2716
 //   k_knn2           M10  BFMatcher(NORM_HAMMING).knnMatch(k=2)                       Frame.cc:1300
 //   k_grid_build     M2   Frame::AssignFeaturesToGrid / PosInGrid -> CSR              Frame.cc:444-478, 852-862
-//   k_sbp_candidates M3   Frame::GetFeaturesInArea + Hamming, one wave per query      Frame.cc:755-850
+//   k_sbp_candidates2 M3  Frame::GetFeaturesInArea + Hamming, a 32-lane half-wave per query (k_sbp_candidates: one wave per query,
+//                         the -DSBP_HALF=0 build and the body of the wide-window fallback)     Frame.cc:755-850
 //   k_sbp_resolve    M4/M5 serial-order resolution of SearchByProjection (one wave per frame), rotation histogram
 //                                                                                      ORBmatcher.cc:59-255, 2244-2509
 //   k_bow            M6   SearchByBoW(KF,F): one workgroup per pair, one wave per shared vocabulary node  :323-587
