@@ -148,6 +148,17 @@ def test_hip_fuzz_search_by_projection(hip_lib, i):
               stereo=bool(rng.integers(2)), occupied=bool(rng.integers(2)), seed=i, scene_kw=kw)
 
 
+@pytest.mark.parametrize("i", range(2))
+def test_emu_fuzz_search_by_projection(emu_lib, i):
+    """CPU-tier slice of the random sweep (small scenes): list-length-packed resolver batches, clashes, both modes, stereo gate / occupancy."""
+    rng = np.random.default_rng(900 + i)
+    kw = dict(W=int(rng.integers(320, 640)), H=int(rng.integers(240, 480)), nf=300, seed=int(rng.integers(1000)),
+              shift=(int(rng.integers(-6, 7)), int(rng.integers(-6, 7))))
+    mode = MODE_BEST_ONLY if i % 2 else MODE_LOCAL_MAP
+    check_sbp(emu_lib, "emu", mode, int(rng.choice([3, 7, 15, 30])), float(rng.choice([0.6, 0.8, 0.9])), bool(rng.integers(2)),
+              stereo=bool(rng.integers(2)), occupied=bool(rng.integers(2)), seed=i, scene_kw=kw)
+
+
 def _overflow_case(lib, backend, max_queries=None):
     """> 64 candidates per query: the resolver's inline re-enumeration path."""
     S = scene()
