@@ -547,8 +547,9 @@ def main():
                          dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
-        if "extract_match" in extra:
+        if "extract_match" in extra and float(t[1].item()) > 0:
             extra["extract_match"]["frames_per_s"] = round(world * B / (float(t[1].item()) * 1e-3), 1)
+        if "lba" in extra and float(t[2].item()) > 0:
             extra["lba"]["linearizations_per_s"] = round(world * args.lba_windows / (float(t[2].item()) * 1e-3), 1)
 
     if rank == 0:
