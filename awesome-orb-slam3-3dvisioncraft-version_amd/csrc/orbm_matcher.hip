@@ -926,15 +926,21 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
 }
 
 // ============================================================================================================
-// M6  SearchByBoW(KeyFrame*, Frame&)
+// M6  SearchByBoW(KeyFrame*, Frame&)  ORBmatcher.cc:323-587   and   SearchByBoW(KeyFrame*, KeyFrame*)  ORBmatcher.cc:984-1124
 // ============================================================================================================
+// KK = the key-frame / key-frame overload: the inner side has its own validity flags (`!pMP2 || pMP2->isBad()`, :1049-1053), the blocking
+// state is vbMatched2, the acceptance is `bestDist1 < TH_LOW` (strict, :1072) and the result is indexed by the OUTER feature
+// (vpMatches12[idx1], :1076); the rotation histogram therefore culls by idx1 (:1088, :1117).  fbin[] (LDS, per inner feature) is
+// vbMatched2 and carries the match's bin; each inner feature is matched at most once, so the cull finds idx1's bin through match12[idx1].
 struct BowArgs {
     orbm_bow_side kf, f;
     const uint8_t* kf_valid;
+    const uint8_t* f_valid;   // KK only
     float nn_ratio; int check_orientation;
-    int32_t* f_match; int32_t* nmatches;
+    int32_t* f_match; int32_t* nmatches;   // KK: f_match = match12 [batch][kf.cap_f]
 };
 
+template <bool KK>
 static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -954,11 +960,13 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
     const float* kang = A.kf.angle + (size_t)b * A.kf.cap_f;
     const float* fang = A.f.angle + (size_t)b * A.f.cap_f;
     const uint8_t* kvalid = A.kf_valid + (size_t)b * A.kf.cap_f;
-    int32_t* f_match = A.f_match + (size_t)b * A.f.cap_f;
-    const int nleft = A.f.n_left ? A.f.n_left[b] : -1;
+    int32_t* f_match = A.f_match + (size_t)b * (KK ? A.kf.cap_f : A.f.cap_f);
+    const uint8_t* fvalid = KK ? A.f_valid + (size_t)b * A.f.cap_f : nullptr;
+    const int nleft = (!KK && A.f.n_left) ? A.f.n_left[b] : -1;
     if (tid < 32) hist[tid] = 0;
     if (tid < 8) ctl[tid] = 0;
-    for (int i = tid; i < A.f.cap_f; i += 256) { f_match[i] = -1; fbin[i] = -1; }
+    for (int i = tid; i < A.f.cap_f; i += 256) { if (!KK) f_match[i] = -1; fbin[i] = -1; }
+    if (KK) for (int i = tid; i < A.kf.cap_f; i += 256) f_match[i] = -1;
     // the merge walk of the two sorted FeatureVectors (ORBmatcher.cc:343, 553-560) = intersection of the id lists
     for (int k = tid; k < nkn; k += 256) {
         const int key = kid[k];
@@ -984,7 +992,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
                 const int p = base + lane;
                 if (p < fe) {
                     const int realIdxF = ffe[p];
-                    if (fbin[realIdxF] == -1) {   // !vpMapPointMatches[realIdxF]  (fbin != -1 <=> matched during this call; LDS only on the serial chain)
+                    if (fbin[realIdxF] == -1 && (!KK || fvalid[realIdxF])) {   // !vpMapPointMatches[realIdxF] / !vbMatched2[idx2] && pMP2 good  (fbin != -1 <=> matched during this call; LDS only on the serial chain)
                         const uint32_t key = ((uint32_t)hamming(dKF, load_desc(fdesc + (size_t)realIdxF * 32)) << 20) | (uint32_t)(p - fs);
                         if (nleft < 0 || realIdxF < nleft) {
                             if (key < k1) { k2 = k1; k1 = key; idx1 = realIdxF; }
@@ -1003,7 +1011,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
             const int l1 = __ffsll((long long)__ballot(iBest)) - 1;
             const int bestIdxF = __shfl(idx1, l1);
             const int bestDist1 = (int)(m1 >> 20), bestDist2 = m2 == 0xFFFFFFFFu ? 256 : (int)(m2 >> 20);
-            if (bestDist1 > ORBM_TH_LOW) continue;
+            if (KK ? bestDist1 >= ORBM_TH_LOW : bestDist1 > ORBM_TH_LOW) continue;   // `<= TH_LOW` :453 vs `< TH_LOW` :1072
             const bool accL = (float)bestDist1 < A.nn_ratio * (float)bestDist2;   // :455
             int bestIdxFR = -1;
             if (nleft >= 0) {   // right camera: accepted whenever bestDist1R <= TH_LOW (the ratio test is short-circuited by `|| true`, :509)
@@ -1019,7 +1027,7 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
                     for (int side = 0; side < 2; side++) {
                         const int idxF = side == 0 ? (accL ? bestIdxF : -1) : bestIdxFR;
                         if (idxF < 0) continue;
-                        f_match[idxF] = realIdxKF;
+                        if (KK) f_match[realIdxKF] = idxF; else f_match[idxF] = realIdxKF;
                         int bin = 30;  // "accepted, orientation unchecked"
                         if (A.check_orientation) {
                             float rot = kang[realIdxKF] - fang[idxF];
@@ -1054,9 +1062,19 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
         }
         __syncthreads();
         const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
-        for (int j = tid; j < A.f.cap_f; j += 256) {
-            const int bin = fbin[j];
-            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) { f_match[j] = -1; atomicAdd(&ctl[5], 1); }
+        if (KK) {
+            for (int i = tid; i < A.kf.cap_f; i += 256) {
+                const int j = f_match[i];
+                if (j >= 0) {
+                    const int bin = fbin[j];
+                    if (bin != ind1 && bin != ind2 && bin != ind3) { f_match[i] = -1; atomicAdd(&ctl[5], 1); }
+                }
+            }
+        } else {
+            for (int j = tid; j < A.f.cap_f; j += 256) {
+                const int bin = fbin[j];
+                if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) { f_match[j] = -1; atomicAdd(&ctl[5], 1); }
+            }
         }
         __syncthreads();
     }
@@ -1293,9 +1311,24 @@ extern "C" int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_v
     const size_t smem = (32 + 8 + (size_t)kf->cap_nodes) * 4 + (((size_t)f->cap_f + 15) & ~(size_t)15);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     BowArgs A;
-    A.kf = *kf; A.f = *f; A.kf_valid = d_kf_valid; A.nn_ratio = nn_ratio; A.check_orientation = check_orientation;
+    A.kf = *kf; A.f = *f; A.kf_valid = d_kf_valid; A.f_valid = nullptr; A.nn_ratio = nn_ratio; A.check_orientation = check_orientation;
     A.f_match = d_f_match; A.nmatches = d_nmatches;
-    hipLaunchKernelGGL(k_bow, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_bow<false>, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    return launch_status();
+}
+
+extern "C" int orbm_search_by_bow_kf(const orbm_bow_side* kf1, const uint8_t* d_valid1, const orbm_bow_side* kf2, const uint8_t* d_valid2, int batch,
+                                     float nn_ratio, int check_orientation, int32_t* d_match12, int32_t* d_nmatches, void* stream) {
+    if (!kf1 || !kf2 || !d_valid1 || !d_valid2 || !d_match12 || !d_nmatches || batch < 1 || kf1->cap_f < 1 || kf2->cap_f < 1 || kf1->cap_nodes < 1 ||
+        kf2->cap_nodes < 1)
+        return ORB_E_INVALID;
+    const size_t smem = (32 + 8 + (size_t)kf1->cap_nodes) * 4 + (((size_t)kf2->cap_f + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    BowArgs A;
+    A.kf = *kf1; A.f = *kf2; A.kf_valid = d_valid1; A.f_valid = d_valid2; A.nn_ratio = nn_ratio; A.check_orientation = check_orientation;
+    A.f.n_left = nullptr;
+    A.f_match = d_match12; A.nmatches = d_nmatches;
+    hipLaunchKernelGGL(k_bow<true>, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
     return launch_status();
 }
 

@@ -84,6 +84,7 @@ def bind(lib):
         "orbm_search_by_projection": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
                                             vp, vp, vp, vp, vp]),
         "orbm_search_by_bow": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), i32, f32, i32, vp, vp, vp]),
+        "orbm_search_by_bow_kf": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), vp, i32, f32, i32, vp, vp, vp]),
         "orbm_grid_build_rig": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(GridParams), vp, vp, vp]),
         "orbm_search_by_projection_rig": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
                                                 vp, vp, vp, vp, vp]),
@@ -191,6 +192,21 @@ class ORBmatcher:
         self._check(self._L.orbm_search_by_bow(C.byref(a), _ptr(kf_valid), C.byref(b), B, self.mfNNratio, int(self.mbCheckOrientation),
                                                _ptr(f_match), _ptr(nmatches), _stream(f["desc"])))
         return f_match, nmatches
+
+    # -- SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:984-1124; LoopClosing.cc:697) on FeatureVector CSRs
+    def SearchByBoWKF(self, kf1, valid1, kf2, valid2):
+        """kf1 / kf2 as in SearchByBoW; valid1 / valid2 [B,cap] u8 = feature holds a good map point (and is a left-camera feature on a rig).
+        -> (vpMatches12 as indices into key frame 2 or -1 [B,cap1] int32, nmatches [B])"""
+        def side(d):
+            return BowSide(_ptr(d["desc"]).value, _ptr(d["angle"]).value, _ptr(d["node_id"]).value, _ptr(d["node_start"]).value,
+                           _ptr(d["feat_idx"]).value, _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1], None)
+        B = kf1["desc"].shape[0]
+        m12 = _like(kf1["desc"], (B, kf1["desc"].shape[1]), np.int32)
+        nmatches = _like(kf1["desc"], (B,), np.int32)
+        a, b = side(kf1), side(kf2)
+        self._check(self._L.orbm_search_by_bow_kf(C.byref(a), _ptr(valid1), C.byref(b), _ptr(valid2), B, self.mfNNratio,
+                                                  int(self.mbCheckOrientation), _ptr(m12), _ptr(nmatches), _stream(kf1["desc"])))
+        return m12, nmatches
 
     # -- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:838-979)
     def SearchForInitialization(self, kps1, desc1, n1, kps2, desc2, n2, grid_start2, grid_idx2, prev_matched, grid, windowSize=10):

@@ -319,6 +319,15 @@ typedef struct orbm_bow_side {
 int orbm_search_by_bow(const orbm_bow_side* kf, const uint8_t* d_kf_valid, const orbm_bow_side* f, int batch,
                        float nn_ratio, int check_orientation, int32_t* d_f_match, int32_t* d_nmatches, void* stream);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:984-1124; call site
+ * LoopClosing.cc:697).  Both FeatureVectors as CSR (n_left of the sides is ignored).  valid1[i] / valid2[i] != 0 where the key frame's
+ * feature i holds a map point that is not bad (:1025-1028, :1049-1053) and, for a fisheye-rig key frame (NLeft != -1), i < mvKeysUn.size()
+ * (:1020-1022, :1043-1045) — the adapter folds both conditions into the flag.  Output match12[b][i1] = index of the pKF2 feature whose
+ * map point vpMatches12[i1] holds, or -1 ([batch][kf1->cap_f]); nmatches[b] = the return value.  Unlike the (KeyFrame, Frame) overload the
+ * acceptance is `bestDist1 < TH_LOW` (strict, :1072) and a pKF2 feature is taken at most once (vbMatched2, :1077). */
+int orbm_search_by_bow_kf(const orbm_bow_side* kf1, const uint8_t* d_valid1, const orbm_bow_side* kf2, const uint8_t* d_valid2, int batch,
+                          float nn_ratio, int check_orientation, int32_t* d_match12, int32_t* d_nmatches, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * SURVEY.md N2 — the DBoW2 step between the extractor and SearchByBoW: Frame::ComputeBoW (reference src/Frame.cc:865-872) =
  * TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup = 4)

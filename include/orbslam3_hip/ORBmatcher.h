@@ -6,6 +6,7 @@
 // `SearchByProjection*` scatter the result back in the reference's serial order (mvpMapPoints[idx] = pMP).
 #ifndef ORBSLAM3_HIP_ORBMATCHER_H
 #define ORBSLAM3_HIP_ORBMATCHER_H
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -174,7 +175,9 @@ public:
                      const std::vector<orbm_query>& q21, const std::vector<uint8_t>& q21desc, std::vector<int>& matches12) {
         const int n1 = KF1.N, n2 = KF2.N;
         matches12.assign(n1, -1);
-        if (n1 == 0 || n2 == 0 || (int)q12.size() != n1 || (int)q21.size() != n2) return 0;
+        if ((int)q12.size() != n1 || (int)q21.size() != n2 || q12desc.size() != (size_t)n1 * 32 || q21desc.size() != (size_t)n2 * 32)
+            throw std::invalid_argument("SearchBySim3: one query (and one 32-byte descriptor) per keypoint of each key frame is required");
+        if (n1 == 0 || n2 == 0) return 0;
         const int32_t counts[2] = {n1, n2};
         const int32_t* dc = cnt_.upload(counts, 2);
         int32_t* vn1 = (int32_t*)qm_.ensure((size_t)n1 * 4);
@@ -289,6 +292,41 @@ public:
         if (orbm_search_by_bow(&s[0], dv, &s[1], 1, mfNNratio, mbCheckOrientation ? 1 : 0, dm, dnm, nullptr) != ORB_OK) throw std::runtime_error("orbm_search_by_bow");
         int nmatches = 0;
         orb_memcpy_d2h(fMatch.data(), dm, (size_t)F.N * 4, nullptr);
+        orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        return nmatches;
+    }
+
+    // ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.h:68, ORBmatcher.cc:984-1124; call site
+    // LoopClosing.cc:697).  K1 / K2 as KeyFrameView; hasMapPoint[i] = "GetMapPointMatches()[i] exists and is not bad" AND, for a fisheye-rig
+    // key frame (NLeft != -1), i < mvKeysUn.size() (:1020-1022, :1043-1045).  matches12[i1] = index of the pKF2 feature whose map point
+    // vpMatches12[i1] receives, or -1.
+    int SearchByBoW(const KeyFrameView& K1, const float* angle1, const KeyFrameView& K2, const float* angle2, std::vector<int>& matches12) {
+        matches12.assign(K1.N, -1);
+        if (K1.N == 0 || K2.N == 0 || K1.nodeId.empty() || K2.nodeId.empty()) return 0;
+        orbm_bow_side s[2];
+        const KeyFrameView* K[2] = {&K1, &K2};
+        const float* ang[2] = {angle1, angle2};
+        int32_t nn[2] = {(int32_t)K1.nodeId.size(), (int32_t)K2.nodeId.size()};
+        const int32_t* dnn = cnt_.upload(nn, 2);
+        const uint8_t* dv[2];
+        for (int i = 0; i < 2; i++) {
+            s[i].desc = td_[i].upload(K[i]->descriptors, (size_t)K[i]->N * 32);
+            s[i].angle = ta_[i].upload(ang[i], K[i]->N);
+            s[i].node_id = tn_[i].upload(K[i]->nodeId.data(), K[i]->nodeId.size());
+            s[i].node_start = ts_[i].upload(K[i]->nodeStart.data(), K[i]->nodeStart.size());
+            s[i].feat_idx = tf_[i].upload(K[i]->featIdx.data(), K[i]->featIdx.size());
+            s[i].n_nodes = dnn + i;
+            s[i].cap_f = K[i]->N; s[i].cap_nodes = nn[i];
+            s[i].n_left = nullptr;
+            dv[i] = tm_[i].upload(K[i]->hasMapPoint, K[i]->N);
+        }
+        int32_t* dm = (int32_t*)qm_.ensure((size_t)K1.N * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        if (orbm_search_by_bow_kf(&s[0], dv[0], &s[1], dv[1], 1, mfNNratio, mbCheckOrientation ? 1 : 0, dm, dnm, nullptr) != ORB_OK)
+            throw std::runtime_error("orbm_search_by_bow_kf");
+        int nmatches = 0;
+        orb_memcpy_d2h(matches12.data(), dm, (size_t)K1.N * 4, nullptr);
         orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
         if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
         return nmatches;

@@ -292,6 +292,72 @@ int omo_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
     return nmatches;
 }
 
+// SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)  ORBmatcher.cc:984-1124 (call site LoopClosing.cc:697).
+// valid1[i] / valid2[i]: the key frame's feature i holds a map point that is not bad (`!pMP1 / pMP1->isBad()` :1025-1028, `!pMP2 /
+// pMP2->isBad()` :1049-1053) AND, for a fisheye-rig key frame, i < mvKeysUn.size() (:1020-1022, :1043-1045) — the caller folds both
+// into the flag.  match12[i1] = index of the KF2 feature whose map point vpMatches12[i1] holds, or -1.  Differences from the
+// (KeyFrame, Frame) overload that matter bit for bit: the acceptance is `bestDist1 < TH_LOW` (strict, :1072), the blocking state is
+// vbMatched2 (never reset by the orientation cull), and the rotation histogram holds idx1 (:1088).
+int omo_search_by_bow_kf(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, const int32_t* node_id1,
+                         const int32_t* node_start1, const int32_t* feat1, int nodes1, int n1, const uint8_t* desc2,
+                         const float* angle2, const uint8_t* valid2, const int32_t* node_id2, const int32_t* node_start2,
+                         const int32_t* feat2, int nodes2, int n2, float nnratio, int checkOri, int32_t* match12) {
+    std::vector<int> vpMatches12(n1, -1);
+    std::vector<bool> vbMatched2(n2, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    int f1it = 0, f2it = 0;
+    auto lower_bound = [](const int32_t* ids, int n, int key) { int lo = 0, hi = n; while (lo < hi) { int m = (lo + hi) / 2; if (ids[m] < key) lo = m + 1; else hi = m; } return lo; };
+    while (f1it != nodes1 && f2it != nodes2) {
+        if (node_id1[f1it] == node_id2[f2it]) {
+            for (int i1 = node_start1[f1it]; i1 < node_start1[f1it + 1]; i1++) {
+                const size_t idx1 = feat1[i1];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = node_start2[f2it]; i2 < node_start2[f2it + 1]; i2++) {
+                    const size_t idx2 = feat2[i2];
+                    if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                    const int dist = DescriptorDistance(d1, desc2 + idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+                    else if (dist < bestDist2) { bestDist2 = dist; }
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        vpMatches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (checkOri) {
+                            float rot = angle1[idx1] - angle2[bestIdx2];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (node_id1[f1it] < node_id2[f2it]) {
+            f1it = lower_bound(node_id1, nodes1, node_id2[f2it]);
+        } else {
+            f2it = lower_bound(node_id2, nodes2, node_id1[f1it]);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { vpMatches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < n1; i++) match12[i] = vpMatches12[i];
+    return nmatches;
+}
+
 // cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2): ascending train scan, strict '<' insertion [recalled, Appendix B5]
 void omo_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* out_idx, int32_t* out_dist) {
     for (int i = 0; i < nq; i++) {

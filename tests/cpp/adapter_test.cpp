@@ -33,6 +33,8 @@ void obw_destroy(void*);
 int obw_transform(void*, const uint8_t*, int, int, int32_t*, int32_t*, double*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, double*);
 int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
                       const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
+int omo_search_by_bow_kf(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, const uint8_t*, const float*,
+                         const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float, int, int32_t*);
 void ofr_undistort_keypoints(const void*, int, const float*, void*);
 void ofr_image_bounds(const float*, int, int, float*);
 int ofr_stereo_fisheye(const void*, const uint8_t*, int, int, const void*, const uint8_t*, int, int, const float*, const float*, int32_t*, int32_t*, float*, float*);
@@ -195,6 +197,21 @@ int main() {
                                               dB.data(), angB.data(), K2.N, K2.nodeId.data(), K2.nodeStart.data(), K2.featIdx.data(), (int)K2.nodeId.size(),
                                               0.7f, 1, ofm.data(), nl);
             CHECK(nb == onb && nb > 10 && std::memcmp(ofm.data(), fm.data(), ofm.size() * 4) == 0);
+        }
+        {   // SearchByBoW(KeyFrame*, KeyFrame*) (ORBmatcher.cc:984-1124): map-point validity on both sides, result indexed by key frame 1
+            std::vector<uint8_t> v1(kA.size()), v2(kB.size());
+            for (size_t i = 0; i < v1.size(); i++) v1[i] = (i % 7) != 2;
+            for (size_t i = 0; i < v2.size(); i++) v2[i] = (i % 5) != 4;
+            K1.hasMapPoint = v1.data(); K2.hasMapPoint = v2.data();
+            orbslam3_hip::ORBmatcher mk(0.8f, true);
+            std::vector<int> m12;
+            const int nk = mk.SearchByBoW(K1, angA.data(), K2, angB.data(), m12);
+            std::vector<int32_t> om12(kA.size());
+            const int onk = omo_search_by_bow_kf(dA.data(), angA.data(), v1.data(), K1.nodeId.data(), K1.nodeStart.data(), K1.featIdx.data(), (int)K1.nodeId.size(), K1.N,
+                                                 dB.data(), angB.data(), v2.data(), K2.nodeId.data(), K2.nodeStart.data(), K2.featIdx.data(), (int)K2.nodeId.size(), K2.N,
+                                                 0.8f, 1, om12.data());
+            CHECK(nk == onk && nk > 10 && std::memcmp(om12.data(), m12.data(), om12.size() * 4) == 0);
+            K1.hasMapPoint = valid.data(); K2.hasMapPoint = mp2.data();
         }
         std::printf("adapter N1: init %d, fuse %d, triangulation %d\n", ni, nf, nt);
     }

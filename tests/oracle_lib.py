@@ -219,6 +219,19 @@ def search_by_bow(kf, kf_valid, f, nnratio, check_ori, f_nleft=-1):
     return f_match[:fN], n
 
 
+def search_by_bow_kf(kf1, valid1, kf2, valid2, nnratio, check_ori):
+    L = lib()
+    L.omo_search_by_bow_kf.restype = C.c_int
+    L.omo_search_by_bow_kf.argtypes = ([C.c_void_p] * 6 + [C.c_int, C.c_int]) * 2 + [C.c_float, C.c_int, C.c_void_p]
+    n1, n2 = kf1["desc"].shape[0], kf2["desc"].shape[0]
+    m12 = np.zeros(max(n1, 1), np.int32)
+    args = []
+    for kf, v, n in ((kf1, valid1, n1), (kf2, valid2, n2)):
+        args += [_p(kf["desc"]), _p(kf["angle"]), _p(v), _p(kf["node_id"]), _p(kf["node_start"]), _p(kf["feat_idx"]), int(kf["n_nodes"]), n]
+    n = L.omo_search_by_bow_kf(*args, nnratio, int(check_ori), _p(m12))
+    return m12[:n1], n
+
+
 def knn2(q, t):
     L = lib()
     L.omo_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

@@ -337,3 +337,103 @@ def test_hip_search_by_bow_fisheye_rig(hip_lib, frac):
 @pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.9, False), (0.6, True)])
 def test_hip_search_by_bow(hip_lib, ratio, ori):
     _bow_case(hip_lib, "hip", ratio, ori)
+
+
+# ---- SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)  ORBmatcher.cc:984-1124 (LoopClosing.cc:697) -------------------------------------------
+def _drop_nodes(ids, st, fe, keep_mask):
+    starts, feats = [0], []
+    for k in np.nonzero(keep_mask)[0]:
+        feats += fe[st[k]:st[k + 1]].tolist(); starts.append(len(feats))
+    return ids[keep_mask], np.array(starts, np.int32), np.array(feats, np.int32)
+
+
+def _bow_kf_case(lib, backend, nnratio, ori, scene_kw=None, seed=5, drop=(7, 3), valid_frac=(0.8, 0.85), rig_nleft=None):
+    """Both sides carry map-point validity; nodes are dropped on BOTH sides (lower_bound skips in both directions); optional rig key frames
+    (features >= NLeft are folded into the validity flags like the adapter does)."""
+    S = scene(**(scene_kw or {}))
+    rng = np.random.default_rng(seed)
+    ka, da, kb, db = S["ka"], S["da"], S["kb"], S["db"]
+    id1, st1, fe1 = feature_vector(da)
+    id2, st2, fe2 = feature_vector(db)
+    id1, st1, fe1 = _drop_nodes(id1, st1, fe1, id1 % drop[0] != drop[1])
+    id2, st2, fe2 = _drop_nodes(id2, st2, fe2, id2 % (drop[0] + 4) != 1)
+    v1 = (rng.random(len(ka)) < valid_frac[0]).astype(np.uint8)
+    v2 = (rng.random(len(kb)) < valid_frac[1]).astype(np.uint8)
+    if rig_nleft is not None:
+        v1[int(rig_nleft * len(ka)):] = 0; v2[int(rig_nleft * len(kb)):] = 0
+    o1 = dict(desc=da, angle=np.ascontiguousarray(ka["angle"]), node_id=id1, node_start=st1, feat_idx=fe1, n_nodes=len(id1))
+    o2 = dict(desc=db, angle=np.ascontiguousarray(kb["angle"]), node_id=id2, node_start=st2, feat_idx=fe2, n_nodes=len(id2))
+    om, on = O.search_by_bow_kf(o1, v1, o2, v2, nnratio, ori)
+    B = 2
+
+    def slab(d, cap_f, cap_n):
+        out = dict(desc=np.zeros((B, cap_f, 32), np.uint8), angle=np.zeros((B, cap_f), np.float32), node_id=np.zeros((B, cap_n), np.int32),
+                   node_start=np.zeros((B, cap_n + 1), np.int32), feat_idx=np.zeros((B, cap_f), np.int32), n_nodes=np.full(B, d["n_nodes"], np.int32))
+        n = len(d["desc"])
+        out["desc"][:, :n] = d["desc"]; out["angle"][:, :n] = d["angle"]; out["node_id"][:, :d["n_nodes"]] = d["node_id"]
+        out["node_start"][:, :d["n_nodes"] + 1] = d["node_start"]; out["feat_idx"][:, :len(d["feat_idx"])] = d["feat_idx"]
+        return {k: to_dev(v, backend) for k, v in out.items()}
+    c1, c2 = len(ka) + 4, len(kb) + 9
+    V1 = np.zeros((B, c1), np.uint8); V1[:, :len(ka)] = v1
+    V2 = np.ones((B, c2), np.uint8); V2[:, :len(kb)] = v2     # slack entries flagged valid: they must never be reached through the CSR
+    m = orbhip.ORBmatcher(nnratio, ori, lib=lib)
+    m12, nm = [to_host(x) for x in m.SearchByBoWKF(slab(o1, c1, 128), to_dev(V1, backend), slab(o2, c2, 110), to_dev(V2, backend))]
+    for b in range(B):
+        assert nm[b] == on, (nm[b], on)
+        assert np.array_equal(m12[b, :len(ka)], om)
+        assert (m12[b, len(ka):] == -1).all()
+    got = om[om >= 0]
+    assert len(np.unique(got)) == len(got)          # vbMatched2: a KF2 feature is taken at most once
+    assert v1[om >= 0].all() and v2[got].all()      # only features holding good map points take part
+    return on
+
+
+BOW_KF_CASES = [
+    ("ratio07_ori", 0.7, True, None, 5, (7, 3), (0.8, 0.85), None),
+    ("ratio09_no_ori", 0.9, False, None, 6, (5, 0), (0.6, 0.95), None),
+    ("scene2_ratio08", 0.8, True, dict(W=400, H=300, nf=500, seed=77, shift=(3, 5)), 7, (9, 2), (1.0, 1.0), None),
+    ("scene3_sparse_mps", 0.75, True, dict(W=520, H=380, nf=800, seed=91, shift=(-5, 2)), 8, (4, 1), (0.3, 0.4), None),
+    ("rig_keyframes", 0.7, True, None, 9, (7, 3), (0.9, 0.9), 0.6),
+]
+
+
+@pytest.mark.parametrize("case", BOW_KF_CASES[:3] + BOW_KF_CASES[4:], ids=lambda c: c[0])
+def test_emu_search_by_bow_keyframes(emu_lib, case):
+    n = _bow_kf_case(emu_lib, "emu", *case[1:])
+    assert n > (20 if case[0] != "scene3_sparse_mps" else 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BOW_KF_CASES, ids=lambda c: c[0])
+def test_hip_search_by_bow_keyframes(hip_lib, case):
+    n = _bow_kf_case(hip_lib, "hip", *case[1:])
+    assert n > (20 if case[0] != "scene3_sparse_mps" else 3)
+
+
+def test_oracle_search_by_bow_keyframes_known_answers():
+    """Hand-built node: strict `bestDist1 < TH_LOW` (a distance of exactly 50 is refused, the (KeyFrame, Frame) overload accepts it),
+    first minimum wins, and a KF2 feature taken by an earlier KF1 feature is invisible to later ones."""
+    def bits(n):
+        d = np.zeros(32, np.uint8)
+        d[:n // 8] = 255
+        if n % 8:
+            d[n // 8] = (1 << (n % 8)) - 1
+        return d
+    z = bits(0)
+    d1 = np.stack([z, z])                           # two KF1 features, both in node 4
+    d2 = np.stack([bits(50), bits(10), bits(10)])   # KF2: distances 50, 10, 10 to z
+    s1 = dict(desc=d1, angle=np.zeros(2, np.float32), node_id=np.array([4], np.int32), node_start=np.array([0, 2], np.int32),
+              feat_idx=np.array([0, 1], np.int32), n_nodes=1)
+    s2 = dict(desc=d2, angle=np.zeros(3, np.float32), node_id=np.array([4], np.int32), node_start=np.array([0, 3], np.int32),
+              feat_idx=np.array([0, 1, 2], np.int32), n_nodes=1)
+    ones = lambda n: np.ones(n, np.uint8)
+    # feature 0: best 10 (idx 1, first of the equals), second 10 -> ratio test 10 < 0.9*10 fails; feature 1 likewise: no matches
+    m, n = O.search_by_bow_kf(s1, ones(2), s2, ones(3), 0.9, False)
+    assert n == 0 and m.tolist() == [-1, -1]
+    # with KF2 feature 2 invalid: feature 0 takes idx 1 (10 < 0.9*50); feature 1 then only sees idx 0 at distance 50 -> not < TH_LOW
+    m, n = O.search_by_bow_kf(s1, ones(2), s2, np.array([1, 1, 0], np.uint8), 0.9, False)
+    assert n == 1 and m.tolist() == [1, -1]
+    # the (KeyFrame, Frame) overload accepts distance 50 (`<= TH_LOW`, :453): same data, second feature matches idx 0
+    fm, fn = O.search_by_bow(s1, ones(2), dict(s2, desc=d2[:2], angle=np.zeros(2, np.float32), node_start=np.array([0, 2], np.int32),
+                                               feat_idx=np.array([0, 1], np.int32)), 0.9, False)
+    assert fn == 2 and fm.tolist() == [1, 0]
