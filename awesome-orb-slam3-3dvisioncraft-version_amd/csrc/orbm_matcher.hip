@@ -1226,6 +1226,32 @@ static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
 // ============================================================================================================
 static int launch_status() { return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP; }
 
+// ---- optional per-kernel device timing of the projection search (bench.py's roofline legs): HIP events recorded on the launch stream
+// around k_grid_build / k_sbp_candidates2 / k_sbp_resolve while enabled.  Process-wide and not re-entrant: a measurement facility only.
+static struct { bool on = false, made = false, have_grid = false, have_sbp = false; hipEvent_t ev[5]; } g_mt;
+static bool mt_ready() {
+    if (!g_mt.on) return false;
+    if (!g_mt.made) {
+        for (auto& e : g_mt.ev) if (hipEventCreate(&e) != hipSuccess) return false;
+        g_mt.made = true;
+    }
+    return true;
+}
+extern "C" int orbm_enable_timing(int on) { g_mt.on = on != 0; g_mt.have_grid = g_mt.have_sbp = false; return ORB_OK; }
+extern "C" int orbm_last_timing(float* ms3) {
+    if (!ms3) return ORB_E_INVALID;
+    ms3[0] = ms3[1] = ms3[2] = 0.f;
+    if (!g_mt.made) return ORB_OK;
+    if (g_mt.have_grid) {
+        if (hipEventSynchronize(g_mt.ev[1]) != hipSuccess || hipEventElapsedTime(&ms3[0], g_mt.ev[0], g_mt.ev[1]) != hipSuccess) return ORB_E_HIP;
+    }
+    if (g_mt.have_sbp) {
+        if (hipEventSynchronize(g_mt.ev[4]) != hipSuccess || hipEventElapsedTime(&ms3[1], g_mt.ev[2], g_mt.ev[3]) != hipSuccess ||
+            hipEventElapsedTime(&ms3[2], g_mt.ev[3], g_mt.ev[4]) != hipSuccess) return ORB_E_HIP;
+    }
+    return ORB_OK;
+}
+
 extern "C" int orbm_hamming(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int batch, uint16_t* d_out, void* stream) {
     if (!d_q || !d_t || !d_out || nq < 1 || nt < 1 || batch < 1) return ORB_E_INVALID;
     hipLaunchKernelGGL(k_hamming, dim3((nt + 255) / 256, (nq + 15) / 16, batch), dim3(256), 512, (hipStream_t)stream, d_q, nq, d_t, nt, d_out);
@@ -1243,8 +1269,11 @@ extern "C" int orbm_knn2(const uint8_t* d_q, const int32_t* d_nq, int cap_q, con
 extern "C" int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
                                const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
     if (!d_kps || !d_nkp || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
+    const bool timed = mt_ready();
+    if (timed) hipEventRecord(g_mt.ev[0], (hipStream_t)stream);
     hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (2 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
                        *gp, d_grid_start, d_grid_idx, (const int32_t*)nullptr, GRID_CELLS);
+    if (timed) { hipEventRecord(g_mt.ev[1], (hipStream_t)stream); g_mt.have_grid = true; }
     return launch_status();
 }
 
@@ -1276,12 +1305,16 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     A.cells = cells; A.kp_link = d_kp_link;
     A.chi2_gate = 0; A.q_dist = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
+    const bool timed = mt_ready();
+    if (timed) hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
 #if SBP_HALF
     hipLaunchKernelGGL(k_sbp_candidates2, dim3((cap_q + 7) / 8, batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #else
     hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #endif
+    if (timed) hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
+    if (timed) { hipEventRecord(g_mt.ev[4], (hipStream_t)stream); g_mt.have_sbp = true; }
     return launch_status();
 }
 

@@ -85,6 +85,8 @@ def bind(lib):
                                             vp, vp, vp, vp, vp]),
         "orbm_search_by_bow": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), i32, f32, i32, vp, vp, vp]),
         "orbm_search_by_bow_kf": (i32, [C.POINTER(BowSide), vp, C.POINTER(BowSide), vp, i32, f32, i32, vp, vp, vp]),
+        "orbm_enable_timing": (i32, [i32]),
+        "orbm_last_timing": (i32, [vp]),
         "orbm_grid_build_rig": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(GridParams), vp, vp, vp]),
         "orbm_search_by_projection_rig": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(SearchParams),
                                                 vp, vp, vp, vp, vp]),
@@ -110,6 +112,15 @@ class ORBmatcher:
         if rc != 0:
             raise OrbHipError(rc, "orbm call failed")
 
+    # -- measurement facility: device time of the last grid build / projection search kernels (HIP events on the launch stream)
+    def enable_timing(self, on=True):
+        self._check(self._L.orbm_enable_timing(int(bool(on))))
+
+    def last_timing(self):
+        ms = np.zeros(3, np.float32)
+        self._check(self._L.orbm_last_timing(ms.ctypes.data_as(C.c_void_p)))
+        return dict(grid_build=float(ms[0]), sbp_candidates=float(ms[1]), sbp_resolve=float(ms[2]))
+
     # -- ORBmatcher::DescriptorDistance for all pairs (ORBmatcher.cc:2700-2716): q [B,nq,32], t [B,nt,32] -> [B,nq,nt] uint16
     def DescriptorDistance(self, q, t):
         B, nq, _ = q.shape
@@ -127,22 +138,20 @@ class ORBmatcher:
         return idx, dist
 
     # -- Frame::AssignFeaturesToGrid (Frame.cc:444-478): kps [B,cap,7] f32 (orb_keypoint), counts int32 (stride in elements)
-    def grid_build(self, kps, counts, grid, count_stride=1):
+    def grid_build(self, kps, counts, grid, count_stride=1, out=None):
         B, cap = kps.shape[0], kps.shape[1]
-        gs = _like(kps, (B, GRID_COLS * GRID_ROWS + 1), np.int32)
-        gi = _like(kps, (B, cap), np.int32)
+        gs, gi = out if out is not None else (_like(kps, (B, GRID_COLS * GRID_ROWS + 1), np.int32), _like(kps, (B, cap), np.int32))
         gp = GridParams(*grid)
         self._check(self._L.orbm_grid_build(_ptr(kps), _ptr(counts), count_stride, cap, B, C.byref(gp), _ptr(gs), _ptr(gi), _stream(kps)))
         return gs, gi
 
     # -- SearchByProjection (ORBmatcher.cc:59-255 mode LOCAL_MAP / :2244-2509 mode BEST_ONLY) on flattened records
     def SearchByProjection(self, kps, desc, counts, grid_start, grid_idx, queries, qdesc, nq, grid, mode, th_dist=TH_HIGH,
-                           u_right=None, occupied0=None, count_stride=1, work=None):
+                           u_right=None, occupied0=None, count_stride=1, work=None, out=None):
+        """out = (q_match [B,cap_q], kp_match [B,cap_k], nmatches [B]) int32 buffers of an earlier call may be passed back in (every entry is rewritten)."""
         B, cap_k = kps.shape[0], kps.shape[1]
         cap_q = qdesc.shape[1]
-        q_match = _like(kps, (B, cap_q), np.int32)
-        kp_match = _like(kps, (B, cap_k), np.int32)
-        nmatches = _like(kps, (B,), np.int32)
+        q_match, kp_match, nmatches = out if out is not None else (_like(kps, (B, cap_q), np.int32), _like(kps, (B, cap_k), np.int32), _like(kps, (B,), np.int32))
         if work is None:
             work = _like(kps, (self._L.orbm_search_workspace_bytes(B, cap_q),), np.uint8)
         prm = SearchParams(mode, th_dist, self.mfNNratio, int(self.mbCheckOrientation), GridParams(*grid))

@@ -228,6 +228,12 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
                               const orbm_search_params* params, int32_t* d_q_match, int32_t* d_kp_match, int32_t* d_nmatches,
                               void* d_work, void* stream);
 
+/* Measurement facility (bench.py's roofline legs), the stage-2 counterpart of orbx_last_timing: while enabled, HIP events are recorded on the launch
+ * stream around the kernels of orbm_grid_build and orbm_search_by_projection; orbm_last_timing synchronises on them and returns the device time of the
+ * last call's kernels: ms[0] = grid build, ms[1] = candidate enumeration + Hamming, ms[2] = serial-order resolution.  Process-wide, not re-entrant. */
+int orbm_enable_timing(int on);
+int orbm_last_timing(float* ms3);
+
 /* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:2008-2220) = orbm_fuse in both directions (each map point
  * keeps its own best candidate in [L-1, L] with bestDist <= TH_HIGH and no chi2 gate: vnMatch1 / vnMatch2, :2044-2119 and :2122-2201) followed by
  * this agreement pass (:2203-2219): out12[b][i1] = idx2 iff match12[b][i1] == idx2 and match21[b][idx2] == i1, else -1; nfound[b] = the return value. */

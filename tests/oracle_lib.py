@@ -169,8 +169,30 @@ def bench_extract_mt(frames, nthreads, frames_per_thread, nfeatures=1000, lap=(0
     frames = np.ascontiguousarray(frames, np.uint8)
     B, H, W = frames.shape
     tot = C.c_long(0)
+    lib().oro_bench_tune_allocator(nthreads)
     s = lib().oro_bench_extract_mt(_p(frames), B, W, H, nfeatures, 1.2, 8, 20, 7, lap[0], lap[1], nthreads, frames_per_thread, C.byref(tot))
     return s, tot.value
+
+
+def bench_extract_match_mt(frames, nthreads, frames_per_thread, cam9, grid4, queries, qdesc, nq, th_dist=100, nnratio=0.9, check_ori=True,
+                           do_match=True, nfeatures=1000, lap=(0, 1000)):
+    """oracle/bench_oracle.cpp: extract (+ UndistortKeyPoints + grid + motion-model SearchByProjection) per frame in native threads.
+    -> (seconds, total keypoints, total matches)"""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    B, H, W = frames.shape
+    L = lib()
+    L.oro_bench_extract_match_mt.restype = C.c_double
+    L.oro_bench_extract_match_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cam9 = np.ascontiguousarray(cam9, np.float32); grid4 = np.ascontiguousarray(grid4, np.float32)
+    queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8); nq = np.ascontiguousarray(nq, np.int32)
+    cap_q = qdesc.shape[1]
+    assert queries.nbytes == B * cap_q * 28 and qdesc.shape == (B, cap_q, 32) and nq.shape == (B,)
+    kp, mt = C.c_long(0), C.c_long(0)
+    s = L.oro_bench_extract_match_mt(_p(frames), B, W, H, nfeatures, 1.2, 8, 20, 7, lap[0], lap[1], _p(cam9), _p(grid4), _p(queries), _p(qdesc), _p(nq),
+                                     cap_q, th_dist, nnratio, int(check_ori), int(do_match), nthreads, frames_per_thread, C.byref(kp), C.byref(mt))
+    return s, kp.value, mt.value
 
 
 # ---- stage 2 (oracle/match_oracle.cpp) ------------------------------------------------------------------

@@ -41,6 +41,47 @@ out = {"tag": tag, "note": "bytes per launch; FETCH_SIZE on gfx950 counts 64 B p
 for k, v in pmc.items():
     fr, wr = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
     out["kernels"][k] = {"fetch_raw": fr, "write": wr, "traffic_raw": fr + wr, "traffic_corrected": 2 * fr + wr}
+# which build / workload these passes belong to (bench.py refuses to quote `traffic` from a PMC pass of other kernel sources)
+sys.path.insert(0, root)
+import bench  # noqa: E402
+out["source_sha"] = bench.source_sha()
+out["workload"] = [752, 480, 1000, 512]
 json.dump(out, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+
+# SQ passes (tools/gpu_profile.sh sq1 / sq2): per-kernel means per dispatch + the derived figures the roofline discussion uses
+sq = {}
+for kind in ("sq1", "sq2"):
+    fdb = os.path.join(src, kind, "pmc_results.db")
+    if not os.path.exists(fdb):
+        continue
+    d = sqlite3.connect(fdb)
+    for name, ctr, n, mean in d.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection group by kernel_name,counter_name"):
+        if name.startswith("k_"):
+            sq.setdefault(name.split("(")[0], {})[ctr] = mean
+if sq:
+    dur = {r[0].split("(")[0]: r[1] for r in c.execute("select name,average from top_kernels")}
+    cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+            "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY",
+            "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+    with open(os.path.join(dst, tag + "_sq.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc <8 SQ counters> (two separate passes, tools/gpu_profile.sh), same command; means per dispatch.  SQ_*_CYCLES / SQ_WAIT_* / "
+                "SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md).  Derived: valu_per_wave = SQ_INSTS_VALU / SQ_WAVES; "
+                "wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls); wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt / barrier); "
+                "valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
+                "waves_per_simd = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE x 1024 SIMDs) = mean resident waves per SIMD while the kernel runs\n")
+        f.write("kernel,avg_us," + ",".join(cols) + ",valu_per_wave,wait_inst_frac,wait_any_frac,valu_active_frac,lds_conflict_frac,waves_per_simd\n")
+        for k in sorted(sq):
+            v = sq[k]
+            g = lambda n: v.get(n, float("nan"))
+            wc = g("SQ_WAVE_CYCLES")
+            derived = [g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_WAIT_INST_ANY") / wc, g("SQ_WAIT_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc,
+                       g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else float("nan"),
+                       wc * 4.0 / (g("GRBM_GUI_ACTIVE") * 1024.0) if g("GRBM_GUI_ACTIVE") else float("nan")]
+            f.write("%s,%.1f,%s,%s\n" % (k, dur.get(k, float("nan")), ",".join("%.6g" % g(n) for n in cols), ",".join("%.4f" % x for x in derived)))
+    print(open(os.path.join(dst, tag + "_sq.csv")).read())
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    import shutil
+    shutil.copy(bj, os.path.join(dst, tag + "_bench.json"))
 print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
 print(open(os.path.join(dst, tag + "_pmc.csv")).read())
