@@ -119,99 +119,10 @@ extern "C" int orbf_stereo_from_rgbd(const orb_keypoint* d_kps, const orb_keypoi
 // train descriptor: broadcast loads), ratio test, triangulation, gates.  Float32 cv::Mat arithmetic / libm float calls / cv::SVD of the reference
 // follow rule R4 (the same rule oracle/frame_oracle.cpp states): transcendental functions in double on the float argument,
 // rounded to float; float products as double-accumulated sums rounded once; the null vector of the 4x4 system by cyclic Jacobi on A^T A in double.
-static __device__ void kb8_unproject(const float* p, const float u, const float v, float* ray) {   // KannalaBrandt8.cpp:101-124
-    const float pwx = (u - p[2]) / p[0], pwy = (v - p[3]) / p[1];
-    float scale = 1.f;
-    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
-    theta_d = fminf(fmaxf(-(float)(3.14159265358979323846 / 2.0), theta_d), (float)(3.14159265358979323846 / 2.0));
-    if (theta_d > 1e-8) {
-        float theta = theta_d;
-        for (int j = 0; j < 10; j++) {
-            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
-            const float k0_theta2 = p[4] * theta2, k1_theta4 = p[5] * theta4, k2_theta6 = p[6] * theta6, k3_theta8 = p[7] * theta8;
-            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
-                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
-            theta = theta - theta_fix;
-            if (fabsf(theta_fix) < 1e-6f) break;
-        }
-        scale = (float)tan((double)theta) / theta_d;
-    }
-    ray[0] = pwx * scale; ray[1] = pwy * scale; ray[2] = 1.f;
-}
-static __device__ void kb8_project_f(const float* p, const float* X, float* uv) {   // KannalaBrandt8.cpp:28-42
-    const float x2_plus_y2 = X[0] * X[0] + X[1] * X[1];
-    const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)X[2]);
-    const float psi = (float)atan2((double)X[1], (double)X[0]);
-    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
-    const float r = theta + p[4] * theta3 + p[5] * theta5 + p[6] * theta7 + p[7] * theta9;
-    uv[0] = (float)((double)(p[0] * r) * cos((double)psi) + (double)p[2]);
-    uv[1] = (float)((double)(p[1] * r) * sin((double)psi) + (double)p[3]);
-}
-static __device__ void null_vector4(const float* A, float* v4) {
-    double M[16], V[16];
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            double s = 0;
-            for (int k = 0; k < 4; k++) s += (double)A[k * 4 + i] * (double)A[k * 4 + j];
-            M[i * 4 + j] = s; V[i * 4 + j] = i == j ? 1.0 : 0.0;
-        }
-    for (int sweep = 0; sweep < 8; sweep++)
-        for (int pI = 0; pI < 3; pI++)
-            for (int q = pI + 1; q < 4; q++) {
-                const double apq = M[pI * 4 + q];
-                if (apq == 0.0) continue;
-                const double th = (M[q * 4 + q] - M[pI * 4 + pI]) / (2.0 * apq);
-                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 4; k++) { const double a = M[k * 4 + pI], b = M[k * 4 + q]; M[k * 4 + pI] = c * a - sn * b; M[k * 4 + q] = sn * a + c * b; }
-                for (int k = 0; k < 4; k++) { const double a = M[pI * 4 + k], b = M[q * 4 + k]; M[pI * 4 + k] = c * a - sn * b; M[q * 4 + k] = sn * a + c * b; }
-                for (int k = 0; k < 4; k++) { const double a = V[k * 4 + pI], b = V[k * 4 + q]; V[k * 4 + pI] = c * a - sn * b; V[k * 4 + q] = sn * a + c * b; }
-            }
-    int m = 0;
-    for (int i = 1; i < 4; i++) if (M[i * 4 + i] < M[m * 4 + m]) m = i;
-    for (int k = 0; k < 4; k++) v4[k] = (float)V[k * 4 + m];
-}
-static __device__ __forceinline__ float fdot3(const float* a, const float* b) { return (float)((double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2]); }
-static __device__ float triangulate_matches(const orbf_fisheye_rig& G, const orb_keypoint& kp1, const orb_keypoint& kp2, const float sigmaLevel, const float unc,
-                                            float* x3D) {
-    float r1[3], r2[3], r21[3];
-    kb8_unproject(G.k_left, kp1.x, kp1.y, r1);
-    kb8_unproject(G.k_right, kp2.x, kp2.y, r2);
-    for (int i = 0; i < 3; i++) r21[i] = fdot3(G.R_lr + 3 * i, r2);
-    const double n1 = sqrt((double)r1[0] * r1[0] + (double)r1[1] * r1[1] + (double)r1[2] * r1[2]);
-    const double n2 = sqrt((double)r21[0] * r21[0] + (double)r21[1] * r21[1] + (double)r21[2] * r21[2]);
-    const double dotp = (double)r1[0] * r21[0] + (double)r1[1] * r21[1] + (double)r1[2] * r21[2];
-    const float cosParallaxRays = (float)(dotp / (n1 * n2));
-    if (cosParallaxRays > 0.9998) return -1;
-    float R21[9], t21[3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R21[i * 3 + j] = G.R_lr[j * 3 + i];
-    for (int i = 0; i < 3; i++) t21[i] = -fdot3(R21 + 3 * i, G.t_lr);
-    float A[16];
-    for (int c = 0; c < 4; c++) {
-        const float T1r0 = c == 0 ? 1.f : 0.f, T1r1 = c == 1 ? 1.f : 0.f, T1r2 = c == 2 ? 1.f : 0.f;
-        const float T2r0 = c < 3 ? R21[c] : t21[0], T2r1 = c < 3 ? R21[3 + c] : t21[1], T2r2 = c < 3 ? R21[6 + c] : t21[2];
-        A[c] = r1[0] * T1r2 - T1r0;
-        A[4 + c] = r1[1] * T1r2 - T1r1;
-        A[8 + c] = r2[0] * T2r2 - T2r0;
-        A[12 + c] = r2[1] * T2r2 - T2r1;
-    }
-    float v4[4];
-    null_vector4(A, v4);
-    for (int i = 0; i < 3; i++) x3D[i] = v4[i] / v4[3];
-    const float z1 = x3D[2];
-    if (z1 <= 0) return -1;
-    const float z2 = fdot3(R21 + 6, x3D) + t21[2];
-    if (z2 <= 0) return -1;
-    float uv1[2];
-    kb8_project_f(G.k_left, x3D, uv1);
-    const float errX1 = uv1[0] - kp1.x, errY1 = uv1[1] - kp1.y;
-    if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -1;
-    float x3D2[3], uv2[2];
-    for (int i = 0; i < 3; i++) x3D2[i] = fdot3(R21 + 3 * i, x3D) + t21[i];
-    kb8_project_f(G.k_right, x3D2, uv2);
-    const float errX2 = uv2[0] - kp2.x, errY2 = uv2[1] - kp2.y;
-    if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -1;
-    return z1;
+#include "kb8_geom.inc"
+static __device__ __forceinline__ float triangulate_matches(const orbf_fisheye_rig& G, const orb_keypoint& kp1, const orb_keypoint& kp2, const float sigmaLevel,
+                                                            const float unc, float* x3D) {
+    return kb8_triangulate_matches(G.k_left, G.k_right, G.R_lr, G.t_lr, kp1, kp2, sigmaLevel, unc, x3D);
 }
 
 struct FishArgs {

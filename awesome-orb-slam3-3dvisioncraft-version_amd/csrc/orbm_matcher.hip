@@ -1087,13 +1087,20 @@ static __global__ __launch_bounds__(256) void k_bow(BowArgs A) {
 // The reference never sets vbMatched2, so every KF1 feature is independent: its match is the gate-passing candidate of the shared
 // vocabulary node with the smallest distance <= TH_LOW, the LAST one among equals (the `dist>bestDist -> continue` update rule).
 // One workgroup per key-frame pair, one wave per shared node, lanes over the node's KF2 features.
+// KB8 = key frames with KannalaBrandt8 cameras (one camera, or a fisheye rig with mpCamera2): the gate is KannalaBrandt8::epipolarConstrain =
+// TriangulateMatches(...) > 0.0001f (KannalaBrandt8.cpp:235-238, 334-400; rule R4) with the (R12, t12, camera) combination the reference picks
+// per candidate from (bRight1, bRight2) (ORBmatcher.cc:1280-1315); bStereo1 / bStereo2 are false for such key frames (mvuRight is not set
+// by the fisheye Frame constructor), the epipole test only applies without a second camera (:1269).
 struct TriArgs {
     orbm_tri_side k1, k2;
     const orbm_tri_pair* pairs;
+    const orbm_tri_kb8_pair* kb8; const int32_t* nleft1; const int32_t* nleft2;   // KB8 only
     int only_stereo, coarse, check_orientation;
     int32_t* match12; int32_t* nmatches;
 };
+#include "kb8_geom.inc"
 
+template <bool KB8>
 static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1116,7 +1123,10 @@ static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
     const float* ur2 = A.k2.u_right ? A.k2.u_right + (size_t)b * A.k2.cap_f : nullptr;
     const uint8_t* mp1 = A.k1.has_mp + (size_t)b * A.k1.cap_f;
     const uint8_t* mp2 = A.k2.has_mp + (size_t)b * A.k2.cap_f;
-    const orbm_tri_pair& P = A.pairs[b];
+    const orbm_tri_pair* const Pp = KB8 ? nullptr : A.pairs + b;          // exactly one of the two pair records exists
+    const orbm_tri_kb8_pair* const Qp = KB8 ? A.kb8 + b : nullptr;
+    const bool rig = KB8 && Qp->n_cams == 2;
+    const int nl1 = rig ? A.nleft1[b] : -1, nl2 = rig ? A.nleft2[b] : -1;
     int32_t* match12 = A.match12 + (size_t)b * A.k1.cap_f;
     if (tid < 32) hist[tid] = 0;
     if (tid < 8) ctl[tid] = 0;
@@ -1130,7 +1140,10 @@ static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
     __syncthreads();
     float F[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) F[i] = P.F12[i];
+    for (int i = 0; i < 9; i++) F[i] = KB8 ? 0.f : Pp->F12[i];
+    const float epx = KB8 ? Qp->ep[0] : Pp->ep[0], epy = KB8 ? Qp->ep[1] : Pp->ep[1];
+    const float* sf2 = KB8 ? Qp->scale_factors_2 : Pp->scale_factors_2;
+    const float* sg2 = KB8 ? Qp->level_sigma2_2 : Pp->level_sigma2_2;
     int myMatches = 0;
     for (int k = wave; k < nn1; k += 4) {
         const int n2 = pair2[k];
@@ -1139,9 +1152,10 @@ static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
         for (int i1 = st1[k]; i1 < st1[k + 1]; i1++) {
             const int idx1 = fe1[i1];
             if (mp1[idx1]) continue;
-            const bool bStereo1 = ur1 && ur1[idx1] >= 0;
+            const bool bStereo1 = !KB8 && ur1 && ur1[idx1] >= 0;
             if (A.only_stereo && !bStereo1) continue;
             const orb_keypoint kp1 = kp1s[idx1];
+            const int bRight1 = (nl1 >= 0 && idx1 >= nl1) ? 1 : 0;
             const Desc d1 = load_desc(d1s + (size_t)idx1 * 32);
             // Pinhole.cpp:162-165 epipolar line of kp1 in image 2
             const float la = kp1.x * F[0] + kp1.y * F[3] + F[6];
@@ -1155,20 +1169,28 @@ static __global__ __launch_bounds__(256) void k_tri(TriArgs A) {
                 if (p >= e2) continue;
                 const int idx2 = fe2[p];
                 if (mp2[idx2]) continue;
-                const bool bStereo2 = ur2 && ur2[idx2] >= 0;
+                const bool bStereo2 = !KB8 && ur2 && ur2[idx2] >= 0;
                 if (A.only_stereo && !bStereo2) continue;
                 const int dist = hamming(d1, load_desc(d2s + (size_t)idx2 * 32));
                 if (dist > ORBM_TH_LOW) continue;
                 const orb_keypoint kp2 = kp2s[idx2];
-                if (!bStereo1 && !bStereo2) {   // :1269-1277 too close to the epipole
-                    const float distex = P.ep[0] - kp2.x, distey = P.ep[1] - kp2.y;
-                    if (distex * distex + distey * distey < 100 * P.scale_factors_2[kp2.octave & 15]) continue;
+                if (!bStereo1 && !bStereo2 && !rig) {   // :1269-1277 too close to the epipole (not with a second camera)
+                    const float distex = epx - kp2.x, distey = epy - kp2.y;
+                    if (distex * distex + distey * distey < 100 * sf2[kp2.octave & 15]) continue;
                 }
                 bool ok = A.coarse != 0;
-                if (!ok && den != 0) {
+                if (KB8) {
+                    if (!ok) {
+                        const int bRight2 = (nl2 >= 0 && idx2 >= nl2) ? 1 : 0;
+                        const int combo = bRight1 * 2 + bRight2;
+                        float x3D[3];
+                        ok = kb8_triangulate_matches(Qp->k1[bRight1], Qp->k2[bRight2], Qp->R12[combo], Qp->t12[combo], kp1, kp2, Qp->level_sigma2_1[kp1.octave & 15],
+                                                     sg2[kp2.octave & 15], x3D) > 0.0001f;
+                    }
+                } else if (!ok && den != 0) {
                     const float num = la * kp2.x + lb * kp2.y + lc;
                     const float dsqr = num * num / den;
-                    ok = (double)dsqr < 3.84 * (double)P.level_sigma2_2[kp2.octave & 15];
+                    ok = (double)dsqr < 3.84 * (double)sg2[kp2.octave & 15];
                 }
                 if (!ok) continue;
                 const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(0xFFFFF - ((p - s2) & 0xFFFFF));
@@ -1270,10 +1292,10 @@ extern "C" int orbm_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, 
                                const orbm_grid_params* gp, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
     if (!d_kps || !d_nkp || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
     const bool timed = mt_ready();
-    if (timed) hipEventRecord(g_mt.ev[0], (hipStream_t)stream);
+    if (timed) (void)hipEventRecord(g_mt.ev[0], (hipStream_t)stream);
     hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (2 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
                        *gp, d_grid_start, d_grid_idx, (const int32_t*)nullptr, GRID_CELLS);
-    if (timed) { hipEventRecord(g_mt.ev[1], (hipStream_t)stream); g_mt.have_grid = true; }
+    if (timed) { (void)hipEventRecord(g_mt.ev[1], (hipStream_t)stream); g_mt.have_grid = true; }
     return launch_status();
 }
 
@@ -1306,15 +1328,15 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     A.chi2_gate = 0; A.q_dist = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
     const bool timed = mt_ready();
-    if (timed) hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
+    if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
 #if SBP_HALF
     hipLaunchKernelGGL(k_sbp_candidates2, dim3((cap_q + 7) / 8, batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #else
     hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #endif
-    if (timed) hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
+    if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
-    if (timed) { hipEventRecord(g_mt.ev[4], (hipStream_t)stream); g_mt.have_sbp = true; }
+    if (timed) { (void)hipEventRecord(g_mt.ev[4], (hipStream_t)stream); g_mt.have_sbp = true; }
     return launch_status();
 }
 
@@ -1394,8 +1416,25 @@ extern "C" int orbm_search_for_triangulation(const orbm_tri_side* kf1, const orb
     if (smem > 64 * 1024) return ORB_E_INVALID;
     TriArgs A;
     A.k1 = *kf1; A.k2 = *kf2; A.pairs = d_pairs; A.only_stereo = only_stereo; A.coarse = coarse; A.check_orientation = check_orientation;
+    A.kb8 = nullptr; A.nleft1 = A.nleft2 = nullptr;
     A.match12 = d_match12; A.nmatches = d_nmatches;
-    hipLaunchKernelGGL(k_tri, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_tri<false>, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
+    return launch_status();
+}
+
+extern "C" int orbm_search_for_triangulation_kb8(const orbm_tri_side* kf1, const orbm_tri_side* kf2, const int32_t* d_nleft1, const int32_t* d_nleft2,
+                                                 const orbm_tri_kb8_pair* d_pairs, int batch, int only_stereo, int coarse, int check_orientation,
+                                                 int32_t* d_match12, int32_t* d_nmatches, void* stream) {
+    if (!kf1 || !kf2 || !d_pairs || !d_nleft1 || !d_nleft2 || !d_match12 || !d_nmatches || batch < 1 || kf1->cap_f < 1 || kf2->cap_f < 1 ||
+        kf1->cap_nodes < 1 || kf2->cap_nodes < 1 || !kf1->kps || !kf2->kps || !kf1->desc || !kf2->desc || !kf1->has_mp || !kf2->has_mp)
+        return ORB_E_INVALID;
+    const size_t smem = (32 + 8 + (size_t)kf1->cap_nodes) * 4 + (((size_t)kf1->cap_f + 15) & ~(size_t)15);
+    if (smem > 64 * 1024) return ORB_E_INVALID;
+    TriArgs A;
+    A.k1 = *kf1; A.k2 = *kf2; A.pairs = nullptr; A.only_stereo = only_stereo; A.coarse = coarse; A.check_orientation = check_orientation;
+    A.kb8 = d_pairs; A.nleft1 = d_nleft1; A.nleft2 = d_nleft2;
+    A.match12 = d_match12; A.nmatches = d_nmatches;
+    hipLaunchKernelGGL(k_tri<true>, dim3(batch), dim3(256), smem, (hipStream_t)stream, A);
     return launch_status();
 }
 

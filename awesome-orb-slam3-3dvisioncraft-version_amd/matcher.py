@@ -49,6 +49,12 @@ TRI_PAIR_DTYPE = np.dtype([("F12", "<f4", (9,)), ("ep", "<f4", (2,)), ("level_si
 assert TRI_PAIR_DTYPE.itemsize == 176
 
 
+TRI_KB8_PAIR_DTYPE = np.dtype([("n_cams", "<i4"), ("reserved", "<i4"), ("k1", "<f4", (2, 8)), ("k2", "<f4", (2, 8)), ("R12", "<f4", (4, 9)),
+                               ("t12", "<f4", (4, 3)), ("ep", "<f4", (2,)), ("level_sigma2_1", "<f4", (16,)), ("level_sigma2_2", "<f4", (16,)),
+                               ("scale_factors_2", "<f4", (16,))])
+assert TRI_KB8_PAIR_DTYPE.itemsize == 528
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -92,6 +98,7 @@ def bind(lib):
                                                 vp, vp, vp, vp, vp]),
         "orbm_fuse": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.POINTER(FuseParams), vp, vp, vp, vp]),
         "orbm_search_for_triangulation": (i32, [C.POINTER(TriSide), C.POINTER(TriSide), vp, i32, i32, i32, i32, vp, vp, vp]),
+        "orbm_search_for_triangulation_kb8": (i32, [C.POINTER(TriSide), C.POINTER(TriSide), vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "orbm_mutual_matches": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
@@ -287,4 +294,19 @@ class ORBmatcher:
         a, b = side(kf1), side(kf2)
         self._check(self._L.orbm_search_for_triangulation(C.byref(a), C.byref(b), _ptr(pairs), B, int(bOnlyStereo), int(bCoarse),
                                                           int(self.mbCheckOrientation), _ptr(m12), _ptr(nm), _stream(kf1["desc"])))
+        return m12, nm
+
+    # -- SearchForTriangulation on KannalaBrandt8 key frames (monocular fisheye or rig with mpCamera2): ORBmatcher.cc:1138-1428 rig branches
+    def SearchForTriangulationKB8(self, kf1, kf2, n_left1, n_left2, pairs, bOnlyStereo=False, bCoarse=False):
+        """kf1 / kf2 as in SearchForTriangulation with kps = [mvKeys | mvKeysRight] (u_right ignored); n_left* [B] int32 (NLeft; unused when
+        n_cams = 1); pairs: u8 view of TRI_KB8_PAIR_DTYPE[B].  -> (vMatches12 [B,cap1] int32, nmatches [B])"""
+        def side(d):
+            return TriSide(_ptr(d["kps"]).value, _ptr(d["desc"]).value, None, _ptr(d["has_mp"]).value, _ptr(d["node_id"]).value,
+                           _ptr(d["node_start"]).value, _ptr(d["feat_idx"]).value, _ptr(d["n_nodes"]).value, d["desc"].shape[1], d["node_id"].shape[1])
+        B = kf1["desc"].shape[0]
+        m12 = _like(kf1["desc"], (B, kf1["desc"].shape[1]), np.int32)
+        nm = _like(kf1["desc"], (B,), np.int32)
+        a, b = side(kf1), side(kf2)
+        self._check(self._L.orbm_search_for_triangulation_kb8(C.byref(a), C.byref(b), _ptr(n_left1), _ptr(n_left2), _ptr(pairs), B, int(bOnlyStereo),
+                                                              int(bCoarse), int(self.mbCheckOrientation), _ptr(m12), _ptr(nm), _stream(kf1["desc"])))
         return m12, nm

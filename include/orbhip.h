@@ -305,6 +305,26 @@ int orbm_search_for_triangulation(const orbm_tri_side* kf1, const orbm_tri_side*
                                   int only_stereo, int coarse, int check_orientation, int32_t* d_match12, int32_t* d_nmatches,
                                   void* stream);
 
+/* The same search for key frames whose cameras are KannalaBrandt8 (BASELINE configs[3]): a monocular fisheye camera
+ * (n_cams = 1) or a fisheye rig with mpCamera2 (n_cams = 2; kps / desc = the concatenation [mvKeys | mvKeysRight] like a rig Frame — NOT
+ * mvKeysUn, ORBmatcher.cc:1249-1251 — with d_nleft*[b] = NLeft, features >= NLeft belong to the right camera).  The gate is
+ * KannalaBrandt8::epipolarConstrain = TriangulateMatches(pCamera2, kp1, kp2, R12, t12, mvLevelSigma2_1[kp1.octave], mvLevelSigma2_2[kp2.octave]) >
+ * 0.0001f (KannalaBrandt8.cpp:235-238, 334-400) with the (camera, R12, t12) combination chosen per candidate from (bRight1, bRight2)
+ * (ORBmatcher.cc:1280-1315).  bStereo1 / bStereo2 are false for such key frames (u_right of the sides is ignored), so only_stereo yields no
+ * match; the epipole test (:1269-1277) applies only when n_cams = 1.  The float32 cv::Mat / libm / cv::SVD steps inside TriangulateMatches
+ * follow rule R4, like orbf_stereo_fisheye_matches: parity vs a real OpenCV build is unpinned for them. */
+typedef struct orbm_tri_kb8_pair {
+    int32_t n_cams, reserved;
+    float k1[2][8], k2[2][8];     /* mvParameters of pKF1->mpCamera / mpCamera2 and of pKF2->mpCamera / mpCamera2 */
+    float R12[4][9], t12[4][3];   /* row-major, index bRight1*2 + bRight2: Rll, Rlr, Rrl, Rrr / tll, tlr, trl, trr (ORBmatcher.cc:1181-1193) as the adapter's
+                                   * cv::Mat expressions evaluate them; n_cams = 1: entry 0 = R12, t12 (:1176-1177) */
+    float ep[2];                  /* pKF2->mpCamera->project(R2w*Cw + t2w) (:1149-1152); read only when n_cams = 1 */
+    float level_sigma2_1[16], level_sigma2_2[16], scale_factors_2[16];   /* pKF1->mvLevelSigma2, pKF2->mvLevelSigma2, pKF2->mvScaleFactors */
+} orbm_tri_kb8_pair;
+int orbm_search_for_triangulation_kb8(const orbm_tri_side* kf1, const orbm_tri_side* kf2, const int32_t* d_nleft1, const int32_t* d_nleft2,
+                                      const orbm_tri_kb8_pair* d_pairs, int batch, int only_stereo, int coarse, int check_orientation,
+                                      int32_t* d_match12, int32_t* d_nmatches, void* stream);
+
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:323-587, Nleft == -1 branch).
  * FeatureVector of each side as CSR: node ids ascending (std::map order), node_start[k..k+1] delimit feat_idx[] (the
  * feature indices of that node in insertion order).  kf_valid[i] != 0 where the KF feature holds a good map point.

@@ -263,6 +263,44 @@ public:
         return nmatches;
     }
 
+    // The same call for key frames with KannalaBrandt8 cameras — a fisheye rig (pKF->mpCamera2 != NULL: K.keysUn = [mvKeys | mvKeysRight],
+    // nLeft = pKF->NLeft) or one fisheye camera (nLeft = -1).  `pair` carries what the reference computes before its loops (ORBmatcher.cc:1144-1193):
+    // the four (R12, t12) combinations, both cameras' parameters, the epipole and the level tables; see orbm_tri_kb8_pair in orbhip.h.
+    int SearchForTriangulationKB8(const KeyFrameView& K1, int nLeft1, const KeyFrameView& K2, int nLeft2, const orbm_tri_kb8_pair& pair,
+                                  std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bOnlyStereo, bool bCoarse = false) {
+        vMatchedPairs.clear();
+        if (K1.N == 0 || K2.N == 0 || K1.nodeId.empty() || K2.nodeId.empty()) return 0;
+        orbm_tri_side s[2];
+        const KeyFrameView* K[2] = {&K1, &K2};
+        int32_t nn[4] = {(int32_t)K1.nodeId.size(), (int32_t)K2.nodeId.size(), nLeft1, nLeft2};
+        const int32_t* dnn = cnt_.upload(nn, 4);
+        for (int i = 0; i < 2; i++) {
+            s[i].kps = tk_[i].upload(K[i]->keysUn, K[i]->N);
+            s[i].desc = td_[i].upload(K[i]->descriptors, (size_t)K[i]->N * 32);
+            s[i].u_right = nullptr;
+            s[i].has_mp = tm_[i].upload(K[i]->hasMapPoint, K[i]->N);
+            s[i].node_id = tn_[i].upload(K[i]->nodeId.data(), K[i]->nodeId.size());
+            s[i].node_start = ts_[i].upload(K[i]->nodeStart.data(), K[i]->nodeStart.size());
+            s[i].feat_idx = tf_[i].upload(K[i]->featIdx.data(), K[i]->featIdx.size());
+            s[i].n_nodes = dnn + i;
+            s[i].cap_f = K[i]->N; s[i].cap_nodes = nn[i];
+        }
+        const orbm_tri_kb8_pair* dP = q_.upload(&pair, 1);
+        int32_t* dm = (int32_t*)qm_.ensure((size_t)K1.N * 4);
+        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        if (orbm_search_for_triangulation_kb8(&s[0], &s[1], dnn + 2, dnn + 3, dP, 1, bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0, mbCheckOrientation ? 1 : 0, dm, dnm,
+                                              nullptr) != ORB_OK)
+            throw std::runtime_error("orbm_search_for_triangulation_kb8");
+        std::vector<int32_t> m12(K1.N);
+        int nmatches = 0;
+        orb_memcpy_d2h(m12.data(), dm, (size_t)K1.N * 4, nullptr);
+        orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
+        if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        for (int i = 0; i < K1.N; i++)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));   // :1415-1422
+        return nmatches;
+    }
+
     // ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (ORBmatcher.h:67, ORBmatcher.cc:323-587).
     // KF / F as KeyFrameView (descriptors + mFeatVec CSR; hasMapPoint on the KF side = "pKF map point exists and is not bad");
     // angleKF / angleF = keypoint angles (mvKeysUn / mvKeys / mvKeysRight as the reference picks them); nLeftF = F.Nleft (-1: one camera).

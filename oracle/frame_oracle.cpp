@@ -145,6 +145,13 @@ float triangulateMatches(const float* p1, const float* p2, const KeyPoint& kp1, 
 }  // namespace
 
 extern "C" {
+// KannalaBrandt8::TriangulateMatches for the matcher oracle (SearchForTriangulation on fisheye key frames): returns z1 or -1
+float ofr_triangulate_matches(const float* p1, const float* p2, const void* kp1, const void* kp2, const float* R12, const float* t12, float sigmaLevel,
+                              float unc, float* x3D) {
+    return triangulateMatches(p1, p2, *(const KeyPoint*)kp1, *(const KeyPoint*)kp2, R12, t12, sigmaLevel, unc, x3D);
+}
+float ofr_kb8_project(const float* p, const float* X, float* uv) { kb8ProjectF(p, X, uv); return uv[0]; }
+
 // Frame::UndistortKeyPoints (Frame.cc:874-925).  cam = fx, fy, cx, cy, k1, k2, p1, p2, k3
 void ofr_undistort_keypoints(const void* kps_in, int n, const float cam[9], void* kps_out) {
     const KeyPoint* in = (const KeyPoint*)kps_in;

@@ -730,4 +730,98 @@ int omo_search_for_triangulation(const void* s1_, const void* s2_, const float* 
     return nmatches;
 }
 
+// M12 on KannalaBrandt8 key frames (monocular fisheye: n_cams = 1; fisheye rig with mpCamera2: n_cams = 2).  ORBmatcher.cc:1138-1428 with the
+// rig branches: kp = mvKeys / mvKeysRight (concatenated in K.kps, :1249-1251 / :1261-1263), bStereo1 = bStereo2 = false (mvuRight is unset),
+// the epipole test only without a second camera (:1269), the (R12, t12, pCamera1, pCamera2) combination per candidate (:1280-1315) and
+// pCamera1->epipolarConstrain(...) = KannalaBrandt8::TriangulateMatches(...) > 0.0001f (KannalaBrandt8.cpp:235-238; frame_oracle.cpp, rule R4).
+struct TriKb8Pair {
+    int32_t n_cams, reserved;
+    float k1[2][8], k2[2][8];
+    float R12[4][9], t12[4][3];
+    float ep[2];
+    float level_sigma2_1[16], level_sigma2_2[16], scale_factors_2[16];
+};
+float ofr_triangulate_matches(const float*, const float*, const void*, const void*, const float*, const float*, float, float, float*);
+int omo_search_for_triangulation_kb8(const void* s1_, const void* s2_, int nleft1, int nleft2, const void* pair_, int bOnlyStereo, int bCoarse,
+                                     int checkOri, int32_t* matches12) {
+    const TriSide& K1 = *(const TriSide*)s1_;
+    const TriSide& K2 = *(const TriSide*)s2_;
+    const TriKb8Pair& Q = *(const TriKb8Pair*)pair_;
+    const bool hasCam2 = Q.n_cams == 2;
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(K2.N, false);
+    std::vector<int> vMatches12(K1.N, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto lower_bound = [](const int32_t* ids, int n, int key) { int lo = 0, hi = n; while (lo < hi) { int m = (lo + hi) / 2; if (ids[m] < key) lo = m + 1; else hi = m; } return lo; };
+    const float* R12 = Q.R12[0]; const float* t12 = Q.t12[0];
+    const float* pCamera1 = Q.k1[0]; const float* pCamera2 = Q.k2[0];
+    int f1 = 0, f2 = 0;
+    while (f1 != K1.n_nodes && f2 != K2.n_nodes) {
+        if (K1.node_id[f1] == K2.node_id[f2]) {
+            for (int i1 = K1.node_start[f1]; i1 < K1.node_start[f1 + 1]; i1++) {
+                const size_t idx1 = K1.feat[i1];
+                if (K1.has_mp[idx1]) continue;
+                const bool bStereo1 = false;   // (!pKF1->mpCamera2 && mvuRight[idx1] >= 0): mvuRight is -1 for fisheye frames
+                if (bOnlyStereo) if (!bStereo1) continue;
+                const KeyPoint& kp1 = K1.kps[idx1];
+                const bool bRight1 = (!hasCam2 || (int)idx1 < nleft1) ? false : true;
+                const uint8_t* d1 = K1.desc + idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = K2.node_start[f2]; i2 < K2.node_start[f2 + 1]; i2++) {
+                    size_t idx2 = K2.feat[i2];
+                    if (vbMatched2[idx2] || K2.has_mp[idx2]) continue;
+                    const bool bStereo2 = false;
+                    if (bOnlyStereo) if (!bStereo2) continue;
+                    const int dist = DescriptorDistance(d1, K2.desc + idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = K2.kps[idx2];
+                    const bool bRight2 = (!hasCam2 || (int)idx2 < nleft2) ? false : true;
+                    if (!bStereo1 && !bStereo2 && !hasCam2) {
+                        const float distex = Q.ep[0] - kp2.x, distey = Q.ep[1] - kp2.y;
+                        if (distex * distex + distey * distey < 100 * Q.scale_factors_2[kp2.octave]) continue;
+                    }
+                    if (hasCam2) {
+                        const int c = (bRight1 ? 2 : 0) + (bRight2 ? 1 : 0);
+                        R12 = Q.R12[c]; t12 = Q.t12[c];
+                        pCamera1 = Q.k1[bRight1 ? 1 : 0]; pCamera2 = Q.k2[bRight2 ? 1 : 0];
+                    }
+                    float p3D[3];
+                    if (ofr_triangulate_matches(pCamera1, pCamera2, &kp1, &kp2, R12, t12, Q.level_sigma2_1[kp1.octave], Q.level_sigma2_2[kp2.octave], p3D) > 0.0001f ||
+                        bCoarse) {
+                        bestIdx2 = (int)idx2; bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    const KeyPoint& kp2 = K2.kps[bestIdx2];
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back((int)idx1);
+                    }
+                }
+            }
+            f1++; f2++;
+        } else if (K1.node_id[f1] < K2.node_id[f2]) {
+            f1 = lower_bound(K1.node_id, K1.n_nodes, K2.node_id[f2]);
+        } else {
+            f2 = lower_bound(K2.node_id, K2.n_nodes, K1.node_id[f1]);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < K1.N; i++) matches12[i] = vMatches12[i];
+    return nmatches;
+}
+
 }  // extern "C"

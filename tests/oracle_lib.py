@@ -388,6 +388,25 @@ def search_for_triangulation(k1, k2, F12, ep, level_sigma2_2, scale_factors_2, o
 
 
 # ---- DBoW2 vocabulary + transform (oracle/bow_oracle.cpp) --------------------------------------------------------------
+def search_for_triangulation_kb8(k1, k2, nleft1, nleft2, pair, only_stereo, coarse, check_ori):
+    """KannalaBrandt8 key frames (oracle/match_oracle.cpp omo_search_for_triangulation_kb8); pair: one TRI_KB8_PAIR_DTYPE record"""
+    L = lib()
+    L.omo_search_for_triangulation_kb8.restype = C.c_int
+    L.omo_search_for_triangulation_kb8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    keep = []
+
+    def side(d):
+        arrs = [np.ascontiguousarray(d["kps"]), np.ascontiguousarray(d["desc"]), None, np.ascontiguousarray(d["has_mp"], np.uint8),
+                np.ascontiguousarray(d["node_id"], np.int32), np.ascontiguousarray(d["node_start"], np.int32), np.ascontiguousarray(d["feat_idx"], np.int32)]
+        keep.append(arrs)
+        return _TriSide(*[(a.ctypes.data if a is not None else None) for a in arrs], int(d["n_nodes"]), len(arrs[1]))
+    a, b = side(k1), side(k2)
+    pair = np.ascontiguousarray(pair)
+    m12 = np.zeros(max(a.N, 1), np.int32)
+    n = L.omo_search_for_triangulation_kb8(C.addressof(a), C.addressof(b), int(nleft1), int(nleft2), _p(pair), int(only_stereo), int(coarse), int(check_ori), _p(m12))
+    return m12[:a.N], n
+
+
 class OracleVocabulary:
     def __init__(self, file_bytes):
         L = lib()

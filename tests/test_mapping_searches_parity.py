@@ -225,3 +225,133 @@ def test_emu_search_by_sim3(emu_lib, th):
 @pytest.mark.parametrize("th", [7.5, 3.0, 15.0])
 def test_hip_search_by_sim3(hip_lib, th):
     _sim3_case(hip_lib, "hip", th)
+
+
+# ---- SearchForTriangulation on KannalaBrandt8 key frames (fisheye rig with mpCamera2, or one fisheye camera) ------------------------------
+# ORBmatcher.cc:1138-1428 rig branches + KannalaBrandt8::epipolarConstrain (KannalaBrandt8.cpp:235-238 -> TriangulateMatches :334-400, rule R4)
+from orbhip._lib import KP_DTYPE  # noqa: E402
+from orbhip.lba import _kb8_project, _rodrigues  # noqa: E402
+from orbhip.matcher import TRI_KB8_PAIR_DTYPE  # noqa: E402
+
+KB_A = np.float32([190.978, 190.973, 254.932, 256.897, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673])   # TUM_512.yaml-like
+KB_B = np.float32([190.442, 190.434, 252.597, 254.917, 0.0034003171, 0.0017662670, -0.0026630025, 0.00032995968])
+
+
+def kb8_keyframe_pair(seed, n_pts=420, rig=True, n_distract=60, wrong_geometry=False):
+    """Two key frames of one fisheye rig (or of one fisheye camera) looking at the same 3-D points: per key frame the concatenation
+    [mvKeys | mvKeysRight], descriptors, GetMapPoint flags and a FeatureVector in which both views of a point share a node."""
+    rng = np.random.default_rng(seed)
+    R_rl = _rodrigues(np.array([0.003, -0.011, 0.002])); t_rl = np.array([-0.101, 0.0012, -0.0007])     # x_right = R_rl x_left + t_rl
+    T = []                                                                                               # [kf][cam] -> (R_cw, t_cw)
+    for kf, (w, t) in enumerate((((0.01, -0.02, 0.005), (0.0, 0.0, 0.0)), ((-0.03, 0.05, -0.01), (-0.35, 0.04, 0.06)))):
+        Rl, tl = _rodrigues(np.array(w)), np.array(t)
+        T.append([(Rl, tl), (R_rl @ Rl, R_rl @ tl + t_rl)])
+    X = np.stack([rng.uniform(-4, 4, n_pts), rng.uniform(-3, 3, n_pts), rng.uniform(1.5, 9, n_pts)], 1)
+    base_desc = rng.integers(0, 256, (n_pts, 32), dtype=np.uint8)
+    base_ang = rng.uniform(0, 360, n_pts)
+    kb = (KB_A, KB_B)
+    sides, nlefts = [], []
+    for kf in range(2):
+        kps, descs, nodes = [], [], []
+        for cam in range(2 if rig else 1):
+            R, t = T[kf][cam]
+            Xc = X @ R.T + t
+            u, v, th = _kb8_project(kb[cam].astype(np.float64), Xc)
+            vis = (Xc[:, 2] > 0.3) & (th < 1.25) & (u > 5) & (u < 507) & (v > 5) & (v < 507) & (rng.random(n_pts) < 0.8)
+            ids = np.nonzero(vis)[0]
+            k = np.zeros(len(ids) + n_distract, KP_DTYPE)
+            k["x"][:len(ids)] = u[ids] + rng.normal(0, 0.35, len(ids)); k["y"][:len(ids)] = v[ids] + rng.normal(0, 0.35, len(ids))
+            k["x"][len(ids):] = rng.uniform(20, 490, n_distract); k["y"][len(ids):] = rng.uniform(20, 490, n_distract)
+            k["octave"] = rng.integers(0, 4, len(k)); k["size"], k["response"], k["class_id"] = 31, 40, -1
+            k["angle"][:len(ids)] = (base_ang[ids] + 12.0 * kf + rng.normal(0, 2, len(ids))) % 360
+            k["angle"][len(ids):] = rng.uniform(0, 360, n_distract)
+            flips = np.zeros((len(ids), 256), np.uint8)
+            for i in range(len(ids)):
+                flips[i, rng.choice(256, int(rng.integers(0, 30)), replace=False)] = 1
+            d_true = base_desc[ids] ^ np.packbits(flips, axis=1, bitorder="little")
+            # distractors: half of them copy a real point's descriptor (and its node) at a wrong image position -> only the geometric gate rejects them
+            src = rng.choice(n_pts, n_distract)
+            d_dis = np.where((np.arange(n_distract) % 2 == 0)[:, None], base_desc[src], rng.integers(0, 256, (n_distract, 32), dtype=np.uint8))
+            kps.append(k); descs.append(np.concatenate([d_true, d_dis]).astype(np.uint8))
+            nodes.append(np.concatenate([ids % 37, src % 37]))
+        nlefts.append(len(kps[0]) if rig else -1)
+        k_all, d_all, node = np.concatenate(kps), np.concatenate(descs), np.concatenate(nodes)
+        perm = rng.permutation(len(kps[0]))      # feature order inside each camera is unrelated to the point order
+        k_all[:len(perm)], d_all[:len(perm)], node[:len(perm)] = k_all[perm], d_all[perm], node[perm]
+        ids_n = np.unique(node)
+        start, feat = [0], []
+        for nid in ids_n:
+            feat += np.nonzero(node == nid)[0].tolist(); start.append(len(feat))
+        sides.append(dict(kps=k_all, desc=d_all, u_right=None, has_mp=(rng.random(len(k_all)) < 0.25).astype(np.uint8), node_id=ids_n.astype(np.int32),
+                          node_start=np.array(start, np.int32), feat_idx=np.array(feat, np.int32), n_nodes=len(ids_n)))
+    pair = np.zeros(1, TRI_KB8_PAIR_DTYPE)
+    pair["n_cams"] = 2 if rig else 1
+    pair["k1"][0] = [KB_A, KB_B]; pair["k2"][0] = [KB_A, KB_B]
+    for b1 in range(2):
+        for b2 in range(2):
+            R1, t1 = T[0][b1 if rig else 0]; R2, t2 = T[1][b2 if rig else 0]
+            R12 = (R1.astype(np.float32) @ R2.astype(np.float32).T).astype(np.float32)          # ORBmatcher.cc:1176-1177, 1181-1193 in CV_32F
+            t12 = (-(R12 @ t2.astype(np.float32)) + t1.astype(np.float32)).astype(np.float32)
+            if wrong_geometry:
+                t12 = (t12[[1, 2, 0]] * np.float32(-1.5)).astype(np.float32)
+            pair["R12"][0, b1 * 2 + b2] = R12.reshape(9); pair["t12"][0, b1 * 2 + b2] = t12
+    R1, t1 = T[0][0]; R2, t2 = T[1][0]
+    C2 = R2 @ (-R1.T @ t1) + t2                                                                    # KF1's camera centre in KF2's camera frame (:1144-1148)
+    ue, ve, _ = _kb8_project(KB_A.astype(np.float64), C2[None])
+    pair["ep"][0] = [ue[0], ve[0]]
+    sf = (np.float32(1.2) ** np.arange(16, dtype=np.float32)).astype(np.float32)
+    pair["scale_factors_2"][0] = sf; pair["level_sigma2_1"][0] = sf * sf; pair["level_sigma2_2"][0] = sf * sf
+    return sides, nlefts, pair
+
+
+def _tri_kb8_case(lib, backend, rig, only_stereo, coarse, ori, seed=3):
+    variants = [kb8_keyframe_pair(seed, rig=rig), kb8_keyframe_pair(seed, rig=rig, wrong_geometry=True), kb8_keyframe_pair(seed + 1, n_pts=150, rig=rig, n_distract=200)]
+    B = len(variants)
+    c1 = max(len(v[0][0]["kps"]) for v in variants) + 5
+    c2 = max(len(v[0][1]["kps"]) for v in variants) + 9
+    d = lambda a: to_dev(a, backend)
+
+    def slabs(which, cap_f, cap_n):
+        o = dict(kps=np.zeros((B, cap_f, 7), np.float32), desc=np.zeros((B, cap_f, 32), np.uint8), has_mp=np.zeros((B, cap_f), np.uint8),
+                 node_id=np.zeros((B, cap_n), np.int32), node_start=np.zeros((B, cap_n + 1), np.int32), feat_idx=np.zeros((B, cap_f), np.int32),
+                 n_nodes=np.zeros(B, np.int32))
+        for b, v in enumerate(variants):
+            s = v[0][which]
+            n, nn = len(s["kps"]), s["n_nodes"]
+            o["kps"][b, :n] = kp_f32(s["kps"]); o["desc"][b, :n] = s["desc"]; o["has_mp"][b, :n] = s["has_mp"]
+            o["node_id"][b, :nn] = s["node_id"]; o["node_start"][b, :nn + 1] = s["node_start"]; o["feat_idx"][b, :len(s["feat_idx"])] = s["feat_idx"]
+            o["n_nodes"][b] = nn
+        return {k: d(v) for k, v in o.items()}
+    pairs = np.concatenate([v[2] for v in variants])
+    nl1 = np.array([v[1][0] for v in variants], np.int32); nl2 = np.array([v[1][1] for v in variants], np.int32)
+    m = orbhip.ORBmatcher(0.6, ori, lib=lib)
+    m12, nm = [to_host(x) for x in m.SearchForTriangulationKB8(slabs(0, c1, 40), slabs(1, c2, 44), d(nl1), d(nl2), d(pairs.view(np.uint8).reshape(B, -1)),
+                                                               only_stereo, coarse)]
+    counts = []
+    for b, (sides, nlefts, pair) in enumerate(variants):
+        om, on = O.search_for_triangulation_kb8(sides[0], sides[1], nlefts[0], nlefts[1], pair, only_stereo, coarse, ori)
+        n1 = len(sides[0]["kps"])
+        assert nm[b] == on, (b, nm[b], on)
+        assert np.array_equal(m12[b, :n1], om) and (m12[b, n1:] == -1).all(), b
+        counts.append(on)
+    if only_stereo:
+        assert counts == [0, 0, 0]            # bStereo1 is false for fisheye key frames (:1241-1245)
+    elif coarse:
+        assert counts[0] > 100 and counts[1] > 100   # bCoarse short-circuits the gate: geometry is irrelevant
+    else:
+        assert counts[0] > 60 and counts[1] < 0.5 * counts[0], counts   # the gate accepts the true geometry and refuses most of a wrong one
+    return counts
+
+
+TRI_KB8 = [(True, False, False, True), (False, False, False, True), (True, False, True, False), (True, True, False, True), (False, False, False, False)]
+
+
+@pytest.mark.parametrize("rig,only_stereo,coarse,ori", TRI_KB8[:4])
+def test_emu_search_for_triangulation_kb8(emu_lib, rig, only_stereo, coarse, ori):
+    _tri_kb8_case(emu_lib, "emu", rig, only_stereo, coarse, ori)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rig,only_stereo,coarse,ori", TRI_KB8)
+def test_hip_search_for_triangulation_kb8(hip_lib, rig, only_stereo, coarse, ori):
+    _tri_kb8_case(hip_lib, "hip", rig, only_stereo, coarse, ori)
