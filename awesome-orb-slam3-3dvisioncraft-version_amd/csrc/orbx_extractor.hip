@@ -336,6 +336,43 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
     return max(A, -B);
 }
 
+// The same score when the corner's polarity is known (a FAST-9 corner cannot have both a brighter and a darker 9-arc: 9 + 9 > 16):
+// only the passing side's "max over arcs of min" is needed — the other side's is <= 0 < S.  m = 0: ring brighter than the centre
+// (e = x - v), m = -1: darker (e = ~x - ~v = v - x); one v_xad_u32 per ring pixel.
+static __device__ __forceinline__ int fast_S_pol(const uint8_t* c, const int pitch, const int m) {
+    const int nv = -((int)c[0] ^ m);
+    int e[16];
+#ifdef HIP_EMULATED
+#define LD(k, dx, dy) e[k] = ((int)c[(dy) * pitch + (dx)] ^ m) + nv;
+#else   // (x ^ m) + nv is ONE v_xad_u32; left to itself the compiler hoists v ^ m and emits an xor and a subtract per ring pixel
+#define LD(k, dx, dy) asm("v_xad_u32 %0, %1, %2, %3" : "=v"(e[k]) : "v"((int)c[(dy) * pitch + (dx)]), "v"(m), "v"(nv));
+#endif
+    RING16(LD)
+#undef LD
+    int lo2[16], lo4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) lo2[i] = min(e[i], e[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
+    int A = -256;
+#pragma unroll
+    for (int i = 0; i < 16; i++) A = max(A, min(min(lo4[i], lo4[(i + 4) & 15]), e[(i + 8) & 15]));
+    return A;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave, register-only: four row_shr steps inside each row of 16 lanes, then the two DPP row
+// broadcasts gfx9 has for exactly this purpose (row 1/3 += lane 15 of the row before, rows 2-3 += lane 31).  No LDS round trips (a
+// __shfl_up scan is seven dependent ds_bpermute).  All 64 lanes must be active.
+static __device__ __forceinline__ int wave_scan_incl(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // LDS layout of k_fast (dynamic region), sizes fixed per handle:
 //   img[imgBytes] | smap[imgBytes] | q1[FAST_QCAP] u16 | q2[FAST_Q2CAP] u16 | colTab[FAST_TW] u8 | sh[8 + FAST_MAXCELLS] int
 // q1: pixels that passed the 4-point cardinal pre-test in the current row chunk; q2: every corner (S > min(ini,min)) of the tile.
@@ -350,6 +387,9 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
                      // 43x48-byte patches overlap heavily and gain 2-3 % from it.  Kept switchable.
 #endif
 #define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
+#define FAST_PITCH 144            // LDS row pitch of every tile: 128 detection columns + 6 (ROI overlap) + 4 (dword alignment of the detection
+                                  // region) rounded up to 16-byte rows.  A compile-time constant, so the 7 ring rows of the classification and of
+                                  // the score are instruction offsets instead of address arithmetic (k_fast is VALU-issue bound).
 #define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)   // 16 rows: each of the 4 waves owns 8 rows x 64 columns = FAST_QCAP/4 pixels
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice: one chunk's survivors + up to 63 carried over from the previous chunk
 
@@ -385,7 +425,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     // LDS column 0 = image column iniX-1, so that the detection region starts at byte 4 of every LDS row: detection column c
     // lives in dword 1 + c/4, which lets stage 1 treat one dword = 4 pixels per lane (rows are staged with a byte shift).
     const int xal = iniX - 1;
-    const int pitch = ((maxX - xal) + 15) & ~15;   // 16-byte rows: staged and cleared with 128-bit LDS stores
+    constexpr int pitch = FAST_PITCH;               // 16-byte rows: staged and cleared with 128-bit LDS stores
+    const int wbytes = ((maxX - xal) + 15) & ~15;   // bytes of a row that are actually staged
     const int rows = maxY - iniY;
     // detection region of the tile, local coordinates (cv::FAST skips a 3-px frame of each ROI; ROIs overlap by 6)
     const int dx0 = 4, dxe = maxX - 3 - xal;
@@ -405,7 +446,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         // merges them into dwordx4 + dword) -> four funnel shifts -> one 128-bit LDS store each for the image and the score map
         const uint32_t sh8 = (uint32_t)(xal & 3);
         const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + (xal & ~3);
-        const int gq = pitch >> 4;                       // 16-byte groups per LDS row
+        const int gq = wbytes >> 4;                      // 16-byte groups staged per LDS row
         const int ng = rows * gq;
         const int safe = L.w - (xal & ~3);               // bytes of an image row that may be read from src
         int r = tid / gq, c = tid - r * gq;
@@ -418,9 +459,10 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 const int left = safe - 16 * c;
                 w0 = left >= 4 ? g[0] : 0u; w1 = left >= 8 ? g[1] : 0u; w2 = left >= 12 ? g[2] : 0u; w3 = left >= 16 ? g[3] : 0u; w4 = 0u;
             }
-            ((uint4*)img)[i] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh8), __builtin_amdgcn_alignbyte(w2, w1, sh8),
-                                          __builtin_amdgcn_alignbyte(w3, w2, sh8), __builtin_amdgcn_alignbyte(w4, w3, sh8));
-            ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
+            const int li = r * (FAST_PITCH / 16) + c;
+            ((uint4*)img)[li] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh8), __builtin_amdgcn_alignbyte(w2, w1, sh8),
+                                           __builtin_amdgcn_alignbyte(w3, w2, sh8), __builtin_amdgcn_alignbyte(w4, w3, sh8));
+            ((uint4*)smap)[li] = make_uint4(0u, 0u, 0u, 0u);
             r += dr; c += dc;
             if (c >= gq) { c -= gq; r++; }
         }
@@ -439,13 +481,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const int wave = tid >> 6;
     const int dcol = lane & 31, rsub = lane >> 5;       // stage 1: lane = one LDS dword (4 detection columns) of one row
     uint16_t* q1w = q1 + wave * FAST_Q1W;               // 512 entries (4 rows x 128 columns per chunk, exact bound) + the carried remainder
-    uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);
-    int n2w = 0;                                        // corners of this wave (wave-uniform)
+    uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);       // this wave's corner list: brighter-ring corners from the front, darker-ring ones from the back
+    int n2b = 0, n2d = 0;                               // corners of this wave by polarity (wave-uniform)
     int nq = 0;                                         // survivors carried over from the previous chunk (< 64, at the front of q1w)
     bool ovf = false;
     // stage 2 of one batch of 64 queue entries: full ring classification -> this wave's q2 slice
     auto classify = [&](const int i, const bool valid) {
-        bool corner = false;
+        bool corner = false, bright = false;
         int ent = 0;
         if (valid) {
             ent = q1w[i];
@@ -458,12 +500,16 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 #define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; const uint32_t z = (uint32_t)(x * -65535 + K); acc = (acc >> 1) | (z & 0x80008000u); }
             RING16(CL)
 #undef CL
-            corner = ring_has9(acc >> 16) || ring_has9(acc & 0xFFFFu);
+            bright = ring_has9(acc >> 16);
+            corner = bright || ring_has9(acc & 0xFFFFu);
         }
-        const unsigned long long m = __ballot(corner);
-        const int slot = n2w + __popcll(m & ((1ull << lane) - 1ull));
-        if (corner) { if (slot < FAST_Q2CAP / 4) q2w[slot] = (uint16_t)ent; else ovf = true; }
-        n2w += __popcll(m);
+        const unsigned long long mc = __ballot(corner), mb = __ballot(bright);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int nb = __popcll(mb), nd = __popcll(mc) - nb;
+        if (n2b + n2d + nb + nd <= FAST_Q2CAP / 4) {
+            if (corner) q2w[bright ? n2b + __popcll(mb & below) : FAST_Q2CAP / 4 - 1 - n2d - __popcll(mc & ~mb & below)] = (uint16_t)ent;
+            n2b += nb; n2d += nd;
+        } else if (mc) ovf = true;
     };
     typedef unsigned short u16x2 __attribute__((vector_size(4)));
     typedef short i16x2 __attribute__((vector_size(4)));
@@ -515,13 +561,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             }
         }
         const int cnt = __popc(mask);
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        const int n1 = nq + __shfl(incl, 63);
+        const int incl = wave_scan_incl(cnt);
+        const int n1 = nq + __builtin_amdgcn_readlane(incl, 63);
         {
             int slot = nq + incl - cnt;
             while (mask) {
@@ -555,12 +596,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    n2w = min(n2w, FAST_Q2CAP / 4);
-    // ---- stage 3: exact score of this wave's corners (dense)
+    const int n2w = n2b + n2d;                          // <= FAST_Q2CAP / 4 (a batch that would not fit sets the overflow flag instead)
+    // entry i of the wave's corner list: the brighter-ring corners [0, n2b) sit at the front of the slice, the darker-ring ones at its back
+#define Q2SLOT(i) ((i) < n2b ? (i) : FAST_Q2CAP / 4 - 1 - ((i) - n2b))
+    // ---- stage 3: exact score of this wave's corners (dense lanes; only the passing polarity's arcs are evaluated)
     for (int i = lane; i < n2w; i += 64) {
-        const int ent = q2w[i];
+        const int ent = q2w[Q2SLOT(i)];
         const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-        smap[pos] = (uint8_t)(fast_S(img + pos, pitch) - 1);   // S > t0 >= 0 here
+        smap[pos] = (uint8_t)(fast_S_pol(img + pos, pitch, i < n2b ? 0 : -1) - 1);   // S > t0 >= 0 here
     }
     __syncthreads();
     const bool overflow = sh[4] != 0;
@@ -569,7 +612,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         // ---- NMS over the corner lists: strict maximum over the 8 neighbours inside the same cell's detection region.
         //      survive(T) = s >= T && localmax (threshold-independent localmax, DESIGN.md "FAST as set algebra").
         for (int i = lane; i < n2w; i += 64) {
-            const int ent = q2w[i];
+            const int ent = q2w[Q2SLOT(i)];
             const int rx = ent & 255;
             const uint8_t* m = smap + (dy0 + (ent >> 8)) * pitch + dx0 + rx;
             const int s = m[0], ct = colTab[rx];
@@ -577,13 +620,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
             if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
             if (ok) {
-                q2w[i] = (uint16_t)(ent | 0x8000);
+                q2w[Q2SLOT(i)] = (uint16_t)(ent | 0x8000);
                 if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
             }
         }
         __syncthreads();
         for (int i = lane; i < n2w; i += 64) {
-            const int ent = q2w[i];
+            const int ent = q2w[Q2SLOT(i)];
             if (!(ent & 0x8000)) continue;
             const int rx = ent & 255, ry = (ent >> 8) & 127;
             const int s = smap[(dy0 + ry) * pitch + dx0 + rx];
@@ -649,6 +692,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     uint32_t* out = P.cand + (size_t)frame * P.candFrame + L.candOff;
     for (int i = tid; i < ne; i += 256)
         if (gbase + i < L.candCap) out[gbase + i] = elist[i];
+#undef Q2SLOT
 }
 
 // ============================================================================================================
@@ -1201,6 +1245,8 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
     __syncthreads();
     float angle = 0.f;
     int* vflag = (int*)(orb_smem + 4 * DESC_WAVE_STRIDE);   // [4] this wave holds a keypoint
+    int* mom = vflag + 4;                                   // [4][2] m01, m10 of the four keypoints
+    float* trig = (float*)(mom + 8);                        // [4][3] angle (degrees), sin, cos — computed once per keypoint by lanes 0..3 of wave 0
     if (lane == 0) vflag[wave] = valid ? 1 : 0;
     if (valid) {
         // lane r owns patch row r: 12 aligned dword LDS reads, realigned by the wave-uniform column offset ox into packed dwords
@@ -1257,9 +1303,17 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
             m10 += __shfl_xor(m10, off);
             m01 += __shfl_xor(m01, off);
         }
-        angle = fast_atan2_deg((float)m01, (float)m10);
+        if (lane == 0) { mom[2 * wave] = m01; mom[2 * wave + 1] = m10; }
     }
     __syncthreads();
+    // fastAtan2 and the double-precision sin/cos are wave-uniform work (~130 VALU instructions that every lane of every wave would repeat):
+    // four lanes of wave 0 do them for the four keypoints while the block runs the column pass
+    if (threadIdx.x < 4 && vflag[threadIdx.x]) {
+        const float ang = fast_atan2_deg((float)mom[2 * threadIdx.x], (float)mom[2 * threadIdx.x + 1]);
+        float sn, cs;
+        det_sincos(ang * (float)(3.1415926535897932384626433832795 / 180.f), &sn, &cs);
+        trig[3 * threadIdx.x] = ang; trig[3 * threadIdx.x + 1] = sn; trig[3 * threadIdx.x + 2] = cs;
+    }
     // column pass, block-cooperative: 4 keypoints x 37 columns x 2 row halves = 296 independent tasks over 256 threads
     // (a wave-private lane-per-column pass keeps only 37 of 64 lanes busy).  A task filters 19 rows of one column with
     // v_dot2_u32_u16 on vertical pairs (rows 0..18, or 18..36 so that the pair loads stay dword aligned; row 18 is written twice
@@ -1292,16 +1346,19 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
     __syncthreads();
     if (!valid) return;
     // rBRIEF (ORBextractor.cc:106-145): lane i evaluates pairs 4i..4i+3
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    det_sincos(angle * factorPI, &b, &a);
+    angle = trig[3 * wave];
+    const float b = trig[3 * wave + 1], a = trig[3 * wave + 2];
     uint32_t nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+        // the two points of a pair are rotated together on packed float pairs (v_pk_mul_f32 / v_pk_add_f32: the same IEEE mul, mul, add per
+        // component as the scalar form, no contraction)
+        typedef float f32x2 __attribute__((vector_size(8)));
         const float4 pt = c_patternf[lane * 4 + j];
-        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
-        const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+        const f32x2 X = {pt.x, pt.z}, Y = {pt.y, pt.w}, Bv = {b, b}, Av = {a, a};
+        const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
+        const int r0 = __float2int_rn(R[0]), q0 = __float2int_rn(Q[0]);
+        const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
         const int t0 = blur[(18 + r0) * DBP + 18 + q0], t1 = blur[(18 + r1) * DBP + 18 + q1];
         nib |= (uint32_t)(t0 < t1) << j;
     }
@@ -1705,7 +1762,8 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     }
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size();
-    h->fastImgBytes = (maxRows * maxPitch + 15) & ~15;
+    if (maxPitch > FAST_PITCH) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST tile wider than FAST_PITCH"); }
+    h->fastImgBytes = (maxRows * FAST_PITCH + 15) & ~15;
     h->fastSmem = (size_t)2 * h->fastImgBytes + 4 * FAST_Q1W * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
     // 92 B per node with the second child-count buffer, 76 without: very large nFeatures fall back to two key walks per round
     h->octMerge = (size_t)(256 + 16) * 4 + (size_t)nodeCap * 92 + 15 <= 150 * 1024 ? 1 : 0;
@@ -1882,7 +1940,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         D.unitStart[0] = 0;
         for (int l = 0; l < nl; l++) D.unitStart[l + 1] = D.unitStart[l] + (h->lv[l].selCap + 3) / 4;
         D.groups = D.unitStart[nl]; D.batch = batch;
-        hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 16, st, D);
+        hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 96, st, D);
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
     if (!h->capturing) h->timed = true;

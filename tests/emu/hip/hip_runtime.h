@@ -249,6 +249,20 @@ template <class T> inline T __shfl_up(T v, int d, int width = 64) {
     return __shfl(v, (l - d >= 0 ? l - d : l), 64);
 }
 inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l, 64); }   // lane index must be wave-uniform
+// v_mov_b32_dpp as __builtin_amdgcn_update_dpp: the controls the kernels use — row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
+// A lane whose row / bank is masked out, or whose source lane lies outside its row, keeps `old` (bound_ctrl = false) or gets 0 (true).
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int l = emu::lane(), row = l >> 4, pos = l & 15;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (pos - n >= 0) from = l - n; }
+    else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }
+    else if (ctrl == 0x143) { if (row >= 2) from = 31; }
+    else { fprintf(stderr, "hip_emu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
+    const int got = (int)(unsigned)emu::exchange((uint64_t)(unsigned)src, from < 0 ? l : from);
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (pos >> 2)) & 1)) return old;
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return got;
+}
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (sh & 31));
 }
