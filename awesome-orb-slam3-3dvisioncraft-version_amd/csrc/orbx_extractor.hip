@@ -11,6 +11,8 @@
 // LDS: every kernel carves the dynamic region `orb_smem` only (16-byte aligned base, no static LDS).
 #include <hip/hip_runtime.h>
 
+#include <climits>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -22,6 +24,18 @@
 #include "../../include/orbhip.h"
 
 #define ORBX_MAX_LEVELS 16
+// Phase timers for kernel experiments (-DORBX_PROF builds under exp_so/ only; never in the product build): lane 0 of every wave adds the
+// s_memtime delta of each phase to g_prof[kernel][phase]; orbx_debug_prof() reads and clears them.
+#ifdef ORBX_PROF
+__device__ unsigned long long g_prof[2][8][256];   // [kernel][phase][shard]: sharded so that the end-of-wave atomics do not serialise
+#define PROF_DECL unsigned long long prof_t = clock64(), prof_d[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_MARK(k, slot) do { const unsigned long long t_ = clock64(); prof_d[slot] += t_ - prof_t; prof_t = t_; } while (0)
+#define PROF_FLUSH(k) do { if ((threadIdx.x & 63) < 8) atomicAdd(&g_prof[k][threadIdx.x & 7][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 255], prof_d[threadIdx.x & 7]); } while (0)
+#else
+#define PROF_DECL do {} while (0)
+#define PROF_MARK(k, slot) do {} while (0)
+#define PROF_FLUSH(k) do {} while (0)
+#endif
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:72
 #define ORBX_MINB 16          // EDGE_THRESHOLD-3, ORBextractor.cc:769
 #define FAST_QCAP 2048        // corner queue entries (u16) per chunk
@@ -379,7 +393,8 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 // Queue entries are (row << 8 | col) inside the tile's detection region (<= 66 rows x <= 256 cols); q2 bit 15 = local maximum.
 // The emit list reuses q1 (FAST_QCAP/2 u32 entries).
 #ifndef FAST_Q2CAP
-#define FAST_Q2CAP 2048   // corners per tile kept in LDS; more -> whole-tile fallback (tests build with a tiny value to cover it)
+#define FAST_Q2CAP 2016   // corners per tile kept in LDS (504 per wave); more -> whole-tile fallback (tests build with a tiny value to cover it).
+                          // 2016 rather than 2048: at 752x480 the kernel's LDS is then 20 480 B = 8 workgroups per CU instead of 7 (0.97 vs 1.00 ms)
 #endif
 #ifndef FAST_XCD
 #define FAST_XCD 0   // 1: frame-per-XCD mapping (xcd_frame_unit) for k_fast too.  Measured on MI355X: 1.162 ms vs 1.137 ms with the plain (tile, frame)
@@ -408,14 +423,24 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    PROF_DECL;
+    // the tile record is workgroup-uniform: read it through the scalar path (constant address space) — as a plain global load it is a
+    // vector-memory round trip of its own in front of everything else
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+    static_assert(sizeof(FastTile) == 8, "FastTile is read as one 64-bit scalar");
+#define FAST_TILE_AT(i) __builtin_bit_cast(FastTile, *(const unsigned long long __attribute__((address_space(4)))*)(unsigned long long)(P.tiles + (i)))
+#else
+#define FAST_TILE_AT(i) (P.tiles[i])
+#endif
 #if FAST_XCD
     int frame, tileIdx;
     if (!xcd_frame_unit(P.nTiles, P.batch, &frame, &tileIdx)) return;
-    const FastTile T = P.tiles[tileIdx];
+    const FastTile T = FAST_TILE_AT(tileIdx);
 #else
-    const FastTile T = P.tiles[blockIdx.x];
+    const FastTile T = FAST_TILE_AT(blockIdx.x);
     const int frame = blockIdx.y;
 #endif
+#undef FAST_TILE_AT
     const FastLevel& L = P.lv[T.level];
 
     const int iniY = ORBX_MINB + T.cellRow * L.hCell;
@@ -442,27 +467,55 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     uint8_t* colTab = (uint8_t*)(q2 + FAST_Q2CAP);    // per detection column: cell | leftEdge<<6 | rightEdge<<7
     int* sh = (int*)(colTab + FAST_TW);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
 
-    {   // stage the tile and clear the score map, 16 bytes per lane and step: five consecutive aligned dwords of the row (the compiler
-        // merges them into dwordx4 + dword) -> four funnel shifts -> one 128-bit LDS store each for the image and the score map
+    {   // stage the tile, 16 bytes per lane and step: five consecutive aligned dwords of the row (the compiler merges them into dwordx4 +
+        // dword) -> four funnel shifts -> one 128-bit LDS store.  ALL global loads of the tile are issued before the first one is consumed
+        // (a plain `for` over the steps waits for each step's data before issuing the next: two to three memory round trips in series at
+        // the head of a workgroup that lives ~14 us), and the score map is cleared while they are in flight.
         const uint32_t sh8 = (uint32_t)(xal & 3);
         const uint8_t* src = L.base + (size_t)frame * L.frameStride + (size_t)iniY * L.rowStride + (xal & ~3);
         const int gq = wbytes >> 4;                      // 16-byte groups staged per LDS row
         const int ng = rows * gq;
         const int safe = L.w - (xal & ~3);               // bytes of an image row that may be read from src
-        int r = tid / gq, c = tid - r * gq;
         const int dr = 256 / gq, dc = 256 - dr * gq;
-        for (int i = tid; i < ng; i += 256) {
-            const uint32_t* g = (const uint32_t*)(src + (size_t)r * L.rowStride + 16 * c);
-            uint32_t w0, w1, w2, w3, w4;
-            if (16 * c + 20 <= safe) { w0 = g[0]; w1 = g[1]; w2 = g[2]; w3 = g[3]; w4 = g[4]; }
-            else {   // last group of a row near the right image border: dword-wise, nothing past the row (columns there are never tested)
-                const int left = safe - 16 * c;
-                w0 = left >= 4 ? g[0] : 0u; w1 = left >= 8 ? g[1] : 0u; w2 = left >= 12 ? g[2] : 0u; w3 = left >= 16 ? g[3] : 0u; w4 = 0u;
+        // Only the tile at the right image border can reach past the end of an image row.  The test is workgroup-uniform: everywhere else
+        // a step is dwordx4 + dword with no per-lane branch (a per-lane branch makes the compiler drain the outstanding loads at its join —
+        // both sides write the same registers); in the border tile a dword that would start past the row's end re-reads the row's last
+        // dword instead (those columns are never tested).
+        const bool edge = gq * 16 + 4 > safe;
+        const int lastOff = (safe - 4) & ~3;
+        auto fetch = [&](const int r, const int c, uint32_t* w) {
+            const uint8_t* g = src + (size_t)r * L.rowStride;
+            if (!edge) {
+                const uint32_t* gw = (const uint32_t*)(g + 16 * c);
+                w[0] = gw[0]; w[1] = gw[1]; w[2] = gw[2]; w[3] = gw[3]; w[4] = gw[4];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) w[k] = *(const uint32_t*)(g + min(16 * c + 4 * k, lastOff));
             }
-            const int li = r * (FAST_PITCH / 16) + c;
-            ((uint4*)img)[li] = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh8), __builtin_amdgcn_alignbyte(w2, w1, sh8),
-                                           __builtin_amdgcn_alignbyte(w3, w2, sh8), __builtin_amdgcn_alignbyte(w4, w3, sh8));
-            ((uint4*)smap)[li] = make_uint4(0u, 0u, 0u, 0u);
+        };
+        auto put = [&](const int r, const int c, const uint32_t* w) {
+            ((uint4*)img)[r * (FAST_PITCH / 16) + c] = make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], sh8), __builtin_amdgcn_alignbyte(w[2], w[1], sh8),
+                                                                 __builtin_amdgcn_alignbyte(w[3], w[2], sh8), __builtin_amdgcn_alignbyte(w[4], w[3], sh8));
+        };
+        constexpr int NS = 3;                            // steps held in registers: 768 groups = 85 rows of 144 bytes (a cell row is ~36 rows)
+        uint32_t w[NS][5];
+        int rr[NS], cc[NS];
+        int r = tid / gq, c = tid - r * gq;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            rr[k] = r; cc[k] = c;
+            if (tid + 256 * k < ng) fetch(r, c, w[k]);
+            r += dr; c += dc;
+            if (c >= gq) { c -= gq; r++; }
+        }
+        for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+            if (tid + 256 * k < ng) put(rr[k], cc[k], w[k]);
+        for (int i = tid + 256 * NS; i < ng; i += 256) {   // taller tiles than any configuration in use: the plain loop for the rest
+            uint32_t wx[5];
+            fetch(r, c, wx);
+            put(r, c, wx);
             r += dr; c += dc;
             if (c >= gq) { c -= gq; r++; }
         }
@@ -473,7 +526,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             colTab[tid] = (uint8_t)(cell | (cx == 0 ? 0x40 : 0) | (cx + 1 >= cw ? 0x80 : 0));
         }
     }
+    PROF_MARK(0, 0);   // prologue + staging issue
     __syncthreads();
+    PROF_MARK(0, 1);   // staging wait
 
     const int t0 = min(P.iniTh, P.minTh);
     // Stages 1-3 are wave-private: wave w owns columns (w&1)*64.. of the rows with parity (w>>1), compacts its own survivors
@@ -592,6 +647,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (nq > 0) classify(lane, lane < nq);
+    PROF_MARK(0, 2);   // stage 1 + compaction + stage 2
     if (ovf) sh[4] = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -605,7 +661,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
         smap[pos] = (uint8_t)(fast_S_pol(img + pos, pitch, i < n2b ? 0 : -1) - 1);   // S > t0 >= 0 here
     }
+    PROF_MARK(0, 3);   // stage 3
     __syncthreads();
+    PROF_MARK(0, 4);   // barrier after stage 3
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
     if (!overflow) {
@@ -684,14 +742,17 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             __syncthreads();
         }
     }
+    PROF_MARK(0, 5);   // NMS + per-cell retry + list
     const int ne = min(sh[1], FAST_QCAP / 2);
-    if (ne == 0) return;
+    if (ne == 0) { PROF_FLUSH(0); return; }
     if (tid == 0) sh[2] = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, ne);
     __syncthreads();
     const int gbase = sh[2];
     uint32_t* out = P.cand + (size_t)frame * P.candFrame + L.candOff;
     for (int i = tid; i < ne; i += 256)
         if (gbase + i < L.candCap) out[gbase + i] = elist[i];
+    PROF_MARK(0, 6);   // emit
+    PROF_FLUSH(0);
 #undef Q2SLOT
 }
 
@@ -1176,11 +1237,29 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
                       // 76 VGPRs / 5648 B of LDS per wave gave 6 workgroups per CU (0.850 ms on MI355X), 72 VGPRs 7 (0.792 ms); with the row-pass
                       // buffer aliased onto the patch (DESC_ALIAS) it is 57 VGPRs, 4896 B and 8 workgroups (0.759 ms)
 #endif
-static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams P) {
+#ifndef DESC_WPB
+#define DESC_WPB 1    // keypoints (= waves) per workgroup: 1 (every wave its own workgroup: no cross-wave barrier coupling, wave-level LDS hand-offs;
+                      // the column pass runs over the wave's own 111 tasks) or 4 (block-cooperative column pass, trig shared by 4 keypoints).
+                      // MI355X, batch 512: 0.635 ms vs 0.694 ms.
+#endif
+#if DESC_WPB == 1   // one wave per workgroup: LDS hand-offs need program order inside the wave only
+#define DESC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define DESC_SYNC() __syncthreads()
+#endif
+static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(DescParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int frame, grp;
+#if DESC_WPB == 4
     if (!xcd_frame_unit(P.groups, P.batch, &frame, &grp)) return;
+    const int kwave = wave;                     // keypoint of the group this wave serves
+#else
+    if (!xcd_frame_unit(P.groups * 4, P.batch, &frame, &grp)) return;
+    const int kwave = grp & 3;
+    grp >>= 2;
+#endif
+    PROF_DECL;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DESC_ROWP_OFF);
     uint8_t* blur = patch + DESC_BLUR_OFF;
@@ -1189,27 +1268,35 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
     // global round trip, together with the per-level counts that are only needed for `valid` and, at the very end, for the output slot;
     // the patch rows are the second round trip.  (Locating keypoint g through the prefix sums of the counts first cost a third one, and
     // this kernel's load phase is latency bound.)
-    int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if (grp >= P.unitStart[l]) level = l;
-    const int pos = (grp - P.unitStart[level]) * 4 + wave;
+    // Everything of this prologue is ONE memory round trip: the level follows from a fixed-trip compare chain over the kernel-argument table
+    // (unused entries hold INT_MAX; a loop bounded by nlevels compiles to one dependent scalar load per level), and the per-level counts are
+    // fetched by lanes 0..nlevels-1 with two coalesced loads next to the keypoint record and reduced in registers (a scalar loop over the
+    // levels compiles to one dependent round trip per level: that was a third of the kernel's wave time).
+    int level = 0, ustart = 0;
+#pragma unroll
+    for (int l = 1; l < ORBX_MAX_LEVELS; l++) { const int us = P.unitStart[l]; if (grp >= us) { level = l; ustart = us; } }
+    const int pos = (grp - ustart) * 4 + kwave;
     const DescLevel& L = P.lv[level];
     const bool inSlab = pos < L.selCap;
     uint32_t key = 0, aux = 0;
+    int myN = 0, myL = 0;
+    if (lane < P.nlevels) {
+        myN = P.selCount[(size_t)frame * P.nlevels + lane];
+        myL = P.lapCount[(size_t)frame * P.nlevels + lane];
+    }
     if (inSlab) {
         key = P.sel[(size_t)frame * P.selFrame + L.selOff + pos];
         aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
     }
-    const int* sc = P.selCount + (size_t)frame * P.nlevels;
-    const int* lc = P.lapCount + (size_t)frame * P.nlevels;
-    int nTotal = 0, monoBase = 0, lapBase = 0, monoTotal = 0, nLevel = 0;
-    for (int l = 0; l < P.nlevels; l++) {
-        const int n = sc[l], nl = lc[l];
-        if (l == level) { nLevel = n; monoBase = monoTotal; lapBase = nTotal - monoTotal; }
-        nTotal += n;
-        monoTotal += n - nl;
-    }
-    if (grp == 0 && wave == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
+    const int myM = myN - myL;                                  // monocular keypoints of level `lane`
+    const int inclN = wave_scan_incl(myN), inclM = wave_scan_incl(myM);
+    const int nTotal = __builtin_amdgcn_readlane(inclN, 63), monoTotal = __builtin_amdgcn_readlane(inclM, 63);
+    const int nLevel = __builtin_amdgcn_readlane(myN, level);
+    const int monoBase = __builtin_amdgcn_readlane(inclM - myM, level);               // monocular keypoints of the levels before this one
+    const int lapBase = __builtin_amdgcn_readlane(inclN - myN, level) - monoBase;     // lapping-area keypoints of the levels before this one
+    if (grp == 0 && kwave == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
     const bool valid = inSlab && pos < nLevel;
+    PROF_MARK(1, 0);   // record + counts (first global round trip)
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
     int ox = 0;   // column of the patch's first pixel inside the LDS rows
     if (valid) {
@@ -1242,9 +1329,14 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
             }
         }
     }
-    __syncthreads();
+    PROF_MARK(1, 1);   // patch rows (second round trip) -> LDS
+    DESC_SYNC();
+    PROF_MARK(1, 2);   // barrier 1
+#ifndef DESC_KO
+#define DESC_KO 0   // experiment builds only: 1 no column pass, 2 no row pass, 3 no rBRIEF, 4 no IC_Angle (results are wrong; timing split)
+#endif
     float angle = 0.f;
-    int* vflag = (int*)(orb_smem + 4 * DESC_WAVE_STRIDE);   // [4] this wave holds a keypoint
+    int* vflag = (int*)(orb_smem + DESC_WPB * DESC_WAVE_STRIDE);   // [4] this wave holds a keypoint
     int* mom = vflag + 4;                                   // [4][2] m01, m10 of the four keypoints
     float* trig = (float*)(mom + 8);                        // [4][3] angle (degrees), sin, cos — computed once per keypoint by lanes 0..3 of wave 0
     if (lane == 0) vflag[wave] = valid ? 1 : 0;
@@ -1265,7 +1357,7 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
             // column u = byte index - 21.  m10 = sum u*I = sum (u+15)*I - 15*sum I over the row's masked bytes (weights 0..30 fit u8).
             const int v = lane - 21;
             const int av = v < 0 ? -v : v;
-            if (av <= 15) {
+            if (av <= 15 && DESC_KO != 4) {
                 const uint32_t* mk = c_icmask[av];
                 uint32_t s1 = 0, sw = 0;
 #pragma unroll
@@ -1286,7 +1378,7 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < DP) {
+        if (lane < DP && DESC_KO != 2) {
             // Gaussian row pass: k = cvRound(256*g) = {18,34,49,55,49,34,18}; out(c) = dot4(bytes c..c+3, k[0..3]) + dot4(bytes c+4..c+7,
             // {k[4..6],0}); sums <= 255*257 fit u16
             const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
@@ -1305,35 +1397,46 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
         }
         if (lane == 0) { mom[2 * wave] = m01; mom[2 * wave + 1] = m10; }
     }
-    __syncthreads();
+    PROF_MARK(1, 3);   // row reads + IC_Angle + row pass
+    DESC_SYNC();
+    PROF_MARK(1, 4);   // barrier 2
     // fastAtan2 and the double-precision sin/cos are wave-uniform work (~130 VALU instructions that every lane of every wave would repeat):
     // four lanes of wave 0 do them for the four keypoints while the block runs the column pass
-    if (threadIdx.x < 4 && vflag[threadIdx.x]) {
+    if (threadIdx.x < DESC_WPB && vflag[threadIdx.x]) {
         const float ang = fast_atan2_deg((float)mom[2 * threadIdx.x], (float)mom[2 * threadIdx.x + 1]);
         float sn, cs;
         det_sincos(ang * (float)(3.1415926535897932384626433832795 / 180.f), &sn, &cs);
         trig[3 * threadIdx.x] = ang; trig[3 * threadIdx.x + 1] = sn; trig[3 * threadIdx.x + 2] = cs;
     }
-    // column pass, block-cooperative: 4 keypoints x 37 columns x 2 row halves = 296 independent tasks over 256 threads
-    // (a wave-private lane-per-column pass keeps only 37 of 64 lanes busy).  A task filters 19 rows of one column with
-    // v_dot2_u32_u16 on vertical pairs (rows 0..18, or 18..36 so that the pair loads stay dword aligned; row 18 is written twice
-    // with the same value); out = (sum + 32768) >> 16, saturated
-    for (int t = threadIdx.x; t < 4 * 2 * DB; t += 256) {
-        const int w = t / (2 * DB), rem = t - w * (2 * DB);
-        const int half = rem >= DB ? 1 : 0, col = rem - half * DB;
+    // column pass: a task filters DESC_CLEN rows of one column with v_dot2_u32_u16 on vertical pairs (segments start on even rows so that the
+    // pair loads stay dword aligned; the row shared by two segments is written twice with the same value); out = (sum + 32768) >> 16, saturated.
+    //   4 keypoints per block: 4 x 37 columns x 2 segments of 19 rows = 296 tasks over 256 threads (1.16 rounds of 19 rows);
+    //   1 keypoint per block:      37 columns x 3 segments of 13 rows = 111 tasks over  64 lanes   (2 rounds of 13 rows; two segments would be
+    //                               74 tasks = 2 rounds of 19 rows with 10 live lanes in the second).
+#if DESC_WPB == 1
+#define DESC_CSEG 3
+#define DESC_CLEN 13
+#else
+#define DESC_CSEG 2
+#define DESC_CLEN 19
+#endif
+    for (int t = threadIdx.x; t < (DESC_KO == 1 ? 0 : DESC_WPB * DESC_CSEG * DB); t += 64 * DESC_WPB) {
+        const int w = t / (DESC_CSEG * DB), rem = t - w * (DESC_CSEG * DB);
+        const int seg = rem / DB, col = rem - seg * DB;
         if (!vflag[w]) continue;
-        const int r0 = half ? 18 : 0;
+        const int r0 = seg * (DESC_CLEN - 1);
         const uint32_t* cp = (const uint32_t*)((const uint16_t*)(orb_smem + w * DESC_WAVE_STRIDE + DESC_ROWP_OFF) + col * DRP + r0);
         uint8_t* bl = orb_smem + w * DESC_WAVE_STRIDE + DESC_BLUR_OFF + r0 * DBP + col;
         typedef unsigned short u16x2 __attribute__((vector_size(4)));
-        uint32_t E[13], O[12];   // E[k] = rows (r0+2k, r0+2k+1), O[k] = rows (r0+2k+1, r0+2k+2)
+        constexpr int NE = (DESC_CLEN + 7) / 2;
+        uint32_t E[NE], O[NE - 1];   // E[k] = rows (r0+2k, r0+2k+1), O[k] = rows (r0+2k+1, r0+2k+2)
 #pragma unroll
-        for (int k = 0; k < 13; k++) E[k] = cp[k];
+        for (int k = 0; k < NE; k++) E[k] = cp[k];
 #pragma unroll
-        for (int k = 0; k < 12; k++) O[k] = __builtin_amdgcn_alignbyte(E[k + 1], E[k], 2u);
+        for (int k = 0; k < NE - 1; k++) O[k] = __builtin_amdgcn_alignbyte(E[k + 1], E[k], 2u);
         const u16x2 Wa = {18, 34}, Wb = {49, 55}, Wc = {49, 34}, Wd = {18, 0};
 #pragma unroll
-        for (int j = 0; j < 19; j++) {
+        for (int j = 0; j < DESC_CLEN; j++) {
             const uint32_t* Q = (j & 1) ? O : E;
             const int m = j >> 1;
             uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[m]), Wa, 32768u, false);
@@ -1343,14 +1446,16 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
             bl[j * DBP] = (uint8_t)min(acc >> 16, 255u);
         }
     }
-    __syncthreads();
+    PROF_MARK(1, 5);   // trig (wave 0) + column pass
+    DESC_SYNC();
+    PROF_MARK(1, 6);   // barrier 3
     if (!valid) return;
     // rBRIEF (ORBextractor.cc:106-145): lane i evaluates pairs 4i..4i+3
     angle = trig[3 * wave];
     const float b = trig[3 * wave + 1], a = trig[3 * wave + 2];
     uint32_t nib = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < (DESC_KO == 3 ? 0 : 4); j++) {
         // the two points of a pair are rotated together on packed float pairs (v_pk_mul_f32 / v_pk_add_f32: the same IEEE mul, mul, add per
         // component as the scalar form, no contraction)
         typedef float f32x2 __attribute__((vector_size(8)));
@@ -1387,6 +1492,8 @@ static __global__ __launch_bounds__(256, DESC_WAVES) void k_describe(DescParams 
         }
         ((uint32_t*)(P.kps + (size_t)frame * P.cap + idx))[lane] = w;
     }
+    PROF_MARK(1, 7);   // rBRIEF + outputs
+    PROF_FLUSH(1);
 }
 
 struct Desc { uint32_t w[8]; };
@@ -1939,8 +2046,9 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         D.nlevels = nl; D.kps = d_kps; D.desc = d_desc; D.cap = cap_per_frame; D.counts = d_counts;
         D.unitStart[0] = 0;
         for (int l = 0; l < nl; l++) D.unitStart[l + 1] = D.unitStart[l] + (h->lv[l].selCap + 3) / 4;
+        for (int l = nl + 1; l <= ORBX_MAX_LEVELS; l++) D.unitStart[l] = INT_MAX;
         D.groups = D.unitStart[nl]; D.batch = batch;
-        hipLaunchKernelGGL(k_describe, dim3(D.groups * 8 * ((batch + 7) / 8)), dim3(256), 4 * DESC_WAVE_STRIDE + 96, st, D);
+        hipLaunchKernelGGL(k_describe, dim3(D.groups * (4 / DESC_WPB) * 8 * ((batch + 7) / 8)), dim3(64 * DESC_WPB), DESC_WPB * DESC_WAVE_STRIDE + 96, st, D);
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
     if (!h->capturing) h->timed = true;
@@ -2099,6 +2207,17 @@ extern "C" int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t*
     }
     return ORB_OK;
 }
+
+#ifdef ORBX_PROF
+extern "C" int orbx_debug_prof(unsigned long long* out32, int clear) {
+    static unsigned long long z[2 * 8 * 256], r[2 * 8 * 256];
+    if (hipDeviceSynchronize() != hipSuccess) return ORB_E_HIP;
+    if (hipMemcpyFromSymbol(r, HIP_SYMBOL(g_prof), sizeof(r)) != hipSuccess) return ORB_E_HIP;
+    for (int k = 0; k < 16; k++) { out32[k] = 0; for (int i = 0; i < 256; i++) out32[k] += r[k * 256 + i]; }
+    if (clear && hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return ORB_E_HIP;
+    return ORB_OK;
+}
+#endif
 
 extern "C" int orbx_last_timing(orbx_handle h, float* ms5) {
     if (!h || !ms5 || !h->timed) return ORB_E_INVALID;
