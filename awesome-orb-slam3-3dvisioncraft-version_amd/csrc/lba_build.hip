@@ -459,6 +459,7 @@ struct LmArgs {
     double* posesBak; double* pointsBak;
     double* Dinv; double* db;               // [cap_l][9], [cap_l][3]
     double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
+    double* panExt;                         // [np6][CH_LD] per window: Cholesky panel of systems too large for LDS, else nullptr
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
     int32_t* pairCnt; int32_t* pairOff; int2* pairList; int pairCap;   // co-visibility lists, see k_lm_pairs
@@ -811,7 +812,9 @@ static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t*
     const int b = blockIdx.x;
     if (!A.st[b].needTrial) return;
     const int n = nfreeArr[b] * 6, ld = A.np6;
-    if (!wg_chol_solve(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem) && threadIdx.x == 0) A.st[b].ok = 0;
+    if (!wg_chol_solve(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem, A.panExt ? A.panExt + (size_t)b * ld * CH_LD : nullptr) &&
+        threadIdx.x == 0)
+        A.st[b].ok = 0;
 }
 
 static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {
@@ -986,6 +989,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * p->cap_l * p->cap_p * 4);                                       // observation table
     s += lm_align(B * (size_t)p->cap_p * p->cap_p * 4) + lm_align(B * ((size_t)p->cap_p * p->cap_p + 1) * 4) + lm_align(B * 4);   // pair counts, offsets, overflow
     s += lm_align(B * (size_t)p->cap_e * LM_PAIRS_PER_EDGE * 8);                      // co-visibility lists
+    if (np6 > WG_CHOL_LDS_MAX_LD) s += lm_align(B * np6 * CH_LD * 8);                 // out-of-LDS Cholesky panel (only if ALL poses could be free)
     return s;
 }
 
@@ -994,10 +998,25 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     lba_system dummy;
     memset(&dummy, 0, sizeof(dummy));
     int rc = lba_check(prob, batch, &dummy);
-    if (rc != ORB_OK || !d_workspace || iterations < 0 || prob->cap_p > 180) return ORB_E_INVALID;   // LDS panel: 6*cap_p rows x 17 doubles <= 160 KiB
+    if (rc != ORB_OK || !d_workspace || iterations < 0) return ORB_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const lba_problem& P = *prob;
-    const size_t B = (size_t)batch, np6 = (size_t)P.cap_p * 6;
+    // The reduced camera system holds the FREE poses only (fixed key frames — lFixedCameras, Optimizer.cc:2011-2039 — feed the Schur terms
+    // through their edges but own no Hessian block): its dimension is 6 x the largest free-pose count of the batch, not 6 x cap_p.
+    std::vector<int32_t> nf((size_t)batch);
+    {
+        std::vector<int32_t> hid((size_t)batch * P.cap_p), npz((size_t)batch);
+        if (hipMemcpyAsync(hid.data(), P.pose_hidx, hid.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipMemcpyAsync(npz.data(), P.n_poses, (size_t)batch * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+        for (int b = 0; b < batch; b++) {
+            int m = 0;
+            for (int i = 0; i < std::min(npz[b], P.cap_p); i++) m = std::max(m, hid[(size_t)b * P.cap_p + i] + 1);
+            nf[b] = m;
+        }
+    }
+    const int maxFree = std::max(1, *std::max_element(nf.begin(), nf.end()));
+    const size_t B = (size_t)batch, np6 = (size_t)maxFree * 6, np6cap = (size_t)P.cap_p * 6;
     const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + 255) / 256) + 1;
     char* w = (char*)d_workspace;
     auto take = [&](size_t bytes) { char* p = w; w += lm_align(bytes); return p; };
@@ -1009,7 +1028,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     A.S.Hpl = (double*)take(B * P.cap_e * 18 * 8);
     A.posesBak = (double*)take(B * P.cap_p * 7 * 8); A.pointsBak = (double*)take(B * P.cap_l * 3 * 8);
     A.Dinv = (double*)take(B * P.cap_l * 9 * 8); A.db = (double*)take(B * P.cap_l * 3 * 8);
-    A.Hs = (double*)take(B * np6 * np6 * 8); A.xp = (double*)take(B * np6 * 8); A.xl = (double*)take(B * P.cap_l * 3 * 8);
+    A.Hs = (double*)take(B * np6cap * np6cap * 8); A.xp = (double*)take(B * np6cap * 8); A.xl = (double*)take(B * P.cap_l * 3 * 8);   // used with ld = np6
     A.part = (double*)take(B * nPart * 8); A.st = (LmState*)take(B * sizeof(LmState));
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
@@ -1019,21 +1038,17 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     A.pairCap = P.cap_e * LM_PAIRS_PER_EDGE; A.pairList = (int2*)take(B * (size_t)A.pairCap * 8);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
-    // number of free poses per window (Hessian size) from pose_hidx
-    {
-        std::vector<int32_t> hid(B * P.cap_p), npz(B), nf(B);
-        if (hipMemcpyAsync(hid.data(), P.pose_hidx, hid.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
-        if (hipMemcpyAsync(npz.data(), P.n_poses, B * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
-        for (size_t b = 0; b < B; b++) {
-            int m = 0;
-            for (int i = 0; i < std::min(npz[b], P.cap_p); i++) m = std::max(m, hid[b * P.cap_p + i] + 1);
-            nf[b] = m;
-        }
-        if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+    if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+    // Cholesky panel: LDS while 6 x maxFree rows x 17 doubles fit (<= 180 free key frames — every LocalBundleAdjustment window); beyond that
+    // (GlobalBundleAdjustemnt of a large map) the panel lives in the workspace and LDS holds the right-hand side only
+    A.panExt = nullptr;
+    if (np6 > WG_CHOL_LDS_MAX_LD) {
+        if (np6cap <= WG_CHOL_LDS_MAX_LD) return ORB_E_INVALID;   // cannot happen: np6 <= np6cap
+        A.panExt = (double*)take(B * np6cap * CH_LD * 8);
     }
-    const size_t cholSmem = (np6 * CH_LD + 256 + np6 + CH_NB * CH_LD) * 8 + 16;
+    const size_t cholSmem = A.panExt ? wg_chol_smem_bytes_ext((int)np6) : wg_chol_smem_bytes((int)np6);
+    if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)
     if (cholSmem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
         return ORB_E_HIP;

@@ -121,12 +121,34 @@ def build_match_queries(kps, counts, scale, cap):
     return q, nq, src
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 hardware threads but
+    run the container under a 16-CPU quota: threads beyond the quota only add throttling).  -> (cores, quota or None)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except Exception:   # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p_
+        except Exception:   # noqa: BLE001
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(frames, q, qdesc, nq, cam9, grid4, budget_s=24.0):
     """Oracle (reference algorithm restated, g++ -O3) on this host in native threads (oracle/bench_oracle.cpp): one extractor per thread,
     one frame per thread at a time (the reference extracts one image on one thread, Frame.cc:111-114), each frame = ORBextractor +
     UndistortKeyPoints + AssignFeaturesToGrid + motion-model SearchByProjection with the same prepared projection records as the GPU step."""
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cores()
     run = lambda nt, per, match: O.bench_extract_match_mt(frames, nt, per, cam9, grid4, q, qdesc, nq, 100, 0.9, True, do_match=match, nfeatures=NFEAT)
     s1, _, _ = run(1, 6, True)          # warm + calibrate
     fps1 = 6 / s1
@@ -137,7 +159,7 @@ def cpu_baseline(frames, q, qdesc, nq, cam9, grid4, budget_s=24.0):
     fps1x = n1 / s1x
     # thread-count sweep: one frame per thread at a time; the best aggregate is the baseline, the per-core figure is reported next to it
     sweep, best = [], None
-    for nt in sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores}):
+    for nt in sorted({max(1, cores // 2), cores, min(2 * cores, os.cpu_count() or cores)}):
         per_thread = max(4, int(fps1 * budget_s / 6))
         sN, kp, mt = run(nt, per_thread, True)
         fpsN = nt * per_thread / sN
@@ -146,8 +168,8 @@ def cpu_baseline(frames, q, qdesc, nq, cam9, grid4, budget_s=24.0):
             best = (fpsN, nt, per_thread, kp / (nt * per_thread), mt / (nt * per_thread))
     fpsN, nt, per_thread, meankp, meanmt = best
     return {"value": round(fpsN, 2), "unit": "frames/s", "cores": nt, "kind": "port",
-            "per_core": round(fpsN / nt, 2), "single_thread": round(fps1, 2), "single_thread_extract_only": round(fps1x, 2), "sweep": sweep,
-            "sample": "extract + UndistortKeyPoints + grid + SearchByProjection per frame; best of a thread-count sweep on a %d-thread host: %d native "
+            "per_core": round(fpsN / nt, 2), "host_threads": os.cpu_count(), "cpu_quota": quota, "single_thread": round(fps1, 2), "single_thread_extract_only": round(fps1x, 2), "sweep": sweep,
+            "sample": "extract + UndistortKeyPoints + grid + SearchByProjection per frame; best of a thread-count sweep around the %d CPUs this container may use: %d native "
                       "threads x %d frames (round-robin over %d frames of the same synthetic %dx%d batch), oracle = reference algorithm restated, "
                       "g++ -O3, per-thread malloc arenas; single thread: %.2f frames/s over %d frames; mean %.1f keypoints, %.1f matches per frame"
                       % (cores, nt, per_thread, len(frames), W, H, fps1, n1, meankp, meanmt)}

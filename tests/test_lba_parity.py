@@ -183,3 +183,48 @@ def test_hip_global_ba_parameterisation(hip_lib):
     # without the Huber kernel the 5 % gross outliers of the synthetic windows pull hard: 10 iterations amplify the summation-order
     # difference to ~2e-7 (measured 1.8e-7 on MI355X); the bar is 1e-4
     check_optimize(hip_lib, "hip", ("mono", "stereo", "body"), 10, huber=(0.0, 0.0), pose_tol=1e-6)
+
+
+# ---- lba_optimize sizes the reduced camera system by the FREE key frames (round-1 limit: cap_p <= 180 including the fixed ones) -------------
+def _many_fixed(lib, backend):
+    """A local window whose fixed key frames (lFixedCameras, Optimizer.cc:2011-2039: every key frame that sees a local point) far outnumber the
+    optimised ones: 214 poses, 14 free.  The reference puts no limit on them."""
+    w, cams = synth_window(31, 214, 200, 260, 7, "mono")
+    assert (w["pose_hidx"] >= 0).sum() == 14 and len(w["poses"]) > 180
+    L = LbaWindows([w], cams, to_dev(backend), lib=lib, huber=HUBER)
+    stats = L.optimize(5)
+    op, ox, ost = O.lba_optimize(w, cams, HUBER, 5)
+    assert stats[0, 0] == ost[0] and stats[0, 3] == ost[3]
+    assert np.abs(to_host(L.d["poses"])[0, :214] - op).max() < 1e-7
+    assert np.abs(to_host(L.d["points"])[0, :len(ox)] - ox).max() < 1e-6
+
+
+def test_emu_lba_optimize_many_fixed_keyframes(emu_lib):
+    _many_fixed(emu_lib, "emu")
+
+
+@pytest.mark.gpu
+def test_hip_lba_optimize_many_fixed_keyframes(hip_lib):
+    _many_fixed(hip_lib, "hip")
+
+
+def test_emu_lba_optimize_global_memory_panel():
+    """WG_CHOL_LDS_MAX_LD=30: every window's reduced system (>= 42 unknowns) is 'too large for LDS', so the Cholesky panel lives in the
+    workspace (the path GlobalBundleAdjustemnt of a map with more than 180 free key frames takes); results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_LDS_MAX_LD=30",), tag="cholext")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+@pytest.mark.gpu
+def test_hip_global_ba_more_than_180_free_keyframes(hip_lib):
+    """Optimizer::BundleAdjustment over a map of 200 key frames (first one fixed): 199 free poses = 1194 unknowns, beyond the LDS panel."""
+    w, cams = synth_window(41, 200, 1, 2500, 8, "mono")
+    assert (w["pose_hidx"] >= 0).sum() == 199
+    L = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=(0.0, 0.0))
+    stats = L.optimize(3)
+    op, ox, ost = O.lba_optimize(w, cams, (0.0, 0.0), 3)
+    assert stats[0, 0] == ost[0] and stats[0, 3] == ost[3]
+    assert np.abs(to_host(L.d["poses"])[0, :200] - op).max() < 1e-6
