@@ -993,8 +993,8 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     return s;
 }
 
-extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
-                            const volatile int* abort_flag, void* stream) {
+static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                             const volatile int* abort_flag, const volatile unsigned char* abort_byte, void* stream) {
     lba_system dummy;
     memset(&dummy, 0, sizeof(dummy));
     int rc = lba_check(prob, batch, &dummy);
@@ -1097,7 +1097,7 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
             int more = 0;
             if (hipMemcpyAsync(&more, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
             if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
-            if (abort_flag && *abort_flag) { aborted = 1; break; }
+            if ((abort_flag && *abort_flag) || (abort_byte && *abort_byte)) { aborted = 1; break; }
             if (!more) break;
         }
         hipLaunchKernelGGL(k_lm_end, dim3(gB), dim3(64), 0, st, A, batch);
@@ -1121,6 +1121,17 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
     }
     if (hipGetLastError() != hipSuccess) return ORB_E_HIP;
     return aborted ? ORB_E_ABORTED : ORB_OK;
+}
+
+extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                            const volatile int* abort_flag, void* stream) {
+    return lba_optimize_impl(prob, batch, iterations, d_workspace, h_stats, abort_flag, nullptr, stream);
+}
+// the same with the reference's own stop flag type: Optimizer::LocalBundleAdjustment receives `bool* pbStopFlag` (a byte LocalMapping sets from
+// another thread, LocalMapping.cc:1189) and hands it to g2o's setForceStopFlag (Optimizer.cc:1975-1976)
+extern "C" int lba_optimize_stopflag(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                                     const volatile unsigned char* pb_stop_flag, void* stream) {
+    return lba_optimize_impl(prob, batch, iterations, d_workspace, h_stats, nullptr, pb_stop_flag, stream);
 }
 
 // ============================================================================================================

@@ -910,7 +910,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
             if (q_match[q] >= 0) {
                 const int bin = (int)A.work[((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 1];
                 if (bin != ind1 && bin != ind2 && bin != ind3) {
-                    kp_match[q_match[q]] = -1;      // CurrentFrame.mvpMapPoints[...] = NULL, :2499
+                    kp_match[q_match[q]] = -2;      // CurrentFrame.mvpMapPoints[...] = NULL, :2499 (-2: claimed during the call, then culled)
                     atomicAdd(&ctl[3], 1);
                 }
             }

@@ -218,7 +218,8 @@ typedef struct orbm_search_params {
  * Frame side: kps (x,y,octave,angle of mvKeysUn), desc, u_right (mvuRight, may be NULL = mono), occupied0 (may be NULL;
  * non-zero = mvpMapPoints[idx] already holds an observed point), CSR grid from orbm_grid_build.
  * Outputs: q_match[b][q] = matched keypoint index or -1; kp_match[b][idx] = index of the query whose map point
- * mvpMapPoints[idx] holds after the call (-1 = none / culled); nmatches[b] = the reference's return value.
+ * mvpMapPoints[idx] holds after the call, -1 = untouched by the call (mvpMapPoints[idx] keeps its value), -2 = claimed during the
+ * call and then set to NULL by the orientation cull (ORBmatcher.cc:2499, :2637); nmatches[b] = the reference's return value.
  * d_work: scratch of orbm_search_workspace_bytes(batch, cap_q) bytes. */
 size_t orbm_search_workspace_bytes(int batch, int cap_q);
 int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
@@ -461,6 +462,12 @@ int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out
 size_t lba_lm_workspace_bytes(const lba_problem* prob, int batch);
 int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
                  const volatile int* abort_flag, void* stream);
+/* The same call polling the reference's own stop flag: Optimizer::LocalBundleAdjustment gets `bool* pbStopFlag` (one byte, set by LocalMapping from
+ * another thread) and passes it to g2o's setForceStopFlag (Optimizer.cc:1975-1976); pb_stop_flag may be NULL. */
+int lba_optimize_stopflag(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
+                          const volatile unsigned char* pb_stop_flag, void* stream);
+/* lba_optimize returns ORB_E_CAPACITY when the reduced camera system (6 unknowns per FREE key frame; fixed key frames do not count) no
+ * longer fits the solver's LDS budget (> ~3 300 free key frames): callers fall back to their CPU solver for such a map. */
 
 /* SURVEY.md N3 — Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:907-1273): the motion-only BA that follows
  * every matcher call in Tracking (Tracking.cc:2210,2395,2468).  One pose vertex, unary reprojection edges

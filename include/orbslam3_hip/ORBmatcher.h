@@ -79,19 +79,36 @@ public:
         kpMatch.assign(n, -1);
         queryMatch.assign(nq, -1);
         if (n == 0 || nq == 0) return 0;
-        const orb_keypoint* dk = kps_.upload(F.keysUn, n);
-        const uint8_t* dd = desc_.upload(F.descriptors, (size_t)n * 32);
-        const float* dur = F.uRight ? ur_.upload(F.uRight, n) : nullptr;
-        const uint8_t* docc = F.occupied ? occ_.upload(F.occupied, n) : nullptr;
-        const orbm_query* dq = q_.upload(queries.data(), nq);
-        const uint8_t* dqd = qd_.upload(qdesc.data(), (size_t)nq * 32);
-        int32_t counts[2] = {n, nq};
-        const int32_t* dc = cnt_.upload(counts, 2);
+        // ONE packed host->device transfer per call: every input is laid out in a host staging block (256-byte aligned sections) that mirrors a
+        // persistent device block; ONE device->host transfer brings back [q_match | kp_match | nmatches].  The buffers only ever grow.
+        size_t off = 0;
+        auto sec = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t oK = sec((size_t)n * sizeof(orb_keypoint)), oD = sec((size_t)n * 32), oU = sec(F.uRight ? (size_t)n * 4 : 0),
+                     oO = sec(F.occupied ? (size_t)n : 0), oQ = sec((size_t)nq * sizeof(orbm_query)), oQD = sec((size_t)nq * 32), oC = sec(16),
+                     oL = sec((F.Nleft != -1 && F.kpLink) ? (size_t)n * 4 : 0);
+        stage_.resize(off);
+        std::memcpy(&stage_[oK], F.keysUn, (size_t)n * sizeof(orb_keypoint));
+        std::memcpy(&stage_[oD], F.descriptors, (size_t)n * 32);
+        if (F.uRight) std::memcpy(&stage_[oU], F.uRight, (size_t)n * 4);
+        if (F.occupied) std::memcpy(&stage_[oO], F.occupied, (size_t)n);
+        std::memcpy(&stage_[oQ], queries.data(), (size_t)nq * sizeof(orbm_query));
+        std::memcpy(&stage_[oQD], qdesc.data(), (size_t)nq * 32);
+        const int32_t counts[3] = {n, nq, F.Nleft};
+        std::memcpy(&stage_[oC], counts, sizeof(counts));
+        if (F.Nleft != -1 && F.kpLink) std::memcpy(&stage_[oL], F.kpLink, (size_t)n * 4);
+        uint8_t* dIn = in_.upload(stage_.data(), off);
+        const orb_keypoint* dk = (const orb_keypoint*)(dIn + oK);
+        const uint8_t* dd = dIn + oD;
+        const float* dur = F.uRight ? (const float*)(dIn + oU) : nullptr;
+        const uint8_t* docc = F.occupied ? dIn + oO : nullptr;
+        const orbm_query* dq = (const orbm_query*)(dIn + oQ);
+        const uint8_t* dqd = dIn + oQD;
+        const int32_t* dc = (const int32_t*)(dIn + oC);
         int32_t* gs = (int32_t*)gs_.ensure((2 * ORBM_GRID_COLS * ORBM_GRID_ROWS + 1) * 4);
         int32_t* gi = (int32_t*)gi_.ensure((size_t)n * 4);
-        int32_t* dqm = (int32_t*)qm_.ensure((size_t)nq * 4);
-        int32_t* dkm = (int32_t*)km_.ensure((size_t)n * 4);
-        int32_t* dnm = (int32_t*)nm_.ensure(4);
+        const size_t oQM = 0, oKM = ((size_t)nq * 4 + 255) & ~(size_t)255, oNM = oKM + (((size_t)n * 4 + 255) & ~(size_t)255);
+        uint8_t* dOut = (uint8_t*)out_.ensure(oNM + 256);
+        int32_t* dqm = (int32_t*)(dOut + oQM); int32_t* dkm = (int32_t*)(dOut + oKM); int32_t* dnm = (int32_t*)(dOut + oNM);
         void* work = work_.ensure(orbm_search_workspace_bytes(1, nq));
         orbm_search_params prm{mode, thDist, mfNNratio, mbCheckOrientation ? 1 : 0, F.grid};
         if (F.Nleft == -1) {
@@ -99,17 +116,18 @@ public:
             if (orbm_search_by_projection(dk, dd, dur, docc, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
                 throw std::runtime_error("orbm_search_by_projection");
         } else {
-            const int32_t* dnl = nl_.upload(&F.Nleft, 1);
-            const int32_t* dlk = F.kpLink ? lk_.upload(F.kpLink, n) : nullptr;
-            if (orbm_grid_build_rig(dk, dc, dnl, 1, n, 1, &F.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build_rig");
+            const int32_t* dlk = F.kpLink ? (const int32_t*)(dIn + oL) : nullptr;
+            if (orbm_grid_build_rig(dk, dc, dc + 2, 1, n, 1, &F.grid, gs, gi, nullptr) != ORB_OK) throw std::runtime_error("orbm_grid_build_rig");
             if (orbm_search_by_projection_rig(dk, dd, docc, dlk, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
                 throw std::runtime_error("orbm_search_by_projection_rig");
         }
-        int nmatches = 0;
-        orb_memcpy_d2h(kpMatch.data(), dkm, (size_t)n * 4, nullptr);
-        orb_memcpy_d2h(queryMatch.data(), dqm, (size_t)nq * 4, nullptr);
-        orb_memcpy_d2h(&nmatches, dnm, 4, nullptr);
+        back_.resize(oNM + 4);
+        orb_memcpy_d2h(back_.data(), dOut, oNM + 4, nullptr);
         if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
+        std::memcpy(queryMatch.data(), &back_[oQM], (size_t)nq * 4);
+        std::memcpy(kpMatch.data(), &back_[oKM], (size_t)n * 4);
+        int nmatches = 0;
+        std::memcpy(&nmatches, &back_[oNM], 4);
         return nmatches;
     }
 
@@ -374,7 +392,8 @@ public:
     bool mbCheckOrientation;
 
 private:
-    detail::DevBuf kps_, desc_, ur_, occ_, q_, qd_, cnt_, gs_, gi_, qm_, km_, nm_, work_;
+    detail::DevBuf kps_, desc_, ur_, occ_, q_, qd_, cnt_, gs_, gi_, qm_, km_, nm_, work_, in_, out_;
+    std::vector<uint8_t> stage_, back_;   // host mirrors of the packed input / output blocks of SearchByProjection
     detail::DevBuf tk_[2], td_[2], tu_[2], tm_[2], tn_[2], ts_[2], tf_[2], nl_, lk_, ta_[2];
 };
 

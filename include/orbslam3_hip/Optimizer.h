@@ -71,14 +71,17 @@ public:
     // optimizer.optimize(iterations) (Optimizer.cc:2205 / :2290): Levenberg-Marquardt with Schur complement on the device.
     // Poses / points held by this object are updated (read them back with pose(i) / point(i)); returns the iterations run.
     // pbStopFlag is polled between lambda trials like g2o's terminate().
-    int optimize(int iterations, const volatile int* pbStopFlag = nullptr, double* finalChi2 = nullptr) {
+    int optimize(int iterations, const volatile int* pbStopFlag = nullptr, double* finalChi2 = nullptr, const bool* pbStopFlagBool = nullptr) {
         upload();
         const int np = (int)hidx_.size(), nl = (int)points_.size() / 3, ne = (int)edges_.size();
         lba_problem P{};
         fillProblem(P, np, nl, ne);
         void* ws = lm_ws_.ensure(lba_lm_workspace_bytes(&P, 1));
         double stats[4] = {0, 0, 0, 0};
-        const int rc = lba_optimize(&P, 1, iterations, ws, stats, pbStopFlag, nullptr);
+        static_assert(sizeof(bool) == 1, "the reference's bool* pbStopFlag is polled as one byte");
+        const int rc = pbStopFlagBool ? lba_optimize_stopflag(&P, 1, iterations, ws, stats, (const volatile unsigned char*)pbStopFlagBool, nullptr)
+                                      : lba_optimize(&P, 1, iterations, ws, stats, pbStopFlag, nullptr);
+        if (rc == ORB_E_CAPACITY) throw std::length_error("lba_optimize: reduced camera system too large for the device solver (fall back to g2o)");
         if (rc != ORB_OK && rc != ORB_E_ABORTED) throw std::runtime_error("lba_optimize failed");
         orb_memcpy_d2h(poses_.data(), dPoses_, poses_.size() * 8, nullptr);
         orb_memcpy_d2h(points_.data(), dPoints_, points_.size() * 8, nullptr);
@@ -86,6 +89,7 @@ public:
         if (finalChi2) *finalChi2 = stats[1];
         return (int)stats[0];
     }
+    int edgeKind(int i) const { return edges_[i].kind; }           // LBA_EDGE_* of the i-th added edge
     const double* pose(int i) const { return &poses_[7 * i]; }     // t(x y z), q(x y z w) — SE3Quat estimate
     const double* point(int i) const { return &points_[3 * i]; }
 

@@ -1,0 +1,355 @@
+// integration/ORBmatcher_hip.cc — the reference-signature bodies of ORB_SLAM3::ORBmatcher's searches over liborbhip.so.
+//
+// Drop-in for the same-named member functions of src/ORBmatcher.cc (reference include/ORBmatcher.h:46-68): compile this file INSIDE the
+// ORB-SLAM3 tree instead of those bodies (integration/README.md), with -DORBHIP_WITH_ORBSLAM3 and <orbhip>/include on the include path.
+// Tracking / LocalMapping / LoopClosing call it unchanged.  Every function is gather -> one adapter call -> scatter:
+//   * the gather loop is the reference's own loop header and skip conditions (cited per block) with the inner window search removed —
+//     all cv::Mat expressions are the reference's, so the projected values are bit-identical to the reference's by construction;
+//   * the adapter (include/orbslam3_hip/ORBmatcher.h) does one packed upload, the device search and one packed download on persistent
+//     device buffers (one thread-local adapter per calling thread — Tracking, LocalMapping and LoopClosing each own one);
+//   * the scatter applies the result in the reference's serial order (mvpMapPoints[idx] = pMP, vpMatched[idx] = pMP, ...).
+// tests/test_glue.py compiles this file against minimal mock declarations of the classes (tests/cpp/mock_orbslam3) and checks every
+// function against the oracle's literal restatement of the reference loop.
+#ifdef ORBHIP_WITH_ORBSLAM3
+#include "ORBmatcher.h"
+
+#include <cmath>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include <orbslam3_hip/ORBmatcher.h>
+
+namespace ORB_SLAM3 {
+
+namespace {
+orbslam3_hip::ORBmatcher& device_matcher(float nnratio, bool checkOri) {
+    static thread_local orbslam3_hip::ORBmatcher m;   // persistent device buffers, grown on demand
+    m.mfNNratio = nnratio; m.mbCheckOrientation = checkOri;
+    return m;
+}
+static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint is the 28-byte record of orbhip.h");
+
+// What the searches read from a Frame (Nleft == -1: mvKeysUn; fisheye rig: the concatenation [mvKeys | mvKeysRight] the reference indexes
+// with idx / idx - Nleft, and mvLeftToRightMatch / mvRightToLeftMatch as global partner links).
+struct FrameGather {
+    std::vector<orb_keypoint> keys;       // rig only
+    std::vector<uint8_t> occ;
+    std::vector<int32_t> link;
+    orbslam3_hip::FrameView V;
+    // occupied(i): the skip rule of the search at hand on F.mvpMapPoints[i] (Observations() > 0, or != NULL for the relocalisation search)
+    template <class OccFn> FrameGather(const Frame& F, OccFn occupied, bool useURight) {
+        V.N = F.N;
+        V.descriptors = F.mDescriptors.data;
+        V.grid = orbm_grid_params{Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv};
+        occ.resize(F.N);
+        for (int i = 0; i < F.N; i++) occ[i] = occupied(F.mvpMapPoints[i]) ? 1 : 0;
+        V.occupied = occ.data();
+        if (F.Nleft == -1) {
+            V.keysUn = (const orb_keypoint*)F.mvKeysUn.data();
+            V.uRight = useURight ? F.mvuRight.data() : nullptr;
+        } else {
+            keys.resize(F.N);
+            std::memcpy(keys.data(), F.mvKeys.data(), (size_t)F.Nleft * sizeof(orb_keypoint));
+            std::memcpy(keys.data() + F.Nleft, F.mvKeysRight.data(), (size_t)(F.N - F.Nleft) * sizeof(orb_keypoint));
+            V.keysUn = keys.data();
+            V.Nleft = F.Nleft;
+            link.assign(F.N, -1);
+            for (int i = 0; i < F.Nleft; i++) if (F.mvLeftToRightMatch[i] != -1) link[i] = F.mvLeftToRightMatch[i] + F.Nleft;
+            for (int i = F.Nleft; i < F.N; i++) link[i] = F.mvRightToLeftMatch[i - F.Nleft];
+            V.kpLink = link.data();
+        }
+    }
+};
+
+// DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) -> the CSR of orbm_bow_side: map order = ascending node id
+void flatten_featvec(const DBoW2::FeatureVector& fv, orbslam3_hip::ORBmatcher::KeyFrameView& K) {
+    K.nodeStart.push_back(0);
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+        K.nodeId.push_back((int32_t)it->first);
+        K.featIdx.insert(K.featIdx.end(), it->second.begin(), it->second.end());
+        K.nodeStart.push_back((int32_t)K.featIdx.size());
+    }
+}
+}  // namespace
+
+// ---- SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   ORBmatcher.cc:59-255, Tracking.cc:2964 ------
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) {
+    FrameGather G(F, [](MapPoint* p) { return p && p->Observations() > 0; }, true);   // :125-127 (left), :212-214 (right)
+    const bool rig = F.Nleft != -1;
+    std::vector<orbm_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<MapPoint*> owner;   // query -> map point
+    q.reserve(vpMapPoints.size() * (rig ? 2 : 1)); owner.reserve(q.capacity());
+    const bool bFactor = th != 1.0;
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+        MapPoint* pMP = vpMapPoints[iMP];
+        if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;   // :73-74
+        if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;  // :77-78
+        if (pMP->isBad()) continue;                                  // :81-82
+        const uint32_t obs = pMP->Observations() > 0 ? ORBM_Q_HAS_OBS : 0u;
+        orbm_query ql{};                                             // left camera, :85-181
+        if (pMP->mbTrackInView) {
+            const int& nPredictedLevel = pMP->mnTrackScaleLevel;
+            float r = RadiusByViewingCos(pMP->mTrackViewCos);
+            if (bFactor) r *= th;
+            ql = orbm_query{pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], pMP->mTrackProjXR, 0.f,
+                            (int16_t)(nPredictedLevel - 1), (int16_t)nPredictedLevel, ORBM_Q_VALID | obs | (rig ? 0u : ORBM_Q_STEREO)};
+        }
+        const bool right = rig && pMP->mbTrackInViewR && pMP->mnTrackScaleLevelR != -1;   // :184-187
+        if (!pMP->mbTrackInView && !right) continue;
+        const cv::Mat MPdescriptor = pMP->GetDescriptor();
+        // the left query — or, for a point only the right camera sees, a placeholder with flags = 0 that keeps the (left, right-twin) pairing aligned
+        q.push_back(ql); owner.push_back(pMP);
+        qd.insert(qd.end(), MPdescriptor.data, MPdescriptor.data + 32);
+        if (right) {
+            const int& nPredictedLevel = pMP->mnTrackScaleLevelR;
+            const float r = RadiusByViewingCos(pMP->mTrackViewCosR);   // not multiplied by th (:190)
+            q.push_back(orbm_query{pMP->mTrackProjXR, pMP->mTrackProjYR, r * F.mvScaleFactors[nPredictedLevel], 0.f, 0.f, (int16_t)(nPredictedLevel - 1),
+                                   (int16_t)nPredictedLevel, ORBM_Q_VALID | obs | ORBM_Q_RIGHT | ORBM_Q_TWIN});
+            owner.push_back(pMP);
+            qd.insert(qd.end(), MPdescriptor.data, MPdescriptor.data + 32);
+        }
+    }
+    std::vector<int> kpMatch, qMatch;
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchByProjection(G.V, q, qd, ORBM_MODE_LOCAL_MAP, TH_HIGH, kpMatch, qMatch);
+    for (int idx = 0; idx < F.N; idx++)   // F.mvpMapPoints[bestIdx] = pMP (:171, :174, :241, :246): the holder after the serial loop
+        if (kpMatch[idx] >= 0) F.mvpMapPoints[idx] = owner[kpMatch[idx]];
+    return nmatches;
+}
+
+// ---- SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)   ORBmatcher.cc:2244-2509, Tracking.cc:2363-2378 --------
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    FrameGather G(CurrentFrame, [](MapPoint* p) { return p && p->Observations() > 0; }, true);   // :2347-2349
+    const bool rig = CurrentFrame.Nleft != -1;
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat twc = -Rcw.t() * tcw;
+    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tlw = LastFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat tlc = Rlw * twc + tlw;
+    const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+    std::vector<orbm_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<MapPoint*> owner;
+    for (int i = 0; i < LastFrame.N; i++) {
+        MapPoint* pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        if (invzc < 0) continue;
+        cv::Point2f uv = CurrentFrame.mpCamera->project(x3Dc);
+        if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
+        if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
+        const int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+        const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+        // GetFeaturesInArea level window: forward [nLastOctave, -1], backward [0, nLastOctave], else [nLastOctave-1, nLastOctave+1] (:2310-2326)
+        const int16_t lo = bForward ? nLastOctave : (bBackward ? 0 : nLastOctave - 1), hi = bForward ? -1 : (bBackward ? nLastOctave : nLastOctave + 1);
+        const cv::KeyPoint& kpLF = (LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+        // a keypoint taken earlier in this call is skipped by later points iff its new holder has Observations() > 0 (:2347-2349); the temporal
+        // points Tracking::UpdateLastFrame creates have none and may be overwritten
+        const uint32_t flagsObs = pMP->Observations() > 0 ? ORBM_Q_HAS_OBS : 0u;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        q.push_back(orbm_query{uv.x, uv.y, radius, uv.x - CurrentFrame.mbf * invzc, kpLF.angle, lo, hi, ORBM_Q_VALID | flagsObs | (rig ? 0u : ORBM_Q_STEREO)});
+        owner.push_back(pMP);
+        qd.insert(qd.end(), dMP.data, dMP.data + 32);
+        if (rig) {   // :2403-2460: the same point through the right camera
+            cv::Mat x3Dr = CurrentFrame.mTrl.colRange(0, 3).rowRange(0, 3) * x3Dc + CurrentFrame.mTrl.col(3);
+            cv::Point2f uvr = CurrentFrame.mpCamera->project(x3Dr);
+            q.push_back(orbm_query{uvr.x, uvr.y, radius, 0.f, kpLF.angle, lo, hi, ORBM_Q_VALID | flagsObs | ORBM_Q_RIGHT | ORBM_Q_TWIN});
+            owner.push_back(pMP);
+            qd.insert(qd.end(), dMP.data, dMP.data + 32);
+        }
+    }
+    std::vector<int> kpMatch, qMatch;
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchByProjection(G.V, q, qd, ORBM_MODE_BEST_ONLY, TH_HIGH, kpMatch, qMatch);
+    // scatter: a keypoint claimed during the call holds its final claimant (:2372, :2432), or NULL if the orientation cull removed it (:2499,
+    // kpMatch == -2); untouched keypoints (-1) keep what they held
+    for (int idx = 0; idx < CurrentFrame.N; idx++) {
+        if (kpMatch[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = owner[kpMatch[idx]];
+        else if (kpMatch[idx] == -2) CurrentFrame.mvpMapPoints[idx] = static_cast<MapPoint*>(NULL);
+    }
+    return nmatches;
+}
+
+// ---- SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   ORBmatcher.cc:2520-2652, Tracking.cc:3403,3417 (relocalisation) ----
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
+    FrameGather G(CurrentFrame, [](MapPoint* p) { return p != NULL; }, false);   // `if(CurrentFrame.mvpMapPoints[i2]) continue;` :2586
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+    std::vector<orbm_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<MapPoint*> owner;
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+        MapPoint* pMP = vpMPs[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const cv::Point2f uv = CurrentFrame.mpCamera->project(x3Dc);
+        if (uv.x < CurrentFrame.mnMinX || uv.x > CurrentFrame.mnMaxX) continue;
+        if (uv.y < CurrentFrame.mnMinY || uv.y > CurrentFrame.mnMaxY) continue;
+        cv::Mat PO = x3Dw - Ow;
+        float dist3D = cv::norm(PO);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        q.push_back(orbm_query{uv.x, uv.y, radius, 0.f, pKF->mvKeysUn[i].angle, (int16_t)(nPredictedLevel - 1), (int16_t)(nPredictedLevel + 1),
+                               ORBM_Q_VALID | ORBM_Q_HAS_OBS});   // any point placed during the call blocks its keypoint (mvpMapPoints[i2] != NULL)
+        owner.push_back(pMP);
+        qd.insert(qd.end(), dMP.data, dMP.data + 32);
+    }
+    std::vector<int> kpMatch, qMatch;
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchByProjection(G.V, q, qd, ORBM_MODE_BEST_ONLY, ORBdist, kpMatch, qMatch);
+    for (int idx = 0; idx < CurrentFrame.N; idx++) {
+        if (kpMatch[idx] >= 0) CurrentFrame.mvpMapPoints[idx] = owner[kpMatch[idx]];
+        else if (kpMatch[idx] == -2) CurrentFrame.mvpMapPoints[idx] = NULL;   // :2637
+    }
+    return nmatches;
+}
+
+// ---- the two Sim3 projection searches of loop closing / merging   ORBmatcher.cc:593-706 and :708-824 ------------------------------------
+namespace {
+struct Sim3Gather {
+    std::vector<orbm_query> q;
+    std::vector<uint8_t> qd;
+    std::vector<int> src;   // query -> index into vpPoints
+};
+// the projection loop both overloads share (:600-652 / :716-768), verbatim conditions
+Sim3Gather gather_sim3(KeyFrame* pKF, const cv::Mat& Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<MapPoint*>& vpMatched, int th) {
+    cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+    const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+    cv::Mat Rcw = sRcw / scw;
+    cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+    cv::Mat Ow = -Rcw.t() * tcw;
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    Sim3Gather S;
+    for (int iMP = 0, iendMP = vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float x = p3Dc.at<float>(0), y = p3Dc.at<float>(1), z = p3Dc.at<float>(2);
+        const cv::Point2f uv = pKF->mpCamera->project(cv::Point3f(x, y, z));
+        if (!pKF->IsInImage(uv.x, uv.y)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist = cv::norm(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist) continue;
+        int nPredictedLevel = pMP->PredictScale(dist, pKF);
+        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const cv::Mat dMP = pMP->GetDescriptor();
+        // KeyFrame::GetFeaturesInArea has no level filter; the loop keeps [nPredictedLevel-1, nPredictedLevel] (:671-674): same candidates, same order
+        S.q.push_back(orbm_query{uv.x, uv.y, radius, 0.f, 0.f, (int16_t)(nPredictedLevel - 1), (int16_t)nPredictedLevel, ORBM_Q_VALID | ORBM_Q_HAS_OBS});
+        S.src.push_back(iMP);
+        S.qd.insert(S.qd.end(), dMP.data, dMP.data + 32);
+    }
+    return S;
+}
+orbslam3_hip::FrameView keyframe_view(KeyFrame* pKF, std::vector<uint8_t>& occ, const std::vector<MapPoint*>& vpMatched) {
+    orbslam3_hip::FrameView V;
+    V.N = (int)pKF->mvKeysUn.size();
+    V.keysUn = (const orb_keypoint*)pKF->mvKeysUn.data();
+    V.descriptors = pKF->mDescriptors.data;
+    V.grid = orbm_grid_params{(float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv};
+    occ.resize(V.N);
+    for (int i = 0; i < V.N; i++) occ[i] = vpMatched[i] ? 1 : 0;   // `if(vpMatched[idx]) continue;` :668
+    V.occupied = occ.data();
+    return V;
+}
+}  // namespace
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th, float ratioHamming) {
+    const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, vpMatched, th);
+    std::vector<uint8_t> occ;
+    const orbslam3_hip::FrameView V = keyframe_view(pKF, occ, vpMatched);
+    std::vector<int> kpMatch, qMatch;
+    // bestDist <= TH_LOW*ratioHamming (:686) with an integer distance <=> bestDist <= floor(TH_LOW*ratioHamming); no orientation check in this search
+    const int thDist = (int)std::floor((float)TH_LOW * ratioHamming);
+    const int nmatches = device_matcher(mfNNratio, false).SearchByProjection(V, S.q, S.qd, ORBM_MODE_BEST_ONLY, thDist, kpMatch, qMatch);
+    for (int idx = 0; idx < V.N; idx++)
+        if (kpMatch[idx] >= 0) vpMatched[idx] = vpPoints[S.src[kpMatch[idx]]];   // :688
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<KeyFrame*>& vpPointsKFs,
+                                   std::vector<MapPoint*>& vpMatched, std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming) {
+    const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, vpMatched, th);
+    std::vector<uint8_t> occ;
+    const orbslam3_hip::FrameView V = keyframe_view(pKF, occ, vpMatched);
+    std::vector<int> kpMatch, qMatch;
+    const int thDist = (int)std::floor((float)TH_LOW * ratioHamming);
+    const int nmatches = device_matcher(mfNNratio, false).SearchByProjection(V, S.q, S.qd, ORBM_MODE_BEST_ONLY, thDist, kpMatch, qMatch);
+    for (int idx = 0; idx < V.N; idx++)
+        if (kpMatch[idx] >= 0) { vpMatched[idx] = vpPoints[S.src[kpMatch[idx]]]; vpMatchedKF[idx] = vpPointsKFs[S.src[kpMatch[idx]]]; }   // :806-807
+    return nmatches;
+}
+
+// ---- SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   ORBmatcher.cc:323-587, Tracking.cc:2185 / :3340 ------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+    const int nKF = (int)vpMapPointsKF.size();
+    orbslam3_hip::ORBmatcher::KeyFrameView K, Fv;
+    std::vector<uint8_t> valid(nKF);
+    for (int i = 0; i < nKF; i++) valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();   // :360-366
+    std::vector<float> angK(nKF), angF(F.N);
+    for (int i = 0; i < nKF; i++)   // kp of :481-484
+        angK[i] = (!pKF->mpCamera2) ? pKF->mvKeysUn[i].angle : (i >= pKF->NLeft) ? pKF->mvKeysRight[i - pKF->NLeft].angle : pKF->mvKeys[i].angle;
+    for (int i = 0; i < F.N; i++)     // Fkp of :493-496 / :527-530
+        angF[i] = (F.Nleft == -1 || i < F.Nleft) ? F.mvKeys[i].angle : F.mvKeysRight[i - F.Nleft].angle;
+    K.N = nKF; K.descriptors = pKF->mDescriptors.data; K.hasMapPoint = valid.data();
+    Fv.N = F.N; Fv.descriptors = F.mDescriptors.data;
+    flatten_featvec(pKF->mFeatVec, K);
+    flatten_featvec(F.mFeatVec, Fv);
+    std::vector<int> fMatch;
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchByBoW(K, angK.data(), Fv, angF.data(), F.Nleft, fMatch);
+    for (int j = 0; j < F.N; j++)
+        if (fMatch[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[fMatch[j]];   // :473, :513
+    return nmatches;
+}
+
+// ---- SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)   ORBmatcher.cc:984-1124, LoopClosing.cc:697 --------------------------------------------
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+    KeyFrame* kf[2] = {pKF1, pKF2};
+    const std::vector<MapPoint*>* mps[2] = {&vpMapPoints1, &vpMapPoints2};
+    orbslam3_hip::ORBmatcher::KeyFrameView K[2];
+    std::vector<uint8_t> valid[2];
+    std::vector<float> ang[2];
+    for (int s = 0; s < 2; s++) {
+        const int n = (int)mps[s]->size(), nUn = (int)kf[s]->mvKeysUn.size();
+        valid[s].resize(n); ang[s].assign(n, 0.f);
+        for (int i = 0; i < n; i++) {
+            MapPoint* p = (*mps[s])[i];
+            // `NLeft != -1 && idx >= mvKeysUn.size()` (:1020-1022, :1043-1045) and `!pMP || pMP->isBad()` (:1025-1028, :1049-1053)
+            valid[s][i] = !(kf[s]->NLeft != -1 && i >= nUn) && p && !p->isBad();
+            if (i < nUn) ang[s][i] = kf[s]->mvKeysUn[i].angle;   // vKeysUn1[idx1].angle / vKeysUn2[bestIdx2].angle :1082
+        }
+        K[s].N = n; K[s].descriptors = kf[s]->mDescriptors.data; K[s].hasMapPoint = valid[s].data();
+        flatten_featvec(kf[s]->mFeatVec, K[s]);
+    }
+    std::vector<int> m12;
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchByBoW(K[0], ang[0].data(), K[1], ang[1].data(), m12);
+    for (size_t i = 0; i < m12.size(); i++)
+        if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];   // :1076
+    return nmatches;
+}
+
+}  // namespace ORB_SLAM3
+#endif  // ORBHIP_WITH_ORBSLAM3

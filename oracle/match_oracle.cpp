@@ -203,7 +203,7 @@ int omo_search_by_projection(const void* kps, const uint8_t* desc, const float* 
         ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (size_t j = 0; j < rotHist[i].size(); j++) { holder[rotHist[i][j]] = -1; nmatches--; }
+                for (size_t j = 0; j < rotHist[i].size(); j++) { holder[rotHist[i][j]] = -2; nmatches--; }   // NULL written by the orientation cull (reported as -2: "claimed during the call, then culled")
     }
     for (int i = 0; i < n; i++) kp_match[i] = holder[i];
     // a query's match is reported only while its keypoint still holds it
@@ -464,7 +464,7 @@ int omo_search_by_projection_rig(const void* kps, const uint8_t* desc, const uin
         ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (size_t j = 0; j < rotHist[i].size(); j++) { holder[rotHist[i][j]] = -1; nmatches--; }
+                for (size_t j = 0; j < rotHist[i].size(); j++) { holder[rotHist[i][j]] = -2; nmatches--; }   // NULL written by the orientation cull (reported as -2: "claimed during the call, then culled")
     }
     for (int i = 0; i < n; i++) kp_match[i] = holder[i];
     for (int q = 0; q < nq; q++)

@@ -1,0 +1,393 @@
+// Compile-and-run check of the reference-signature glue (integration/*.cc) against the mock declarations in tests/cpp/mock_orbslam3:
+// every function is driven through the reference's own signature on mock Frame / KeyFrame / MapPoint objects and compared with the oracle's
+// literal restatement of the reference loop on independently flattened inputs (matcher) or with the flattened LbaLinearizer path (LBA).
+// Built by tests/test_glue.py against the emulated library (CPU tier) or the real liborbhip.so (GPU tier).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "ORBmatcher.h"
+#include "Optimizer.h"
+#include <orbslam3_hip/Optimizer.h>
+
+extern "C" {
+void* oro_create(int, float, int, int, int);
+void oro_destroy(void*);
+int oro_extract(void*, const uint8_t*, int, int, int, int, int, void*, uint8_t*, int, int*);
+int omo_search_by_projection(const void*, const uint8_t*, const float*, const uint8_t*, int, float, float, float, float, const void*,
+                             const uint8_t*, int, int, int, float, int, int32_t*, int32_t*);
+int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
+                      const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
+int omo_search_by_bow_kf(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, const uint8_t*, const float*,
+                         const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float, int, int32_t*);
+}
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+using namespace ORB_SLAM3;
+// the parts of the reference's ORBmatcher.cc / Frame.cc that stay where they are
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+float ORBmatcher::RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5 : 4.0; }   // ORBmatcher.cc:260-266
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+
+static uint32_t rng_state = 4242u;
+static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+static float frand(float a, float b) { return a + (b - a) * (float)(rnd() % 100000) / 100000.f; }
+
+static std::vector<uint8_t> make_image(int W, int H, int dx, int dy) {
+    std::vector<uint8_t> img((size_t)W * H, 110);
+    uint32_t st = 777u;
+    auto r = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+    for (int k = 0; k < 220; k++) {
+        const int cx = r() % W + dx, cy = r() % H + dy, hw = 3 + r() % 25, hh = 3 + r() % 25, g = 20 + r() % 215;
+        for (int y = cy - hh; y <= cy + hh; y++)
+            for (int x = cx - hw; x <= cx + hw; x++)
+                if (x >= 0 && x < W && y >= 0 && y < H) img[(size_t)y * W + x] = (uint8_t)g;
+    }
+    return img;
+}
+struct Query { float u, v, radius, uRight, angle; int16_t minLevel, maxLevel; uint32_t flags; };   // == orbm_query == the oracle's Query
+
+static cv::Mat descMat(const std::vector<uint8_t>& d) { cv::Mat m((int)d.size() / 32, 32, CV_8U); std::memcpy(m.data, d.data(), d.size()); return m; }
+static DBoW2::FeatureVector featVec(const std::vector<uint8_t>& d, int n, int dropMod) {
+    DBoW2::FeatureVector fv;
+    for (int i = 0; i < n; i++) {
+        const unsigned node = ((d[(size_t)i * 32] >> 4) * 7 + (d[(size_t)i * 32 + 9] >> 5) * 3) % 40;
+        if (dropMod && node % dropMod == 1) continue;
+        fv[node].push_back((unsigned)i);
+    }
+    return fv;
+}
+static void csr(const DBoW2::FeatureVector& fv, std::vector<int32_t>& id, std::vector<int32_t>& st, std::vector<int32_t>& fe) {
+    st.push_back(0);
+    for (auto& kv : fv) { id.push_back((int32_t)kv.first); for (unsigned f : kv.second) fe.push_back((int32_t)f); st.push_back((int32_t)fe.size()); }
+}
+
+int main() {
+    const int W = 480, H = 360, NF = 600;
+    const float fx = 400.f, fy = 400.f, cx = 240.f, cy = 180.f;
+    std::vector<float> sf(8), invSig2(8);
+    sf[0] = 1.f; for (int i = 1; i < 8; i++) sf[i] = sf[i - 1] * 1.2f;
+    for (int i = 0; i < 8; i++) invSig2[i] = 1.f / (sf[i] * sf[i]);
+    // two views of one scene extracted by the oracle: A (the "last frame" / key frame) and B = A moved by (5,-3) (the current frame)
+    std::vector<cv::KeyPoint> kA(4 * NF), kB(4 * NF);
+    std::vector<uint8_t> dA((size_t)4 * NF * 32), dB((size_t)4 * NF * 32);
+    int nA = 0, nB = 0;
+    {
+        void* o = oro_create(NF, 1.2f, 8, 20, 7);
+        auto a = make_image(W, H, 0, 0), b = make_image(W, H, 5, -3);
+        oro_extract(o, a.data(), W, H, W, 0, 0, kA.data(), dA.data(), 4 * NF, &nA);
+        oro_extract(o, b.data(), W, H, W, 0, 0, kB.data(), dB.data(), 4 * NF, &nB);
+        oro_destroy(o);
+        kA.resize(nA); kB.resize(nB); dA.resize((size_t)nA * 32); dB.resize((size_t)nB * 32);
+    }
+    CHECK(nA > 400 && nB > 400);
+    Frame::mnMinX = 0; Frame::mnMaxX = W; Frame::mnMinY = 0; Frame::mnMaxY = H;
+    Frame::mfGridElementWidthInv = 64.f / W; Frame::mfGridElementHeightInv = 48.f / H;
+    Pinhole cam(fx, fy, cx, cy);
+    auto fresh_frame = [&]() {
+        Frame F;
+        F.N = nB; F.mvKeys = kB; F.mvKeysUn = kB; F.mvuRight.assign(nB, -1.f); F.mDescriptors = descMat(dB);
+        F.mvpMapPoints.assign(nB, (MapPoint*)NULL); F.mvbOutlier.assign(nB, false); F.mvScaleFactors = sf; F.mpCamera = &cam;
+        F.mTcw = cv::Mat::eye(4, 4, CV_32F); F.mbf = 40.f; F.mb = 0.1f; F.mfLogScaleFactor = std::log(1.2f);
+        for (int i = 0; i < nB; i++) if (i % 3 == 0) F.mvuRight[i] = kB[i].pt.x - frand(2.f, 30.f);
+        return F;
+    };
+    // map points = A's keypoints lifted to 3-D at the current frame's pose (identity), so that they project to A's position + (5,-3) in B
+    std::vector<MapPoint> mps(nA);
+    std::vector<MapPoint*> vpMPs(nA);
+    for (int i = 0; i < nA; i++) {
+        MapPoint& p = mps[i];
+        const float u = kA[i].pt.x + 5.f, v = kA[i].pt.y - 3.f, z = frand(2.f, 8.f);
+        p.mWorldPos = cv::Mat(3, 1, CV_32F);
+        p.mWorldPos.at<float>(0) = (u - cx) / fx * z; p.mWorldPos.at<float>(1) = (v - cy) / fy * z; p.mWorldPos.at<float>(2) = z;
+        p.mNormalVector = cv::Mat(3, 1, CV_32F);
+        const float nrm = (float)cv::norm(p.mWorldPos);
+        for (int k = 0; k < 3; k++) p.mNormalVector.at<float>(k) = p.mWorldPos.at<float>(k) / nrm;
+        p.mDescriptor = cv::Mat(1, 32, CV_8U); std::memcpy(p.mDescriptor.data, &dA[(size_t)i * 32], 32);
+        p.nObs = (i % 11 == 0) ? 0 : 3; p.mnId = i; p.mbBad = (i % 29 == 7);
+        p.mfMaxDistance = nrm * sf[kA[i].octave] * 1.05f; p.mfMinDistance = p.mfMaxDistance / sf[7] * 0.5f;
+        p.mbTrackInView = (i % 13 != 5); p.mTrackProjX = u; p.mTrackProjY = v; p.mTrackProjXR = u - 40.f / z; p.mTrackDepth = z;
+        p.mnTrackScaleLevel = kA[i].octave; p.mTrackViewCos = (i % 3 == 0) ? 0.9990f : 0.95f;
+        vpMPs[i] = &p;
+    }
+    const float grid[4] = {0.f, 0.f, 64.f / W, 48.f / H};
+    auto oracle = [&](const Frame& F, const std::vector<uint8_t>& occ, bool useUR, const std::vector<Query>& q, const std::vector<uint8_t>& qd, int mode, int thDist,
+                      float ratio, int ori, std::vector<int32_t>& km) {
+        std::vector<int32_t> qm(q.size() + 1);
+        km.assign(F.N + 1, -1);
+        return omo_search_by_projection(F.mvKeysUn.data(), F.mDescriptors.data, useUR ? F.mvuRight.data() : nullptr, occ.data(), F.N, grid[0], grid[1], grid[2], grid[3],
+                                        q.data(), qd.data(), (int)q.size(), mode, thDist, ratio, ori, qm.data(), km.data());
+    };
+
+    // ---- 1. local-map search (Tracking::SearchLocalPoints) ----
+    for (float th : {1.f, 3.f}) {
+        Frame F = fresh_frame();
+        MapPoint pre; pre.nObs = 2;
+        for (int i = 0; i < nB; i += 9) F.mvpMapPoints[i] = &pre;     // keypoints that already hold an observed point
+        std::vector<uint8_t> occ(nB, 0);
+        for (int i = 0; i < nB; i++) occ[i] = F.mvpMapPoints[i] != NULL;
+        std::vector<Query> q; std::vector<uint8_t> qd; std::vector<int> own;
+        for (int i = 0; i < nA; i++) {
+            MapPoint& p = mps[i];
+            if (!p.mbTrackInView || p.mbBad) continue;
+            float r = (p.mTrackViewCos > 0.998 ? 2.5f : 4.0f); if (th != 1.f) r *= th;
+            q.push_back(Query{p.mTrackProjX, p.mTrackProjY, r * sf[p.mnTrackScaleLevel], p.mTrackProjXR, 0.f, (int16_t)(p.mnTrackScaleLevel - 1), (int16_t)p.mnTrackScaleLevel,
+                              1u | 2u | (p.nObs > 0 ? 4u : 0u)});
+            qd.insert(qd.end(), &dA[(size_t)i * 32], &dA[(size_t)i * 32] + 32); own.push_back(i);
+        }
+        std::vector<int32_t> km;
+        const int on = oracle(F, occ, true, q, qd, 0, 100, 0.8f, 1, km);
+        ORBmatcher m(0.8f, true);
+        const int n = m.SearchByProjection(F, vpMPs, th);
+        CHECK(n == on && n > 100);
+        for (int i = 0; i < nB; i++) CHECK(F.mvpMapPoints[i] == (km[i] >= 0 ? &mps[own[km[i]]] : (occ[i] ? &pre : (MapPoint*)NULL)));
+        std::printf("glue local-map th=%.0f: %d matches\n", th, n);
+    }
+    // ---- 2. motion-model search (Tracking::TrackWithMotionModel): LastFrame = A with its map points ----
+    {
+        Frame Last;
+        Last.N = nA; Last.mvKeys = kA; Last.mvKeysUn = kA; Last.mvpMapPoints = vpMPs; Last.mvbOutlier.assign(nA, false); Last.mTcw = cv::Mat::eye(4, 4, CV_32F);
+        for (int i = 0; i < nA; i += 17) Last.mvbOutlier[i] = true;
+        for (int i = 0; i < nA; i += 23) Last.mvpMapPoints[i] = NULL;
+        for (int mono = 0; mono < 2; mono++) {
+            Frame F = fresh_frame();
+            std::vector<uint8_t> occ(nB, 0);
+            std::vector<Query> q; std::vector<uint8_t> qd; std::vector<int> own;
+            for (int i = 0; i < nA; i++) {
+                if (!Last.mvpMapPoints[i] || Last.mvbOutlier[i]) continue;
+                MapPoint& p = mps[i];
+                const float X = p.mWorldPos.at<float>(0), Y = p.mWorldPos.at<float>(1), Z = p.mWorldPos.at<float>(2);
+                const float invz = 1.0 / Z;
+                const float u = fx * X / Z + cx, v = fy * Y / Z + cy;
+                if (u < 0 || u > W || v < 0 || v > H) continue;
+                const int o = kA[i].octave;
+                q.push_back(Query{u, v, 7.f * sf[o], u - 40.f * invz, kA[i].angle, (int16_t)(o - 1), (int16_t)(o + 1), 1u | 2u | (p.nObs > 0 ? 4u : 0u)});
+                qd.insert(qd.end(), &dA[(size_t)i * 32], &dA[(size_t)i * 32] + 32); own.push_back(i);
+            }
+            std::vector<int32_t> km;
+            const int on = oracle(F, occ, true, q, qd, 1, 100, 0.9f, 1, km);
+            ORBmatcher m(0.9f, true);
+            const int n = m.SearchByProjection(F, Last, 7.f, mono != 0);
+            CHECK(n == on && n > 100);
+            for (int i = 0; i < nB; i++) CHECK(F.mvpMapPoints[i] == (km[i] >= 0 ? &mps[own[km[i]]] : (MapPoint*)NULL));
+            std::printf("glue motion-model bMono=%d: %d matches\n", mono, n);
+        }
+    }
+    // key frame A (for the relocalisation, Sim3 and BoW searches)
+    KeyFrame KFa(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+    KFa.N = nA; KFa.mvKeys = kA; KFa.mvKeysUn = kA; KFa.mvuRight.assign(nA, -1.f); KFa.mDescriptors = descMat(dA); KFa.mvpMapPoints = vpMPs;
+    KFa.mpCamera = &cam; KFa.mfLogScaleFactor = std::log(1.2f); KFa.mFeatVec = featVec(dA, nA, 0);
+    for (int i = 0; i < nA; i += 19) KFa.mvpMapPoints[i] = NULL;
+    // ---- 3. relocalisation search ----
+    {
+        Frame F = fresh_frame();
+        MapPoint pre; pre.nObs = 0;
+        for (int i = 0; i < nB; i += 7) F.mvpMapPoints[i] = &pre;     // already-found points block regardless of their observations (:2586)
+        std::set<MapPoint*> found;
+        for (int i = 0; i < nA; i += 5) found.insert(&mps[i]);
+        std::vector<uint8_t> occ(nB);
+        for (int i = 0; i < nB; i++) occ[i] = F.mvpMapPoints[i] != NULL;
+        std::vector<Query> q; std::vector<uint8_t> qd; std::vector<int> own;
+        for (int i = 0; i < nA; i++) {
+            MapPoint* p = KFa.mvpMapPoints[i];
+            if (!p || p->mbBad || found.count(p)) continue;
+            const float X = p->mWorldPos.at<float>(0), Y = p->mWorldPos.at<float>(1), Z = p->mWorldPos.at<float>(2);
+            const float u = fx * X / Z + cx, v = fy * Y / Z + cy;
+            if (u < 0 || u > W || v < 0 || v > H) continue;
+            const float dist3D = (float)cv::norm(p->mWorldPos);
+            if (dist3D < p->GetMinDistanceInvariance() || dist3D > p->GetMaxDistanceInvariance()) continue;
+            const int L = p->PredictScale(dist3D, &F);
+            q.push_back(Query{u, v, 10.f * sf[L], 0.f, kA[i].angle, (int16_t)(L - 1), (int16_t)(L + 1), 1u | 4u});
+            qd.insert(qd.end(), &dA[(size_t)i * 32], &dA[(size_t)i * 32] + 32); own.push_back(i);
+        }
+        std::vector<int32_t> km;
+        const int on = oracle(F, occ, false, q, qd, 1, 64, 0.9f, 1, km);
+        ORBmatcher m(0.9f, true);
+        const int n = m.SearchByProjection(F, &KFa, found, 10.f, 64);
+        CHECK(n == on && n > 50);
+        for (int i = 0; i < nB; i++) CHECK(F.mvpMapPoints[i] == (km[i] >= 0 ? &mps[own[km[i]]] : (occ[i] ? &pre : (MapPoint*)NULL)));
+        std::printf("glue relocalisation: %d matches\n", n);
+    }
+    // ---- 4./5. Sim3 projection searches into key frame B ----
+    {
+        KeyFrame KFb(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+        KFb.N = nB; KFb.mvKeys = kB; KFb.mvKeysUn = kB; KFb.mvuRight.assign(nB, -1.f); KFb.mDescriptors = descMat(dB); KFb.mpCamera = &cam;
+        KFb.mfLogScaleFactor = std::log(1.2f);
+        cv::Mat Scw = cv::Mat::eye(4, 4, CV_32F);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) Scw.at<float>(r, c) *= 1.5f;   // s = 1.5, R = I, t = 0: projections unchanged
+        std::vector<MapPoint*> matched(nB, (MapPoint*)NULL), matched2;
+        for (int i = 0; i < nB; i += 6) matched[i] = &mps[(i * 7) % nA];
+        matched2 = matched;
+        std::set<MapPoint*> already(matched.begin(), matched.end());
+        already.erase((MapPoint*)NULL);
+        std::vector<uint8_t> occ(nB);
+        for (int i = 0; i < nB; i++) occ[i] = matched[i] != NULL;
+        Frame Fb; Fb.N = nB; Fb.mvKeysUn = kB; Fb.mDescriptors = descMat(dB);
+        std::vector<Query> q; std::vector<uint8_t> qd; std::vector<int> own;
+        for (int i = 0; i < nA; i++) {
+            MapPoint* p = &mps[i];
+            if (p->mbBad || already.count(p)) continue;
+            const float X = p->mWorldPos.at<float>(0), Y = p->mWorldPos.at<float>(1), Z = p->mWorldPos.at<float>(2);
+            const float u = fx * X / Z + cx, v = fy * Y / Z + cy;
+            if (!KFb.IsInImage(u, v)) continue;
+            const float dist = (float)cv::norm(p->mWorldPos);
+            if (dist < p->GetMinDistanceInvariance() || dist > p->GetMaxDistanceInvariance()) continue;
+            const int L = p->PredictScale(dist, &KFb);
+            q.push_back(Query{u, v, 8.f * sf[L], 0.f, 0.f, (int16_t)(L - 1), (int16_t)L, 1u | 4u});
+            qd.insert(qd.end(), &dA[(size_t)i * 32], &dA[(size_t)i * 32] + 32); own.push_back(i);
+        }
+        std::vector<int32_t> km;
+        const int on = oracle(Fb, occ, false, q, qd, 1, 37, 0.9f, 0, km);   // floor(50 * 0.75)
+        ORBmatcher m(0.75f, true);
+        const int n = m.SearchByProjection(&KFb, Scw, vpMPs, matched, 8, 0.75f);
+        CHECK(n == on && n > 30);
+        for (int i = 0; i < nB; i++) CHECK(matched[i] == (km[i] >= 0 ? &mps[own[km[i]]] : matched2[i]));
+        std::vector<KeyFrame*> srcKF(nA, &KFa), matchedKF(nB, (KeyFrame*)NULL);
+        std::vector<MapPoint*> matched3 = matched2;
+        const int n2 = m.SearchByProjection(&KFb, Scw, vpMPs, srcKF, matched3, matchedKF, 8, 0.75f);
+        CHECK(n2 == on);
+        for (int i = 0; i < nB; i++) CHECK(matched3[i] == matched[i] && matchedKF[i] == (km[i] >= 0 ? &KFa : (KeyFrame*)NULL));
+        std::printf("glue Sim3 searches: %d matches\n", n);
+    }
+    // ---- 6./7. SearchByBoW ----
+    {
+        Frame F = fresh_frame();
+        F.mFeatVec = featVec(dB, nB, 7);
+        std::vector<uint8_t> valid(nA);
+        for (int i = 0; i < nA; i++) valid[i] = KFa.mvpMapPoints[i] && !KFa.mvpMapPoints[i]->mbBad;
+        std::vector<int32_t> id1, st1, fe1, id2, st2, fe2;
+        csr(KFa.mFeatVec, id1, st1, fe1); csr(F.mFeatVec, id2, st2, fe2);
+        std::vector<float> angA(nA), angB(nB);
+        for (int i = 0; i < nA; i++) angA[i] = kA[i].angle;
+        for (int i = 0; i < nB; i++) angB[i] = kB[i].angle;
+        std::vector<int32_t> ofm(nB);
+        const int on = omo_search_by_bow(dA.data(), angA.data(), valid.data(), id1.data(), st1.data(), fe1.data(), (int)id1.size(), dB.data(), angB.data(), nB, id2.data(),
+                                         st2.data(), fe2.data(), (int)id2.size(), 0.7f, 1, ofm.data(), -1);
+        ORBmatcher m(0.7f, true);
+        std::vector<MapPoint*> vpMatches;
+        const int n = m.SearchByBoW(&KFa, F, vpMatches);
+        CHECK(n == on && n > 10 && (int)vpMatches.size() == nB);
+        for (int j = 0; j < nB; j++) CHECK(vpMatches[j] == (ofm[j] >= 0 ? KFa.mvpMapPoints[ofm[j]] : (MapPoint*)NULL));
+        // key frame / key frame
+        KeyFrame KFb(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+        std::vector<MapPoint> mpsB(nB);
+        KFb.N = nB; KFb.mvKeys = kB; KFb.mvKeysUn = kB; KFb.mDescriptors = descMat(dB); KFb.mFeatVec = F.mFeatVec; KFb.mvpMapPoints.assign(nB, (MapPoint*)NULL);
+        std::vector<uint8_t> valid2(nB, 0);
+        for (int i = 0; i < nB; i++) if (i % 5 != 4) { KFb.mvpMapPoints[i] = &mpsB[i]; mpsB[i].mbBad = (i % 31 == 3); valid2[i] = !mpsB[i].mbBad; }
+        std::vector<int32_t> om12(nA);
+        const int onk = omo_search_by_bow_kf(dA.data(), angA.data(), valid.data(), id1.data(), st1.data(), fe1.data(), (int)id1.size(), nA, dB.data(), angB.data(),
+                                             valid2.data(), id2.data(), st2.data(), fe2.data(), (int)id2.size(), nB, 0.8f, 1, om12.data());
+        ORBmatcher mk(0.8f, true);
+        std::vector<MapPoint*> vp12;
+        const int nk = mk.SearchByBoW(&KFa, &KFb, vp12);
+        CHECK(nk == onk && nk > 10 && (int)vp12.size() == nA);
+        for (int i = 0; i < nA; i++) CHECK(vp12[i] == (om12[i] >= 0 ? KFb.mvpMapPoints[om12[i]] : (MapPoint*)NULL));
+        std::printf("glue SearchByBoW: KF-F %d, KF-KF %d matches\n", n, nk);
+    }
+    // ---- 8. Optimizer::LocalBundleAdjustment on a small mock map, against the flattened LbaLinearizer path driven by hand ----
+    {
+        Map map; map.mnInitKFid = 0;
+        const int NK = 9, NP = 260;
+        std::vector<KeyFrame*> kfs;
+        std::vector<MapPoint> pts(NP);
+        std::vector<cv::Mat> Xtrue(NP);
+        for (int j = 0; j < NP; j++) {
+            Xtrue[j] = cv::Mat(3, 1, CV_32F);
+            Xtrue[j].at<float>(0) = frand(-3.f, 3.f); Xtrue[j].at<float>(1) = frand(-2.f, 2.f); Xtrue[j].at<float>(2) = frand(4.f, 9.f);
+            pts[j].mnId = j; pts[j].mpMap = &map; pts[j].mWorldPos = Xtrue[j].clone();
+            for (int k = 0; k < 3; k++) pts[j].mWorldPos.at<float>(k) += frand(-0.03f, 0.03f);
+        }
+        for (int k = 0; k < NK; k++) {
+            KeyFrame* kf = new KeyFrame(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+            kf->mnId = k; kf->mpMap = &map; kf->mpCamera = &cam;
+            cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+            const float a = 0.02f * k;
+            T.at<float>(0, 0) = std::cos(a); T.at<float>(0, 2) = std::sin(a); T.at<float>(2, 0) = -std::sin(a); T.at<float>(2, 2) = std::cos(a);
+            T.at<float>(0, 3) = -0.15f * k; T.at<float>(1, 3) = 0.01f * k;
+            // observations from the TRUE pose; the stored pose is perturbed
+            for (int j = 0; j < NP; j++) {
+                if ((j + 3 * k) % 4 == 0) continue;
+                cv::Mat Xc = T.rowRange(0, 3).colRange(0, 3) * Xtrue[j] + T.rowRange(0, 3).col(3);
+                const float z = Xc.at<float>(2), u = fx * Xc.at<float>(0) / z + cx, v = fy * Xc.at<float>(1) / z + cy;
+                if (z < 0.5f || u < 5 || u > W - 5 || v < 5 || v > H - 5) continue;
+                cv::KeyPoint kp; kp.pt = cv::Point2f(u + frand(-0.5f, 0.5f), v + frand(-0.5f, 0.5f)); kp.octave = (int)(rnd() % 4);
+                if ((j * 7 + k) % 41 == 0) kp.pt.x += 35.f;   // a gross outlier observation
+                const int idx = (int)kf->mvKeysUn.size();
+                kf->mvKeysUn.push_back(kp); kf->mvKeys.push_back(kp);
+                kf->mvuRight.push_back((j % 3 == 0) ? kp.pt.x - 40.f / z : -1.f);
+                kf->mvpMapPoints.push_back(&pts[j]);
+                pts[j].mObservations[kf] = std::make_tuple(idx, -1);
+            }
+            kf->N = (int)kf->mvKeysUn.size();
+            if (k > 0) { T.at<float>(0, 3) += frand(-0.02f, 0.02f); T.at<float>(2, 3) += frand(-0.02f, 0.02f); }
+            kf->Tcw = T;
+            kfs.push_back(kf);
+        }
+        KeyFrame* cur = kfs[NK - 1];
+        for (int k = NK - 2; k >= 3; k--) cur->mvpOrderedConnectedKeyFrames.push_back(kfs[k]);   // key frames 0..2 only see local points: fixed cameras
+        // the flattened path, driven by hand in the order the glue must produce (poses by ascending id; edges landmark-major in GetObservations order)
+        orbslam3_hip::LbaLinearizer L;
+        std::map<KeyFrame*, int> pidx;
+        lba_camera c{}; c.model = LBA_CAM_PINHOLE; c.p[0] = fx; c.p[1] = fy; c.p[2] = cx; c.p[3] = cy; c.bf = 40.0; c.trl_q[3] = 1.0;
+        const int camId = L.addCamera(c);
+        for (int k = 0; k < NK; k++) { double p7[7]; orbslam3_hip::LbaLinearizer::poseFromTcw(kfs[k]->Tcw.ptr<float>(), 4, p7); pidx[kfs[k]] = L.addPose(p7, k < 3); }
+        // local map points in the glue's discovery order: key frames cur, NK-2 .. 3, their map-point vectors in index order
+        std::vector<MapPoint*> order; std::set<MapPoint*> seen;
+        std::vector<KeyFrame*> locals = {cur};
+        for (KeyFrame* k : cur->mvpOrderedConnectedKeyFrames) locals.push_back(k);
+        for (KeyFrame* k : locals) for (MapPoint* p : k->mvpMapPoints) if (p && !seen.count(p)) { seen.insert(p); order.push_back(p); }
+        std::vector<std::pair<KeyFrame*, MapPoint*>> eref; std::vector<bool> est;
+        std::map<MapPoint*, int> lidx;
+        for (MapPoint* p : order) {
+            const double X[3] = {p->mWorldPos.at<float>(0), p->mWorldPos.at<float>(1), p->mWorldPos.at<float>(2)};
+            const int l = L.addPoint(X); lidx[p] = l;
+            for (auto& ob : p->mObservations) {
+                KeyFrame* k = ob.first; const int i = std::get<0>(ob.second);
+                const cv::KeyPoint& kp = k->mvKeysUn[i];
+                const bool st = k->mvuRight[i] >= 0;
+                L.addEdge(pidx[k], l, st ? LBA_EDGE_STEREO : LBA_EDGE_MONO, camId, kp.pt.x, kp.pt.y, st ? k->mvuRight[i] : 0.f, invSig2[kp.octave]);
+                eref.push_back(std::make_pair(k, p)); est.push_back(st);
+            }
+        }
+        orbslam3_hip::LbaHostSystem S0; L.computeErrors(S0);
+        L.optimize(5); L.optimize(10);
+        orbslam3_hip::LbaHostSystem S; L.computeErrors(S);
+        CHECK(S.robustChi2 < 0.7 * S0.robustChi2);   // it really optimised
+        int nOut = 0;
+        for (size_t i = 0; i < eref.size(); i++) if (S.chi2[i] > (est[i] ? 7.815 : 5.991) || !(S.depth[i] > 0)) nOut++;
+        // the glue
+        int numFixed = -1; bool stop = false;
+        Optimizer::LocalBundleAdjustment(cur, &stop, &map, numFixed);
+        CHECK(numFixed == 3);
+        int erased = 0;
+        for (KeyFrame* k : kfs) erased += k->nErased;
+        CHECK(erased == nOut && nOut > 3 && nOut < (int)eref.size() / 4);
+        for (int k = 0; k < NK; k++) {
+            const double* p7 = L.pose(pidx[kfs[k]]);
+            if (k < 3) { CHECK(kfs[k]->nPoseSets == 0); continue; }
+            CHECK(kfs[k]->nPoseSets == 1);
+            for (int r = 0; r < 3; r++) CHECK(kfs[k]->Tcw.at<float>(r, 3) == (float)p7[r]);   // identical to the flattened path, bit for bit
+        }
+        for (MapPoint* p : order) {
+            const double* X = L.point(lidx[p]);
+            for (int r = 0; r < 3; r++) CHECK(p->mWorldPos.at<float>(r) == (float)X[r]);
+            CHECK(p->nNormalUpdates == 1);
+        }
+        CHECK(order.size() > 200);
+        CHECK(map.mnMapChange == 1);
+        // pbStopFlag raised before the call: nothing is touched
+        stop = true; const int before = kfs[5]->nPoseSets;
+        Optimizer::LocalBundleAdjustment(cur, &stop, &map, numFixed);
+        CHECK(kfs[5]->nPoseSets == before);
+        std::printf("glue LocalBundleAdjustment: %zu edges, %d erased observations, %d fixed key frames\n", eref.size(), nOut, numFixed);
+        for (KeyFrame* k : kfs) delete k;
+    }
+    std::printf("glue_test OK\n");
+    return 0;
+}

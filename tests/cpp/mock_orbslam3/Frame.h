@@ -1,0 +1,31 @@
+// TEST INFRASTRUCTURE (see README.md): include/Frame.h — members used by the glue
+#pragma once
+#include <opencv2/core/core.hpp>
+#include <vector>
+#include "GeometricCamera.h"
+#include "MapPoint.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+namespace ORB_SLAM3 {
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+class Frame {
+public:
+    int N = 0;
+    float mbf = 0, mb = 0;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    DBoW2::FeatureVector mFeatVec;
+    cv::Mat mDescriptors, mDescriptorsRight;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = 0;
+    std::vector<float> mvScaleFactors;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    int Nleft = -1, Nright = -1;
+    std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
+    cv::Mat mTlr, mRlr, mtlr, mTrl;
+};
+}  // namespace ORB_SLAM3

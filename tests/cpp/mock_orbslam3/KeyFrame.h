@@ -1,0 +1,67 @@
+// TEST INFRASTRUCTURE (see README.md): include/KeyFrame.h — members used by the glue
+#pragma once
+#include <opencv2/core/core.hpp>
+#include <algorithm>
+#include <vector>
+#include "GeometricCamera.h"
+#include "Map.h"
+#include "MapPoint.h"
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+namespace ORB_SLAM3 {
+class KeyFrame {
+public:
+    KeyFrame(float fx_, float fy_, float cx_, float cy_, float mbf_, int nleft, int minx, int miny, int maxx, int maxy, float gwInv, float ghInv,
+             const std::vector<float>& scale, const std::vector<float>& invSigma2)
+        : mnGridCols(64), mnGridRows(48), mfGridElementWidthInv(gwInv), mfGridElementHeightInv(ghInv), fx(fx_), fy(fy_), cx(cx_), cy(cy_), mbf(mbf_),
+          mvScaleFactors(scale), mvInvLevelSigma2(invSigma2), mnMinX(minx), mnMinY(miny), mnMaxX(maxx), mnMaxY(maxy), NLeft(nleft), NRight(-1) {}
+    void SetPose(const cv::Mat& Tcw_) { Tcw = Tcw_.clone(); nPoseSets++; }
+    cv::Mat GetPose() { return Tcw.clone(); }
+    std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
+    void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; nErased++; }
+    std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
+    bool isBad() { return mbBad; }
+    Map* GetMap() { return mpMap; }
+    long unsigned int mnId = 0;
+    const int mnGridCols, mnGridRows;
+    const float mfGridElementWidthInv, mfGridElementHeightInv;
+    long unsigned int mnBALocalForKF = 0, mnBAFixedForKF = 0;
+    const float fx, fy, cx, cy, mbf;
+    int N = 0;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
+    const std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = 0;
+    const int mnMinX, mnMinY, mnMaxX, mnMaxY;
+    GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    cv::Mat mTrl;
+    const int NLeft, NRight;
+    // state
+    cv::Mat Tcw;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
+    bool mbBad = false;
+    Map* mpMap = nullptr;
+    int nPoseSets = 0, nErased = 0;
+};
+// MapPoint::PredictScale (MapPoint.cc:513-547)
+inline int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF) {
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0; else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
+}  // namespace ORB_SLAM3
+#include "Frame.h"
+namespace ORB_SLAM3 {
+inline int MapPoint::PredictScale(const float& currentDist, Frame* pF) {
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0; else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
+}  // namespace ORB_SLAM3

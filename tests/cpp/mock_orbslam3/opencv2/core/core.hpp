@@ -1,0 +1,65 @@
+// TEST INFRASTRUCTURE: the sliver of cv:: the integration glue uses (see ../../README.md).  cv::Mat here is a small dense matrix with value
+// semantics (CV_32F or CV_8U); float products accumulate in double and round once (OpenCV's small-matrix GEMM does the same).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#define CV_8U 0
+#define CV_32F 5
+namespace cv {
+struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
+struct Point3f { float x, y, z; Point3f(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {} };
+struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
+static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    unsigned char* data = nullptr;
+    Mat() {}
+    Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_((size_t)r * c * esz(), 0) { data = buf_.data(); }
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), type_(o.type_), buf_(o.buf_) { data = buf_.empty() ? nullptr : buf_.data(); }
+    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; type_ = o.type_; buf_ = o.buf_; data = buf_.empty() ? nullptr : buf_.data(); return *this; }
+    static Mat eye(int r, int c, int type) { Mat m(r, c, type); for (int i = 0; i < r && i < c; i++) m.at<float>(i, i) = 1.f; return m; }
+    bool empty() const { return buf_.empty(); }
+    int type() const { return type_; }
+    Mat clone() const { return *this; }
+    template <class T> T& at(int r, int c) { return ((T*)data)[(size_t)r * cols + c]; }
+    template <class T> const T& at(int r, int c) const { return ((const T*)data)[(size_t)r * cols + c]; }
+    template <class T> T& at(int i) { return ((T*)data)[i]; }
+    template <class T> const T& at(int i) const { return ((const T*)data)[i]; }
+    template <class T> T* ptr(int r = 0) { return (T*)data + (size_t)r * cols; }
+    template <class T> const T* ptr(int r = 0) const { return (const T*)data + (size_t)r * cols; }
+    Mat rowRange(int a, int b) const { return block(a, b, 0, cols); }
+    Mat colRange(int a, int b) const { return block(0, rows, a, b); }
+    Mat row(int r) const { return block(r, r + 1, 0, cols); }
+    Mat col(int c) const { return block(0, rows, c, c + 1); }
+    Mat t() const { Mat m(cols, rows, CV_32F); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.at<float>(c, r) = at<float>(r, c); return m; }
+    double dot(const Mat& o) const { double s = 0; for (int i = 0; i < rows * cols; i++) s += (double)at<float>(i) * (double)o.at<float>(i); return s; }
+    Mat inv() const {   // rigid 4x4 [R t; 0 1] only (Converter / write-back use)
+        Mat m = eye(4, 4, CV_32F);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m.at<float>(r, c) = at<float>(c, r);
+        for (int r = 0; r < 3; r++) { double s = 0; for (int k = 0; k < 3; k++) s += (double)at<float>(k, r) * (double)at<float>(k, 3); m.at<float>(r, 3) = (float)-s; }
+        return m;
+    }
+private:
+    int type_ = CV_32F;
+    std::vector<unsigned char> buf_;
+    size_t esz() const { return type_ == CV_32F ? 4 : 1; }
+    Mat block(int r0, int r1, int c0, int c1) const {
+        Mat m(r1 - r0, c1 - c0, type_);
+        for (int r = r0; r < r1; r++) memcpy(m.data + (size_t)(r - r0) * m.cols * esz(), data + ((size_t)r * cols + c0) * esz(), (size_t)(c1 - c0) * esz());
+        return m;
+    }
+};
+inline Mat operator*(const Mat& a, const Mat& b) {
+    Mat m(a.rows, b.cols, CV_32F);
+    for (int r = 0; r < a.rows; r++) for (int c = 0; c < b.cols; c++) { double s = 0; for (int k = 0; k < a.cols; k++) s += (double)a.at<float>(r, k) * (double)b.at<float>(k, c); m.at<float>(r, c) = (float)s; }
+    return m;
+}
+inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) + b.at<float>(i); return m; }
+inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) - b.at<float>(i); return m; }
+inline Mat operator-(const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = -a.at<float>(i); return m; }
+inline Mat operator/(const Mat& a, float s) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) / s; return m; }
+inline double norm(const Mat& a) { return std::sqrt(a.dot(a)); }
+}  // namespace cv

@@ -1,0 +1,35 @@
+"""The reference-signature glue (integration/ORBmatcher_hip.cc, integration/Optimizer_hip.cc) compiled with -DORBHIP_WITH_ORBSLAM3 against the
+minimal mock declarations in tests/cpp/mock_orbslam3 (boundary test infrastructure, see its README) and run: the 5 SearchByProjection overloads,
+both SearchByBoW overloads and LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) must reproduce the oracle / the flattened path.
+CPU tier = emulated library, GPU tier = the real liborbhip.so."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_and_run(libpath, tag, tmp_path):
+    exe = str(tmp_path / ("glue_test_" + tag))
+    libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)[3:-3]
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir], stdout=subprocess.DEVNULL)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-DORBHIP_WITH_ORBSLAM3", "-I", os.path.join(ROOT, "tests", "cpp", "mock_orbslam3"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "glue_test.cpp"), os.path.join(ROOT, "integration", "ORBmatcher_hip.cc"),
+           os.path.join(ROOT, "integration", "Optimizer_hip.cc"), "-L", libdir, "-l" + libname, "-L", odir, "-loracle", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lpthread", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "glue_test OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_reference_signature_glue_on_emulated_library(emu_lib, tmp_path):
+    import build_emu
+    _build_and_run(build_emu.OUT, "emu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_reference_signature_glue_on_hip_library(hip_lib, tmp_path):
+    from orbhip import _lib
+    _build_and_run(_lib.LIB_PATH, "hip", tmp_path)
