@@ -221,10 +221,12 @@ def test_emu_lba_optimize_global_memory_panel():
 @pytest.mark.gpu
 def test_hip_global_ba_more_than_180_free_keyframes(hip_lib):
     """Optimizer::BundleAdjustment over a map of 200 key frames (first one fixed): 199 free poses = 1194 unknowns, beyond the LDS panel."""
-    w, cams = synth_window(41, 200, 1, 2500, 8, "mono")
+    # stereo observations: with one fixed key frame a monocular map keeps its scale gauge freedom, the reduced system is singular up to the LM
+    # damping and two correct solvers legitimately walk different lambda sequences (seen on MI355X: 17 vs 3 trials on a 170-KF mono map)
+    w, cams = synth_window(41, 200, 1, 2500, 8, "stereo")
     assert (w["pose_hidx"] >= 0).sum() == 199
     L = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=(0.0, 0.0))
     stats = L.optimize(3)
     op, ox, ost = O.lba_optimize(w, cams, (0.0, 0.0), 3)
     assert stats[0, 0] == ost[0] and stats[0, 3] == ost[3]
-    assert np.abs(to_host(L.d["poses"])[0, :200] - op).max() < 1e-6
+    assert np.abs(to_host(L.d["poses"])[0, :200] - op).max() < 1e-5   # 1194 unknowns, no robust kernel; the bar is 1e-4
