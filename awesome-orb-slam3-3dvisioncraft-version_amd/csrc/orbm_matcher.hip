@@ -327,13 +327,17 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
     const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int half = lane >> 5, hl = lane & 31;
     uint32_t* lst2 = (uint32_t*)orb_smem + wv * 2 * SBP_CAPC;       // two lists of SBP_CAPC entries per wave
-    const int nq = min(A.nq[b], A.cap_q);
+    // the query record and its descriptor do not depend on the counts: they are fetched in the same memory round trip (clamping the index
+    // with nq instead of cap_q makes the compiler wait for nq first — one more dependent round trip on a kernel that is a chain of them)
     const int q0 = (blockIdx.x * 4 + wv) * 2;
-    if (q0 >= nq) return;
-    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
     const int q = q0 + half;
+    const size_t qslot = (size_t)b * A.cap_q + min(q, A.cap_q - 1);
+    const orbm_query Q = A.queries[qslot];
+    const Desc qd = load_desc(A.qdesc + qslot * 32);
+    const int nq = min(A.nq[b], A.cap_q);
+    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+    if (q0 >= nq) return;
     const bool live = q < nq;
-    const orbm_query Q = A.queries[(size_t)b * A.cap_q + min(q, nq - 1)];
     const bool valid = live && (Q.flags & ORBM_Q_VALID);
     // window geometry (Frame.cc:779-806), per half
     const orbm_grid_params& g = A.prm.grid;
@@ -378,8 +382,7 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
         return;
     }
     uint32_t* lst = lst2 + half * SBP_CAPC;
-    uint32_t* w = A.work + ((size_t)b * A.cap_q + min(q, nq - 1)) * SBP_WORK_PER_Q;
-    const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + min(q, nq - 1)) * 32);
+    uint32_t* w = A.work + qslot * SBP_WORK_PER_Q;
     const int minLevel = Q.min_level, maxLevel = Q.max_level;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
