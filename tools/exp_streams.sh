@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: the headline step with one and with two HIP streams.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for st in 1 2; do
+for st in 2 3; do
   python bench.py --no-cpu-baseline --headline-only --steps 20 --warmup 3 --streams $st 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms']

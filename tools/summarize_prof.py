@@ -18,7 +18,7 @@ os.makedirs(dst, exist_ok=True)
 
 c = sqlite3.connect(os.path.join(src, "stats", "trace_results.db"))
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline  (durations in us)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --streams 1  (durations in us)\n")
     f.write("kernel,calls,total_us,average_us,percentage\n")
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         f.write("%s,%d,%.1f,%.3f,%.2f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
@@ -68,7 +68,7 @@ if sq:
                 "SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md).  Derived: valu_per_wave = SQ_INSTS_VALU / SQ_WAVES; "
                 "wait_inst_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls); wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt / barrier); "
                 "valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
-                "waves_per_simd = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE x 1024 SIMDs) = mean resident waves per SIMD while the kernel runs\n")
+                "waves_per_simd = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = mean resident waves per SIMD while the kernel runs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)\n")
         f.write("kernel,avg_us," + ",".join(cols) + ",valu_per_wave,wait_inst_frac,wait_any_frac,valu_active_frac,lds_conflict_frac,waves_per_simd\n")
         for k in sorted(sq):
             v = sq[k]
@@ -76,7 +76,7 @@ if sq:
             wc = g("SQ_WAVE_CYCLES")
             derived = [g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_WAIT_INST_ANY") / wc, g("SQ_WAIT_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc,
                        g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else float("nan"),
-                       wc * 4.0 / (g("GRBM_GUI_ACTIVE") * 1024.0) if g("GRBM_GUI_ACTIVE") else float("nan")]
+                       wc * 4.0 / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0) if g("GRBM_GUI_ACTIVE") else float("nan")]
             f.write("%s,%.1f,%s,%s\n" % (k, dur.get(k, float("nan")), ",".join("%.6g" % g(n) for n in cols), ",".join("%.4f" % x for x in derived)))
     print(open(os.path.join(dst, tag + "_sq.csv")).read())
 bj = os.path.join(src, "bench.json")
