@@ -440,8 +440,7 @@ extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_
 //   k_lm_maxdiag     computeLambdaInit                       optimization_algorithm_levenberg.cpp:171-186
 //   k_lm_begin       per-iteration bookkeeping               :85-105
 //   k_lm_dinv        (Hll + lambda I)^-1, Dinv*b_l           block_solver.hpp:381-397 (+ setLambda :564-589)
-//   k_lm_obs / k_lm_schur_blocks   landmark x pose observation table; one wave per lower-triangle 6x6 block of Hschur
-//                    (+ the coefficient rows on the diagonal), fixed butterfly -> deterministic, no f64 atomics   :398-432
+//   k_lm_schur_rows  Schur complement, one workgroup per block row of Hschur (+ the coefficient rows)   :398-432
 //   k_lm_chol        dense in-place Cholesky + two triangular solves, one workgroup per window   (linear_solver_eigen.h:94-123)
 //   k_lm_backsub     x_l = Dinv (b_l - Hpl^T x_p), X += x_l, scale partials            block_solver.hpp:461-481, levenberg.cpp:188-195
 //   k_lm_update_pose T <- exp(x_p) * T                       types_six_dof_expmap.h:73-76, se3quat.h:223-256
@@ -462,8 +461,6 @@ struct LmArgs {
     double* panExt;                         // [np6][CH_LD] per window: Cholesky panel of systems too large for LDS, else nullptr
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
-    int32_t* pairCnt; int32_t* pairOff; int2* pairList; int pairCap;   // co-visibility lists, see k_lm_pairs
-    int32_t* pairOvf;                       // [batch] 1: the window's lists did not fit -> table-lookup Schur kernel
 };
 
 static __global__ void k_lm_init(LmArgs A, int batch) {
@@ -573,249 +570,121 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
     for (int r = 0; r < 3; r++) db[r] = o[r] * bl[0] + o[3 + r] * bl[1] + o[6 + r] * bl[2];
 }
 
-// obs[l][pose] = first edge of pose `pose` on landmark l (or INT_MAX): the co-observation lookup of the Schur complement
-static __global__ __launch_bounds__(256) void k_lm_obs(LmArgs A, int* obs) {
-    const lba_problem& P = A.P;
-    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
-    const int ne = min(P.n_edges[b], P.cap_e);
-    if (e >= ne) return;
-    const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
-    atomicMin(&obs[((size_t)b * P.cap_l + E.point) * P.cap_p + E.pose], e);
-}
-
-// One wave per lower-triangle block Hschur(h1, h2), h1 >= h2: lanes stride over the edges of pose i1, look the landmark up in the
-// observation table of pose i2 and accumulate  -B_i Dinv B_j^T  in registers; a fixed butterfly adds the 64 partials ->
-// deterministic, no f64 atomics, every block written exactly once (block_solver.hpp:398-432).  The diagonal wave also produces
-// the _bschur rows  b_p - sum_e B_i (Dinv b_l).
-// Co-visibility lists (built once per lba_optimize call: the graph structure is constant over all iterations and lambda trials).
-// For every lower-triangle block (i1, i2) of the reduced camera system: the (e1, e2) pairs "edge e1 of pose i1 and the first edge e2 of
-// pose i2 on the same landmark", in the order of pose i1's edge list.  k_lm_pairs<false> counts them, k_lm_pairs_scan turns the
-// counts into offsets, k_lm_pairs<true> fills the lists (wave per block; ballot compaction keeps the order deterministic).
-// The per-trial Schur kernel then streams its list instead of probing the landmark x pose table for every edge of pose i1
-// (~9x fewer probes: a block of two poses typically shares 10-20 % of pose i1's landmarks, and the probes were random 4-byte reads).
-template <bool FILL>
-static __global__ __launch_bounds__(256) void k_lm_pairs(LmArgs A, const int* obs) {
-    const lba_problem& P = A.P;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
-    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
-    if (i1 >= P.cap_p) return;
-    int32_t* cnt = A.pairCnt + (size_t)b * P.cap_p * P.cap_p;
-    bool live = i1 < np && i2 < np;
-    if (live) {
-        const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
-        const int h1 = hidx[i1], h2 = hidx[i2];
-        live = h1 >= 0 && h2 >= 0 && h1 >= h2;
-    }
-    if (!live) { if (!FILL && lane == 0) cnt[pairId] = 0; return; }
-    if (FILL && A.pairOvf[b]) return;
-    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
-    const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
-    const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
-    const int* ob = obs + (size_t)b * P.cap_l * P.cap_p;
-    int2* list = FILL ? A.pairList + (size_t)b * A.pairCap + A.pairOff[(size_t)b * (P.cap_p * P.cap_p + 1) + pairId] : nullptr;
-    int n = 0;
-    for (int k0 = s0; k0 < s1; k0 += 64) {
-        const int k = k0 + lane;
-        int e1 = 0, e2 = 0;
-        bool hit = false;
-        if (k < s1) {
-            e1 = pe[k];
-            e2 = ob[(size_t)edges[e1].point * P.cap_p + i2];
-            hit = e2 < ne;
-        }
-        const unsigned long long m = __ballot(hit);
-        if (FILL && hit) list[n + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(e1, e2);
-        n += __popcll(m);
-    }
-    if (!FILL && lane == 0) cnt[pairId] = n;
-}
-
-static __global__ __launch_bounds__(256) void k_lm_pairs_scan(LmArgs A) {
+// Schur complement, one workgroup per free pose (= block row h1 of the reduced camera system).  Edges are stored landmark-major, so the edges a
+// row's edge e1 pairs with are the contiguous run of its landmark: a lane takes one edge of the pose, forms B_i Dinv once (block_solver.hpp:404)
+// and walks the run; every partner edge of a free pose h2 <= h1 contributes  -B_i Dinv B_j^T  to block (h1, h2) (block_solver.hpp:398-432).
+// The row's blocks live in LDS ([h2][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
+// table, each B_i Dinv formed once per edge instead of once per block.  The four waves of the workgroup add into the same LDS row, so the
+// summation order of a block is not fixed from run to run (differences at the 1e-16 level; the bar on poses is 1e-4).  The diagonal block
+// also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
+// Rows longer than `rowCap` blocks (LDS) are produced in column chunks, walking the pose's edges once per chunk.
+#define SCH_LD 37
+#ifndef LM_SCHUR_ROWCAP
+#define LM_SCHUR_ROWCAP 384   // blocks of a row held in LDS at once (384 x 37 doubles = 111 KiB); tests build with a tiny value to cover the chunking
+#endif
+static inline size_t lm_schur_smem_bytes(int rowCap, int cap_p) { return ((size_t)rowCap * SCH_LD + 24) * sizeof(double) + (size_t)cap_p * sizeof(int32_t); }
+static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    int* scratch = (int*)orb_smem;   // [256]
+    double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
+    double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [4][6]
+    int32_t* hid = (int32_t*)(coefw + 24);            // [cap_p] Hessian index of every pose of the window
     const lba_problem& P = A.P;
-    const int b = blockIdx.x, tid = threadIdx.x, nblk = P.cap_p * P.cap_p;
-    const int32_t* cnt = A.pairCnt + (size_t)b * nblk;
-    int32_t* off = A.pairOff + (size_t)b * (nblk + 1);
-    const int per = (nblk + 255) / 256, s0 = tid * per, s1 = min(s0 + per, nblk);
-    int sum = 0;
-    for (int i = s0; i < s1; i++) sum += cnt[i];
-    scratch[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const int v = tid >= o ? scratch[tid - o] : 0;
-        __syncthreads();
-        scratch[tid] += v;
-        __syncthreads();
-    }
-    int run = scratch[tid] - sum;
-    for (int i = s0; i < s1; i++) { off[i] = run; run += cnt[i]; }
-    if (tid == 255) { off[nblk] = scratch[255]; A.pairOvf[b] = scratch[255] > A.pairCap ? 1 : 0; }
-}
-
-// Schur complement from the co-visibility lists: same arithmetic as k_lm_schur_blocks, the list replaces walk + table probe.
-static __global__ __launch_bounds__(256) void k_lm_schur_lists(LmArgs A) {
-    const lba_problem& P = A.P;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    if (!A.st[b].needTrial || A.pairOvf[b]) return;
-    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!A.st[b].needTrial) return;
     const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
-    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
-    if (i1 >= np || i2 >= np) return;
+    const int i1 = P.cap_p - 1 - (int)blockIdx.x;     // late (long) rows first
+    if (i1 >= np) return;
     const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
-    const int h1 = hidx[i1], h2 = hidx[i2];
-    if (h1 < 0 || h2 < 0 || h1 < h2) return;
-    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
-    const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
-    const int32_t* off = A.pairOff + (size_t)b * (P.cap_p * P.cap_p + 1);
-    const int2* list = A.pairList + (size_t)b * A.pairCap;
-    const int s0 = off[pairId], s1 = off[pairId + 1];
-    const bool diag = i1 == i2;
-    double acc[36], coef[6];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) coef[k] = 0;
-    for (int k = s0 + lane; k < s1; k += 64) {
-        const int2 pr = list[k];
-        const int e1 = pr.x;
-        int e2 = pr.y;
-        const int l = edges[e1].point;
-        // B_i * Dinv (block_solver.hpp:404), 6x3 column-major, recomputed here instead of stored per edge
-        const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
-        const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
-        double BDi[18];
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int r = 0; r < 6; r++) BDi[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
-        const int m1 = min(lms[l + 1], ne);
-        for (; e2 < m1 && edges[e2].pose == i2; e2++) {       // the edges of one pose on a landmark are adjacent (mono + body twin)
-            const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + e2) * 18;
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-#pragma unroll
-                for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
-        }
-        if (diag) {
-            const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
-#pragma unroll
-            for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 36; k++)
-        for (int off2 = 32; off2 > 0; off2 >>= 1) acc[k] += __shfl_xor(acc[k], off2);
-    const int np6 = A.np6;
-    double* Hs = A.Hs + (size_t)b * np6 * np6;
-    if (diag) {
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            for (int off2 = 32; off2 > 0; off2 >>= 1) coef[k] += __shfl_xor(coef[k], off2);
-        if (lane < 6) {
-            double c = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) if (lane == k) c = coef[k];
-            A.xp[(size_t)b * np6 + h1 * 6 + lane] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + lane] - c;
-        }
-    }
-    if (lane < 36) {
-        double v = 0;
-#pragma unroll
-        for (int k = 0; k < 36; k++) if (lane == k) v = acc[k];
-        if (diag) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + lane] + ((lane % 7 == 0) ? A.st[b].lambda : 0.0);   // _Hpp->add(_Hschur) + setLambda
-        const int c = lane / 6, r = lane - c * 6;
-        Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
-    }
-}
-
-static __global__ __launch_bounds__(256) void k_lm_schur_blocks(LmArgs A, const int* obs) {
-    const lba_problem& P = A.P;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    if (!A.st[b].needTrial || !A.pairOvf[b]) return;   // fallback for windows whose co-visibility lists did not fit the workspace
-    const int pairId = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
-    const int i1 = pairId / P.cap_p, i2 = pairId - i1 * P.cap_p;
-    if (i1 >= np || i2 >= np) return;
-    const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
-    const int h1 = hidx[i1], h2 = hidx[i2];
-    if (h1 < 0 || h2 < 0 || h1 < h2) return;
+    const int h1 = hidx[i1];
+    if (h1 < 0) return;
+    for (int t = tid; t < P.cap_p; t += 256) hid[t] = t < np ? hidx[t] : -1;
     const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
     const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
     const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+    const double* Hpl = A.S.Hpl + (size_t)b * P.cap_e * 18;
+    const double* Dinv = A.Dinv + (size_t)b * P.cap_l * 9;
     const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
-    const int* ob = obs + (size_t)b * P.cap_l * P.cap_p;
-    const bool diag = i1 == i2;
-    double acc[36], coef[6];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) coef[k] = 0;
-    for (int k = s0 + lane; k < s1; k += 64) {
-        const int e1 = pe[k];
-        const int l = edges[e1].point;
-        int e2 = ob[(size_t)l * P.cap_p + i2];
-        if (e2 >= ne) continue;                               // pose i2 does not observe this landmark
-        // B_i * Dinv (block_solver.hpp:404), 6x3 column-major, recomputed here instead of stored per edge
-        const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + e1) * 18;
-        const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
-        double BDi[18];
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int r = 0; r < 6; r++) BDi[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
-        const int m1 = min(lms[l + 1], ne);
-        for (; e2 < m1 && edges[e2].pose == i2; e2++) {       // the edges of one pose on a landmark are adjacent (mono + body twin)
-            const double* Bj = A.S.Hpl + ((size_t)b * P.cap_e + e2) * 18;
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-#pragma unroll
-                for (int r = 0; r < 6; r++) acc[c * 6 + r] -= BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c];
-        }
-        if (diag) {
-            const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
-#pragma unroll
-            for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 36; k++)
-        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
     const int np6 = A.np6;
     double* Hs = A.Hs + (size_t)b * np6 * np6;
-    if (diag) {
+    double coef[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-            for (int off = 32; off > 0; off >>= 1) coef[k] += __shfl_xor(coef[k], off);
-        if (lane < 6) {
-            double c = 0;
+    for (int k = 0; k < 6; k++) coef[k] = 0;
+    for (int c0 = 0; c0 <= h1; c0 += rowCap) {
+        const int nblk = min(rowCap, h1 + 1 - c0);
+        for (int t = tid; t < nblk * SCH_LD; t += 256) Srow[t] = 0.0;
+        __syncthreads();
+        for (int k = s0 + tid; k < s1; k += 256) {
+            const int e1 = pe[k];
+            const int l = edges[e1].point;
+            const double* Bi = Hpl + (size_t)e1 * 18;
+            const double* Di = Dinv + (size_t)l * 9;
+            double BDi[18];     // B_i * Dinv, 6x3 column-major
 #pragma unroll
-            for (int k = 0; k < 6; k++) if (lane == k) c = coef[k];
-            A.xp[(size_t)b * np6 + h1 * 6 + lane] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + lane] - c;
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 6; r++) BDi[c * 6 + r] = Bi[r] * Di[c * 3] + Bi[6 + r] * Di[c * 3 + 1] + Bi[12 + r] * Di[c * 3 + 2];
+            if (c0 == 0) {
+                const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
+#pragma unroll
+                for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
+            }
+            const int m1 = min(lms[l + 1], ne);
+            for (int e2 = lms[l]; e2 < m1; e2++) {
+                const int h2 = hid[edges[e2].pose] - c0;
+                if (h2 < 0 || h2 >= nblk) continue;   // fixed pose, upper triangle (h2 > h1) or another column chunk
+                const double* Bj = Hpl + (size_t)e2 * 18;
+                double* blk = Srow + h2 * SCH_LD;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int r = 0; r < 6; r++) atomicAdd(blk + c * 6 + r, -(BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c]));
+            }
         }
+        __syncthreads();
+        for (int t = tid; t < nblk * 36; t += 256) {
+            const int q = t / 36, k = t - q * 36, h2 = c0 + q;
+            double v = Srow[q * SCH_LD + k];
+            if (h2 == h1) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
+            const int c = k / 6, r = k - c * 6;
+            Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
+        }
+        __syncthreads();
     }
-    if (lane < 36) {
-        double v = 0;
 #pragma unroll
-        for (int k = 0; k < 36; k++) if (lane == k) v = acc[k];
-        if (diag) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + lane] + ((lane % 7 == 0) ? A.st[b].lambda : 0.0);   // _Hpp->add(_Hschur) + setLambda
-        const int c = lane / 6, r = lane - c * 6;
-        Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
+    for (int k = 0; k < 6; k++)
+        for (int off = 32; off > 0; off >>= 1) coef[k] += __shfl_xor(coef[k], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) coefw[wave * 6 + k] = coef[k];
     }
+    __syncthreads();
+    if (tid < 6) A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - (((coefw[tid] + coefw[6 + tid]) + coefw[12 + tid]) + coefw[18 + tid]);
 }
 
 #include "dense_chol.inc"
-static __global__ __launch_bounds__(256) void k_lm_chol(LmArgs A, const int32_t* nfreeArr) {
+#ifndef LM_CHOL_NT
+#define LM_CHOL_NT 512    // 8 waves per window: the factorisation is one workgroup per window, its trailing update a global-memory latency problem
+#endif
+template <int NB>
+static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const int32_t* nfreeArr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x;
     if (!A.st[b].needTrial) return;
     const int n = nfreeArr[b] * 6, ld = A.np6;
-    if (!wg_chol_solve(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem, A.panExt ? A.panExt + (size_t)b * ld * CH_LD : nullptr) &&
+    if (!wg_chol_solve<LM_CHOL_NT, NB>(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem, A.panExt ? A.panExt + (size_t)b * ld * (NB + 1) : nullptr) &&
         threadIdx.x == 0)
         A.st[b].ok = 0;
 }
+
+#ifdef CHOL_PROF
+extern "C" int lba_debug_chol_prof(unsigned long long* out8, int clear) {
+    static unsigned long long z[8];
+    if (hipDeviceSynchronize() != hipSuccess) return ORB_E_HIP;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cholprof), sizeof(z)) != hipSuccess) return ORB_E_HIP;
+    if (clear && hipMemcpyToSymbol(HIP_SYMBOL(g_cholprof), z, sizeof(z)) != hipSuccess) return ORB_E_HIP;
+    return ORB_OK;
+}
+#endif
 
 static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int capP7, int capL3) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -973,7 +842,6 @@ static __global__ void k_lm_end(LmArgs A, int batch) {
 
 static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-#define LM_PAIRS_PER_EDGE 8   // list capacity per window = 8 x cap_e (e1, e2) pairs; a window that needs more takes the table-probe kernel
 extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     if (!p || batch < 1) return 0;
     const size_t B = (size_t)batch, np6 = (size_t)p->cap_p * 6;
@@ -986,9 +854,6 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
-    s += lm_align(B * p->cap_l * p->cap_p * 4);                                       // observation table
-    s += lm_align(B * (size_t)p->cap_p * p->cap_p * 4) + lm_align(B * ((size_t)p->cap_p * p->cap_p + 1) * 4) + lm_align(B * 4);   // pair counts, offsets, overflow
-    s += lm_align(B * (size_t)p->cap_e * LM_PAIRS_PER_EDGE * 8);                      // co-visibility lists
     if (np6 > WG_CHOL_LDS_MAX_LD) s += lm_align(B * np6 * CH_LD * 8);                 // out-of-LDS Cholesky panel (only if ALL poses could be free)
     return s;
 }
@@ -1032,10 +897,6 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     A.part = (double*)take(B * nPart * 8); A.st = (LmState*)take(B * sizeof(LmState));
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
-    int* obs = (int*)take(B * P.cap_l * P.cap_p * 4);
-    A.pairCnt = (int32_t*)take(B * (size_t)P.cap_p * P.cap_p * 4); A.pairOff = (int32_t*)take(B * ((size_t)P.cap_p * P.cap_p + 1) * 4);
-    A.pairOvf = (int32_t*)take(B * 4);
-    A.pairCap = P.cap_e * LM_PAIRS_PER_EDGE; A.pairList = (int2*)take(B * (size_t)A.pairCap * 8);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
@@ -1047,24 +908,26 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         if (np6cap <= WG_CHOL_LDS_MAX_LD) return ORB_E_INVALID;   // cannot happen: np6 <= np6cap
         A.panExt = (double*)take(B * np6cap * CH_LD * 8);
     }
-    const size_t cholSmem = A.panExt ? wg_chol_smem_bytes_ext((int)np6) : wg_chol_smem_bytes((int)np6);
+    // panel width 32 while 6 x maxFree x 33 doubles fit LDS (<= 90 free key frames), else 16
+    const bool nb32 = !A.panExt && np6 <= WG_CHOL_NB32_MAX_LD;
+    const size_t cholSmem = A.panExt ? wg_chol_smem_bytes_ext_t<LM_CHOL_NT, CH_NB>((int)np6)
+                                     : nb32 ? wg_chol_smem_bytes_t<LM_CHOL_NT, 32>((int)np6) : wg_chol_smem_bytes_t<LM_CHOL_NT, CH_NB>((int)np6);
     if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)
     if (cholSmem > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k_lm_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
+        hipFuncSetAttribute(nb32 ? (const void*)k_lm_chol<32> : (const void*)k_lm_chol<CH_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
         return ORB_E_HIP;
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
     const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch);
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
-    if (hipMemsetAsync(obs, 0x7F, B * P.cap_l * P.cap_p * 4, st) != hipSuccess) return ORB_E_HIP;   // 0x7F7F7F7F > any edge index
-    hipLaunchKernelGGL(k_lm_obs, gE, dim3(256), 0, st, A, obs);
-    {   // co-visibility lists of the reduced camera system's blocks (structure only: once per call)
-        const dim3 gP((P.cap_p * P.cap_p + 3) / 4, batch);
-        hipLaunchKernelGGL(k_lm_pairs<false>, gP, dim3(256), 0, st, A, (const int*)obs);
-        hipLaunchKernelGGL(k_lm_pairs_scan, dim3(batch), dim3(256), 256 * 4, st, A);
-        hipLaunchKernelGGL(k_lm_pairs<true>, gP, dim3(256), 0, st, A, (const int*)obs);
-    }
+    // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
+    const int rowCap = std::min(maxFree, LM_SCHUR_ROWCAP);
+    const size_t schurSmem = lm_schur_smem_bytes(rowCap, P.cap_p);
+    if (schurSmem > 160 * 1024) return ORB_E_CAPACITY;   // cap_p beyond ~10 000 poses
+    if (schurSmem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_lm_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurSmem) != hipSuccess)
+        return ORB_E_HIP;
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
         // computeActiveErrors + activeRobustChi2, buildSystem
@@ -1084,9 +947,9 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_lists, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_blocks, dim3((P.cap_p * P.cap_p + 3) / 4, batch), dim3(256), 0, st, A, (const int*)obs);   // overflow windows only
-            hipLaunchKernelGGL(k_lm_chol, dim3(batch), dim3(256), cholSmem, st, A, (const int32_t*)nfree);
+            hipLaunchKernelGGL(k_lm_schur_rows, dim3(P.cap_p, batch), dim3(256), schurSmem, st, A, rowCap);
+            if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
+            else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);

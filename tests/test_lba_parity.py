@@ -218,6 +218,37 @@ def test_emu_lba_optimize_global_memory_panel():
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
+def test_emu_lba_optimize_schur_row_chunks():
+    """LM_SCHUR_ROWCAP=3: every row of the reduced camera system longer than three blocks is produced in column chunks (the path a map with more
+    than 384 free key frames takes); results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_SCHUR_ROWCAP=3",), tag="schurchunk")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+def test_emu_lba_optimize_narrow_panel():
+    """WG_CHOL_NB32_MAX_LD=12: the 16-column LDS panel (the width windows of 89 ... 176 free key frames take on the GPU) instead of the 32-column one."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MAX_LD=12",), tag="cholnb16")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+@pytest.mark.gpu
+def test_hip_lba_optimize_120_free_keyframes(hip_lib):
+    """720 unknowns: 16-column Cholesky panel in LDS (between the 32-column panel's 88 free key frames and the global-memory panel's 177+)."""
+    w, cams = synth_window(43, 130, 10, 2000, 8, "stereo")
+    assert (w["pose_hidx"] >= 0).sum() == 120
+    L = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=(0.0, 0.0))
+    stats = L.optimize(3)
+    op, ox, ost = O.lba_optimize(w, cams, (0.0, 0.0), 3)
+    assert stats[0, 0] == ost[0] and stats[0, 3] == ost[3]
+    assert np.abs(to_host(L.d["poses"])[0, :130] - op).max() < 1e-5
+
+
 @pytest.mark.gpu
 def test_hip_global_ba_more_than_180_free_keyframes(hip_lib):
     """Optimizer::BundleAdjustment over a map of 200 key frames (first one fixed): 199 free poses = 1194 unknowns, beyond the LDS panel."""
