@@ -570,10 +570,12 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
     for (int r = 0; r < 3; r++) db[r] = o[r] * bl[0] + o[3 + r] * bl[1] + o[6 + r] * bl[2];
 }
 
-// Schur complement, one workgroup per free pose (= block row h1 of the reduced camera system).  Edges are stored landmark-major, so the edges a
-// row's edge e1 pairs with are the contiguous run of its landmark: a lane takes one edge of the pose, forms B_i Dinv once (block_solver.hpp:404)
-// and walks the run; every partner edge of a free pose h2 <= h1 contributes  -B_i Dinv B_j^T  to block (h1, h2) (block_solver.hpp:398-432).
-// The row's blocks live in LDS ([h2][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
+// Schur complement, one workgroup per free pose h1.  Edges are stored landmark-major, so the edges a pose's edge e1 pairs with are the
+// contiguous run of its landmark: a lane takes one edge of the pose, forms B_i Dinv once (block_solver.hpp:404) and walks the run; every
+// partner edge of a free pose h2 contributes  -B_i Dinv B_j^T  to block (h1, h2) (block_solver.hpp:398-432).  Of the symmetric matrix
+// workgroup h1 produces the blocks at cyclic distance d = (h1 - h2) mod n <= n/2 — the lower-triangle ones directly, the others transposed —
+// so every workgroup of a window has the same amount of work (a triangular split would give the last pose n times the work of the first).
+// The workgroup's blocks live in LDS ([d][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
 // table, each B_i Dinv formed once per edge instead of once per block.  The four waves of the workgroup add into the same LDS row, so the
 // summation order of a block is not fixed from run to run (differences at the 1e-16 level; the bar on poses is 1e-4).  The diagonal block
 // also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
@@ -583,16 +585,27 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
 #define LM_SCHUR_ROWCAP 384   // blocks of a row held in LDS at once (384 x 37 doubles = 111 KiB); tests build with a tiny value to cover the chunking
 #endif
 static inline size_t lm_schur_smem_bytes(int rowCap, int cap_p) { return ((size_t)rowCap * SCH_LD + 24) * sizeof(double) + (size_t)cap_p * sizeof(int32_t); }
-static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowCap) {
+static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
     double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [4][6]
     int32_t* hid = (int32_t*)(coefw + 24);            // [cap_p] Hessian index of every pose of the window
     const lba_problem& P = A.P;
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef LM_SCHUR_NO_XCD
+    // All rows of a window run on ONE XCD, back to back (workgroup w is dispatched to XCD w % 8): the rows walk the same landmark-major edge
+    // array in the same direction, so a run of B_j blocks fetched for one row is still in that XCD's L2 when the window's other rows want it.
+    const int slot = (int)blockIdx.x >> 3;
+    const int b = (slot / P.cap_p) * 8 + ((int)blockIdx.x & 7);
+    if (b >= batch) return;
+    const int i1 = P.cap_p - 1 - slot % P.cap_p;      // late (long) rows first
+#else
+    const int b = (int)blockIdx.x / P.cap_p;
+    const int i1 = P.cap_p - 1 - (int)blockIdx.x % P.cap_p;
+    if (b >= batch) return;
+#endif
     if (!A.st[b].needTrial) return;
     const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
-    const int i1 = P.cap_p - 1 - (int)blockIdx.x;     // late (long) rows first
     if (i1 >= np) return;
     const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
     const int h1 = hidx[i1];
@@ -609,8 +622,11 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
     double coef[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) coef[k] = 0;
-    for (int c0 = 0; c0 <= h1; c0 += rowCap) {
-        const int nblk = min(rowCap, h1 + 1 - c0);
+    // partner h2 belongs to this workgroup iff d = (h1 - h2) mod n <= (n - 1) / 2, or (n even) d == n / 2 and h1 < h2
+    const int n = nfreeArr[b], dlo = (n - 1) >> 1, dtie = (n & 1) ? -1 : (n >> 1);
+    const int nslot = (n >> 1) + 1;                   // slots d = 0 .. n / 2
+    for (int c0 = 0; c0 < nslot; c0 += rowCap) {
+        const int nblk = min(rowCap, nslot - c0);
         for (int t = tid; t < nblk * SCH_LD; t += 256) Srow[t] = 0.0;
         __syncthreads();
         for (int k = s0 + tid; k < s1; k += 256) {
@@ -630,10 +646,15 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
             }
             const int m1 = min(lms[l + 1], ne);
             for (int e2 = lms[l]; e2 < m1; e2++) {
-                const int h2 = hid[edges[e2].pose] - c0;
-                if (h2 < 0 || h2 >= nblk) continue;   // fixed pose, upper triangle (h2 > h1) or another column chunk
+                const int h2 = hid[edges[e2].pose];
+                if (h2 < 0) continue;                 // fixed pose
+                int d = h1 - h2;
+                d += d < 0 ? n : 0;
+                if (d > dlo && !(d == dtie && h1 < h2)) continue;   // the block belongs to workgroup h2
+                d -= c0;
+                if (d < 0 || d >= nblk) continue;     // another column chunk
                 const double* Bj = Hpl + (size_t)e2 * 18;
-                double* blk = Srow + h2 * SCH_LD;
+                double* blk = Srow + d * SCH_LD;
 #pragma unroll
                 for (int c = 0; c < 6; c++)
 #pragma unroll
@@ -642,11 +663,14 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
         }
         __syncthreads();
         for (int t = tid; t < nblk * 36; t += 256) {
-            const int q = t / 36, k = t - q * 36, h2 = c0 + q;
+            const int q = t / 36, k = t - q * 36, d = c0 + q;
+            if (d == dtie && 2 * h1 >= n) continue;               // the tie slot belongs to the lower pose of the antipodal pair
+            const int h2 = h1 - d + (h1 < d ? n : 0);
             double v = Srow[q * SCH_LD + k];
-            if (h2 == h1) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
-            const int c = k / 6, r = k - c * 6;
-            Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // row block h1, column block h2 (lower triangle)
+            if (d == 0) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
+            const int c = k / 6, r = k - c * 6;                   // entry (r, c) of block (h1, h2)
+            if (h2 <= h1) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // lower triangle: row block h1, column block h2
+            else Hs[(size_t)(h1 * 6 + r) * np6 + h2 * 6 + c] = v;              // transposed into block (h2, h1)
         }
         __syncthreads();
     }
@@ -922,7 +946,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch);
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
-    const int rowCap = std::min(maxFree, LM_SCHUR_ROWCAP);
+    const int rowCap = std::min(maxFree / 2 + 1, LM_SCHUR_ROWCAP);
     const size_t schurSmem = lm_schur_smem_bytes(rowCap, P.cap_p);
     if (schurSmem > 160 * 1024) return ORB_E_CAPACITY;   // cap_p beyond ~10 000 poses
     if (schurSmem > 64 * 1024 &&
@@ -947,7 +971,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_rows, dim3(P.cap_p, batch), dim3(256), schurSmem, st, A, rowCap);
+            hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
             if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
