@@ -229,6 +229,7 @@ struct LbaArgs { lba_problem P; lba_system S; };
 static __global__ __launch_bounds__(LBA_CT) void k_lba_landmarks(LbaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
+    double* stage = (double*)orb_smem + LBA_CT * 13;    // [LBA_CT][18] the chunk's H_pl blocks: written per lane, stored to global memory coalesced
     const lba_problem& P = A.P;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nl = min(P.n_points[b], P.cap_l);
@@ -281,7 +282,7 @@ static __global__ __launch_bounds__(LBA_CT) void k_lba_landmarks(LbaArgs A) {
                 }
             }
             if (A.S.Hpl) {
-                double* hp = A.S.Hpl + eo * 18;
+                double* hp = stage + tid * 18;
                 const bool freePose = hidx[E.pose] >= 0;
 #pragma unroll
                 for (int c2 = 0; c2 < 3; c2++)
@@ -297,6 +298,12 @@ static __global__ __launch_bounds__(LBA_CT) void k_lba_landmarks(LbaArgs A) {
             }
         }
         __syncthreads();
+        if (A.S.Hpl) {        // the chunk's H_pl blocks are contiguous in global memory: 16 bytes per lane, consecutive lanes consecutive addresses
+            const int n2 = (min(eEnd, c0 + LBA_CT) - c0) * 9;
+            double2* dst = (double2*)(A.S.Hpl + ((size_t)b * P.cap_e + c0) * 18);
+            const double2* src = (const double2*)stage;
+            for (int i = tid; i < n2; i += LBA_CT) dst[i] = src[i];
+        }
         if (tid < LBA_LB) {   // H_ll += A^T wOmega A, b_l += A^T omega_r in edge order
             const int a0 = max(ls, c0), a1 = min(le, c0 + LBA_CT);
             for (int e = a0; e < a1; e++) {
@@ -417,7 +424,7 @@ extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_sy
     // blocks of fixed poses / rows >= n are defined as zero
     if (out->Hpp && hipMemsetAsync(out->Hpp, 0, (size_t)batch * prob->cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
     if (out->bp && hipMemsetAsync(out->bp, 0, (size_t)batch * prob->cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-    hipLaunchKernelGGL(k_lba_landmarks, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 13 * 8, st, A);
+    hipLaunchKernelGGL(k_lba_landmarks, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
     if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses, dim3(prob->cap_p, batch), dim3(64), 0, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
@@ -532,7 +539,7 @@ static __global__ void k_lm_begin(LmArgs A, int batch) {
     if (b >= batch) return;
     LmState& s = A.st[b];
     if (!s.active) { s.needTrial = 0; return; }
-    s.currentChi = s.tempChi;      // activeRobustChi2 of the state the system was built at
+    if (s.iter == 0) s.currentChi = s.tempChi;      // activeRobustChi2 of the state the system was built at (later iterations: see the caller)
     s.iniChi = s.currentChi;
     if (s.iter == 0) { s.lambda = 1e-50 * s.maxDiag; s.ni = 2; s.nBad = 0; }
     s.rho = 0; s.qmax = 0; s.needTrial = 1;
@@ -716,31 +723,67 @@ static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int ca
     else if (i < nPose + nPoint) { const size_t j = i - nPose; if (A.st[j / capL3].needTrial) A.pointsBak[j] = A.points[j]; }
 }
 
-static __global__ __launch_bounds__(256) void k_lm_backsub(LmArgs A) {
+// Workgroup = LBA_LB landmarks = one contiguous chunk of the landmark-major edge array: the chunk's H_pl blocks are loaded coalesced into LDS
+// (16 bytes per lane, consecutive lanes consecutive addresses — a lane reading its own 144-byte block touches 64 cache lines per
+// instruction), every edge thread forms B_i^T x_p from its LDS copy, the landmark threads subtract them in edge order.
+static __global__ __launch_bounds__(LBA_CT) void k_lm_backsub(LmArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    double* red = (double*)orb_smem;
+    double* stage = (double*)orb_smem;                // [LBA_CT][18]
+    double* tc = stage + LBA_CT * 18;                 // [LBA_CT][3]  B_i^T x_p per edge of the chunk
+    double* red = tc + LBA_CT * 3;                    // [LBA_LB]
     const lba_problem& P = A.P;
-    const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const LmState st = A.st[b];
     double sc = 0;
-    if (st.needTrial && st.ok) {
-        const int nl = min(P.n_points[b], P.cap_l), ne = min(P.n_edges[b], P.cap_e);
-        if (l < nl) {
-            const double* bl = A.S.bl + ((size_t)b * P.cap_l + l) * 3;
-            double cl[3] = {bl[0], bl[1], bl[2]};
-            const int m0 = P.lm_start[(size_t)b * (P.cap_l + 1) + l], m1 = min(P.lm_start[(size_t)b * (P.cap_l + 1) + l + 1], ne);
-            for (int m = m0; m < m1; m++) {
-                const int h = P.pose_hidx[(size_t)b * P.cap_p + P.edges[(size_t)b * P.cap_e + m].pose];
-                if (h < 0) continue;
-                const double* Bi = A.S.Hpl + ((size_t)b * P.cap_e + m) * 18;
-                const double* xp = A.xp + (size_t)b * A.np6 + h * 6;
+    const int nl = min(P.n_points[b], P.cap_l), ne = min(P.n_edges[b], P.cap_e);
+    const int l0 = blockIdx.x * LBA_LB;
+    if (st.needTrial && st.ok && l0 < nl) {           // uniform
+        const int l1 = min(l0 + LBA_LB, nl);
+        const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+        const int eBegin = min(lms[l0], ne), eEnd = min(lms[l1], ne);
+        const int myL = l0 + tid;
+        int ls = 0, le = 0;
+        double cl[3] = {0, 0, 0};
+        const bool mine = tid < LBA_LB && myL < l1;
+        const double* bl = A.S.bl + ((size_t)b * P.cap_l + myL) * 3;
+        if (mine) { ls = min(lms[myL], ne); le = min(lms[myL + 1], ne); cl[0] = bl[0]; cl[1] = bl[1]; cl[2] = bl[2]; }
+        for (int c0 = eBegin; c0 < eEnd; c0 += LBA_CT) {
+            const int cnt = min(eEnd, c0 + LBA_CT) - c0;
+            const double2* src = (const double2*)(A.S.Hpl + ((size_t)b * P.cap_e + c0) * 18);
+            double2* dst = (double2*)stage;
+            int h = -1;
+            if (tid < cnt) h = P.pose_hidx[(size_t)b * P.cap_p + P.edges[(size_t)b * P.cap_e + c0 + tid].pose];   // the chain pose -> index -> x_p runs under the copy
+            for (int i = tid; i < cnt * 9; i += LBA_CT) dst[i] = src[i];
+            double xp[6] = {0, 0, 0, 0, 0, 0};
+            if (h >= 0) {
+                const double* x = A.xp + (size_t)b * A.np6 + h * 6;
 #pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int r = 0; r < 6; r++) cl[c] -= Bi[c * 6 + r] * xp[r];
+                for (int r = 0; r < 6; r++) xp[r] = x[r];
             }
-            const double* Di = A.Dinv + ((size_t)b * P.cap_l + l) * 9;
-            double* X = A.points + ((size_t)b * P.cap_l + l) * 3;
+            __syncthreads();
+            if (tid < cnt) {
+                const double* Bi = stage + tid * 18;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double t = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) t += Bi[c * 6 + r] * xp[r];
+                    tc[tid * 3 + c] = t;      // a fixed pose's block is zero (k_lba_landmarks) and its x_p is taken as zero
+                }
+            }
+            __syncthreads();
+            if (mine) {
+                const int a0 = max(ls, c0), a1 = min(le, c0 + LBA_CT);
+                for (int e = a0; e < a1; e++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) cl[c] -= tc[(e - c0) * 3 + c];
+                }
+            }
+            __syncthreads();
+        }
+        if (mine) {
+            const double* Di = A.Dinv + ((size_t)b * P.cap_l + myL) * 9;
+            double* X = A.points + ((size_t)b * P.cap_l + myL) * 3;
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 const double xl = Di[r] * cl[0] + Di[3 + r] * cl[1] + Di[6 + r] * cl[2];
@@ -749,10 +792,13 @@ static __global__ __launch_bounds__(256) void k_lm_backsub(LmArgs A) {
             }
         }
     }
-    red[threadIdx.x] = sc;
+    if (tid < LBA_LB) red[tid] = sc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) A.part[(size_t)b * A.nPart + blockIdx.x] = red[0];
+    if (tid == 0) {
+        double t = 0;
+        for (int i = 0; i < LBA_LB; i++) t += red[i];
+        A.part[(size_t)b * A.nPart + blockIdx.x] = t;
+    }
 }
 
 static __device__ __forceinline__ Quat quat_from_R(const double m[9]) {   // Eigen Quaterniond(Matrix3d), row-major in
@@ -869,7 +915,7 @@ static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     if (!p || batch < 1) return 0;
     const size_t B = (size_t)batch, np6 = (size_t)p->cap_p * 6;
-    const size_t nPart = (size_t)std::max((p->cap_e + 255) / 256, (p->cap_l + 255) / 256) + 1;
+    const size_t nPart = (size_t)std::max((p->cap_e + 255) / 256, (p->cap_l + LBA_LB - 1) / LBA_LB) + 1;
     size_t s = 0;
     s += lm_align(B * p->cap_p * 36 * 8) + lm_align(B * p->cap_p * 6 * 8);            // Hpp, bp
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Hll, bl
@@ -906,7 +952,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     }
     const int maxFree = std::max(1, *std::max_element(nf.begin(), nf.end()));
     const size_t B = (size_t)batch, np6 = (size_t)maxFree * 6, np6cap = (size_t)P.cap_p * 6;
-    const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + 255) / 256) + 1;
+    const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + LBA_LB - 1) / LBA_LB) + 1;
     char* w = (char*)d_workspace;
     auto take = [&](size_t bytes) { char* p = w; w += lm_align(bytes); return p; };
     LmArgs A;
@@ -943,7 +989,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
-    const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch);
+    const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch), gLB((P.cap_l + LBA_LB - 1) / LBA_LB, batch);
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
     const int rowCap = std::min(maxFree / 2 + 1, LM_SCHUR_ROWCAP);
@@ -954,15 +1000,18 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         return ORB_E_HIP;
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
-        // computeActiveErrors + activeRobustChi2, buildSystem
-        hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-        hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        // computeActiveErrors + activeRobustChi2, buildSystem.  After the first iteration the state is the one the last lambda trial left —
+        // accepted (its chi2 became currentChi) or restored (currentChi unchanged) — so its activeRobustChi2 is currentChi, bit for bit.
+        if (it == 0) {
+            hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        }
         {
             LbaArgs L;
             L.P = P; L.S = A.S;
             if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 13 * 8, st, L);
+            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, L);
             hipLaunchKernelGGL(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
         }
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
@@ -974,9 +1023,9 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
             if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
-            hipLaunchKernelGGL(k_lm_backsub, gL, dim3(256), 256 * 8, st, A);
+            hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(LBA_CT), (LBA_CT * 21 + LBA_LB) * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gL.x, 1, nPart - 1);
+            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gLB.x, 1, nPart - 1);
             hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
             hipLaunchKernelGGL(k_lm_decide, dim3(gB), dim3(64), 0, st, A, batch);
