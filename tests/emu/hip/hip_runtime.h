@@ -248,6 +248,22 @@ template <class T> inline T __shfl_up(T v, int d, int width = 64) {
     int l = emu::lane();
     return __shfl(v, (l - d >= 0 ? l - d : l), 64);
 }
+// v_mfma_f64_16x16x4_f64: D = A B + C on one wave.  Lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]; result register i = D[(l >> 4) + 4 i][l & 15].
+typedef double emu_v4f64 __attribute__((vector_size(32)));
+inline emu_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_v4f64 c, int, int, int) {
+    const int l = emu::lane(), n = l & 15, rg = l >> 4;
+    uint64_t ua, ub;
+    memcpy(&ua, &a, 8); memcpy(&ub, &b, 8);
+    double bk[4];
+    for (int k = 0; k < 4; k++) { const uint64_t u = emu::exchange(ub, n + 16 * k); memcpy(&bk[k], &u, 8); }
+    for (int i = 0; i < 4; i++) {
+        const int row = rg + 4 * i;
+        double acc = c[i];
+        for (int k = 0; k < 4; k++) { const uint64_t u = emu::exchange(ua, row + 16 * k); double ak; memcpy(&ak, &u, 8); acc += ak * bk[k]; }
+        c[i] = acc;
+    }
+    return c;
+}
 inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l, 64); }   // lane index must be wave-uniform
 // v_mov_b32_dpp as __builtin_amdgcn_update_dpp: the controls the kernels use — row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
 // A lane whose row / bank is masked out, or whose source lane lies outside its row, keeps `old` (bound_ctrl = false) or gets 0 (true).
