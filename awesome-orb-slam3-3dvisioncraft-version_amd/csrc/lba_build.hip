@@ -468,6 +468,8 @@ struct LmArgs {
     double* panExt;                         // [np6][CH_LD] per window: Cholesky panel of systems too large for LDS, else nullptr
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
+    int4* rowMeta;                          // [batch][cap_e] per entry of the pose-major edge lists: (edge, landmark, first / end edge of the landmark's run)
+    int32_t* edgeH;                         // [batch][cap_e + 8] Hessian index of each edge's pose (-1: fixed), landmark-major like the edges
 };
 
 static __global__ void k_lm_init(LmArgs A, int batch) {
@@ -587,16 +589,33 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
 // summation order of a block is not fixed from run to run (differences at the 1e-16 level; the bar on poses is 1e-4).  The diagonal block
 // also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
 // Rows longer than `rowCap` blocks (LDS) are produced in column chunks, walking the pose's edges once per chunk.
+// Structure the Schur rows walk, built once per lba_optimize call (constant over iterations and lambda trials): the walk then needs no
+// dependent index loads (pose list -> edge -> landmark -> run bounds; run entry -> edge -> pose -> Hessian index).
+static __global__ __launch_bounds__(256) void k_lm_rowmeta(LmArgs A) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const int ne = min(P.n_edges[b], P.cap_e), np = min(P.n_poses[b], P.cap_p);
+    if (k >= P.cap_e + 8) return;
+    int h = -1;
+    if (k < ne) { const int p = P.edges[(size_t)b * P.cap_e + k].pose; if (p >= 0 && p < np) h = P.pose_hidx[(size_t)b * P.cap_p + p]; }
+    A.edgeH[(size_t)b * (P.cap_e + 8) + k] = h;
+    if (k < ne) {
+        const int e = P.pose_edges[(size_t)b * P.cap_e + k];
+        const int l = P.edges[(size_t)b * P.cap_e + e].point;
+        const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+        A.rowMeta[(size_t)b * P.cap_e + k] = make_int4(e, l, lms[l], min(lms[l + 1], ne));
+    }
+}
+
 #define SCH_LD 37
 #ifndef LM_SCHUR_ROWCAP
 #define LM_SCHUR_ROWCAP 384   // blocks of a row held in LDS at once (384 x 37 doubles = 111 KiB); tests build with a tiny value to cover the chunking
 #endif
-static inline size_t lm_schur_smem_bytes(int rowCap, int cap_p) { return ((size_t)rowCap * SCH_LD + 24) * sizeof(double) + (size_t)cap_p * sizeof(int32_t); }
+static inline size_t lm_schur_smem_bytes(int rowCap) { return ((size_t)rowCap * SCH_LD + 24) * sizeof(double); }
 static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
     double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [4][6]
-    int32_t* hid = (int32_t*)(coefw + 24);            // [cap_p] Hessian index of every pose of the window
     const lba_problem& P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef LM_SCHUR_NO_XCD
@@ -617,10 +636,8 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
     const int32_t* hidx = P.pose_hidx + (size_t)b * P.cap_p;
     const int h1 = hidx[i1];
     if (h1 < 0) return;
-    for (int t = tid; t < P.cap_p; t += 256) hid[t] = t < np ? hidx[t] : -1;
-    const lba_edge* edges = P.edges + (size_t)b * P.cap_e;
-    const int32_t* pe = P.pose_edges + (size_t)b * P.cap_e;
-    const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
+    const int4* meta = A.rowMeta + (size_t)b * P.cap_e;
+    const int32_t* eh = A.edgeH + (size_t)b * (P.cap_e + 8);
     const double* Hpl = A.S.Hpl + (size_t)b * P.cap_e * 18;
     const double* Dinv = A.Dinv + (size_t)b * P.cap_l * 9;
     const int s0 = P.pose_start[(size_t)b * (P.cap_p + 1) + i1], s1 = min(P.pose_start[(size_t)b * (P.cap_p + 1) + i1 + 1], ne);
@@ -637,9 +654,14 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
         for (int t = tid; t < nblk * SCH_LD; t += 256) Srow[t] = 0.0;
         __syncthreads();
         for (int k = s0 + tid; k < s1; k += 256) {
-            const int e1 = pe[k];
-            const int l = edges[e1].point;
-            const double* Bi = Hpl + (size_t)e1 * 18;
+            const int4 mt = meta[k];
+            const int e1 = mt.x, l = mt.y;
+            double Bi[18];
+            {
+                const double* Bg = Hpl + (size_t)e1 * 18;
+#pragma unroll
+                for (int q = 0; q < 18; q++) Bi[q] = Bg[q];
+            }
             const double* Di = Dinv + (size_t)l * 9;
             double BDi[18];     // B_i * Dinv, 6x3 column-major
 #pragma unroll
@@ -651,21 +673,33 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
 #pragma unroll
                 for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
             }
-            const int m1 = min(lms[l + 1], ne);
-            for (int e2 = lms[l]; e2 < m1; e2++) {
-                const int h2 = hid[edges[e2].pose];
-                if (h2 < 0) continue;                 // fixed pose
+            for (int e4 = mt.z; e4 < mt.w; e4 += 4) {
+                int hh[4];
+                __builtin_memcpy(hh, eh + e4, 16);    // four run entries per load (the array is padded past its end)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                const int e2 = e4 + j, h2 = hh[j];
+                if (e2 >= mt.w || h2 < 0) continue;   // end of the run, fixed pose
                 int d = h1 - h2;
                 d += d < 0 ? n : 0;
                 if (d > dlo && !(d == dtie && h1 < h2)) continue;   // the block belongs to workgroup h2
                 d -= c0;
                 if (d < 0 || d >= nblk) continue;     // another column chunk
-                const double* Bj = Hpl + (size_t)e2 * 18;
+                double Bj[18];
+                if (e2 == e1) {                       // the edge with itself: B_i is in registers
+#pragma unroll
+                    for (int q = 0; q < 18; q++) Bj[q] = Bi[q];
+                } else {
+                    const double* Bg = Hpl + (size_t)e2 * 18;
+#pragma unroll
+                    for (int q = 0; q < 18; q++) Bj[q] = Bg[q];
+                }
                 double* blk = Srow + d * SCH_LD;
 #pragma unroll
                 for (int c = 0; c < 6; c++)
 #pragma unroll
                     for (int r = 0; r < 6; r++) atomicAdd(blk + c * 6 + r, -(BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c]));
+                }
             }
         }
         __syncthreads();
@@ -924,6 +958,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
+    s += lm_align(B * p->cap_e * 16) + lm_align(B * ((size_t)p->cap_e + 8) * 4);     // Schur row metadata
     if (np6 > WG_CHOL_LDS_MAX_LD) s += lm_align(B * np6 * CH_LD * 8);                 // out-of-LDS Cholesky panel (only if ALL poses could be free)
     return s;
 }
@@ -967,6 +1002,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     A.part = (double*)take(B * nPart * 8); A.st = (LmState*)take(B * sizeof(LmState));
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
+    A.rowMeta = (int4*)take(B * P.cap_e * 16); A.edgeH = (int32_t*)take(B * ((size_t)P.cap_e + 8) * 4);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
@@ -993,8 +1029,8 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
     const int rowCap = std::min(maxFree / 2 + 1, LM_SCHUR_ROWCAP);
-    const size_t schurSmem = lm_schur_smem_bytes(rowCap, P.cap_p);
-    if (schurSmem > 160 * 1024) return ORB_E_CAPACITY;   // cap_p beyond ~10 000 poses
+    const size_t schurSmem = lm_schur_smem_bytes(rowCap);
+    hipLaunchKernelGGL(k_lm_rowmeta, dim3((P.cap_e + 8 + 255) / 256, batch), dim3(256), 0, st, A);
     if (schurSmem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)k_lm_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurSmem) != hipSuccess)
         return ORB_E_HIP;
