@@ -646,6 +646,11 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
     double coef[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) coef[k] = 0;
+    // every edge pairs with itself (a third of all pairs): those products — the bulk of the diagonal block, symmetric in sum — stay in
+    // registers (lower triangle) and are reduced once per workgroup; LDS atomics take the pairs of different edges only
+    double dacc[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) dacc[k] = 0;
     // partner h2 belongs to this workgroup iff d = (h1 - h2) mod n <= (n - 1) / 2, or (n even) d == n / 2 and h1 < h2
     const int n = nfreeArr[b], dlo = (n - 1) >> 1, dtie = (n & 1) ? -1 : (n >> 1);
     const int nslot = (n >> 1) + 1;                   // slots d = 0 .. n / 2
@@ -672,6 +677,11 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
                 const double* db = A.db + ((size_t)b * P.cap_l + l) * 3;
 #pragma unroll
                 for (int r = 0; r < 6; r++) coef[r] += Bi[r] * db[0] + Bi[6 + r] * db[1] + Bi[12 + r] * db[2];
+                int t = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int r = c; r < 6; r++) dacc[t++] -= BDi[r] * Bi[c] + BDi[6 + r] * Bi[6 + c] + BDi[12 + r] * Bi[12 + c];
             }
             for (int e4 = mt.z; e4 < mt.w; e4 += 4) {
                 int hh[4];
@@ -679,27 +689,31 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                 const int e2 = e4 + j, h2 = hh[j];
-                if (e2 >= mt.w || h2 < 0) continue;   // end of the run, fixed pose
+                if (e2 >= mt.w || h2 < 0 || e2 == e1) continue;   // end of the run, fixed pose, the edge itself (registers, above)
                 int d = h1 - h2;
                 d += d < 0 ? n : 0;
                 if (d > dlo && !(d == dtie && h1 < h2)) continue;   // the block belongs to workgroup h2
                 d -= c0;
                 if (d < 0 || d >= nblk) continue;     // another column chunk
-                double Bj[18];
-                if (e2 == e1) {                       // the edge with itself: B_i is in registers
-#pragma unroll
-                    for (int q = 0; q < 18; q++) Bj[q] = Bi[q];
-                } else {
-                    const double* Bg = Hpl + (size_t)e2 * 18;
-#pragma unroll
-                    for (int q = 0; q < 18; q++) Bj[q] = Bg[q];
-                }
+                const double* Bj = Hpl + (size_t)e2 * 18;
                 double* blk = Srow + d * SCH_LD;
 #pragma unroll
                 for (int c = 0; c < 6; c++)
 #pragma unroll
                     for (int r = 0; r < 6; r++) atomicAdd(blk + c * 6 + r, -(BDi[r] * Bj[c] + BDi[6 + r] * Bj[6 + c] + BDi[12 + r] * Bj[12 + c]));
                 }
+            }
+        }
+        if (c0 == 0) {   // the self-pair sums: wave butterfly, then one lane per wave adds them to slot 0 (both triangles)
+#pragma unroll
+            for (int t = 0; t < 21; t++)
+                for (int off = 32; off > 0; off >>= 1) dacc[t] += __shfl_xor(dacc[t], off);
+            if (lane == 0) {
+                int t = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+#pragma unroll
+                    for (int r = c; r < 6; r++) { atomicAdd(Srow + c * 6 + r, dacc[t]); if (r != c) atomicAdd(Srow + r * 6 + c, dacc[t]); t++; }
             }
         }
         __syncthreads();
