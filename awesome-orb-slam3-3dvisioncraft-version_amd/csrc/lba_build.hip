@@ -774,34 +774,48 @@ static __global__ void k_lm_backup(LmArgs A, size_t nPose, size_t nPoint, int ca
 // Workgroup = LBA_LB landmarks = one contiguous chunk of the landmark-major edge array: the chunk's H_pl blocks are loaded coalesced into LDS
 // (16 bytes per lane, consecutive lanes consecutive addresses — a lane reading its own 144-byte block touches 64 cache lines per
 // instruction), every edge thread forms B_i^T x_p from its LDS copy, the landmark threads subtract them in edge order.
-static __global__ __launch_bounds__(LBA_CT) void k_lm_backsub(LmArgs A) {
+#ifndef BS_CT
+#define BS_CT 128     // edges per chunk = threads per workgroup of the back-substitution
+#endif
+#define BS_LB (BS_CT / 8)   // landmarks per workgroup
+static __global__ __launch_bounds__(BS_CT) void k_lm_backsub(LmArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    double* stage = (double*)orb_smem;                // [LBA_CT][18]
-    double* tc = stage + LBA_CT * 18;                 // [LBA_CT][3]  B_i^T x_p per edge of the chunk
-    double* red = tc + LBA_CT * 3;                    // [LBA_LB]
+    double* stage = (double*)orb_smem;                // [BS_CT][18]
+    double* tc = stage + BS_CT * 18;                 // [BS_CT][3]  B_i^T x_p per edge of the chunk
+    double* red = tc + BS_CT * 3;                    // [BS_LB]
     const lba_problem& P = A.P;
     const int b = blockIdx.y, tid = threadIdx.x;
     const LmState st = A.st[b];
     double sc = 0;
     const int nl = min(P.n_points[b], P.cap_l), ne = min(P.n_edges[b], P.cap_e);
-    const int l0 = blockIdx.x * LBA_LB;
+    const int l0 = blockIdx.x * BS_LB;
     if (st.needTrial && st.ok && l0 < nl) {           // uniform
-        const int l1 = min(l0 + LBA_LB, nl);
+        const int l1 = min(l0 + BS_LB, nl);
         const int32_t* lms = P.lm_start + (size_t)b * (P.cap_l + 1);
         const int eBegin = min(lms[l0], ne), eEnd = min(lms[l1], ne);
         const int myL = l0 + tid;
         int ls = 0, le = 0;
         double cl[3] = {0, 0, 0};
-        const bool mine = tid < LBA_LB && myL < l1;
-        const double* bl = A.S.bl + ((size_t)b * P.cap_l + myL) * 3;
-        if (mine) { ls = min(lms[myL], ne); le = min(lms[myL + 1], ne); cl[0] = bl[0]; cl[1] = bl[1]; cl[2] = bl[2]; }
-        for (int c0 = eBegin; c0 < eEnd; c0 += LBA_CT) {
-            const int cnt = min(eEnd, c0 + LBA_CT) - c0;
+        const bool mine = tid < BS_LB && myL < l1;
+        // everything a landmark thread needs at the end is loaded up front: a workgroup's life is a chain of dependent global loads
+        double blv[3] = {0, 0, 0}, Dv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Xv[3] = {0, 0, 0};
+        double* X = A.points + ((size_t)b * P.cap_l + myL) * 3;
+        if (mine) {
+            ls = min(lms[myL], ne); le = min(lms[myL + 1], ne);
+            const double* bl = A.S.bl + ((size_t)b * P.cap_l + myL) * 3;
+            const double* Di = A.Dinv + ((size_t)b * P.cap_l + myL) * 9;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { blv[r] = bl[r]; Xv[r] = X[r]; cl[r] = blv[r]; }
+#pragma unroll
+            for (int r = 0; r < 9; r++) Dv[r] = Di[r];
+        }
+        for (int c0 = eBegin; c0 < eEnd; c0 += BS_CT) {
+            const int cnt = min(eEnd, c0 + BS_CT) - c0;
             const double2* src = (const double2*)(A.S.Hpl + ((size_t)b * P.cap_e + c0) * 18);
             double2* dst = (double2*)stage;
             int h = -1;
-            if (tid < cnt) h = P.pose_hidx[(size_t)b * P.cap_p + P.edges[(size_t)b * P.cap_e + c0 + tid].pose];   // the chain pose -> index -> x_p runs under the copy
-            for (int i = tid; i < cnt * 9; i += LBA_CT) dst[i] = src[i];
+            if (tid < cnt) h = A.edgeH[(size_t)b * (P.cap_e + 8) + c0 + tid];   // Hessian index of the edge's pose (k_lm_rowmeta); index -> x_p runs under the copy
+            for (int i = tid; i < cnt * 9; i += BS_CT) dst[i] = src[i];
             double xp[6] = {0, 0, 0, 0, 0, 0};
             if (h >= 0) {
                 const double* x = A.xp + (size_t)b * A.np6 + h * 6;
@@ -821,7 +835,7 @@ static __global__ __launch_bounds__(LBA_CT) void k_lm_backsub(LmArgs A) {
             }
             __syncthreads();
             if (mine) {
-                const int a0 = max(ls, c0), a1 = min(le, c0 + LBA_CT);
+                const int a0 = max(ls, c0), a1 = min(le, c0 + BS_CT);
                 for (int e = a0; e < a1; e++) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) cl[c] -= tc[(e - c0) * 3 + c];
@@ -830,21 +844,19 @@ static __global__ __launch_bounds__(LBA_CT) void k_lm_backsub(LmArgs A) {
             __syncthreads();
         }
         if (mine) {
-            const double* Di = A.Dinv + ((size_t)b * P.cap_l + myL) * 9;
-            double* X = A.points + ((size_t)b * P.cap_l + myL) * 3;
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                const double xl = Di[r] * cl[0] + Di[3 + r] * cl[1] + Di[6 + r] * cl[2];
-                sc += xl * (st.lambda * xl + bl[r]);      // computeScale, landmark part
-                X[r] += xl;                               // VertexSBAPointXYZ::oplusImpl
+                const double xl = Dv[r] * cl[0] + Dv[3 + r] * cl[1] + Dv[6 + r] * cl[2];
+                sc += xl * (st.lambda * xl + blv[r]);     // computeScale, landmark part
+                X[r] = Xv[r] + xl;                        // VertexSBAPointXYZ::oplusImpl
             }
         }
     }
-    if (tid < LBA_LB) red[tid] = sc;
+    if (tid < BS_LB) red[tid] = sc;
     __syncthreads();
     if (tid == 0) {
         double t = 0;
-        for (int i = 0; i < LBA_LB; i++) t += red[i];
+        for (int i = 0; i < BS_LB; i++) t += red[i];
         A.part[(size_t)b * A.nPart + blockIdx.x] = t;
     }
 }
@@ -963,7 +975,7 @@ static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     if (!p || batch < 1) return 0;
     const size_t B = (size_t)batch, np6 = (size_t)p->cap_p * 6;
-    const size_t nPart = (size_t)std::max((p->cap_e + 255) / 256, (p->cap_l + LBA_LB - 1) / LBA_LB) + 1;
+    const size_t nPart = (size_t)std::max((p->cap_e + 255) / 256, (p->cap_l + BS_LB - 1) / BS_LB) + 1;
     size_t s = 0;
     s += lm_align(B * p->cap_p * 36 * 8) + lm_align(B * p->cap_p * 6 * 8);            // Hpp, bp
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Hll, bl
@@ -1001,7 +1013,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     }
     const int maxFree = std::max(1, *std::max_element(nf.begin(), nf.end()));
     const size_t B = (size_t)batch, np6 = (size_t)maxFree * 6, np6cap = (size_t)P.cap_p * 6;
-    const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + LBA_LB - 1) / LBA_LB) + 1;
+    const int nPart = std::max((P.cap_e + 255) / 256, (P.cap_l + BS_LB - 1) / BS_LB) + 1;
     char* w = (char*)d_workspace;
     auto take = [&](size_t bytes) { char* p = w; w += lm_align(bytes); return p; };
     LmArgs A;
@@ -1039,7 +1051,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
-    const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch), gLB((P.cap_l + LBA_LB - 1) / LBA_LB, batch);
+    const dim3 gE((P.cap_e + 255) / 256, batch), gL((P.cap_l + 255) / 256, batch), gLB((P.cap_l + BS_LB - 1) / BS_LB, batch);
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
     const int rowCap = std::min(maxFree / 2 + 1, LM_SCHUR_ROWCAP);
@@ -1073,7 +1085,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
             if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
-            hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(LBA_CT), (LBA_CT * 21 + LBA_LB) * 8, st, A);
+            hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gLB.x, 1, nPart - 1);
             hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
