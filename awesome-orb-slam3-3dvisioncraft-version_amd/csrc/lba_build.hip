@@ -224,9 +224,14 @@ struct LbaArgs { lba_problem P; lba_system S; };
 // err, chi2, rho, depth) and parks its H_ll / b_l contribution in LDS; one thread per landmark then adds its edges' contributions in
 // edge order — the same summation order as a serial walk, so H_ll / b_l are bit-identical to the thread-per-landmark formulation, but
 // the expensive part runs with 8x more parallelism (a landmark has ~8 observations) and coalesced edge loads.
-#define LBA_LB 32      // landmarks per workgroup
+#ifndef LBA_CT
 #define LBA_CT 256     // edges per chunk = threads per workgroup
-static __global__ __launch_bounds__(LBA_CT) void k_lba_landmarks(LbaArgs A) {
+#endif
+#define LBA_LB (LBA_CT / 8)   // landmarks per workgroup
+#ifndef LBA_MINW
+#define LBA_MINW 1     // minimum waves per SIMD the register allocation must allow
+#endif
+static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
     double* stage = (double*)orb_smem + LBA_CT * 13;    // [LBA_CT][18] the chunk's H_pl blocks: written per lane, stored to global memory coalesced
