@@ -104,11 +104,51 @@ static __device__ __forceinline__ void cam_project_jac(const lba_camera& c, cons
 }
 
 // computeError (+ linearizeOplus when WITH_JAC) + chi2 + Huber for one edge
-template <bool WITH_JAC>
+// MP: every edge of the batch is an EdgeSE3ProjectXYZ on a pinhole camera (the monocular / pinhole configurations; lba_optimize checks the
+// batch once per call).  Same expressions in the same order as the generic path takes for such an edge — identical results — but the
+// third residual row, the fisheye model and the right-camera transform are gone at compile time: the linearisation kernels need a third
+// fewer registers and multiply no structural zeros.
+template <bool WITH_JAC, bool MP = false>
 static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const SE3& T, const double X[3], const lba_camera& cam,
                                                      double huberMono, double huberStereo, Lin& L) {
     L.e[2] = 0;
-    if (E.kind == LBA_EDGE_STEREO) {
+    if constexpr (MP) {
+        L.D = 2;
+        double proj[2], xl[3];
+        se3_map(T, X, xl);
+        proj[0] = cam.p[0] * xl[0] / xl[2] + cam.p[2];      // Pinhole.cpp:43-49
+        proj[1] = cam.p[1] * xl[1] / xl[2] + cam.p[3];
+        L.depth = xl[2];
+        L.e[0] = (double)E.obs[0] - proj[0];
+        L.e[1] = (double)E.obs[1] - proj[1];
+        if (WITH_JAC) {
+#pragma unroll
+            for (int i = 6; i < 9; i++) L.A[i] = 0.0;
+#pragma unroll
+            for (int i = 12; i < 18; i++) L.B[i] = 0.0;
+            double Rm[9], Jp[6];
+            quat_to_R(T.r, Rm);
+            Jp[0] = cam.p[0] / xl[2]; Jp[1] = 0; Jp[2] = -cam.p[0] * xl[0] / (xl[2] * xl[2]);   // Pinhole.cpp:89-100
+            Jp[3] = 0; Jp[4] = cam.p[1] / xl[2]; Jp[5] = -cam.p[1] * xl[1] / (xl[2] * xl[2]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) Jp[i] = -Jp[i];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) L.A[r * 3 + c] = Jp[r * 3] * Rm[c] + Jp[r * 3 + 1] * Rm[3 + c] + Jp[r * 3 + 2] * Rm[6 + c];
+            const double x = xl[0], y = xl[1], z = xl[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const double m0 = Jp[r * 3], m1 = Jp[r * 3 + 1], m2 = Jp[r * 3 + 2];
+                L.B[r * 6 + 0] = m0 * 0 + m1 * (-z) + m2 * y;
+                L.B[r * 6 + 1] = m0 * z + m1 * 0 + m2 * (-x);
+                L.B[r * 6 + 2] = m0 * (-y) + m1 * x + m2 * 0;
+                L.B[r * 6 + 3] = m0 * 1 + m1 * 0 + m2 * 0;
+                L.B[r * 6 + 4] = m0 * 0 + m1 * 1 + m2 * 0;
+                L.B[r * 6 + 5] = m0 * 0 + m1 * 0 + m2 * 1;
+            }
+        }
+    } else if (E.kind == LBA_EDGE_STEREO) {
         L.D = 3;
         double xt[3];
         se3_map(T, X, xt);
@@ -202,7 +242,7 @@ static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const S
 #pragma unroll
     for (int i = 0; i < 3; i++) chi2 += L.e[i] * s * L.e[i];   // e[2] == 0 for 2-D edges
     L.chi2 = chi2;
-    const double delta = E.kind == LBA_EDGE_STEREO ? huberStereo : huberMono;
+    const double delta = (!MP && E.kind == LBA_EDGE_STEREO) ? huberStereo : huberMono;
     L.rho0 = chi2; L.rho1 = 1.;
     if (delta > 0) {   // RobustKernelHuber::robustify, robust_kernel_impl.cpp:78-91
         const double dsqr = delta * delta;
@@ -225,12 +265,13 @@ struct LbaArgs { lba_problem P; lba_system S; };
 // edge order — the same summation order as a serial walk, so H_ll / b_l are bit-identical to the thread-per-landmark formulation, but
 // the expensive part runs with 8x more parallelism (a landmark has ~8 observations) and coalesced edge loads.
 #ifndef LBA_CT
-#define LBA_CT 256     // edges per chunk = threads per workgroup
+#define LBA_CT 128     // edges per chunk = threads per workgroup (32 KB of LDS: 5 workgroups per CU)
 #endif
 #define LBA_LB (LBA_CT / 8)   // landmarks per workgroup
 #ifndef LBA_MINW
 #define LBA_MINW 1     // minimum waves per SIMD the register allocation must allow
 #endif
+template <bool MP>
 static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
@@ -261,7 +302,7 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
             const double* Xp = points + (size_t)E.point * 3;
             const double X[3] = {Xp[0], Xp[1], Xp[2]};
             Lin L;
-            edge_linearize<true>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+            edge_linearize<true, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
             const size_t eo = (size_t)b * P.cap_e + ei;
             if (A.S.err) { A.S.err[eo * 3] = L.e[0]; A.S.err[eo * 3 + 1] = L.e[1]; A.S.err[eo * 3 + 2] = L.e[2]; }
             if (A.S.chi2) A.S.chi2[eo] = L.chi2;
@@ -327,6 +368,7 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
     }
 }
 
+template <bool MP>
 static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
     const lba_problem& P = A.P;
     const int b = blockIdx.y, pi = blockIdx.x, lane = threadIdx.x;
@@ -348,7 +390,7 @@ static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
         const double* Xp = points + (size_t)E.point * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
         Lin L;
-        edge_linearize<true>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+        edge_linearize<true, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
         const double s = (double)E.inv_sigma2, w = L.rho1 * s;
         double om[3];
         for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
@@ -429,8 +471,8 @@ extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_sy
     // blocks of fixed poses / rows >= n are defined as zero
     if (out->Hpp && hipMemsetAsync(out->Hpp, 0, (size_t)batch * prob->cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
     if (out->bp && hipMemsetAsync(out->bp, 0, (size_t)batch * prob->cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-    hipLaunchKernelGGL(k_lba_landmarks, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
-    if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses, dim3(prob->cap_p, batch), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_lba_landmarks<false>, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
+    if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<false>, dim3(prob->cap_p, batch), dim3(64), 0, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
 
@@ -477,6 +519,15 @@ struct LmArgs {
     int32_t* edgeH;                         // [batch][cap_e + 8] Hessian index of each edge's pose (-1: fixed), landmark-major like the edges
 };
 
+// *flag = 1 unless every edge of the batch is an EdgeSE3ProjectXYZ on a pinhole camera (the <MP> kernels, see edge_linearize)
+static __global__ __launch_bounds__(256) void k_lm_kinds(LmArgs A, int* flag) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= min(P.n_edges[b], P.cap_e)) return;
+    const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
+    if (E.kind != LBA_EDGE_MONO || P.cameras[E.cam].model != LBA_CAM_PINHOLE) *flag = 1;
+}
+
 static __global__ void k_lm_init(LmArgs A, int batch) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
@@ -498,6 +549,7 @@ static __global__ __launch_bounds__(64) void k_lm_sum_partials(LmArgs A, int bat
 }
 
 // computeActiveErrors + per-block partial sums of rho[0] (blocks of 256 edges)
+template <bool MP>
 static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* red = (double*)orb_smem;
@@ -511,7 +563,7 @@ static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
         const double* Xp = A.points + ((size_t)b * P.cap_l + E.point) * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
         Lin L;
-        edge_linearize<false>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+        edge_linearize<false, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
         r0 = L.rho0;
     }
     red[threadIdx.x] = r0;
@@ -1037,7 +1089,13 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
+    int otherKinds = 0;
+    if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
+    hipLaunchKernelGGL(k_lm_kinds, dim3((P.cap_e + 255) / 256, batch), dim3(256), 0, st, A, A.flag);
+    if (hipMemcpyAsync(&otherKinds, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
+    const bool monoPin = !otherKinds;   // monocular pinhole batch: the specialised linearisation / error kernels
+#define LM_LAUNCH_MP(kern, ...) do { if (monoPin) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
     // Cholesky panel: LDS while 6 x maxFree rows x 17 doubles fit (<= 180 free key frames — every LocalBundleAdjustment window); beyond that
     // (GlobalBundleAdjustemnt of a large map) the panel lives in the workspace and LDS holds the right-hand side only
     A.panExt = nullptr;
@@ -1070,7 +1128,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         // computeActiveErrors + activeRobustChi2, buildSystem.  After the first iteration the state is the one the last lambda trial left —
         // accepted (its chi2 became currentChi) or restored (currentChi unchanged) — so its activeRobustChi2 is currentChi, bit for bit.
         if (it == 0) {
-            hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+            LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
         }
         {
@@ -1078,8 +1136,8 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             L.P = P; L.S = A.S;
             if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-            hipLaunchKernelGGL(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, L);
-            hipLaunchKernelGGL(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
+            LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, L);
+            LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
         }
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
@@ -1093,7 +1151,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gLB.x, 1, nPart - 1);
-            hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+            LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
             hipLaunchKernelGGL(k_lm_decide, dim3(gB), dim3(64), 0, st, A, batch);
             hipLaunchKernelGGL(k_lm_restore, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);       // pop
@@ -1114,9 +1172,10 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         std::vector<LmState> on = hs;
         for (auto& s : on) s.active = 1;
         if (hipMemcpyAsync(A.st, on.data(), B * sizeof(LmState), hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
-        hipLaunchKernelGGL(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
+        LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
         std::vector<LmState> fin(B);
+#undef LM_LAUNCH_MP
         if (hipMemcpyAsync(fin.data(), A.st, B * sizeof(LmState), hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
         if (h_stats)
