@@ -462,7 +462,7 @@ static int lba_check(const lba_problem* p, int batch, const lba_system* out) {
     return ORB_OK;
 }
 
-extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, void* stream) {
+static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_system* out, bool monoPin, void* stream) {
     int rc = lba_check(prob, batch, out);
     if (rc != ORB_OK) return rc;
     LbaArgs A;
@@ -471,9 +471,24 @@ extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_sy
     // blocks of fixed poses / rows >= n are defined as zero
     if (out->Hpp && hipMemsetAsync(out->Hpp, 0, (size_t)batch * prob->cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
     if (out->bp && hipMemsetAsync(out->bp, 0, (size_t)batch * prob->cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-    hipLaunchKernelGGL(k_lba_landmarks<false>, dim3((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
-    if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<false>, dim3(prob->cap_p, batch), dim3(64), 0, st, A);
+    const dim3 gL((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), gP(prob->cap_p, batch);
+    if (monoPin) {
+        hipLaunchKernelGGL(k_lba_landmarks<true>, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
+        if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<true>, gP, dim3(64), 0, st, A);
+    } else {
+        hipLaunchKernelGGL(k_lba_landmarks<false>, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
+        if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<false>, gP, dim3(64), 0, st, A);
+    }
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, void* stream) {
+    return lba_build_system_impl(prob, batch, out, false, stream);
+}
+
+extern "C" int lba_build_system_hint(const lba_problem* prob, int batch, const lba_system* out, unsigned hints, void* stream) {
+    if (hints & ~(unsigned)LBA_HINT_MONO_PINHOLE) return ORB_E_INVALID;
+    return lba_build_system_impl(prob, batch, out, (hints & LBA_HINT_MONO_PINHOLE) != 0, stream);
 }
 
 extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream) {

@@ -37,6 +37,8 @@ def bind(lib):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(LbaProblem), C.c_int, C.POINTER(LbaSystem), C.c_void_p]
+    lib.lba_build_system_hint.restype = C.c_int
+    lib.lba_build_system_hint.argtypes = [C.POINTER(LbaProblem), C.c_int, C.POINTER(LbaSystem), C.c_uint, C.c_void_p]
     lib.lba_lm_workspace_bytes.restype = C.c_size_t
     lib.lba_lm_workspace_bytes.argtypes = [C.POINTER(LbaProblem), C.c_int]
     lib.lba_optimize.restype = C.c_int
@@ -84,6 +86,8 @@ class LbaWindows:
         self.d = {k: to_dev(v.view(np.uint8).reshape(B, -1) if v.dtype == EDGE_DTYPE else v) for k, v in h.items()}
         self.d["cameras"] = to_dev(np.ascontiguousarray(cameras).view(np.uint8))
         self.n_cameras = len(cameras)
+        cam_models = np.asarray(cameras["model"])
+        self.mono_pinhole = all((w["edges"]["kind"] == EDGE_MONO).all() and (cam_models[w["edges"]["cam"]] == CAM_PINHOLE).all() for w in windows)
         self.huber = huber
         like = self.d["poses"]
         f8 = np.float64
@@ -103,7 +107,8 @@ class LbaWindows:
 
     def build_system(self, outputs=("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth")):
         P, S = self._structs(outputs)
-        rc = self._L.lba_build_system(C.byref(P), self.B, C.byref(S), _stream(self.d["poses"]))
+        # LBA_HINT_MONO_PINHOLE when the host-side edge arrays say so (the caller flattened the graph: it knows the edge kinds)
+        rc = self._L.lba_build_system_hint(C.byref(P), self.B, C.byref(S), 1 if self.mono_pinhole else 0, _stream(self.d["poses"]))
         if rc != 0:
             raise OrbHipError(rc, "lba_build_system failed")
         return self.out

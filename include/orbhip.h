@@ -448,6 +448,12 @@ typedef struct lba_system {     /* outputs; any pointer may be NULL to skip that
 
 /* BlockSolver::buildSystem (block_solver.hpp:502-560): linearizeOplus + constructQuadraticForm over all active edges. */
 int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, void* stream);
+/* The same with what the caller knows about the graph it flattened.  LBA_HINT_MONO_PINHOLE: EVERY edge of the batch is an EdgeSE3ProjectXYZ
+ * (LBA_EDGE_MONO) on a pinhole camera — a monocular pinhole map (Optimizer.cc:2095-2127 took the `mono` branch for every observation).  The
+ * kernels specialised for it give identical results with a third fewer registers; a hint that does not hold gives wrong blocks (lba_optimize
+ * checks the edges itself, once per call, and needs no hint).  Unknown hint bits: ORB_E_INVALID. */
+#define LBA_HINT_MONO_PINHOLE 1u
+int lba_build_system_hint(const lba_problem* prob, int batch, const lba_system* out, unsigned hints, void* stream);
 /* SparseOptimizer::computeActiveErrors (sparse_optimizer.cpp:61-75): err / chi2 / rho / depth / robust_chi2_sum only. */
 int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream);
 
