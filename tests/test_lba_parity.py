@@ -161,14 +161,21 @@ def test_hip_lba_optimize_matches_oracle(hip_lib, kinds, its):
     check_optimize(hip_lib, "hip", kinds, its)
 
 
-def test_emu_lba_optimize_schur_fallback_path():
-    """LM_PAIRS_PER_EDGE=1 makes every window's co-visibility lists overflow their workspace slab, so the Schur complement runs through the
-    table-probe kernel (the fallback of k_lm_schur_lists); the optimisation must come out the same."""
-    import ctypes
-    import build_emu
-    from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_PAIRS_PER_EDGE=1",), tag="pairs1")))
-    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+@pytest.mark.gpu
+def test_hip_lba_optimize_c5_size(hip_lib):
+    """optimize() at BASELINE configs[4]'s size: 100 key frames (80 free), 20 000 landmarks, ~160 000 monocular edges — 480 unknowns in the
+    reduced camera system, the 32-column Cholesky panel, the monocular-pinhole kernels — and a 60-KF / 6 000-landmark stereo window (the
+    generic kernels) in the same batch class.  Same iteration / lambda-trial counts as the oracle's g2o restatement, poses within 1e-6."""
+    for kind, args in (("mono", (100, 20, 20000)), ("stereo", (60, 10, 6000))):
+        w, cams = synth_window(77, args[0], args[1], args[2], 8, kind)
+        L = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=HUBER)
+        assert L.mono_pinhole == (kind == "mono")
+        stats = L.optimize(2)
+        op, ox, ost = O.lba_optimize(w, cams, HUBER, 2)
+        assert stats[0, 0] == ost[0] and stats[0, 3] == ost[3], (stats[0], ost)
+        assert abs(stats[0, 1] - ost[1]) < 1e-6 * ost[1]
+        assert np.abs(to_host(L.d["poses"])[0, :args[0]] - op).max() < 1e-6
+        assert np.abs(to_host(L.d["points"])[0, :args[2]] - ox).max() < 1e-5
 
 
 def test_emu_global_ba_parameterisation(emu_lib):
