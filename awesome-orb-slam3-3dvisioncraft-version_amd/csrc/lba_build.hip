@@ -651,16 +651,6 @@ static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
     for (int r = 0; r < 3; r++) db[r] = o[r] * bl[0] + o[3 + r] * bl[1] + o[6 + r] * bl[2];
 }
 
-// Schur complement, one workgroup per free pose h1.  Edges are stored landmark-major, so the edges a pose's edge e1 pairs with are the
-// contiguous run of its landmark: a lane takes one edge of the pose, forms B_i Dinv once (block_solver.hpp:404) and walks the run; every
-// partner edge of a free pose h2 contributes  -B_i Dinv B_j^T  to block (h1, h2) (block_solver.hpp:398-432).  Of the symmetric matrix
-// workgroup h1 produces the blocks at cyclic distance d = (h1 - h2) mod n <= n/2 — the lower-triangle ones directly, the others transposed —
-// so every workgroup of a window has the same amount of work (a triangular split would give the last pose n times the work of the first).
-// The workgroup's blocks live in LDS ([d][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
-// table, each B_i Dinv formed once per edge instead of once per block.  The four waves of the workgroup add into the same LDS row, so the
-// summation order of a block is not fixed from run to run (differences at the 1e-16 level; the bar on poses is 1e-4).  The diagonal block
-// also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
-// Rows longer than `rowCap` blocks (LDS) are produced in column chunks, walking the pose's edges once per chunk.
 // Structure the Schur rows walk, built once per lba_optimize call (constant over iterations and lambda trials): the walk then needs no
 // dependent index loads (pose list -> edge -> landmark -> run bounds; run entry -> edge -> pose -> Hessian index).
 static __global__ __launch_bounds__(256) void k_lm_rowmeta(LmArgs A) {
@@ -679,15 +669,32 @@ static __global__ __launch_bounds__(256) void k_lm_rowmeta(LmArgs A) {
     }
 }
 
+// Schur complement, one workgroup per free pose h1.  Edges are stored landmark-major, so the edges a pose's edge e1 pairs with are the
+// contiguous run of its landmark: a lane takes one edge of the pose, forms B_i Dinv once (block_solver.hpp:404) and walks the run; every
+// partner edge of a free pose h2 contributes  -B_i Dinv B_j^T  to block (h1, h2) (block_solver.hpp:398-432).  Of the symmetric matrix
+// workgroup h1 produces the blocks at cyclic distance d = (h1 - h2) mod n <= n/2 — the lower-triangle ones directly, the others transposed —
+// so every workgroup of a window has the same amount of work (a triangular split would give the last pose n times the work of the first).
+// The workgroup's blocks live in LDS ([d][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
+// table, each B_i Dinv formed once per edge instead of once per block.  The workgroup is ONE wave (SCH_NT = 64): a block receives its
+// products in the wave's program order, and runs are bit-identical (tools/dbg_lm_determinism.py: 8 windows x 4 runs on MI355X; with several
+// waves per row the cross-wave order of the atomics, and with it the last bits of the sums, varied from run to run).  The diagonal block
+// also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
+// Rows longer than `rowCap` blocks (LDS) are produced in column chunks, walking the pose's edges once per chunk.
 #define SCH_LD 37
 #ifndef LM_SCHUR_ROWCAP
 #define LM_SCHUR_ROWCAP 384   // blocks of a row held in LDS at once (384 x 37 doubles = 111 KiB); tests build with a tiny value to cover the chunking
 #endif
-static inline size_t lm_schur_smem_bytes(int rowCap) { return ((size_t)rowCap * SCH_LD + 24) * sizeof(double); }
-static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
+#ifndef SCH_NT
+#define SCH_NT 64    // threads per row workgroup: one wave (128 / 256: 0.3 / 2 % slower on MI355X; with one wave a block receives its products in program order)
+#endif
+static inline size_t lm_schur_smem_bytes(int rowCap) { return ((size_t)rowCap * SCH_LD + (SCH_NT / 64) * 6) * sizeof(double); }
+static __global__ __launch_bounds__(SCH_NT) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
+#ifdef LM_SCHUR_FMA
+#pragma clang fp contract(fast)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
-    double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [4][6]
+    double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [SCH_NT / 64][6]
     const lba_problem& P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef LM_SCHUR_NO_XCD
@@ -728,9 +735,9 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
     const int nslot = (n >> 1) + 1;                   // slots d = 0 .. n / 2
     for (int c0 = 0; c0 < nslot; c0 += rowCap) {
         const int nblk = min(rowCap, nslot - c0);
-        for (int t = tid; t < nblk * SCH_LD; t += 256) Srow[t] = 0.0;
+        for (int t = tid; t < nblk * SCH_LD; t += SCH_NT) Srow[t] = 0.0;
         __syncthreads();
-        for (int k = s0 + tid; k < s1; k += 256) {
+        for (int k = s0 + tid; k < s1; k += SCH_NT) {
             const int4 mt = meta[k];
             const int e1 = mt.x, l = mt.y;
             double Bi[18];
@@ -789,7 +796,7 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
             }
         }
         __syncthreads();
-        for (int t = tid; t < nblk * 36; t += 256) {
+        for (int t = tid; t < nblk * 36; t += SCH_NT) {
             const int q = t / 36, k = t - q * 36, d = c0 + q;
             if (d == dtie && 2 * h1 >= n) continue;               // the tie slot belongs to the lower pose of the antipodal pair
             const int h2 = h1 - d + (h1 < d ? n : 0);
@@ -809,7 +816,11 @@ static __global__ __launch_bounds__(256) void k_lm_schur_rows(LmArgs A, int rowC
         for (int k = 0; k < 6; k++) coefw[wave * 6 + k] = coef[k];
     }
     __syncthreads();
-    if (tid < 6) A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - (((coefw[tid] + coefw[6 + tid]) + coefw[12 + tid]) + coefw[18 + tid]);
+    if (tid < 6) {
+        double c = 0;
+        for (int w = 0; w < SCH_NT / 64; w++) c += coefw[w * 6 + tid];
+        A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - c;
+    }
 }
 
 #include "dense_chol.inc"
@@ -1160,7 +1171,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+            hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(SCH_NT), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
             if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
