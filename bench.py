@@ -681,6 +681,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the PMC passes committed with this build (profiles/pmc_latest.json): used only if
         # that file was produced from exactly these kernel sources and this workload, otherwise null (never a stale number)
         traffic, traffic_note = None, "no PMC pass for this build/workload"
+        sq_info = {}
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if pm.get("source_sha") != source_sha():
@@ -689,6 +690,8 @@ def main():
                 traffic_note = "profiles/pmc_latest.json (%s) ran another workload" % pm.get("tag")
             else:
                 traffic = pm["kernels"][names[dom]]["traffic_corrected"]
+                sq_info = {k: pm["kernels"][names[dom]][k] for k in ("valu_insts_per_wave", "waves_per_simd", "simd_cycles_per_valu_inst", "lds_conflict_frac")
+                           if k in pm["kernels"][names[dom]]}
                 traffic_note = "profiles/%s_pmc.csv: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes" % pm.get("tag")
         except Exception:   # noqa: BLE001
             pass
@@ -711,6 +714,9 @@ def main():
                        "backend": (dist.get_backend() if world > 1 else None)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
+                         # SQ counters of the same profile: the kernel's occupancy and issue rate (4 SIMD cycles per wave-level VALU instruction = the
+                         # SIMDs issue VALU back to back: the kernel is instruction-issue bound and its HBM fraction follows from its instruction count)
+                         "occupancy_and_issue": sq_info or None,
                          "algorithmic_bytes_per_launch": pk[dom] * B, "kernel_ms": round(kern[dom], 4),
                          "whole_step_algorithmic_bytes_per_frame": whole_ext + whole_match,
                          "whole_step_frac": round((whole_ext + whole_match) * fps / world / 1e9 / HBM_PEAK_GBS, 5),

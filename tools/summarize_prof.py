@@ -46,7 +46,6 @@ sys.path.insert(0, root)
 import bench  # noqa: E402
 out["source_sha"] = bench.source_sha()
 out["workload"] = [752, 480, 1000, 512]
-json.dump(out, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 
 # SQ passes (tools/gpu_profile.sh sq1 / sq2): per-kernel means per dispatch + the derived figures the roofline discussion uses
 sq = {}
@@ -78,7 +77,14 @@ if sq:
                        g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else float("nan"),
                        wc * 4.0 / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0) if g("GRBM_GUI_ACTIVE") else float("nan")]
             f.write("%s,%.1f,%s,%s\n" % (k, dur.get(k, float("nan")), ",".join("%.6g" % g(n) for n in cols), ",".join("%.4f" % x for x in derived)))
+            # the same figures next to the HBM bytes, for bench.py's roofline object: resident waves per SIMD and the SIMD cycles one wave-level
+            # VALU instruction costs (duration x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU; 4 = a SIMD issuing one wave64 VALU instruction back to back)
+            if k in out["kernels"] and k in dur and g("SQ_INSTS_VALU") == g("SQ_INSTS_VALU"):
+                out["kernels"][k].update({"valu_insts_per_wave": round(derived[0], 1), "waves_per_simd": round(derived[5], 2),
+                                          "simd_cycles_per_valu_inst": round(dur[k] * 1e-6 * 1024 * 2.4e9 / g("SQ_INSTS_VALU"), 2),
+                                          "lds_conflict_frac": round(derived[4], 3)})
     print(open(os.path.join(dst, tag + "_sq.csv")).read())
+json.dump(out, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
     import shutil
