@@ -150,15 +150,19 @@ def check_optimize(lib, backend, kinds, iterations, huber=HUBER, pose_tol=1e-7):
         assert np.abs(poses[b, :npz][w["pose_hidx"] < 0] - w["poses"][w["pose_hidx"] < 0]).max() == 0    # fixed KFs untouched
 
 
-@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono",), 10)], ids=["mono+stereo_5it", "mono_10it"])
+@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono",), 10), (("body", "mixed"), 4)], ids=["mono+stereo_5it", "mono_10it", "body+mixed_4it"])
 def test_emu_lba_optimize_matches_oracle(emu_lib, kinds, its):
-    check_optimize(emu_lib, "emu", kinds, its)
+    # fisheye / right-camera edges: KannalaBrandt8::project rounds theta and psi to float (KannalaBrandt8.cpp:52-66), a step function of the pose —
+    # two double-precision solvers that differ in the last bits can land on different float steps: 2e-7 on these windows (the same figure with the
+    # round-1 Schur / Cholesky kernels), bar 1e-4
+    check_optimize(emu_lib, "emu", kinds, its, pose_tol=1e-6 if "body" in kinds else 1e-7)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono", "mono", "stereo"), 10)], ids=["mono+stereo_5it", "3win_10it"])
+@pytest.mark.parametrize("kinds,its", [(("mono", "stereo"), 5), (("mono", "mono", "stereo"), 10), (("body", "kb8", "mixed"), 5)],
+                         ids=["mono+stereo_5it", "3win_10it", "body+kb8+mixed_5it"])
 def test_hip_lba_optimize_matches_oracle(hip_lib, kinds, its):
-    check_optimize(hip_lib, "hip", kinds, its)
+    check_optimize(hip_lib, "hip", kinds, its, pose_tol=1e-6 if "body" in kinds else 1e-7)
 
 
 @pytest.mark.gpu
