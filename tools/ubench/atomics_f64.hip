@@ -27,15 +27,18 @@ __global__ __launch_bounds__(256) void k_glob_lane(double* S, int nblk, int iter
         for (int k = 0; k < 36; k++) atomicAdd(R + (size_t)b * 36 + k, 1.0);
     }
 }
-__global__ __launch_bounds__(256) void k_lds(double* out, int nblk, int iters) {
+__global__ __launch_bounds__(256) void k_lds(double* out, int nblk, int iters, int activeOf = 1) {
     extern __shared__ double L[];
     for (int i = threadIdx.x; i < nblk * 37; i += 256) L[i] = 0;
     __syncthreads();
     unsigned s = blockIdx.x * 977u + threadIdx.x * 131u + 7u;
     for (int i = 0; i < iters; i++) {
-        const unsigned b = rng(s) % (unsigned)nblk;
+        const unsigned rr = rng(s);
+        const unsigned b = rr % (unsigned)nblk;
+        if ((rr >> 12) % (unsigned)activeOf == 0) {      // 1 of `activeOf` lanes takes part (divergent, like a filtered partner loop)
 #pragma unroll
-        for (int k = 0; k < 36; k++) atomicAdd(&L[b * 37 + k], 1.0);
+            for (int k = 0; k < 36; k++) atomicAdd(&L[b * 37 + k], 1.0);
+        }
     }
     __syncthreads();
     double t = 0;
@@ -61,11 +64,18 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&ms, a, b);
         printf("global lane-per-block adds, %7d WGs/region: %.3f ms -> %.2f G block-adds/s\n", wgPerRegion, ms, grid * 256.0 * iters / ms / 1e6);
     }
+    for (int act : {2, 4, 8}) {
+        const int grid = 2048, iters = 500, nb = 41;
+        hipFuncSetAttribute((const void*)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 400 * 37 * 8);
+        hipEventRecord(a); hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), 400 * 37 * 8, 0, S, nb, iters, act); hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("LDS lane-per-block adds into %d blocks, 1 of %d lanes active: %.3f ms -> %.2f G wave-instructions/s, %.1f G lane-atomics/s\n", nb, act, ms, grid * 4.0 * iters * 36 / ms / 1e6, grid * 256.0 * iters * 36 / act / ms / 1e6);
+    }
     for (int nb : {400, 80}) {
         const int grid = 2048, iters = 500;
         hipFuncSetAttribute((const void*)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 400 * 37 * 8);
-        hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), 400 * 37 * 8, 0, S, nb, 5);
-        hipEventRecord(a); hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), 400 * 37 * 8, 0, S, nb, iters); hipEventRecord(b); hipEventSynchronize(b);
+        hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), 400 * 37 * 8, 0, S, nb, 5, 1);
+        hipEventRecord(a); hipLaunchKernelGGL(k_lds, dim3(grid), dim3(256), 400 * 37 * 8, 0, S, nb, iters, 1); hipEventRecord(b); hipEventSynchronize(b);
         hipEventElapsedTime(&ms, a, b);
         printf("LDS lane-per-block adds into %d blocks: %.3f ms -> %.2f G block-adds/s (%.1f G lane-atomics/s)\n", nb, ms, grid * 256.0 * iters / ms / 1e6, grid * 256.0 * iters * 36 / ms / 1e6);
     }
