@@ -182,9 +182,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3, 4, 5),
                     help="2: the match kernels of step i run on a second HIP stream next to the extraction of step i+1 (double-buffered extractor outputs); "
-                         "3: additionally two extractor handles alternate on two streams (the extractions of consecutive steps overlap); 1: everything in one stream")
+                         "3: additionally two extractor handles alternate on two streams (the extractions of consecutive steps overlap); 4 / 5: three / four "
+                         "handles in rotation (measured on MI355X: 2.33-2.36 ms per step against 2.35 with 3 — nothing left to overlap); 1: everything in one stream")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
@@ -291,17 +292,18 @@ def main():
     # event pair per buffer set orders producer and consumer.  All K steps complete inside the timed region (device-wide synchronize).
     sA = torch.cuda.current_stream(dev)
     sB = torch.cuda.Stream(dev) if args.streams >= 2 else sA
-    sX = [sA, torch.cuda.Stream(dev) if args.streams == 3 else sA]          # extraction stream of buffer set k
-    exs = [ex, orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B) if args.streams == 3 else ex]
-    outs = [out, None]
-    evA = [torch.cuda.Event(), torch.cuda.Event()]
-    evB = [torch.cuda.Event(), torch.cuda.Event()]
-    evB_set = [False, False]
+    nbuf = 1 if args.streams == 1 else max(2, args.streams - 1)             # buffer sets in rotation (>= 3 streams: one extractor handle + stream each)
+    sX = [sA] + [torch.cuda.Stream(dev) if args.streams >= 3 else sA for _ in range(nbuf - 1)]          # extraction stream of buffer set k
+    exs = [ex] + [orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B) if args.streams >= 3 else ex for _ in range(nbuf - 1)]
+    outs = [out] + [None] * (nbuf - 1)
+    evA = [torch.cuda.Event() for _ in range(nbuf)]
+    evB = [torch.cuda.Event() for _ in range(nbuf)]
+    evB_set = [False] * nbuf
     step_no = [0]
 
     def step():
         nonlocal out, res, un, gbuf
-        k = step_no[0] & 1 if args.streams >= 2 else 0
+        k = step_no[0] % nbuf
         step_no[0] += 1
         with torch.cuda.stream(sX[k]):
             if args.streams >= 2 and evB_set[k]:
@@ -330,7 +332,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     torch.cuda.synchronize()
-    step_no[0] = 0; evB_set[0] = evB_set[1] = False
+    step_no[0] = 0; evB_set[:] = [False] * nbuf
     counts = out[2].cpu().numpy()
     nm = res[2].cpu().numpy()
     extra["step"] = {"mean_matches_per_frame": float(nm.mean()), "queries_per_frame": float(nq.mean()), "mean_keypoints": float(counts[:, 0].mean()),
