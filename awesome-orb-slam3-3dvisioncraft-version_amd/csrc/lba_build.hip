@@ -1229,7 +1229,10 @@ extern "C" int lba_optimize_stopflag(const lba_problem* prob, int batch, int ite
 // ============================================================================================================
 struct PLin { int D; double e[3], J[18], chi2; };   // J: 3 x 6 row-major, third row zero for 2-D edges
 
-template <bool WITH_JAC>
+// PH: every edge of the batch is an EdgeSE3ProjectXYZOnlyPose or an EdgeStereoSE3ProjectXYZOnlyPose on a pinhole camera (the monocular, stereo
+// and RGB-D pinhole configurations): the fisheye model and the right-camera (ToBody) edge are gone at compile time; same expressions in the
+// same order as the generic path takes for such edges.
+template <bool WITH_JAC, bool PH = false>
 static __device__ __forceinline__ void pose_linearize(const pose_edge& E, const SE3& T, const lba_camera& cam, PLin& L) {
     const double Xw[3] = {(double)E.xw[0], (double)E.xw[1], (double)E.xw[2]};
     L.e[2] = 0;
@@ -1254,9 +1257,12 @@ static __device__ __forceinline__ void pose_linearize(const pose_edge& E, const 
         double xl[3], xp[3], proj[2];
         se3_map(T, Xw, xl);
         Quat ql = {cam.trl_q[0], cam.trl_q[1], cam.trl_q[2], cam.trl_q[3]};
-        if (E.kind == LBA_EDGE_MONO) {
+        if (PH || E.kind == LBA_EDGE_MONO) {
             xp[0] = xl[0]; xp[1] = xl[1]; xp[2] = xl[2];
-            cam_project(cam, xp, proj);
+            if constexpr (PH) {
+                proj[0] = cam.p[0] * xp[0] / xp[2] + cam.p[2];   // Pinhole.cpp:43-49
+                proj[1] = cam.p[1] * xp[1] / xp[2] + cam.p[3];
+            } else cam_project(cam, xp, proj);
         } else {
             SE3 Trl;
             Trl.r = ql; Trl.t[0] = cam.trl_t[0]; Trl.t[1] = cam.trl_t[1]; Trl.t[2] = cam.trl_t[2];
@@ -1268,10 +1274,13 @@ static __device__ __forceinline__ void pose_linearize(const pose_edge& E, const 
         L.e[0] = (double)E.obs[0] - proj[0]; L.e[1] = (double)E.obs[1] - proj[1];
         if (WITH_JAC) {
             double Jp[6], M[6];
-            cam_project_jac(cam, xp, Jp);
+            if constexpr (PH) {
+                Jp[0] = cam.p[0] / xp[2]; Jp[1] = 0; Jp[2] = -cam.p[0] * xp[0] / (xp[2] * xp[2]);   // Pinhole.cpp:89-100
+                Jp[3] = 0; Jp[4] = cam.p[1] / xp[2]; Jp[5] = -cam.p[1] * xp[1] / (xp[2] * xp[2]);
+            } else cam_project_jac(cam, xp, Jp);
 #pragma unroll
             for (int i = 0; i < 6; i++) Jp[i] = -Jp[i];
-            if (E.kind == LBA_EDGE_MONO) {
+            if (PH || E.kind == LBA_EDGE_MONO) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) M[i] = Jp[i];
             } else {
@@ -1382,6 +1391,7 @@ static __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratc
     }
 }
 
+template <bool PH>
 static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1410,7 +1420,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
                     if (level[e] != 0) continue;
                     const pose_edge E = edges[e];
                     PLin L;
-                    pose_linearize<false>(E, Tc, A.cams[E.cam], L);
+                    pose_linearize<false, PH>(E, Tc, A.cams[E.cam], L);
                     chiLast[e] = L.chi2;
                     double r0 = L.chi2;
                     if (robust) { const double d = E.kind == LBA_EDGE_STEREO ? deltaStereo : deltaMono, dsq = d * d; if (!(L.chi2 <= dsq)) r0 = 2 * sqrt(L.chi2) * d - dsq; }
@@ -1432,7 +1442,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
                         if (level[e] != 0) continue;
                         const pose_edge E = edges[e];
                         PLin L;
-                        pose_linearize<true>(E, T, A.cams[E.cam], L);
+                        pose_linearize<true, PH>(E, T, A.cams[E.cam], L);
                         double rho1 = 1.0;
                         if (robust) { const double d = E.kind == LBA_EDGE_STEREO ? deltaStereo : deltaMono; if (!(L.chi2 <= d * d)) rho1 = d / sqrt(L.chi2); }
                         const double s = (double)E.inv_sigma2;
@@ -1509,7 +1519,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
             const float th2 = 5.991f, th3 = 7.815f;
             for (int e = tid; e < ne; e += POSE_T) {
                 const pose_edge E = edges[e];
-                if (outl[e]) { PLin L; pose_linearize<false>(E, T, A.cams[E.cam], L); chiLast[e] = L.chi2; }
+                if (outl[e]) { PLin L; pose_linearize<false, PH>(E, T, A.cams[E.cam], L); chiLast[e] = L.chi2; }
                 const float chi2 = (float)chiLast[e];
                 if (chi2 > (E.kind == LBA_EDGE_STEREO ? th3 : th2)) { outl[e] = 1; level[e] = 1; nb[0] += 1.0; }
                 else { outl[e] = 0; level[e] = 0; }
@@ -1528,14 +1538,29 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
     }
 }
 
-extern "C" int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
-                             const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
-                             void* stream) {
+static int pose_optimize_impl(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                              const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                              bool pinhole, void* stream) {
     if (!d_poses_in || !d_edges || !d_n_edges || !d_cameras || !d_poses_out || !d_outlier || !d_n_good || cap_e < 1 || batch < 1 || n_cameras < 1)
         return ORB_E_INVALID;
     const size_t smem = (size_t)4 * 28 * 8 + (size_t)cap_e * 8 + 2 * (((size_t)cap_e + 15) & ~(size_t)15);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     PoseOptArgs A{d_poses_in, d_edges, d_n_edges, cap_e, d_cameras, d_poses_out, d_outlier, d_n_good};
-    hipLaunchKernelGGL(k_pose_opt, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
+    if (pinhole) hipLaunchKernelGGL(k_pose_opt<true>, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_pose_opt<false>, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+extern "C" int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                             const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                             void* stream) {
+    return pose_optimize_impl(d_poses_in, d_edges, d_n_edges, cap_e, batch, d_cameras, n_cameras, d_poses_out, d_outlier, d_n_good, false, stream);
+}
+
+extern "C" int pose_optimize_hint(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                                  const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                                  unsigned hints, void* stream) {
+    if (hints & ~(unsigned)LBA_HINT_PINHOLE) return ORB_E_INVALID;
+    return pose_optimize_impl(d_poses_in, d_edges, d_n_edges, cap_e, batch, d_cameras, n_cameras, d_poses_out, d_outlier, d_n_good,
+                              (hints & LBA_HINT_PINHOLE) != 0, stream);
 }

@@ -275,12 +275,19 @@ def bind_pose(lib):
     lib.pose_optimize.restype = C.c_int
     lib.pose_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]
+    lib.pose_optimize_hint.restype = C.c_int
+    lib.pose_optimize_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_uint, C.c_void_p]
     return lib
 
 
-def pose_optimization(poses, edges, n_edges, cameras, lib=None):
+HINT_MONO_PINHOLE, HINT_PINHOLE = 1, 2
+
+
+def pose_optimization(poses, edges, n_edges, cameras, lib=None, pinhole=False):
     """Batched Optimizer::PoseOptimization: poses [B,7] f64 (t, q of Tcw), edges [B,cap_e] POSE_EDGE_DTYPE viewed as u8 [B,cap_e*32],
     n_edges [B] i32, cameras u8 view of CAM_DTYPE[n].  All arrays device tensors (or numpy in the emulated build).
+    pinhole=True: the caller states that every edge is EDGE_MONO / EDGE_STEREO on a pinhole camera (LBA_HINT_PINHOLE: same results, leaner kernel).
     -> (poses_out [B,7], outlier [B,cap_e] u8, n_good [B] i32) — n_good == the reference's return value nInitialCorrespondences-nBad."""
     L = bind_pose(lib if lib is not None else _lib.load())
     B = poses.shape[0]
@@ -289,8 +296,8 @@ def pose_optimization(poses, edges, n_edges, cameras, lib=None):
     outlier = _like(poses, (B, cap_e), np.uint8)
     n_good = _like(poses, (B,), np.int32)
     n_cam = cameras.shape[0] // CAM_DTYPE.itemsize if cameras.dtype != CAM_DTYPE else cameras.shape[0]
-    rc = L.pose_optimize(_ptr(poses), _ptr(edges), _ptr(n_edges), cap_e, B, _ptr(cameras), n_cam, _ptr(out), _ptr(outlier), _ptr(n_good),
-                         _stream(poses))
+    rc = L.pose_optimize_hint(_ptr(poses), _ptr(edges), _ptr(n_edges), cap_e, B, _ptr(cameras), n_cam, _ptr(out), _ptr(outlier), _ptr(n_good),
+                              HINT_PINHOLE if pinhole else 0, _stream(poses))
     if rc != 0:
         raise OrbHipError(rc, "pose_optimize failed")
     return out, outlier, n_good

@@ -420,12 +420,12 @@ def main():
         rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.concatenate([a] * (PB // 64)))).to(dev)
         pP, pE, pN = rep(pf["poses"]), rep(pf["edges"].view(np.uint8).reshape(64, -1)), rep(pf["n_edges"])
         pC = torch.from_numpy(np.ascontiguousarray(pf["cameras"]).view(np.uint8)).to(dev)
-        pose_optimization(pP, pE, pN, pC)
+        pose_optimization(pP, pE, pN, pC, pinhole=True)   # stereo / monocular edges on pinhole cameras
         barrier()
         psteps = 3
         t4 = time.perf_counter()
         for _ in range(psteps):
-            po = pose_optimization(pP, pE, pN, pC)
+            po = pose_optimization(pP, pE, pN, pC, pinhole=True)
         barrier()
         dtp = time.perf_counter() - t4
         extra["pose_optimization"] = {"frames_per_s": round(PB * psteps / dtp, 1), "ms_per_batch": round(dtp / psteps * 1e3, 3), "frames_per_batch": PB,

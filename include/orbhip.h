@@ -491,6 +491,13 @@ typedef struct pose_edge {
 int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
                   const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
                   void* stream);
+/* The same with what the caller knows about the edges it flattened.  LBA_HINT_PINHOLE: EVERY edge is an EdgeSE3ProjectXYZOnlyPose (LBA_EDGE_MONO)
+ * or an EdgeStereoSE3ProjectXYZOnlyPose (LBA_EDGE_STEREO) on a pinhole camera — the monocular, stereo and RGB-D pinhole configurations.
+ * Identical results from a kernel without the fisheye model and the right-camera edge; a hint that does not hold gives wrong poses. */
+#define LBA_HINT_PINHOLE 2u
+int pose_optimize_hint(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
+                       const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
+                       unsigned hints, void* stream);
 
 /* SURVEY.md N4 (tail) — Optimizer::LocalInertialBA (reference src/Optimizer.cc:4753-5365): the visual-inertial local BA of the
  * inertial modes.  Graph (include/G2oTypes.h, src/G2oTypes.cc): VertexPose (ImuCamPose, 6 dof, body-frame right perturbation

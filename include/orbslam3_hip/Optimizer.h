@@ -185,7 +185,11 @@ public:
         double* dO = (double*)o_.ensure(7 * 8 + 16);
         uint8_t* dOut = (uint8_t*)f_.ensure((size_t)ne + 16);
         int32_t* dG = (int32_t*)g_.ensure(16);
-        if (pose_optimize(dP, dE, dN, ne, 1, dC, (int)cams_.size(), dO, dOut, dG, nullptr) != ORB_OK) throw std::runtime_error("pose_optimize");
+        bool pinhole = true;   // the adapter was handed the edges: it knows whether the fisheye model or a right-camera edge occurs
+        for (const pose_edge& e : edges_)
+            if (e.kind == LBA_EDGE_BODY || cams_[(size_t)e.cam].model != LBA_CAM_PINHOLE) { pinhole = false; break; }
+        if (pose_optimize_hint(dP, dE, dN, ne, 1, dC, (int)cams_.size(), dO, dOut, dG, pinhole ? LBA_HINT_PINHOLE : 0u, nullptr) != ORB_OK)
+            throw std::runtime_error("pose_optimize");
         std::vector<uint8_t> fl(ne);
         int32_t good = 0;
         orb_memcpy_d2h(pose7, dO, 56, nullptr);

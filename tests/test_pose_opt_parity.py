@@ -20,11 +20,18 @@ def oracle_batch(f):
 
 
 def run(lib, backend, f):
+    """Through the generic kernel, and — when every edge is monocular / stereo on a pinhole camera — through the LBA_HINT_PINHOLE kernel as
+    well: the two must agree bit for bit (same expressions in the same order)."""
     td = to_dev(backend)
     B, cap = f["edges"].shape
-    out, outl, ng = pose_optimization(td(f["poses"]), td(f["edges"].view(np.uint8).reshape(B, -1)), td(f["n_edges"]),
-                                      td(np.ascontiguousarray(f["cameras"]).view(np.uint8)), lib=lib)
-    return to_host(out), to_host(outl), to_host(ng)
+    args = (td(f["poses"]), td(f["edges"].view(np.uint8).reshape(B, -1)), td(f["n_edges"]), td(np.ascontiguousarray(f["cameras"]).view(np.uint8)))
+    res = [to_host(x) for x in pose_optimization(*args, lib=lib)]
+    valid = np.arange(cap)[None, :] < f["n_edges"][:, None]
+    if (f["edges"]["kind"][valid] != 2).all() and (f["cameras"]["model"][f["edges"]["cam"][valid]] == 0).all():   # no EDGE_BODY, only CAM_PINHOLE
+        hinted = [to_host(x) for x in pose_optimization(*args, lib=lib, pinhole=True)]
+        for a, b in zip(res, hinted):
+            assert np.array_equal(a, b)
+    return res
 
 
 def check(lib, backend, kind, seed, n_pts, batch=5, tol=1e-7, **kw):
