@@ -108,11 +108,14 @@ static __device__ __forceinline__ void cam_project_jac(const lba_camera& c, cons
 // batch once per call).  Same expressions in the same order as the generic path takes for such an edge — identical results — but the
 // third residual row, the fisheye model and the right-camera transform are gone at compile time: the linearisation kernels need a third
 // fewer registers and multiply no structural zeros.
-template <bool WITH_JAC, bool MP = false>
+// KS = 2: every edge is an EdgeSE3ProjectXYZ or an EdgeStereoSE3ProjectXYZ on a pinhole camera (stereo / RGB-D pinhole maps): the stereo
+// branch below (pinhole by construction) or the monocular-pinhole one; the fisheye model and the right-camera edge are gone.
+template <bool WITH_JAC, int KS = 0>
 static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const SE3& T, const double X[3], const lba_camera& cam,
                                                      double huberMono, double huberStereo, Lin& L) {
+    constexpr bool MP = KS == 1;
     L.e[2] = 0;
-    if constexpr (MP) {
+    if (MP || (KS == 2 && E.kind != LBA_EDGE_STEREO)) {
         L.D = 2;
         double proj[2], xl[3];
         se3_map(T, X, xl);
@@ -173,7 +176,7 @@ static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const S
             B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
             B[12] = B[0] - bfd * y / z_2; B[13] = B[1] + bfd * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bfd / z_2;
         }
-    } else {
+    } else if constexpr (KS == 0) {
         L.D = 2;
         if (WITH_JAC) {
 #pragma unroll
@@ -242,7 +245,7 @@ static __device__ __forceinline__ void edge_linearize(const lba_edge& E, const S
 #pragma unroll
     for (int i = 0; i < 3; i++) chi2 += L.e[i] * s * L.e[i];   // e[2] == 0 for 2-D edges
     L.chi2 = chi2;
-    const double delta = (!MP && E.kind == LBA_EDGE_STEREO) ? huberStereo : huberMono;
+    const double delta = (!MP && E.kind == LBA_EDGE_STEREO) ? huberStereo : huberMono;   // KS == 2: runtime kind
     L.rho0 = chi2; L.rho1 = 1.;
     if (delta > 0) {   // RobustKernelHuber::robustify, robust_kernel_impl.cpp:78-91
         const double dsqr = delta * delta;
@@ -271,7 +274,7 @@ struct LbaArgs { lba_problem P; lba_system S; };
 #ifndef LBA_MINW
 #define LBA_MINW 1     // minimum waves per SIMD the register allocation must allow
 #endif
-template <bool MP>
+template <int KS>
 static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
@@ -302,7 +305,7 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
             const double* Xp = points + (size_t)E.point * 3;
             const double X[3] = {Xp[0], Xp[1], Xp[2]};
             Lin L;
-            edge_linearize<true, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+            edge_linearize<true, KS>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
             const size_t eo = (size_t)b * P.cap_e + ei;
             if (A.S.err) { A.S.err[eo * 3] = L.e[0]; A.S.err[eo * 3 + 1] = L.e[1]; A.S.err[eo * 3 + 2] = L.e[2]; }
             if (A.S.chi2) A.S.chi2[eo] = L.chi2;
@@ -368,7 +371,7 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
     }
 }
 
-template <bool MP>
+template <int KS>
 static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
     const lba_problem& P = A.P;
     const int b = blockIdx.y, pi = blockIdx.x, lane = threadIdx.x;
@@ -390,7 +393,7 @@ static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
         const double* Xp = points + (size_t)E.point * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
         Lin L;
-        edge_linearize<true, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+        edge_linearize<true, KS>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
         const double s = (double)E.inv_sigma2, w = L.rho1 * s;
         double om[3];
         for (int i = 0; i < 3; i++) om[i] = -s * L.e[i] * L.rho1;
@@ -462,7 +465,7 @@ static int lba_check(const lba_problem* p, int batch, const lba_system* out) {
     return ORB_OK;
 }
 
-static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_system* out, bool monoPin, void* stream) {
+static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_system* out, int ks, void* stream) {
     int rc = lba_check(prob, batch, out);
     if (rc != ORB_OK) return rc;
     LbaArgs A;
@@ -472,23 +475,20 @@ static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_s
     if (out->Hpp && hipMemsetAsync(out->Hpp, 0, (size_t)batch * prob->cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
     if (out->bp && hipMemsetAsync(out->bp, 0, (size_t)batch * prob->cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
     const dim3 gL((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), gP(prob->cap_p, batch);
-    if (monoPin) {
-        hipLaunchKernelGGL(k_lba_landmarks<true>, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
-        if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<true>, gP, dim3(64), 0, st, A);
-    } else {
-        hipLaunchKernelGGL(k_lba_landmarks<false>, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
-        if (out->Hpp || out->bp) hipLaunchKernelGGL(k_lba_poses<false>, gP, dim3(64), 0, st, A);
-    }
+#define LBA_LAUNCH_KS(kern, ...) do { if (ks == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else if (ks == 2) hipLaunchKernelGGL(kern<2>, __VA_ARGS__); \
+                                      else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
+    LBA_LAUNCH_KS(k_lba_landmarks, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
+    if (out->Hpp || out->bp) LBA_LAUNCH_KS(k_lba_poses, gP, dim3(64), 0, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
 
 extern "C" int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, void* stream) {
-    return lba_build_system_impl(prob, batch, out, false, stream);
+    return lba_build_system_impl(prob, batch, out, 0, stream);
 }
 
 extern "C" int lba_build_system_hint(const lba_problem* prob, int batch, const lba_system* out, unsigned hints, void* stream) {
-    if (hints & ~(unsigned)LBA_HINT_MONO_PINHOLE) return ORB_E_INVALID;
-    return lba_build_system_impl(prob, batch, out, (hints & LBA_HINT_MONO_PINHOLE) != 0, stream);
+    if (hints & ~(unsigned)(LBA_HINT_MONO_PINHOLE | LBA_HINT_PINHOLE)) return ORB_E_INVALID;
+    return lba_build_system_impl(prob, batch, out, (hints & LBA_HINT_MONO_PINHOLE) ? 1 : (hints & LBA_HINT_PINHOLE) ? 2 : 0, stream);
 }
 
 extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream) {
@@ -534,13 +534,15 @@ struct LmArgs {
     int32_t* edgeH;                         // [batch][cap_e + 8] Hessian index of each edge's pose (-1: fixed), landmark-major like the edges
 };
 
-// *flag = 1 unless every edge of the batch is an EdgeSE3ProjectXYZ on a pinhole camera (the <MP> kernels, see edge_linearize)
+// *flag: bit 0 = some edge is neither monocular nor stereo, or its camera is not a pinhole (generic kernels); bit 1 = some edge is stereo
+// (else: the monocular-pinhole kernels, see edge_linearize)
 static __global__ __launch_bounds__(256) void k_lm_kinds(LmArgs A, int* flag) {
     const lba_problem& P = A.P;
     const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= min(P.n_edges[b], P.cap_e)) return;
     const lba_edge E = P.edges[(size_t)b * P.cap_e + e];
-    if (E.kind != LBA_EDGE_MONO || P.cameras[E.cam].model != LBA_CAM_PINHOLE) *flag = 1;
+    const int f = ((E.kind != LBA_EDGE_MONO && E.kind != LBA_EDGE_STEREO) || P.cameras[E.cam].model != LBA_CAM_PINHOLE ? 1 : 0) | (E.kind == LBA_EDGE_STEREO ? 2 : 0);
+    if (f) atomicOr(flag, f);
 }
 
 static __global__ void k_lm_init(LmArgs A, int batch) {
@@ -564,7 +566,7 @@ static __global__ __launch_bounds__(64) void k_lm_sum_partials(LmArgs A, int bat
 }
 
 // computeActiveErrors + per-block partial sums of rho[0] (blocks of 256 edges)
-template <bool MP>
+template <int KS>
 static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* red = (double*)orb_smem;
@@ -578,7 +580,7 @@ static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
         const double* Xp = A.points + ((size_t)b * P.cap_l + E.point) * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
         Lin L;
-        edge_linearize<false, MP>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
+        edge_linearize<false, KS>(E, T, X, P.cameras[E.cam], P.huber_mono, P.huber_stereo, L);
         r0 = L.rho0;
     }
     red[threadIdx.x] = r0;
@@ -1120,8 +1122,9 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     hipLaunchKernelGGL(k_lm_kinds, dim3((P.cap_e + 255) / 256, batch), dim3(256), 0, st, A, A.flag);
     if (hipMemcpyAsync(&otherKinds, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return ORB_E_HIP;
-    const bool monoPin = !otherKinds;   // monocular pinhole batch: the specialised linearisation / error kernels
-#define LM_LAUNCH_MP(kern, ...) do { if (monoPin) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
+    const int ks = (otherKinds & 1) ? 0 : (otherKinds & 2) ? 2 : 1;   // generic / pinhole mono + stereo / monocular pinhole kernels
+#define LM_LAUNCH_MP(kern, ...) do { if (ks == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else if (ks == 2) hipLaunchKernelGGL(kern<2>, __VA_ARGS__); \
+                                     else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
     // Cholesky panel: LDS while 6 x maxFree rows x 17 doubles fit (<= 180 free key frames — every LocalBundleAdjustment window); beyond that
     // (GlobalBundleAdjustemnt of a large map) the panel lives in the workspace and LDS holds the right-hand side only
     A.panExt = nullptr;

@@ -88,6 +88,7 @@ class LbaWindows:
         self.n_cameras = len(cameras)
         cam_models = np.asarray(cameras["model"])
         self.mono_pinhole = all((w["edges"]["kind"] == EDGE_MONO).all() and (cam_models[w["edges"]["cam"]] == CAM_PINHOLE).all() for w in windows)
+        self.pinhole = all((w["edges"]["kind"] != EDGE_BODY).all() and (cam_models[w["edges"]["cam"]] == CAM_PINHOLE).all() for w in windows)
         self.huber = huber
         like = self.d["poses"]
         f8 = np.float64
@@ -107,8 +108,8 @@ class LbaWindows:
 
     def build_system(self, outputs=("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth")):
         P, S = self._structs(outputs)
-        # LBA_HINT_MONO_PINHOLE when the host-side edge arrays say so (the caller flattened the graph: it knows the edge kinds)
-        rc = self._L.lba_build_system_hint(C.byref(P), self.B, C.byref(S), 1 if self.mono_pinhole else 0, _stream(self.d["poses"]))
+        # LBA_HINT_MONO_PINHOLE / LBA_HINT_PINHOLE when the host-side edge arrays say so (the caller flattened the graph: it knows the edge kinds)
+        rc = self._L.lba_build_system_hint(C.byref(P), self.B, C.byref(S), 1 if self.mono_pinhole else 2 if self.pinhole else 0, _stream(self.d["poses"]))
         if rc != 0:
             raise OrbHipError(rc, "lba_build_system failed")
         return self.out

@@ -453,6 +453,7 @@ int lba_build_system(const lba_problem* prob, int batch, const lba_system* out, 
  * kernels specialised for it give identical results with a third fewer registers; a hint that does not hold gives wrong blocks (lba_optimize
  * checks the edges itself, once per call, and needs no hint).  Unknown hint bits: ORB_E_INVALID. */
 #define LBA_HINT_MONO_PINHOLE 1u
+#define LBA_HINT_PINHOLE 2u        /* every edge is LBA_EDGE_MONO or LBA_EDGE_STEREO on a pinhole camera (stereo / RGB-D pinhole maps); also for pose_optimize_hint */
 int lba_build_system_hint(const lba_problem* prob, int batch, const lba_system* out, unsigned hints, void* stream);
 /* SparseOptimizer::computeActiveErrors (sparse_optimizer.cpp:61-75): err / chi2 / rho / depth / robust_chi2_sum only. */
 int lba_compute_errors(const lba_problem* prob, int batch, const lba_system* out, void* stream);
@@ -494,7 +495,6 @@ int pose_optimize(const double* d_poses_in, const pose_edge* d_edges, const int3
 /* The same with what the caller knows about the edges it flattened.  LBA_HINT_PINHOLE: EVERY edge is an EdgeSE3ProjectXYZOnlyPose (LBA_EDGE_MONO)
  * or an EdgeStereoSE3ProjectXYZOnlyPose (LBA_EDGE_STEREO) on a pinhole camera — the monocular, stereo and RGB-D pinhole configurations.
  * Identical results from a kernel without the fisheye model and the right-camera edge; a hint that does not hold gives wrong poses. */
-#define LBA_HINT_PINHOLE 2u
 int pose_optimize_hint(const double* d_poses_in, const pose_edge* d_edges, const int32_t* d_n_edges, int cap_e, int batch,
                        const lba_camera* d_cameras, int n_cameras, double* d_poses_out, uint8_t* d_outlier, int32_t* d_n_good,
                        unsigned hints, void* stream);

@@ -132,8 +132,8 @@ private:
             const bool want = full ? i < 9 : i >= 5;
             *ptr[i] = want ? (double*)out_[i].ensure(sz[i] * 8 + 16) : nullptr;
         }
-        // the adapter flattened the graph itself: it knows whether every edge is an EdgeSE3ProjectXYZ on a pinhole camera
-        const int rc = full ? lba_build_system_hint(&P, 1, &S, monoPinhole() ? LBA_HINT_MONO_PINHOLE : 0u, nullptr) : lba_compute_errors(&P, 1, &S, nullptr);
+        // the adapter flattened the graph itself: it knows whether the fisheye model, right-camera edges or stereo edges occur
+        const int rc = full ? lba_build_system_hint(&P, 1, &S, hints(), nullptr) : lba_compute_errors(&P, 1, &S, nullptr);
         if (rc != ORB_OK) throw std::runtime_error("lba call failed");
         for (int i = 0; i < 9; i++)
             if (*ptr[i]) { host[i]->resize(sz[i]); orb_memcpy_d2h(host[i]->data(), *ptr[i], sz[i] * 8, nullptr); }
@@ -142,10 +142,13 @@ private:
     }
     std::vector<double> poses_, points_;
     std::vector<int32_t> hidx_;
-    bool monoPinhole() const {
-        for (const lba_edge& e : edges_)
-            if (e.kind != LBA_EDGE_MONO || cams_[(size_t)e.cam].model != LBA_CAM_PINHOLE) return false;
-        return true;
+    unsigned hints() const {   // what the edges this adapter was given allow: monocular pinhole, pinhole (monocular + stereo), or nothing
+        bool stereo = false;
+        for (const lba_edge& e : edges_) {
+            if (e.kind == LBA_EDGE_BODY || cams_[(size_t)e.cam].model != LBA_CAM_PINHOLE) return 0u;
+            stereo = stereo || e.kind == LBA_EDGE_STEREO;
+        }
+        return stereo ? LBA_HINT_PINHOLE : LBA_HINT_MONO_PINHOLE;
     }
     std::vector<lba_edge> edges_;
     std::vector<lba_camera> cams_;

@@ -18,11 +18,12 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--kf", type=int, default=100)
 ap.add_argument("--fixed", type=int, default=20)
 ap.add_argument("--points", type=int, default=20000)
+ap.add_argument("--kind", default="mono", help="mono | stereo | kb8 | body | mixed (synth_window)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 wins, cams = [], None
 for i in range(2):
-    w, cams = synth_window(100 + i, args.kf, args.fixed, args.points, 8, "mono")
+    w, cams = synth_window(100 + i, args.kf, args.fixed, args.points, 8, args.kind)
     wins.append(w)
 Lw = LbaWindows([wins[i % 2] for i in range(args.windows)], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
 p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
