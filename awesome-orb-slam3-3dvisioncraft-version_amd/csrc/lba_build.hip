@@ -277,8 +277,11 @@ struct LbaArgs { lba_problem P; lba_system S; };
 template <int KS>
 static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    double (*contrib)[13] = (double (*)[13])orb_smem;   // [LBA_CT edges of the chunk][H_ll 9 (column-major) | b_l 3], padded against bank conflicts
-    double* stage = (double*)orb_smem + LBA_CT * 13;    // [LBA_CT][18] the chunk's H_pl blocks: written per lane, stored to global memory coalesced
+    // ONE LDS region, used twice per chunk: first the chunk's H_pl blocks ([LBA_CT][18]: written per lane, stored to global memory coalesced), then
+    // the per-edge H_ll / b_l contributions ([LBA_CT][13]: H_ll 9 column-major | b_l 3, padded against bank conflicts) — 144 instead of 248 bytes
+    // of LDS per thread: the workgroups per CU are then limited by registers, not by LDS
+    double (*contrib)[13] = (double (*)[13])orb_smem;
+    double* stage = (double*)orb_smem;
     const lba_problem& P = A.P;
     const int b = blockIdx.y, tid = threadIdx.x;
     const int nl = min(P.n_points[b], P.cap_l);
@@ -299,6 +302,7 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
     for (int c0 = eBegin; c0 < eEnd; c0 += LBA_CT) {
         const int ei = c0 + tid;
+        double cv[12];   // this edge's H_ll / b_l contribution, parked in LDS after the H_pl blocks have left it
         if (ei < eEnd) {
             const lba_edge E = edges[ei];
             const SE3 T = load_pose(poses + (size_t)E.pose * 7);
@@ -321,13 +325,13 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
                 double acc = 0;
 #pragma unroll
                 for (int r = 0; r < 3; r++) acc += L.A[r * 3 + c] * om[r];
-                contrib[tid][9 + c] = acc;
+                cv[9 + c] = acc;
 #pragma unroll
                 for (int c2 = 0; c2 < 3; c2++) {
                     double h = 0;
 #pragma unroll
                     for (int r = 0; r < 3; r++) h += L.A[r * 3 + c] * w * L.A[r * 3 + c2];
-                    contrib[tid][c2 * 3 + c] = h;
+                    cv[c2 * 3 + c] = h;
                 }
             }
             if (A.S.Hpl) {
@@ -346,13 +350,19 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
                     }
             }
         }
-        __syncthreads();
         if (A.S.Hpl) {        // the chunk's H_pl blocks are contiguous in global memory: 16 bytes per lane, consecutive lanes consecutive addresses
+            __syncthreads();
             const int n2 = (min(eEnd, c0 + LBA_CT) - c0) * 9;
             double2* dst = (double2*)(A.S.Hpl + ((size_t)b * P.cap_e + c0) * 18);
             const double2* src = (const double2*)stage;
             for (int i = tid; i < n2; i += LBA_CT) dst[i] = src[i];
+            __syncthreads();
         }
+        if (ei < eEnd) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) contrib[tid][i] = cv[i];
+        }
+        __syncthreads();
         if (tid < LBA_LB) {   // H_ll += A^T wOmega A, b_l += A^T omega_r in edge order
             const int a0 = max(ls, c0), a1 = min(le, c0 + LBA_CT);
             for (int e = a0; e < a1; e++) {
@@ -477,7 +487,7 @@ static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_s
     const dim3 gL((prob->cap_l + LBA_LB - 1) / LBA_LB, batch), gP(prob->cap_p, batch);
 #define LBA_LAUNCH_KS(kern, ...) do { if (ks == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else if (ks == 2) hipLaunchKernelGGL(kern<2>, __VA_ARGS__); \
                                       else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
-    LBA_LAUNCH_KS(k_lba_landmarks, gL, dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, A);
+    LBA_LAUNCH_KS(k_lba_landmarks, gL, dim3(LBA_CT), LBA_CT * 18 * 8, st, A);
     if (out->Hpp || out->bp) LBA_LAUNCH_KS(k_lba_poses, gP, dim3(64), 0, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
@@ -1165,7 +1175,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             L.P = P; L.S = A.S;
             if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
-            LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * (13 + 18) * 8, st, L);
+            LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 18 * 8, st, L);
             LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
         }
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
