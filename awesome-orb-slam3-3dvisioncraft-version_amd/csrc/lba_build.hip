@@ -381,10 +381,15 @@ static __global__ __launch_bounds__(LBA_CT, LBA_MINW) void k_lba_landmarks(LbaAr
     }
 }
 
+#ifndef POSES_NT
+#define POSES_NT 256   // threads per pose: a pose of a 100-KF window has ~2 000 edges; one wave per pose leaves a 16-window batch at 1 280 waves of 31 serial steps
+#endif
 template <int KS>
-static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
+static __global__ __launch_bounds__(POSES_NT) void k_lba_poses(LbaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double (*wsum)[27] = (double (*)[27])orb_smem;   // [POSES_NT / 64][27] per-wave sums
     const lba_problem& P = A.P;
-    const int b = blockIdx.y, pi = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.y, pi = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int np = min(P.n_poses[b], P.cap_p);
     if (pi >= np) return;
     const int h = P.pose_hidx[(size_t)b * P.cap_p + pi];
@@ -398,7 +403,7 @@ static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
     double acc[27];  // 21 upper-triangle entries of H_pp (column-major order c2 >= c) + 6 of b_p
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int k = s0 + lane; k < s1; k += 64) {
+    for (int k = s0 + (int)threadIdx.x; k < s1; k += POSES_NT) {
         const lba_edge E = edges[pe[k]];
         const double* Xp = points + (size_t)E.point * 3;
         const double X[3] = {Xp[0], Xp[1], Xp[2]};
@@ -427,13 +432,20 @@ static __global__ __launch_bounds__(64) void k_lba_poses(LbaArgs A) {
     for (int i = 0; i < 27; i++)
         for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off);
     if (lane == 0) {
-        if (A.S.Hpp) {
-            double* o = A.S.Hpp + ((size_t)b * P.cap_p + h) * 36;
-            int t = 0;
-            for (int c2 = 0; c2 < 6; c2++)
-                for (int c = 0; c <= c2; c++) { o[c2 * 6 + c] = acc[t]; o[c * 6 + c2] = acc[t]; t++; }
-        }
-        if (A.S.bp) { double* o = A.S.bp + ((size_t)b * P.cap_p + h) * 6; for (int c = 0; c < 6; c++) o[c] = acc[21 + c]; }
+#pragma unroll
+        for (int i = 0; i < 27; i++) wsum[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {   // waves added in fixed order; entry t of the packed upper triangle is (c, c2) with c <= c2, column-major
+        const int t = threadIdx.x;
+        double v = wsum[0][t];
+        for (int w = 1; w < POSES_NT / 64; w++) v += wsum[w][t];
+        if (t < 21) {
+            int c2 = 0, base = 0;
+            while (base + c2 + 1 <= t) { base += c2 + 1; c2++; }
+            const int c = t - base;
+            if (A.S.Hpp) { double* o = A.S.Hpp + ((size_t)b * P.cap_p + h) * 36; o[c2 * 6 + c] = v; o[c * 6 + c2] = v; }
+        } else if (A.S.bp) A.S.bp[((size_t)b * P.cap_p + h) * 6 + (t - 21)] = v;
     }
 }
 
@@ -488,7 +500,7 @@ static int lba_build_system_impl(const lba_problem* prob, int batch, const lba_s
 #define LBA_LAUNCH_KS(kern, ...) do { if (ks == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__); else if (ks == 2) hipLaunchKernelGGL(kern<2>, __VA_ARGS__); \
                                       else hipLaunchKernelGGL(kern<0>, __VA_ARGS__); } while (0)
     LBA_LAUNCH_KS(k_lba_landmarks, gL, dim3(LBA_CT), LBA_CT * 18 * 8, st, A);
-    if (out->Hpp || out->bp) LBA_LAUNCH_KS(k_lba_poses, gP, dim3(64), 0, st, A);
+    if (out->Hpp || out->bp) LBA_LAUNCH_KS(k_lba_poses, gP, dim3(POSES_NT), (POSES_NT / 64) * 27 * 8, st, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
 
@@ -1176,7 +1188,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.S.Hpp, 0, B * P.cap_p * 36 * 8, st) != hipSuccess) return ORB_E_HIP;
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
             LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 18 * 8, st, L);
-            LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(64), 0, st, L);
+            LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(POSES_NT), (POSES_NT / 64) * 27 * 8, st, L);
         }
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
