@@ -29,6 +29,18 @@ def test_product_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_hint_entry_points_reject_unknown_bits():
+    """lba_build_system_hint / pose_optimize_hint validate the hint word before anything else (argument check only: no GPU work)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "liborbhip.so"))
+    lib.lba_build_system_hint.restype = ctypes.c_int
+    lib.lba_build_system_hint.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+    assert lib.lba_build_system_hint(None, 1, None, 8, None) == -3          # ORB_E_INVALID: unknown hint bit
+    assert lib.lba_build_system_hint(None, 1, None, 1, None) == -3          # known hint, null problem: the ordinary argument check
+    lib.pose_optimize_hint.restype = ctypes.c_int
+    lib.pose_optimize_hint.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 2 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_uint, ctypes.c_void_p]
+    assert lib.pose_optimize_hint(None, None, None, 1, 1, None, 1, None, None, None, 1, None) == -3   # LBA_HINT_MONO_PINHOLE is not a pose_optimize hint
+
+
 def test_loader_has_no_cpu_fallback(tmp_path, monkeypatch):
     from orbhip import _lib
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
