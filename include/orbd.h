@@ -1,0 +1,46 @@
+/* orbd.h — the two exchange steps of the hot path for a C / C++ host that runs one process (or thread) per GPU,
+ * as thin C entry points over RCCL (liborbd.so; liborbhip.so itself needs no peer and does not link RCCL).
+ *
+ * Frames, frame pairs and LBA windows are independent units: a rank runs orbx_ / orbm_ / lba_ on its own units with no collective.
+ * Data crosses ranks in two places only:
+ *   - matching against frames another rank extracted: the fixed-capacity per-frame slabs orbx_extract_batch_dev wrote
+ *     ([cap] keypoint records, [cap] 32-byte descriptors, (n, monoIndex) per frame) are all-gathered — three all-gathers in ONE RCCL group
+ *     launch, no packing copy (the Python mirror orbhip.dist.allgather_frame_blocks packs into one tensor because torch.distributed has no group call);
+ *   - ONE LocalBundleAdjustment window sharded by landmark over several GPUs (BASELINE.json configs[4]): all-reduce of the pose-side
+ *     partial sums H_pp / b_p that lba_build_system produced from each rank's landmarks, all-gather of the pose blocks each rank updated.
+ * `comm` is an ncclComm_t the host created (ncclCommInitRank over its launcher's rendezvous, or orbd_comm_init_all_local for a single
+ * process driving several GPUs).  All calls are asynchronous on `stream`; return ORB_OK / ORB_E_INVALID / ORB_E_HIP (an RCCL error). */
+#ifndef ORBD_H
+#define ORBD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "orbhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* orbd_comm;   /* ncclComm_t */
+
+/* Every rank contributes frames_per_rank frames (pad the last shard); afterwards every rank holds all world * frames_per_rank frames in rank-major
+ * order.  d_kps [frames][cap] orb_keypoint, d_desc [frames][cap][32] u8, d_counts [frames][2] i32 (n, monoIndex) — the layouts of
+ * orbx_extract_batch_dev; the d_all_* slabs are world times as large. */
+int orbd_allgather_frames(orbd_comm comm, int world, int frames_per_rank, int cap, const orb_keypoint* d_kps, const uint8_t* d_desc,
+                          const int32_t* d_counts, orb_keypoint* d_all_kps, uint8_t* d_all_desc, int32_t* d_all_counts, void* stream);
+
+/* In-place sum over the ranks of the pose-side blocks of one landmark-sharded window: d_Hpp [n_free][36], d_bp [n_free][6] doubles
+ * (lba_system.Hpp / .bp of the window, rows of fixed poses are zero on every rank); one RCCL group launch. */
+int orbd_allreduce_pose_system(orbd_comm comm, double* d_Hpp, double* d_bp, int n_free, void* stream);
+
+/* d_local [poses_per_rank][7] doubles (the pose blocks this rank updated) -> d_all [world * poses_per_rank][7], rank-major. */
+int orbd_allgather_pose_blocks(orbd_comm comm, int world, const double* d_local, double* d_all, int poses_per_rank, void* stream);
+
+/* Convenience for a single process that drives n_devices GPUs (and for the 1-GPU test): ncclCommInitAll.  comms[i] belongs to devices[i]. */
+int orbd_comm_init_all_local(int n_devices, const int* devices, orbd_comm* comms);
+int orbd_comm_destroy(orbd_comm comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

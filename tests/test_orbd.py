@@ -1,0 +1,28 @@
+"""liborbd.so (include/orbd.h): the path's two exchange steps as C entry points over RCCL for a C / C++ host."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "liborbd.so")
+
+
+def test_library_exports_every_declared_symbol():
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "orbd.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(orbd_[a-z0-9_]+)\s*\(", txt)))
+    assert {"orbd_allgather_frames", "orbd_allreduce_pose_system", "orbd_allgather_pose_blocks"} <= set(names)
+    if not os.path.exists(SO):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(SO)   # binds librccl.so; loads without a GPU
+    assert not [n for n in names if not hasattr(lib, n)]
+
+
+@pytest.mark.gpu
+def test_single_rank_exchange_on_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "orbd_single_rank.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "exchange OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])

@@ -9,3 +9,6 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
     -Wall -Wno-unused-function -Wno-unused-result -I"$ROOT/include" "$SRC"/*.hip -o "$OUT" "$@"
 echo "built $OUT"
+# the exchange entry points over RCCL (include/orbd.h): host code only, its own small library so that liborbhip.so needs no RCCL
+$HIPCC -O2 -std=c++17 -fPIC -shared -Wall -I"$ROOT/include" "$SRC/orbd_exchange.cpp" -o "$ROOT/awesome-orb-slam3-3dvisioncraft-version_amd/liborbd.so" -L/opt/rocm/lib -lrccl
+echo "built $ROOT/awesome-orb-slam3-3dvisioncraft-version_amd/liborbd.so"
