@@ -405,6 +405,26 @@ def main():
         extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
         extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
         extra["lba"]["lm_windows_per_step"] = args.lm_windows
+        # the same LM on windows of the other edge families (the monocular windows above run the monocular-pinhole kernel instantiation):
+        # stereo / RGB-D pinhole maps (monocular + stereo edges: the pinhole instantiation) and fisheye maps (the generic kernels)
+        for fam, kind in (("stereo_pinhole", "stereo"), ("fisheye", "kb8")):
+            nw = max(8, args.lm_windows // 4)
+            fw, fcams = [], None
+            for i in range(2):
+                w_, fcams = synth_window(300 + i + 10 * rank, 100, 20, 20000, 8, kind)
+                fw.append(w_)
+            Lf = LbaWindows([fw[i % 2] for i in range(nw)], fcams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+            fp0, fx0 = Lf.d["poses"].clone(), Lf.d["points"].clone()
+            Lf.optimize(5)
+            barrier()
+            tf = time.perf_counter()
+            Lf.d["poses"].copy_(fp0); Lf.d["points"].copy_(fx0)
+            fst = Lf.optimize(5)
+            barrier()
+            dtf = time.perf_counter() - tf
+            extra["lba"]["lm_iterations_per_s_" + fam] = round(float(fst[:, 0].sum()) / dtf, 1)
+            extra["lba"]["lm_windows_" + fam] = nw
+            del Lf
         if world == 1 and not args.no_cpu_baseline:   # the oracle's LM (reference algorithm restated, dense Schur/Cholesky) on one host core
             import oracle_lib as O
             from orbhip.lba import HUBER_MONO, HUBER_STEREO
