@@ -713,9 +713,6 @@ static __global__ __launch_bounds__(256) void k_lm_rowmeta(LmArgs A) {
 #endif
 static inline size_t lm_schur_smem_bytes(int rowCap) { return ((size_t)rowCap * SCH_LD + (SCH_NT / 64) * 6) * sizeof(double); }
 static __global__ __launch_bounds__(SCH_NT) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
-#ifdef LM_SCHUR_FMA
-#pragma clang fp contract(fast)
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
     double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [SCH_NT / 64][6]
