@@ -699,25 +699,28 @@ static __global__ __launch_bounds__(256) void k_lm_rowmeta(LmArgs A) {
 // workgroup h1 produces the blocks at cyclic distance d = (h1 - h2) mod n <= n/2 — the lower-triangle ones directly, the others transposed —
 // so every workgroup of a window has the same amount of work (a triangular split would give the last pose n times the work of the first).
 // The workgroup's blocks live in LDS ([d][36], padded to 37) and take the products as ds_add_f64 — no co-visibility lists, no landmark x pose
-// table, each B_i Dinv formed once per edge instead of once per block.  The workgroup is ONE wave (SCH_NT = 64): a block receives its
-// products in the wave's program order, and runs are bit-identical (tools/dbg_lm_determinism.py: 8 windows x 4 runs on MI355X; with several
-// waves per row the cross-wave order of the atomics, and with it the last bits of the sums, varied from run to run).  The diagonal block
+// table, each B_i Dinv formed once per edge instead of once per block.  No two waves add into the same LDS copy: a block receives its
+// products in a wave's program order, and runs are bit-identical (tools/dbg_lm_determinism.py: 8 windows x 4 runs on MI355X; with several
+// waves sharing one copy the cross-wave order of the atomics, and with it the last bits of the sums, varied from run to run).  The diagonal block
 // also takes Hpp + lambda I (_Hpp->add(_Hschur) + setLambda) and the row's _bschur entries  b_p - sum_e B_i (Dinv b_l).
 // Rows longer than `rowCap` blocks (LDS) are produced in column chunks, walking the pose's edges once per chunk.
 #define SCH_LD 37
 #ifndef LM_SCHUR_ROWCAP
 #define LM_SCHUR_ROWCAP 384   // blocks of a row held in LDS at once (384 x 37 doubles = 111 KiB); tests build with a tiny value to cover the chunking
 #endif
-#ifndef SCH_NT
-#define SCH_NT 64    // threads per row workgroup: one wave (128 / 256: 0.3 / 2 % slower on MI355X; with one wave a block receives its products in program order)
-#endif
-static inline size_t lm_schur_smem_bytes(int rowCap) { return ((size_t)rowCap * SCH_LD + (SCH_NT / 64) * 6) * sizeof(double); }
-static __global__ __launch_bounds__(SCH_NT) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
+// NW waves per row, each with its OWN copy of the row's blocks in LDS (so a block still receives a wave's products in program order, and the
+// copies are added in wave order at write-out: bit-reproducible); the same LDS per wave whatever NW is, but a row is finished NW times
+// sooner — what a single LocalMapping call (20 rows in flight on a machine that holds 3 000 waves) needs.
+static inline size_t lm_schur_smem_bytes(int rowCap, int nw) { return ((size_t)nw * rowCap * SCH_LD + nw * 6) * sizeof(double); }
+template <int NW>
+static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
+    constexpr int SCH_NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    double* Srow = (double*)orb_smem;                 // [rowCap][SCH_LD]
-    double* coefw = Srow + (size_t)rowCap * SCH_LD;   // [SCH_NT / 64][6]
-    const lba_problem& P = A.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* Sall = (double*)orb_smem;                 // [NW][rowCap][SCH_LD]
+    double* Srow = Sall + (size_t)wave * rowCap * SCH_LD;   // this wave's copy
+    double* coefw = Sall + (size_t)NW * rowCap * SCH_LD;    // [NW][6]
+    const lba_problem& P = A.P;
 #ifndef LM_SCHUR_NO_XCD
     // All rows of a window run on ONE XCD, back to back (workgroup w is dispatched to XCD w % 8): the rows walk the same landmark-major edge
     // array in the same direction, so a run of B_j blocks fetched for one row is still in that XCD's L2 when the window's other rows want it.
@@ -756,7 +759,7 @@ static __global__ __launch_bounds__(SCH_NT) void k_lm_schur_rows(LmArgs A, int r
     const int nslot = (n >> 1) + 1;                   // slots d = 0 .. n / 2
     for (int c0 = 0; c0 < nslot; c0 += rowCap) {
         const int nblk = min(rowCap, nslot - c0);
-        for (int t = tid; t < nblk * SCH_LD; t += SCH_NT) Srow[t] = 0.0;
+        for (int t = lane; t < nblk * SCH_LD; t += 64) Srow[t] = 0.0;
         __syncthreads();
         for (int k = s0 + tid; k < s1; k += SCH_NT) {
             const int4 mt = meta[k];
@@ -821,7 +824,9 @@ static __global__ __launch_bounds__(SCH_NT) void k_lm_schur_rows(LmArgs A, int r
             const int q = t / 36, k = t - q * 36, d = c0 + q;
             if (d == dtie && 2 * h1 >= n) continue;               // the tie slot belongs to the lower pose of the antipodal pair
             const int h2 = h1 - d + (h1 < d ? n : 0);
-            double v = Srow[q * SCH_LD + k];
+            double v = Sall[q * SCH_LD + k];
+#pragma unroll
+            for (int w = 1; w < NW; w++) v += Sall[(size_t)w * rowCap * SCH_LD + q * SCH_LD + k];   // the waves' copies in wave order
             if (d == 0) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
             const int c = k / 6, r = k - c * 6;                   // entry (r, c) of block (h1, h2)
             if (h2 <= h1) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // lower triangle: row block h1, column block h2
@@ -1166,10 +1171,15 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     hipLaunchKernelGGL(k_lm_init, dim3(gB), dim3(64), 0, st, A, batch);
     // Schur rows: a row's blocks in LDS (37 doubles each); rows of more than LM_SCHUR_ROWCAP blocks are produced in column chunks
     const int rowCap = std::min(maxFree / 2 + 1, LM_SCHUR_ROWCAP);
-    const size_t schurSmem = lm_schur_smem_bytes(rowCap);
+    // waves per row: 4 while the four copies of a row fit 48 KB of LDS (rows of up to 81 blocks = 160 free key frames), else 2, else 1
+    // — but one wave per row once the batch alone fills the machine (256 CUs x 12 resident waves; measured: 58.5 vs 59.7 ms per optimize(5) of
+    // 256 C5-size windows, and 1.62 vs 2.36 ms for one 30-key-frame window)
+    const bool fills = (size_t)batch * (size_t)maxFree >= 3072;
+    const int schurNW = fills ? 1 : lm_schur_smem_bytes(rowCap, 4) <= 48 * 1024 ? 4 : lm_schur_smem_bytes(rowCap, 2) <= 48 * 1024 ? 2 : 1;
+    const size_t schurSmem = lm_schur_smem_bytes(rowCap, schurNW);
     hipLaunchKernelGGL(k_lm_rowmeta, dim3((P.cap_e + 8 + 255) / 256, batch), dim3(256), 0, st, A);
     if (schurSmem > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k_lm_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurSmem) != hipSuccess)
+        hipFuncSetAttribute((const void*)k_lm_schur_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurSmem) != hipSuccess)
         return ORB_E_HIP;
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
@@ -1193,7 +1203,12 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
-            hipLaunchKernelGGL(k_lm_schur_rows, dim3((unsigned)(((batch + 7) / 8) * 8 * P.cap_p)), dim3(SCH_NT), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+            {
+                const dim3 gS((unsigned)(((batch + 7) / 8) * 8 * P.cap_p));
+                if (schurNW == 4) hipLaunchKernelGGL(k_lm_schur_rows<4>, gS, dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+                else if (schurNW == 2) hipLaunchKernelGGL(k_lm_schur_rows<2>, gS, dim3(128), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+                else hipLaunchKernelGGL(k_lm_schur_rows<1>, gS, dim3(64), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+            }
             if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
