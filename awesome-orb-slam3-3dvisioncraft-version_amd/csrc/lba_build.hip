@@ -1156,8 +1156,8 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         if (np6cap <= WG_CHOL_LDS_MAX_LD) return ORB_E_INVALID;   // cannot happen: np6 <= np6cap
         A.panExt = (double*)take(B * np6cap * CH_LD * 8);
     }
-    // panel width 32 while 6 x maxFree x 33 doubles fit LDS (<= 90 free key frames), else 16
-    const bool nb32 = !A.panExt && np6 <= WG_CHOL_NB32_MAX_LD;
+    // panel width 32 for 54 ... 88 free key frames (6 x maxFree x 33 doubles fit LDS; smaller systems are faster with 16: dense_chol.inc), else 16
+    const bool nb32 = !A.panExt && np6 <= WG_CHOL_NB32_MAX_LD && np6 > WG_CHOL_NB32_MIN_LD;
     const size_t cholSmem = A.panExt ? wg_chol_smem_bytes_ext_t<LM_CHOL_NT, CH_NB>((int)np6)
                                      : nb32 ? wg_chol_smem_bytes_t<LM_CHOL_NT, 32>((int)np6) : wg_chol_smem_bytes_t<LM_CHOL_NT, CH_NB>((int)np6);
     if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)

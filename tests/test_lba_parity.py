@@ -239,12 +239,13 @@ def test_emu_lba_optimize_schur_row_chunks():
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
-def test_emu_lba_optimize_narrow_panel():
-    """WG_CHOL_NB32_MAX_LD=12: the 16-column LDS panel (the width windows of 89 ... 176 free key frames take on the GPU) instead of the 32-column one."""
+def test_emu_lba_optimize_wide_panel():
+    """WG_CHOL_NB32_MIN_LD=0: the 32-column Cholesky panel (which the GPU takes for 54 ... 88 free key frames) on the small test windows, which
+    default to 16 columns."""
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MAX_LD=12",), tag="cholnb16")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MIN_LD=0",), tag="cholnb32")))
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
