@@ -5,9 +5,13 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <cstdlib>
 #define CV_8U 0
+#define CV_8UC1 0
 #define CV_32F 5
+#define CV_Assert(expr) do { if (!(expr)) std::abort(); } while (0)
 namespace cv {
+struct Rect { int x, y, width, height; Rect(int x_ = 0, int y_ = 0, int w_ = 0, int h_ = 0) : x(x_), y(y_), width(w_), height(h_) {} };
 struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
 struct Point3f { float x, y, z; Point3f(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {} };
 struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
@@ -15,11 +19,15 @@ static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
 class Mat {
 public:
     int rows = 0, cols = 0;
+    size_t step = 0;     // bytes per row (dense)
     unsigned char* data = nullptr;
     Mat() {}
-    Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_((size_t)r * c * esz(), 0) { data = buf_.data(); }
-    Mat(const Mat& o) : rows(o.rows), cols(o.cols), type_(o.type_), buf_(o.buf_) { data = buf_.empty() ? nullptr : buf_.data(); }
-    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; type_ = o.type_; buf_ = o.buf_; data = buf_.empty() ? nullptr : buf_.data(); return *this; }
+    Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_((size_t)r * c * esz(), 0) { data = buf_.data(); step = (size_t)c * esz(); }
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), step(o.step), type_(o.type_), buf_(o.buf_) { data = buf_.empty() ? nullptr : buf_.data(); }
+    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; step = o.step; type_ = o.type_; buf_ = o.buf_; data = buf_.empty() ? nullptr : buf_.data(); return *this; }
+    Mat operator()(const Rect& r) const { return block(r.y, r.y + r.height, r.x, r.x + r.width); }   // a COPY of the region (value semantics here)
+    void create(int r, int c, int type) { *this = Mat(r, c, type); }
+    void release() { *this = Mat(); }
     static Mat eye(int r, int c, int type) { Mat m(r, c, type); for (int i = 0; i < r && i < c; i++) m.at<float>(i, i) = 1.f; return m; }
     bool empty() const { return buf_.empty(); }
     int type() const { return type_; }
@@ -62,4 +70,24 @@ inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F)
 inline Mat operator-(const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = -a.at<float>(i); return m; }
 inline Mat operator/(const Mat& a, float s) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) / s; return m; }
 inline double norm(const Mat& a) { return std::sqrt(a.dot(a)); }
+// InputArray / OutputArray as the extractor's operator() uses them: a view of one Mat (getMat() of the output proxy hands out the Mat itself)
+class _InputArray {
+public:
+    _InputArray(const Mat& m) : m_(&m) {}
+    bool empty() const { return m_->empty(); }
+    Mat getMat() const { return *m_; }
+private:
+    const Mat* m_;
+};
+class _OutputArray {
+public:
+    _OutputArray(Mat& m) : m_(&m) {}
+    void create(int r, int c, int type) const { m_->create(r, c, type); }
+    void release() const { m_->release(); }
+    Mat& getMat() const { return *m_; }
+private:
+    Mat* m_;
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
 }  // namespace cv

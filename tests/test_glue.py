@@ -33,3 +33,27 @@ def test_reference_signature_glue_on_emulated_library(emu_lib, tmp_path):
 def test_reference_signature_glue_on_hip_library(hip_lib, tmp_path):
     from orbhip import _lib
     _build_and_run(_lib.LIB_PATH, "hip", tmp_path)
+
+
+def _build_and_run_extractor_cv(libpath, tag, tmp_path):
+    """include/orbslam3_hip/ORBextractor.h with -DORBHIP_WITH_OPENCV: the reference's operator()(cv::InputArray, cv::InputArray,
+    vector<cv::KeyPoint>&, cv::OutputArray, vector<int>&) compiled against the mock cv:: declarations and run."""
+    exe = str(tmp_path / ("extractor_cv_test_" + tag))
+    libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)[3:-3]
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-DORBHIP_WITH_OPENCV", "-I", os.path.join(ROOT, "tests", "cpp", "mock_orbslam3"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "extractor_cv_test.cpp"), "-L", libdir, "-l" + libname,
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lpthread", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "extractor_cv_test OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_extractor_opencv_signature_on_emulated_library(emu_lib, tmp_path):
+    import build_emu
+    _build_and_run_extractor_cv(build_emu.OUT, "emu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_extractor_opencv_signature_on_hip_library(hip_lib, tmp_path):
+    from orbhip import _lib
+    _build_and_run_extractor_cv(_lib.LIB_PATH, "hip", tmp_path)
