@@ -168,6 +168,7 @@ class PoseOptimizer {
 public:
     int addCamera(const lba_camera& c) { cams_.push_back(c); return (int)cams_.size() - 1; }
     void clear() { edges_.clear(); }
+    void reset() { edges_.clear(); cams_.clear(); }   // a new frame with (possibly) other cameras; the device buffers stay
     // monocular observation (Optimizer.cc:979-1011, or :1059-1089 for the left fisheye camera)
     void addMono(const float Xw[3], float u, float v, float invSigma2, int cam = 0) { add(Xw, u, v, 0.f, invSigma2, LBA_EDGE_MONO, cam); }
     // stereo observation (Optimizer.cc:1013-1049)

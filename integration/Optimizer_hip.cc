@@ -1,5 +1,5 @@
 // integration/Optimizer_hip.cc — Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) (reference include/Optimizer.h:58,
-// src/Optimizer.cc:1811-2523) over liborbhip.so.
+// src/Optimizer.cc:1811-2523) and Optimizer::PoseOptimization(Frame*) (include/Optimizer.h:53, src/Optimizer.cc:907-1273) over liborbhip.so.
 //
 // Drop-in for the same-named function of src/Optimizer.cc: compile this file INSIDE the ORB-SLAM3 tree instead of that body
 // (integration/README.md), with -DORBHIP_WITH_ORBSLAM3.  LocalMapping calls it unchanged (LocalMapping.cc:236).
@@ -226,6 +226,57 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
         pMP->UpdateNormalAndDepth();
     }
     pMap->IncreaseChangeIndex();
+}
+
+// Optimizer::PoseOptimization(Frame*) (reference include/Optimizer.h:53, src/Optimizer.cc:907-1273; called after every matcher call in Tracking:
+// Tracking.cc:2210, 2395, 2468).  The observation walk (:966-1127) is the reference's, one PoseOptimizer observation per g2o edge in the same
+// order; the four optimise / classify rounds (:1133-1252) are the single call PoseOptimizer::optimize (one launch on the device); pose
+// recovery and return value as :1255-1270.
+int Optimizer::PoseOptimization(Frame* pFrame) {
+    thread_local orbslam3_hip::PoseOptimizer PO;     // device buffers are reused from frame to frame
+    PO.reset();
+    int nInitialCorrespondences = 0;
+    const int N = pFrame->N;
+    std::vector<size_t> vnIndexEdge;                 // feature index of every observation, in edge order
+    vnIndexEdge.reserve(N);
+    const int camL = PO.addCamera(make_camera(pFrame->mpCamera, (double)pFrame->mbf, cv::Mat()));
+    const int camR = pFrame->mpCamera2 ? PO.addCamera(make_camera(pFrame->mpCamera2, (double)pFrame->mbf, pFrame->mTrl)) : -1;
+    {
+        std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
+        for (int i = 0; i < N; i++) {
+            MapPoint* pMP = pFrame->mvpMapPoints[i];
+            if (!pMP) continue;
+            const cv::Mat Xwm = pMP->GetWorldPos();
+            const float Xw[3] = {Xwm.at<float>(0), Xwm.at<float>(1), Xwm.at<float>(2)};
+            if (!pFrame->mpCamera2) {                // Conventional SLAM (:971-1050)
+                nInitialCorrespondences++;
+                pFrame->mvbOutlier[i] = false;
+                const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+                const float invSigma2 = pFrame->mvInvLevelSigma2[kpUn.octave];
+                if (pFrame->mvuRight[i] < 0) PO.addMono(Xw, kpUn.pt.x, kpUn.pt.y, invSigma2, camL);                      // :979-1011
+                else PO.addStereo(Xw, kpUn.pt.x, kpUn.pt.y, pFrame->mvuRight[i], invSigma2, camL);                        // :1013-1049
+            } else {                                 // fisheye rig (:1052-1125): left camera on mvKeys, right camera through mTrl
+                nInitialCorrespondences++;
+                pFrame->mvbOutlier[i] = false;
+                if (i < pFrame->Nleft) {
+                    const cv::KeyPoint kpUn = pFrame->mvKeys[i];
+                    PO.addMono(Xw, kpUn.pt.x, kpUn.pt.y, pFrame->mvInvLevelSigma2[kpUn.octave], camL);
+                } else {
+                    const cv::KeyPoint kpUn = pFrame->mvKeysRight[i - pFrame->Nleft];
+                    PO.addBody(Xw, kpUn.pt.x, kpUn.pt.y, pFrame->mvInvLevelSigma2[kpUn.octave], camR);
+                }
+            }
+            vnIndexEdge.push_back((size_t)i);
+        }
+    }
+    if (nInitialCorrespondences < 3) return 0;       // :1130-1131
+    double p7[7];
+    orbslam3_hip::LbaLinearizer::poseFromTcw(pFrame->mTcw.ptr<float>(), pFrame->mTcw.cols, p7);   // Converter::toSE3Quat(pFrame->mTcw)
+    std::vector<bool> outl;
+    const int nGood = PO.optimize(p7, outl);         // 4 x optimizer.optimize(10) + chi2 classification, Huber dropped for the last round
+    for (size_t k = 0; k < vnIndexEdge.size(); k++) pFrame->mvbOutlier[vnIndexEdge[k]] = outl[k];
+    pFrame->SetPose(pose_to_cvmat(p7));              // :1255-1258
+    return nGood;                                    // nInitialCorrespondences - nBad
 }
 
 }  // namespace ORB_SLAM3

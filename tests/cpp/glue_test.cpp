@@ -21,9 +21,12 @@ int omo_search_by_projection(const void*, const uint8_t*, const float*, const ui
                              const uint8_t*, int, int, int, float, int, int32_t*, int32_t*);
 int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
                       const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
+int opo_pose_optimize(const double* pose_in, const void* edges, int n_edges, const void* cams, double* pose_out, uint8_t* outlier);
 int omo_search_by_bow_kf(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, const uint8_t*, const float*,
                          const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float, int, int32_t*);
 }
+
+std::mutex ORB_SLAM3::MapPoint::mGlobalMutex;
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
 
@@ -387,6 +390,64 @@ int main() {
         CHECK(kfs[5]->nPoseSets == before);
         std::printf("glue LocalBundleAdjustment: %zu edges, %d erased observations, %d fixed key frames\n", eref.size(), nOut, numFixed);
         for (KeyFrame* k : kfs) delete k;
+    }
+    // ---- 9. Optimizer::PoseOptimization(Frame*) on a mock frame (monocular + stereo observations, features without a map point, gross
+    //         outliers), against the oracle's restatement of the g2o schedule on the same edges ----
+    {
+        const float fx = 458.654f, fy = 457.296f, cx = 367.215f, cy = 248.375f, bf = 47.9f;
+        Pinhole cam(fx, fy, cx, cy);
+        Frame F;
+        F.mpCamera = &cam; F.mbf = bf; F.fx = fx; F.fy = fy; F.cx = cx; F.cy = cy;
+        F.N = 420;
+        F.mvInvLevelSigma2.resize(8);
+        for (int l = 0; l < 8; l++) F.mvInvLevelSigma2[l] = 1.0f / std::pow(1.2f, 2.0f * l);
+        F.mvKeysUn.resize(F.N); F.mvuRight.assign(F.N, -1.f); F.mvpMapPoints.assign(F.N, (MapPoint*)NULL); F.mvbOutlier.assign(F.N, true);
+        std::vector<MapPoint> mps(F.N);
+        // true pose: small rotation about y, translation; the frame starts from a perturbed pose
+        const float ang = 0.05f, Rt[9] = {std::cos(ang), 0, std::sin(ang), 0, 1, 0, -std::sin(ang), 0, std::cos(ang)}, tt[3] = {0.1f, -0.05f, 0.2f};
+        std::vector<pose_edge> flat;
+        for (int i = 0; i < F.N; i++) {
+            const float X[3] = {(float)(rnd() % 8000) / 1000.f - 4.f, (float)(rnd() % 4000) / 1000.f - 2.f, 4.f + (float)(rnd() % 6000) / 1000.f};
+            float Xc[3];
+            for (int r = 0; r < 3; r++) Xc[r] = Rt[r * 3] * X[0] + Rt[r * 3 + 1] * X[1] + Rt[r * 3 + 2] * X[2] + tt[r];
+            const int oct = (int)(rnd() % 8);
+            float u = fx * Xc[0] / Xc[2] + cx + ((float)(rnd() % 2000) / 1000.f - 1.f) * 0.6f, v = fy * Xc[1] / Xc[2] + cy + ((float)(rnd() % 2000) / 1000.f - 1.f) * 0.6f;
+            if (i % 11 == 3) { u += 25.f; v -= 18.f; }                         // gross outlier
+            F.mvKeysUn[i].pt = cv::Point2f(u, v); F.mvKeysUn[i].octave = oct;
+            if (i % 3 == 1) F.mvuRight[i] = u - bf / Xc[2] + ((float)(rnd() % 2000) / 1000.f - 1.f) * 0.4f;   // stereo observation
+            if (i % 7 == 5) continue;                                          // a feature without a map point
+            mps[i].mWorldPos = cv::Mat(3, 1, CV_32F);
+            for (int r = 0; r < 3; r++) mps[i].mWorldPos.at<float>(r) = X[r];
+            F.mvpMapPoints[i] = &mps[i];
+            flat.push_back(pose_edge{{X[0], X[1], X[2]}, {u, v, F.mvuRight[i] < 0 ? 0.f : F.mvuRight[i]}, F.mvInvLevelSigma2[oct],
+                                     (int16_t)(F.mvuRight[i] < 0 ? LBA_EDGE_MONO : LBA_EDGE_STEREO), 0});
+        }
+        const float a0 = 0.03f;
+        F.mTcw = cv::Mat::eye(4, 4, CV_32F);
+        F.mTcw.at<float>(0, 0) = std::cos(a0); F.mTcw.at<float>(0, 2) = std::sin(a0); F.mTcw.at<float>(2, 0) = -std::sin(a0); F.mTcw.at<float>(2, 2) = std::cos(a0);
+        F.mTcw.at<float>(0, 3) = 0.05f; F.mTcw.at<float>(1, 3) = 0.f; F.mTcw.at<float>(2, 3) = 0.1f;
+        double p7[7], pref[7];
+        orbslam3_hip::LbaLinearizer::poseFromTcw(F.mTcw.ptr<float>(), 4, p7);
+        lba_camera lc{};
+        lc.model = LBA_CAM_PINHOLE; lc.p[0] = fx; lc.p[1] = fy; lc.p[2] = cx; lc.p[3] = cy; lc.bf = bf; lc.trl_q[3] = 1.0;
+        std::vector<uint8_t> oref(flat.size());
+        const int gref = opo_pose_optimize(p7, flat.data(), (int)flat.size(), &lc, pref, oref.data());
+        const int good = Optimizer::PoseOptimization(&F);
+        CHECK(good == gref && good > 250 && good < (int)flat.size());
+        size_t k = 0;
+        int nOutl = 0;
+        for (int i = 0; i < F.N; i++) {
+            if (!F.mvpMapPoints[i]) { CHECK(F.mvbOutlier[i] == true); continue; }      // untouched
+            CHECK(F.mvbOutlier[i] == (oref[k] != 0));
+            nOutl += oref[k] != 0;
+            k++;
+        }
+        CHECK(k == flat.size() && nOutl >= 30);
+        double q7[7];
+        orbslam3_hip::LbaLinearizer::poseFromTcw(F.mTcw.ptr<float>(), 4, q7);         // the pose SetPose received (float matrix)
+        for (int j = 0; j < 7; j++) CHECK(std::fabs(q7[j] - pref[j]) < 2e-6);
+        for (int r = 0; r < 3; r++) CHECK(std::fabs(F.mTcw.at<float>(r, 3) - tt[r]) < 0.02f);   // and it found the true pose
+        std::printf("glue PoseOptimization: %zu observations, %d inliers, %d outliers\n", flat.size(), good, nOutl);
     }
     std::printf("glue_test OK\n");
     return 0;

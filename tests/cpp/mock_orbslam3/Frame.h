@@ -19,6 +19,9 @@ public:
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<bool> mvbOutlier;
     cv::Mat mTcw;
+    void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }   // Frame.cc:481-485 (UpdatePoseMatrices is not needed by the glue)
+    std::vector<float> mvInvLevelSigma2;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
     int mnScaleLevels = 8;
     float mfLogScaleFactor = 0;
     std::vector<float> mvScaleFactors;

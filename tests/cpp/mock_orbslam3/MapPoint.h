@@ -3,6 +3,7 @@
 #include <opencv2/core/core.hpp>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <tuple>
 namespace ORB_SLAM3 {
 class KeyFrame;
@@ -25,6 +26,7 @@ public:
     int PredictScale(const float& currentDist, Frame* pF);       // MapPoint.cc:531-547
     Map* GetMap() { return mpMap; }
     long unsigned int mnId = 0;
+    static std::mutex mGlobalMutex;   // include/MapPoint.h:112 (defined by the test program)
     // tracking (set by Frame::isInFrustum)
     float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackDepthR = 0, mTrackProjXR = 0, mTrackProjYR = 0;
     bool mbTrackInView = false, mbTrackInViewR = false;

@@ -1,5 +1,6 @@
-// TEST INFRASTRUCTURE (see README.md): include/Optimizer.h:58 — the declaration integration/Optimizer_hip.cc defines
+// TEST INFRASTRUCTURE (see README.md): include/Optimizer.h:53,58 — the declarations integration/Optimizer_hip.cc defines
 #pragma once
+#include "Frame.h"
 #include "KeyFrame.h"
 #include "Map.h"
 #include "MapPoint.h"
@@ -7,5 +8,6 @@ namespace ORB_SLAM3 {
 class Optimizer {
 public:
     void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF);
+    int static PoseOptimization(Frame* pFrame);   // include/Optimizer.h:53
 };
 }  // namespace ORB_SLAM3
