@@ -351,5 +351,100 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
     return nmatches;
 }
 
+// ---- SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)   ORBmatcher.cc:1138-1428, LocalMapping.cc:628 ------
+// The statements before the loops (:1144-1193: epipole, R12 / t12 or the four left / right combinations of a rig) are the reference's cv::Mat
+// expressions; the vocabulary-node walk with the epipolar gate runs on the device.  `F12` is not read — as in the reference, whose
+// GeometricCamera::epipolarConstrain recomputes what it needs from R12, t12 and the calibrations (Pinhole.cpp:155-160, KannalaBrandt8.cpp:235-330).
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                                       const bool bOnlyStereo, const bool bCoarse) {
+    (void)F12;
+    // Compute epipole in second image (:1144-1152)
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat C2 = R2w * Cw + t2w;
+    const cv::Point2f ep = pKF2->mpCamera->project(C2);
+    cv::Mat R1w = pKF1->GetRotation();
+    cv::Mat t1w = pKF1->GetTranslation();
+    GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
+    const bool rig = pKF1->mpCamera2 || pKF2->mpCamera2;
+    const bool fisheye = pCamera1->GetType() == pCamera1->CAM_FISHEYE;
+
+    // what the loops read from a key frame: mvKeysUn (a rig: [mvKeys | mvKeysRight], indexed idx / idx - NLeft :1252-1262), descriptors, mvuRight,
+    // GetMapPoint(idx) != NULL (:1229-1234), mFeatVec
+    KeyFrame* kf[2] = {pKF1, pKF2};
+    orbslam3_hip::ORBmatcher::KeyFrameView K[2];
+    std::vector<orb_keypoint> keys[2];
+    std::vector<uint8_t> has[2];
+    for (int s = 0; s < 2; s++) {
+        const int n = kf[s]->N;
+        K[s].N = n;
+        if (kf[s]->NLeft == -1) K[s].keysUn = (const orb_keypoint*)kf[s]->mvKeysUn.data();
+        else {
+            keys[s].resize(n);
+            std::memcpy(keys[s].data(), kf[s]->mvKeys.data(), (size_t)kf[s]->NLeft * sizeof(orb_keypoint));
+            std::memcpy(keys[s].data() + kf[s]->NLeft, kf[s]->mvKeysRight.data(), (size_t)(n - kf[s]->NLeft) * sizeof(orb_keypoint));
+            K[s].keysUn = keys[s].data();
+        }
+        K[s].descriptors = kf[s]->mDescriptors.data;
+        K[s].uRight = (!rig && !fisheye) ? kf[s]->mvuRight.data() : nullptr;
+        has[s].resize(n);
+        for (int i = 0; i < n; i++) has[s][i] = kf[s]->GetMapPoint(i) ? 1 : 0;
+        K[s].hasMapPoint = has[s].data();
+        flatten_featvec(kf[s]->mFeatVec, K[s]);
+    }
+    orbslam3_hip::ORBmatcher& M = device_matcher(mfNNratio, mbCheckOrientation);
+    const int nLevels = (int)pKF2->mvScaleFactors.size();
+    if (!rig && !fisheye) {
+        // :1176-1177, then Pinhole::epipolarConstrain's matrix (Pinhole.cpp:157-160), evaluated once per pair instead of once per candidate
+        cv::Mat R12 = R1w * R2w.t();
+        cv::Mat t12 = -R1w * R2w.t() * t2w + t1w;
+        cv::Mat t12x = cv::Mat(3, 3, CV_32F);
+        {   // Pinhole::SkewSymmetricMatrix (Pinhole.cpp:195-200)
+            const float x = t12.at<float>(0), y = t12.at<float>(1), z = t12.at<float>(2);
+            const float sk[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+            for (int i = 0; i < 9; i++) t12x.at<float>(i / 3, i % 3) = sk[i];
+        }
+        cv::Mat K1 = pCamera1->toK();
+        cv::Mat K2 = pCamera2->toK();
+        cv::Mat F = K1.t().inv() * t12x * R12 * K2.inv();
+        float Ff[9];
+        for (int i = 0; i < 9; i++) Ff[i] = F.at<float>(i / 3, i % 3);
+        const float epf[2] = {ep.x, ep.y};
+        return M.SearchForTriangulation(K[0], K[1], Ff, epf, pKF2->mvLevelSigma2.data(), pKF2->mvScaleFactors.data(), nLevels, vMatchedPairs,
+                                        bOnlyStereo, bCoarse);
+    }
+    // KannalaBrandt8 key frames — one fisheye camera, or a rig with the four left / right combinations (:1181-1193)
+    orbm_tri_kb8_pair P{};
+    P.n_cams = rig ? 2 : 1;
+    GeometricCamera* cams[2][2] = {{pKF1->mpCamera, pKF1->mpCamera2}, {pKF2->mpCamera, pKF2->mpCamera2}};
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < 8; i++) {
+            if (cams[0][c] && i < (int)cams[0][c]->size()) P.k1[c][i] = cams[0][c]->getParameter(i);
+            if (cams[1][c] && i < (int)cams[1][c]->size()) P.k2[c][i] = cams[1][c]->getParameter(i);
+        }
+    auto put = [&](int idx, const cv::Mat& R, const cv::Mat& t) {
+        for (int i = 0; i < 9; i++) P.R12[idx][i] = R.at<float>(i / 3, i % 3);
+        for (int i = 0; i < 3; i++) P.t12[idx][i] = t.at<float>(i);
+    };
+    if (!rig) put(0, R1w * R2w.t(), -R1w * R2w.t() * t2w + t1w);
+    else {
+        put(0, pKF1->GetRotation() * pKF2->GetRotation().t(), pKF1->GetRotation() * (-pKF2->GetRotation().t() * pKF2->GetTranslation()) + pKF1->GetTranslation());
+        put(1, pKF1->GetRotation() * pKF2->GetRightRotation().t(),
+            pKF1->GetRotation() * (-pKF2->GetRightRotation().t() * pKF2->GetRightTranslation()) + pKF1->GetTranslation());
+        put(2, pKF1->GetRightRotation() * pKF2->GetRotation().t(),
+            pKF1->GetRightRotation() * (-pKF2->GetRotation().t() * pKF2->GetTranslation()) + pKF1->GetRightTranslation());
+        put(3, pKF1->GetRightRotation() * pKF2->GetRightRotation().t(),
+            pKF1->GetRightRotation() * (-pKF2->GetRightRotation().t() * pKF2->GetRightTranslation()) + pKF1->GetRightTranslation());
+    }
+    P.ep[0] = ep.x; P.ep[1] = ep.y;
+    for (int i = 0; i < 16; i++) {
+        if (i < (int)pKF1->mvLevelSigma2.size()) P.level_sigma2_1[i] = pKF1->mvLevelSigma2[i];
+        if (i < (int)pKF2->mvLevelSigma2.size()) P.level_sigma2_2[i] = pKF2->mvLevelSigma2[i];
+        if (i < nLevels) P.scale_factors_2[i] = pKF2->mvScaleFactors[i];
+    }
+    return M.SearchForTriangulationKB8(K[0], pKF1->NLeft, K[1], pKF2->NLeft, P, vMatchedPairs, bOnlyStereo, bCoarse);
+}
+
 }  // namespace ORB_SLAM3
 #endif  // ORBHIP_WITH_ORBSLAM3

@@ -292,6 +292,116 @@ int main() {
         CHECK(nk == onk && nk > 10 && (int)vp12.size() == nA);
         for (int i = 0; i < nA; i++) CHECK(vp12[i] == (om12[i] >= 0 ? KFb.mvpMapPoints[om12[i]] : (MapPoint*)NULL));
         std::printf("glue SearchByBoW: KF-F %d, KF-KF %d matches\n", n, nk);
+        // ---- 7b. SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse): the gather (epipole, R12 / t12, F12 or the
+        //          fisheye pair record, key-frame views) against the flattened adapter driven by hand with the same quantities ----
+        {
+            auto pose = [](float ay, float tx, float ty, float tz) {
+                cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+                T.at<float>(0, 0) = std::cos(ay); T.at<float>(0, 2) = std::sin(ay); T.at<float>(2, 0) = -std::sin(ay); T.at<float>(2, 2) = std::cos(ay);
+                T.at<float>(0, 3) = tx; T.at<float>(1, 3) = ty; T.at<float>(2, 3) = tz;
+                return T;
+            };
+            Pinhole camP(fx, fy, cx, cy);
+            KannalaBrandt8 camK(std::vector<float>{190.978f, 190.973f, 254.93f, 256.9f, 0.0034f, 0.0007f, -0.0020f, 0.0002f});
+            std::vector<float> uRa(nA, -1.f), uRb(nB, -1.f);
+            for (int i = 0; i < nA; i += 3) uRa[i] = kA[i].pt.x - 3.f;
+            for (int i = 0; i < nB; i += 4) uRb[i] = kB[i].pt.x - 2.f;
+            KFa.mvuRight = uRa; KFb.mvuRight = uRb;
+            KFa.SetPose(pose(0.f, 0.f, 0.f, 0.f)); KFb.SetPose(pose(0.02f, -0.35f, 0.01f, 0.02f));
+            std::vector<MapPoint*> keepA = KFa.mvpMapPoints, keepB = KFb.mvpMapPoints;
+            GeometricCamera *camA0 = KFa.mpCamera, *camB0 = KFb.mpCamera;
+            for (int i = 0; i < nA; i++) if (i % 4 != 0) KFa.mvpMapPoints[i] = NULL;     // most features are still untriangulated
+            for (int i = 0; i < nB; i++) if (i % 5 != 0) KFb.mvpMapPoints[i] = NULL;
+            orbslam3_hip::ORBmatcher dev(0.6f, false);
+            orbslam3_hip::ORBmatcher::KeyFrameView Va, Vb;
+            std::vector<uint8_t> ha(nA), hb(nB);
+            for (int i = 0; i < nA; i++) ha[i] = KFa.mvpMapPoints[i] != NULL;
+            for (int i = 0; i < nB; i++) hb[i] = KFb.mvpMapPoints[i] != NULL;
+            Va.N = nA; Va.keysUn = (const orb_keypoint*)KFa.mvKeysUn.data(); Va.descriptors = KFa.mDescriptors.data; Va.uRight = uRa.data(); Va.hasMapPoint = ha.data();
+            Vb.N = nB; Vb.keysUn = (const orb_keypoint*)KFb.mvKeysUn.data(); Vb.descriptors = KFb.mDescriptors.data; Vb.uRight = uRb.data(); Vb.hasMapPoint = hb.data();
+            csr(KFa.mFeatVec, Va.nodeId, Va.nodeStart, Va.featIdx); csr(KFb.mFeatVec, Vb.nodeId, Vb.nodeStart, Vb.featIdx);
+            cv::Mat R1w = KFa.GetRotation(), t1w = KFa.GetTranslation(), R2w = KFb.GetRotation(), t2w = KFb.GetTranslation();
+            cv::Mat R12 = R1w * R2w.t(), t12 = -R1w * R2w.t() * t2w + t1w;
+            cv::Mat C2 = R2w * KFa.GetCameraCenter() + t2w;
+            ORBmatcher mt(0.6f, false);
+            for (int fish = 0; fish < 2; fish++) {
+                KFa.mpCamera = fish ? (GeometricCamera*)&camK : (GeometricCamera*)&camP;
+                KFb.mpCamera = KFa.mpCamera;
+                const cv::Point2f ep = KFb.mpCamera->project(C2);
+                const float epf[2] = {ep.x, ep.y};
+                std::vector<std::pair<size_t, size_t>> want, got;
+                int nw;
+                if (!fish) {
+                    cv::Mat t12x(3, 3, CV_32F);
+                    const float x = t12.at<float>(0), y = t12.at<float>(1), z = t12.at<float>(2), sk[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+                    for (int i = 0; i < 9; i++) t12x.at<float>(i / 3, i % 3) = sk[i];
+                    cv::Mat Fm = camP.toK().t().inv() * t12x * R12 * camP.toK().inv();
+                    float Ff[9];
+                    for (int i = 0; i < 9; i++) Ff[i] = Fm.at<float>(i / 3, i % 3);
+                    nw = dev.SearchForTriangulation(Va, Vb, Ff, epf, KFb.mvLevelSigma2.data(), sf.data(), 8, want, false, false);
+                } else {
+                    orbm_tri_kb8_pair P{};
+                    P.n_cams = 1;
+                    for (int i = 0; i < 8; i++) { P.k1[0][i] = camK.getParameter(i); P.k2[0][i] = camK.getParameter(i); }
+                    for (int i = 0; i < 9; i++) P.R12[0][i] = R12.at<float>(i / 3, i % 3);
+                    for (int i = 0; i < 3; i++) P.t12[0][i] = t12.at<float>(i);
+                    P.ep[0] = ep.x; P.ep[1] = ep.y;
+                    for (int i = 0; i < 8; i++) { P.level_sigma2_1[i] = KFa.mvLevelSigma2[i]; P.level_sigma2_2[i] = KFb.mvLevelSigma2[i]; P.scale_factors_2[i] = sf[i]; }
+                    Va.uRight = Vb.uRight = nullptr;
+                    nw = dev.SearchForTriangulationKB8(Va, -1, Vb, -1, P, want, false, false);
+                }
+                const int ng = mt.SearchForTriangulation(&KFa, &KFb, cv::Mat(), got, false, false);
+                CHECK(ng == nw && got == want);
+                if (!fish) CHECK(ng > 5);
+                std::printf("glue SearchForTriangulation (%s): %d pairs\n", fish ? "fisheye" : "pinhole", ng);
+            }
+            // a fisheye rig: [mvKeys | mvKeysRight], mpCamera2, the four left / right combinations of (R12, t12)
+            {
+                const int nlA = nA / 2, nlB = nB / 2;
+                KeyFrame Ra(fx, fy, cx, cy, 40.f, nlA, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2), Rb(fx, fy, cx, cy, 40.f, nlB, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+                KeyFrame* R[2] = {&Ra, &Rb};
+                const std::vector<cv::KeyPoint>* ks[2] = {&kA, &kB};
+                const int nl[2] = {nlA, nlB}, nn[2] = {nA, nB};
+                std::vector<uint8_t> hr[2];
+                orbslam3_hip::ORBmatcher::KeyFrameView Vr[2];
+                for (int q = 0; q < 2; q++) {
+                    R[q]->N = nn[q];
+                    R[q]->mvKeys.assign(ks[q]->begin(), ks[q]->begin() + nl[q]);
+                    R[q]->mvKeysRight.assign(ks[q]->begin() + nl[q], ks[q]->end());
+                    R[q]->mDescriptors = (q ? KFb : KFa).mDescriptors; R[q]->mFeatVec = (q ? KFb : KFa).mFeatVec;
+                    R[q]->mvpMapPoints = (q ? KFb : KFa).mvpMapPoints;
+                    R[q]->mpCamera = &camK; R[q]->mpCamera2 = &camK;
+                    R[q]->mTlr = pose(0.01f, 0.1f, 0.f, 0.f);
+                    R[q]->SetPose((q ? KFb : KFa).GetPose());
+                    hr[q].resize(nn[q]);
+                    for (int i = 0; i < nn[q]; i++) hr[q][i] = R[q]->mvpMapPoints[i] != NULL;
+                    Vr[q].N = nn[q]; Vr[q].keysUn = (const orb_keypoint*)ks[q]->data(); Vr[q].descriptors = R[q]->mDescriptors.data; Vr[q].hasMapPoint = hr[q].data();
+                    csr(R[q]->mFeatVec, Vr[q].nodeId, Vr[q].nodeStart, Vr[q].featIdx);
+                }
+                orbm_tri_kb8_pair P{};
+                P.n_cams = 2;
+                for (int c = 0; c < 2; c++) for (int i = 0; i < 8; i++) { P.k1[c][i] = camK.getParameter(i); P.k2[c][i] = camK.getParameter(i); }
+                cv::Mat Rl[2] = {Ra.GetRotation(), Rb.GetRotation()}, Rr[2] = {Ra.GetRightRotation(), Rb.GetRightRotation()};
+                cv::Mat tl[2] = {Ra.GetTranslation(), Rb.GetTranslation()}, tr[2] = {Ra.GetRightTranslation(), Rb.GetRightTranslation()};
+                for (int r1 = 0; r1 < 2; r1++)
+                    for (int r2 = 0; r2 < 2; r2++) {
+                        const cv::Mat& A1 = r1 ? Rr[0] : Rl[0]; const cv::Mat& A2 = r2 ? Rr[1] : Rl[1];
+                        const cv::Mat& b1 = r1 ? tr[0] : tl[0]; const cv::Mat& b2 = r2 ? tr[1] : tl[1];
+                        cv::Mat Rc = A1 * A2.t(), tc = A1 * (-A2.t() * b2) + b1;
+                        for (int i = 0; i < 9; i++) P.R12[r1 * 2 + r2][i] = Rc.at<float>(i / 3, i % 3);
+                        for (int i = 0; i < 3; i++) P.t12[r1 * 2 + r2][i] = tc.at<float>(i);
+                    }
+                const cv::Point2f ep = camK.project(Rb.GetRotation() * Ra.GetCameraCenter() + Rb.GetTranslation());
+                P.ep[0] = ep.x; P.ep[1] = ep.y;
+                for (int i = 0; i < 8; i++) { P.level_sigma2_1[i] = Ra.mvLevelSigma2[i]; P.level_sigma2_2[i] = Rb.mvLevelSigma2[i]; P.scale_factors_2[i] = sf[i]; }
+                std::vector<std::pair<size_t, size_t>> want, got;
+                const int nw = dev.SearchForTriangulationKB8(Vr[0], nlA, Vr[1], nlB, P, want, false, false);
+                const int ng = mt.SearchForTriangulation(&Ra, &Rb, cv::Mat(), got, false, false);
+                CHECK(ng == nw && got == want);
+                std::printf("glue SearchForTriangulation (fisheye rig): %d pairs\n", ng);
+            }
+            KFa.mvpMapPoints = keepA; KFb.mvpMapPoints = keepB; KFa.mpCamera = camA0; KFb.mpCamera = camB0;
+        }
     }
     // ---- 8. Optimizer::LocalBundleAdjustment on a small mock map, against the flattened LbaLinearizer path driven by hand ----
     {

@@ -13,9 +13,19 @@ public:
     KeyFrame(float fx_, float fy_, float cx_, float cy_, float mbf_, int nleft, int minx, int miny, int maxx, int maxy, float gwInv, float ghInv,
              const std::vector<float>& scale, const std::vector<float>& invSigma2)
         : mnGridCols(64), mnGridRows(48), mfGridElementWidthInv(gwInv), mfGridElementHeightInv(ghInv), fx(fx_), fy(fy_), cx(cx_), cy(cy_), mbf(mbf_),
-          mvScaleFactors(scale), mvInvLevelSigma2(invSigma2), mnMinX(minx), mnMinY(miny), mnMaxX(maxx), mnMaxY(maxy), NLeft(nleft), NRight(-1) {}
+          mvScaleFactors(scale), mvInvLevelSigma2(invSigma2), mnMinX(minx), mnMinY(miny), mnMaxX(maxx), mnMaxY(maxy), NLeft(nleft), NRight(-1) {
+        for (float s : invSigma2) mvLevelSigma2.push_back(1.0f / s);
+    }
     void SetPose(const cv::Mat& Tcw_) { Tcw = Tcw_.clone(); nPoseSets++; }
     cv::Mat GetPose() { return Tcw.clone(); }
+    cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }                    // KeyFrame.cc:210-214
+    cv::Mat GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }                         // :216-220
+    cv::Mat GetCameraCenter() { return -GetRotation().t() * GetTranslation(); }                    // Ow = -Rwc * tcw (:70-77, :180-184)
+    cv::Mat GetRightRotation() { return mTlr.rowRange(0, 3).colRange(0, 3).t() * GetRotation(); }  // :1289-1296
+    cv::Mat GetRightTranslation() {                                                                // :1299-1308
+        cv::Mat Rrl = mTlr.rowRange(0, 3).colRange(0, 3).t();
+        return Rrl * GetTranslation() + (-Rrl * mTlr.rowRange(0, 3).col(3));
+    }
     std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
     void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; nErased++; }
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
@@ -38,7 +48,8 @@ public:
     float mfLogScaleFactor = 0;
     const int mnMinX, mnMinY, mnMaxX, mnMaxY;
     GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
-    cv::Mat mTrl;
+    cv::Mat mTrl, mTlr;
+    std::vector<float> mvLevelSigma2;
     const int NLeft, NRight;
     // state
     cv::Mat Tcw;

@@ -44,7 +44,16 @@ public:
     Mat col(int c) const { return block(0, rows, c, c + 1); }
     Mat t() const { Mat m(cols, rows, CV_32F); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.at<float>(c, r) = at<float>(r, c); return m; }
     double dot(const Mat& o) const { double s = 0; for (int i = 0; i < rows * cols; i++) s += (double)at<float>(i) * (double)o.at<float>(i); return s; }
-    Mat inv() const {   // rigid 4x4 [R t; 0 1] only (Converter / write-back use)
+    Mat inv() const {   // 3x3 (cofactors in double, rounded once) or a rigid 4x4 [R t; 0 1] (Converter / write-back use)
+        if (rows == 3 && cols == 3) {
+            const double a = at<float>(0, 0), b = at<float>(0, 1), c = at<float>(0, 2), d = at<float>(1, 0), e = at<float>(1, 1), f = at<float>(1, 2),
+                         g = at<float>(2, 0), h = at<float>(2, 1), i = at<float>(2, 2);
+            const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+            const double v[9] = {e * i - f * h, c * h - b * i, b * f - c * e, f * g - d * i, a * i - c * g, c * d - a * f, d * h - e * g, b * g - a * h, a * e - b * d};
+            Mat m(3, 3, CV_32F);
+            for (int k = 0; k < 9; k++) m.at<float>(k / 3, k % 3) = (float)(v[k] / det);
+            return m;
+        }
         Mat m = eye(4, 4, CV_32F);
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m.at<float>(r, c) = at<float>(c, r);
         for (int r = 0; r < 3; r++) { double s = 0; for (int k = 0; k < 3; k++) s += (double)at<float>(k, r) * (double)at<float>(k, 3); m.at<float>(r, 3) = (float)-s; }
