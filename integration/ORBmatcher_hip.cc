@@ -446,5 +446,92 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F
     return M.SearchForTriangulationKB8(K[0], pKF1->NLeft, K[1], pKF2->NLeft, P, vMatchedPairs, bOnlyStereo, bCoarse);
 }
 
+// ---- Fuse(pKF, vpMapPoints, th, bRight)   ORBmatcher.cc:1630-1879, LocalMapping.cc:1006-1042 (every key frame, every neighbour) -----------
+// Per map point the gates and the projection (:1666-1765) are the reference's statements; the window search with the chi2 gate and the
+// best-descriptor choice (:1767-1826) runs on the device for all points at once; Replace / AddObservation (:1828-1855) are applied in index
+// order afterwards.  The map changes while the reference's loop runs — a point that an earlier iteration replaced is bad when its own turn
+// comes, a feature that an earlier iteration gave a map point has one — so isBad() / IsInKeyFrame() are read again at each point's turn and
+// pKF->GetMapPoint(bestIdx) is read at that moment, exactly as the serial loop sees them; the search itself reads nothing that changes.
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
+    cv::Mat Rcw, tcw, Ow;
+    GeometricCamera* pCamera;
+    if (bRight) { Rcw = pKF->GetRightRotation(); tcw = pKF->GetRightTranslation(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
+    else { Rcw = pKF->GetRotation(); tcw = pKF->GetTranslation(); Ow = pKF->GetCameraCenter(); pCamera = pKF->mpCamera; }
+    const float& bf = pKF->mbf;
+    const int nMPs = (int)vpMapPoints.size();
+    std::vector<orbm_query> q((size_t)nMPs);
+    std::vector<uint8_t> qd((size_t)nMPs * 32, 0);
+    for (int i = 0; i < nMPs; i++) {
+        orbm_query& Q = q[i];
+        Q = orbm_query{};
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad()) continue;                    // read again at the point's turn, below
+        else if (pMP->IsInKeyFrame(pKF)) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;        // Depth must be positive
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0), y = p3Dc.at<float>(1), z = p3Dc.at<float>(2);
+        const cv::Point2f uv = pCamera->project(cv::Point3f(x, y, z));
+        if (!pKF->IsInImage(uv.x, uv.y)) continue;     // Point must be inside the image
+        const float ur = uv.x - bf * invz;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;   // Depth must be inside the scale pyramid of the image
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;       // Viewing angle must be less than 60 deg
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        Q.u = uv.x; Q.v = uv.y; Q.u_right = ur;
+        Q.radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        Q.min_level = (int16_t)(nPredictedLevel - 1); Q.max_level = (int16_t)nPredictedLevel;
+        Q.flags = ORBM_Q_VALID;
+        const cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(&qd[(size_t)i * 32], dMP.data, 32);
+    }
+    // the key frame as GetFeaturesInArea(x, y, r, bRight) and the candidate loop index it: mvKeysUn (+ mvuRight), or one side of a rig
+    orbslam3_hip::FrameView V;
+    V.grid = orbm_grid_params{(float)pKF->mnMinX, (float)pKF->mnMinY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv};
+    int idxOffset = 0;
+    if (pKF->NLeft == -1) {
+        V.N = (int)pKF->mvKeysUn.size();
+        V.keysUn = (const orb_keypoint*)pKF->mvKeysUn.data();
+        V.descriptors = pKF->mDescriptors.data;
+        V.uRight = pKF->mvuRight.data();
+    } else if (!bRight) {
+        V.N = pKF->NLeft;
+        V.keysUn = (const orb_keypoint*)pKF->mvKeys.data();
+        V.descriptors = pKF->mDescriptors.data;
+    } else {
+        V.N = (int)pKF->mvKeysRight.size();
+        V.keysUn = (const orb_keypoint*)pKF->mvKeysRight.data();
+        V.descriptors = pKF->mDescriptors.data + (size_t)pKF->NLeft * 32;   // `if(bRight) idx += pKF->NLeft;` :1817
+        idxOffset = pKF->NLeft;
+    }
+    std::vector<int> bestIdx, bestDist;
+    device_matcher(mfNNratio, mbCheckOrientation).Fuse(V, q, qd, pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), bestIdx, bestDist);
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP || bestIdx[i] < 0) continue;          // no candidate at all, or bestDist > TH_LOW (:1828)
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;   // what :1678-1687 sees at this point's turn
+        const int idx = bestIdx[i] + idxOffset;
+        MapPoint* pMPinKF = pKF->GetMapPoint(idx);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, idx);
+            pKF->AddMapPoint(pMP, idx);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
 }  // namespace ORB_SLAM3
 #endif  // ORBHIP_WITH_ORBSLAM3

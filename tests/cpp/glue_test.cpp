@@ -403,6 +403,89 @@ int main() {
             KFa.mvpMapPoints = keepA; KFb.mvpMapPoints = keepB; KFa.mpCamera = camA0; KFb.mpCamera = camB0;
         }
     }
+    // ---- 7c. Fuse(pKF, vpMapPoints, th, bRight = false): map points built to land on chosen features of a key frame; every branch of the serial
+    //          scatter (:1828-1855) and its order dependence — two points on one feature, a point already in the key frame, bad / null points ----
+    {
+        KeyFrame KF(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+        Pinhole camP(fx, fy, cx, cy);
+        KF.mpCamera = &camP; KF.N = nB; KF.mvKeys = kB; KF.mvKeysUn = kB; KF.mDescriptors = descMat(dB); KF.mvuRight.assign(nB, -1.f);
+        KF.mfLogScaleFactor = std::log(1.2f); KF.mnScaleLevels = 8;
+        KF.mvpMapPoints.assign(nB, (MapPoint*)NULL);
+        cv::Mat I4 = cv::Mat::eye(4, 4, CV_32F);
+        KF.SetPose(I4);
+        std::vector<MapPoint> inKF(nB);                 // map points the key frame already has on some features
+        std::vector<int> target;                        // feature index each fused candidate is built for
+        std::vector<MapPoint> cand;
+        cand.reserve(400);
+        std::vector<MapPoint*> vp;
+        auto make = [&](int j, float depth, int nobs) {
+            MapPoint p;
+            const float u = kB[j].pt.x, v = kB[j].pt.y;
+            p.mWorldPos = cv::Mat(3, 1, CV_32F);
+            p.mWorldPos.at<float>(0) = (u - cx) * depth / fx; p.mWorldPos.at<float>(1) = (v - cy) * depth / fy; p.mWorldPos.at<float>(2) = depth;
+            const float d = (float)cv::norm(p.mWorldPos);
+            p.mNormalVector = p.mWorldPos / d;
+            p.mfMaxDistance = d * sf[kB[j].octave] * 0.999f / 1.2f;   // GetMaxDistanceInvariance() = 1.2 * this -> PredictScale == the feature's octave
+            p.mfMinDistance = 0.01f;
+            p.mDescriptor = cv::Mat(1, 32, CV_8U);
+            std::memcpy(p.mDescriptor.data, &dB[(size_t)j * 32], 32);
+            p.mDescriptor.data[j % 32] ^= 0x11;                      // two bits off the feature's own descriptor
+            p.nObs = nobs;
+            return p;
+        };
+        // PredictScale uses mfMaxDistance (not the 1.2x getter): ratio = mfMaxDistance / dist
+        int expectFused = 0;
+        for (int j = 5; j < nB && (int)cand.size() < 300; j += 3) {
+            if (kB[j].octave < 1) continue;                          // level window [oct-1, oct] must contain the feature
+            const int kind = (int)cand.size() % 6;
+            MapPoint p = make(j, 3.f + (j % 7), 3);
+            p.mfMaxDistance = (float)cv::norm(p.mWorldPos) * sf[kB[j].octave] * 0.999f;
+            if (kind == 1) { inKF[j].nObs = 9; KF.mvpMapPoints[j] = &inKF[j]; }          // feature's point has more observations: candidate is replaced by it
+            if (kind == 2) { inKF[j].nObs = 1; KF.mvpMapPoints[j] = &inKF[j]; }          // fewer: the feature's point is replaced by the candidate
+            if (kind == 3) p.mbBad = true;                                               // skipped
+            cand.push_back(p); target.push_back(j);
+        }
+        for (size_t i = 0; i < cand.size(); i++) {
+            vp.push_back(&cand[i]);
+            if (i % 6 == 4) { cand[i].mObservations[&KF] = std::make_tuple(0, -1); }     // already observed in this key frame: skipped
+            if (i % 6 == 5 && i + 6 < cand.size()) {                                     // a second candidate for the SAME feature right behind it
+                MapPoint p2 = make(target[i], 3.f + (target[i] % 7), 7);
+                p2.mfMaxDistance = (float)cv::norm(p2.mWorldPos) * sf[kB[target[i]].octave] * 0.999f;
+                cand.push_back(p2); target.push_back(target[i]);
+            }
+        }
+        vp.clear();
+        for (size_t i = 0; i < cand.size(); i++) vp.push_back(&cand[i]);
+        vp.push_back(NULL);
+        // expectation by construction, applied serially
+        std::vector<MapPoint*> expMP = KF.mvpMapPoints;
+        std::vector<int> expBad(cand.size(), 0), expObs(cand.size());
+        std::vector<int> inBad(nB, 0);
+        for (size_t i = 0; i < cand.size(); i++) expObs[i] = cand[i].nObs, expBad[i] = cand[i].mbBad;
+        auto idxOf = [&](MapPoint* p) { return (int)(p - &cand[0]); };
+        for (size_t i = 0; i < cand.size(); i++) {
+            if (expBad[i] || cand[i].mObservations.count(&KF)) continue;
+            const int j = target[i];
+            MapPoint* in = expMP[j];
+            if (in) {
+                const bool isCand = in >= &cand[0] && in < &cand[0] + cand.size();
+                const int inObs = isCand ? expObs[idxOf(in)] : in->nObs;
+                const bool inIsBad = isCand ? expBad[idxOf(in)] : inBad[j];
+                if (!inIsBad) {
+                    if (inObs > expObs[i]) { expBad[i] = 1; if (isCand) expObs[idxOf(in)] += expObs[i]; }
+                    else { if (isCand) expBad[idxOf(in)] = 1; else inBad[j] = 1; expObs[i] += inObs; }
+                }
+            } else { expMP[j] = &cand[i]; expObs[i]++; }
+            expectFused++;
+        }
+        ORBmatcher mf(0.6f, true);
+        const int nf = mf.Fuse(&KF, vp, 3.0f, false);
+        CHECK(nf == expectFused && nf > 100);
+        for (int j = 0; j < nB; j++) CHECK(KF.mvpMapPoints[j] == expMP[j]);
+        for (size_t i = 0; i < cand.size(); i++) CHECK(cand[i].mbBad == (expBad[i] != 0) && cand[i].nObs == expObs[i]);
+        for (int j = 0; j < nB; j++) CHECK(inKF[j].mbBad == (inBad[j] != 0));
+        std::printf("glue Fuse: %zu candidates, %d fused\n", cand.size(), nf);
+    }
     // ---- 8. Optimizer::LocalBundleAdjustment on a small mock map, against the flattened LbaLinearizer path driven by hand ----
     {
         Map map; map.mnInitKFid = 0;

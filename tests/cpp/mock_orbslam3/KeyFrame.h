@@ -30,6 +30,8 @@ public:
     void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; nErased++; }
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }                  // KeyFrame.cc:437-441
+    cv::Mat GetRightCameraCenter() { return -GetRightRotation().t() * GetRightTranslation(); }
     bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
     bool isBad() { return mbBad; }
     Map* GetMap() { return mpMap; }

@@ -19,6 +19,10 @@ public:
     int Observations() { return nObs; }
     std::map<KeyFrame*, std::tuple<int, int>> GetObservations() { return mObservations; }
     void EraseObservation(KeyFrame* pKF) { mObservations.erase(pKF); nErased++; }
+    bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }                       // MapPoint.cc:405-409
+    void AddObservation(KeyFrame* pKF, int idx) { mObservations[pKF] = std::make_tuple(idx, -1); nObs++; }   // :123-148 (monocular count)
+    void Replace(MapPoint* pMP) { if (pMP == this) return; mbBad = true; mpReplaced = pMP; pMP->nObs += nObs; }   // :281-338, as far as Fuse can observe it
+    MapPoint* mpReplaced = nullptr;
     void UpdateNormalAndDepth() { nNormalUpdates++; }
     float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }

@@ -20,6 +20,7 @@ public:
     int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
                                const bool bCoarse = false);   // include/ORBmatcher.h:74
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false);   // include/ORBmatcher.h:85
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;
