@@ -224,7 +224,8 @@ struct Sim3Gather {
     std::vector<int> src;   // query -> index into vpPoints
 };
 // the projection loop both overloads share (:600-652 / :716-768), verbatim conditions
-Sim3Gather gather_sim3(KeyFrame* pKF, const cv::Mat& Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<MapPoint*>& vpMatched, int th) {
+Sim3Gather gather_sim3(KeyFrame* pKF, const cv::Mat& Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<MapPoint*>& vpMatched, int th,
+                       float thFuse = -1.f) {   // thFuse >= 0: the float `th` of Fuse(pKF, Scw, ...) (:1881) instead of the searches' int
     cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
     const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
     cv::Mat Rcw = sRcw / scw;
@@ -250,7 +251,7 @@ Sim3Gather gather_sim3(KeyFrame* pKF, const cv::Mat& Scw, const std::vector<MapP
         cv::Mat Pn = pMP->GetNormal();
         if (PO.dot(Pn) < 0.5 * dist) continue;
         int nPredictedLevel = pMP->PredictScale(dist, pKF);
-        const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        const float radius = thFuse >= 0.f ? thFuse * pKF->mvScaleFactors[nPredictedLevel] : th * pKF->mvScaleFactors[nPredictedLevel];
         const cv::Mat dMP = pMP->GetDescriptor();
         // KeyFrame::GetFeaturesInArea has no level filter; the loop keeps [nPredictedLevel-1, nPredictedLevel] (:671-674): same candidates, same order
         S.q.push_back(orbm_query{uv.x, uv.y, radius, 0.f, 0.f, (int16_t)(nPredictedLevel - 1), (int16_t)nPredictedLevel, ORBM_Q_VALID | ORBM_Q_HAS_OBS});
@@ -351,6 +352,18 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
     return nmatches;
 }
 
+// ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)   ORBmatcher.cc:838-979, Tracking.cc (monocular initialisation) ----
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) {
+    FrameGather G1(F1, [](MapPoint*) { return false; }, false), G2(F2, [](MapPoint*) { return false; }, false);
+    G1.V.N = (int)F1.mvKeysUn.size(); G2.V.N = (int)F2.mvKeysUn.size();   // the function indexes mvKeysUn (:844, :856-859)
+    std::vector<float> prev(2 * (size_t)G1.V.N);
+    for (int i = 0; i < G1.V.N; i++) { prev[2 * i] = vbPrevMatched[i].x; prev[2 * i + 1] = vbPrevMatched[i].y; }
+    const int nmatches = device_matcher(mfNNratio, mbCheckOrientation).SearchForInitialization(G1.V, G2.V, prev, vnMatches12, windowSize);
+    for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)   // Update prev matched (:972-975)
+        if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
+    return nmatches;
+}
+
 // ---- SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)   ORBmatcher.cc:1138-1428, LocalMapping.cc:628 ------
 // The statements before the loops (:1144-1193: epipole, R12 / t12 or the four left / right combinations of a rig) are the reference's cv::Mat
 // expressions; the vocabulary-node walk with the epipolar gate runs on the device.  `F12` is not read — as in the reference, whose
@@ -446,6 +459,72 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F
     return M.SearchForTriangulationKB8(K[0], pKF1->NLeft, K[1], pKF2->NLeft, P, vMatchedPairs, bOnlyStereo, bCoarse);
 }
 
+// ---- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)   ORBmatcher.cc:2008-2232 (loop closing: more matches under a known Sim3) ------
+// The two projection passes (:2044-2080 key frame 1's points into key frame 2, :2131-2167 the other way) are the reference's statements up to
+// GetFeaturesInArea; both window searches and the mutual-agreement test (:2206-2220) run on the device.
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12,
+                             const float th) {
+    const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation();   // Camera 1 from world
+    cv::Mat R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();   // Camera 2 from world
+    cv::Mat sR12 = s12 * R12;                                          // Transformation between cameras
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+        MapPoint* pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    // one pass: the points of `from` (through Rw, tw into their own camera, then sR, t into the other one) as window queries in `into`
+    auto pass = [&](const std::vector<MapPoint*>& vp, const std::vector<bool>& already, const cv::Mat& Rw, const cv::Mat& tw, const cv::Mat& sR, const cv::Mat& t,
+                    KeyFrame* into, std::vector<orbm_query>& q, std::vector<uint8_t>& qd) {
+        const int N = (int)vp.size();
+        q.assign((size_t)N, orbm_query{});
+        qd.assign((size_t)N * 32, 0);
+        for (int i = 0; i < N; i++) {
+            MapPoint* pMP = vp[i];
+            if (!pMP || already[i]) continue;
+            if (pMP->isBad()) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            cv::Mat p3Dc = Rw * p3Dw + tw;
+            cv::Mat p3Do = sR * p3Dc + t;
+            if (p3Do.at<float>(2) < 0.0) continue;             // Depth must be positive
+            const float invz = 1.0 / p3Do.at<float>(2);
+            const float x = p3Do.at<float>(0) * invz, y = p3Do.at<float>(1) * invz;
+            const float u = fx * x + cx, v = fy * y + cy;
+            if (!into->IsInImage(u, v)) continue;              // Point must be inside the image
+            const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = cv::norm(p3Do);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;   // Depth must be inside the scale invariance region
+            const int nPredictedLevel = pMP->PredictScale(dist3D, into);
+            q[i].u = u; q[i].v = v; q[i].radius = th * into->mvScaleFactors[nPredictedLevel];
+            q[i].min_level = (int16_t)(nPredictedLevel - 1); q[i].max_level = (int16_t)nPredictedLevel;
+            q[i].flags = ORBM_Q_VALID;
+            std::memcpy(&qd[(size_t)i * 32], pMP->GetDescriptor().data, 32);
+        }
+    };
+    std::vector<orbm_query> q12, q21;
+    std::vector<uint8_t> d12, d21;
+    pass(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, q12, d12);
+    pass(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, q21, d21);
+    std::vector<uint8_t> occ1, occ2;
+    const std::vector<MapPoint*> none1(pKF1->mvKeysUn.size(), (MapPoint*)NULL), none2(pKF2->mvKeysUn.size(), (MapPoint*)NULL);
+    const orbslam3_hip::FrameView V1 = keyframe_view(pKF1, occ1, none1), V2 = keyframe_view(pKF2, occ2, none2);
+    std::vector<int> m12;
+    const int nFound = device_matcher(mfNNratio, mbCheckOrientation).SearchBySim3(V1, V2, q12, d12, q21, d21, m12);
+    for (int i1 = 0; i1 < N1; i1++)
+        if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];   // :2214
+    return nFound;
+}
+
 // ---- Fuse(pKF, vpMapPoints, th, bRight)   ORBmatcher.cc:1630-1879, LocalMapping.cc:1006-1042 (every key frame, every neighbour) -----------
 // Per map point the gates and the projection (:1666-1765) are the reference's statements; the window search with the chi2 gate and the
 // best-descriptor choice (:1767-1826) runs on the device for all points at once; Replace / AddObservation (:1828-1855) are applied in index
@@ -527,6 +606,36 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
         } else {
             pMP->AddObservation(pKF, idx);
             pKF->AddMapPoint(pMP, idx);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+// ---- Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)   ORBmatcher.cc:1881-2006 (loop closing / map merging: fuse the points seen from the other side) ----
+// Gates and projection (:1883-1935) are the loop the Sim3 SearchByProjection overloads share (gather_sim3: the same statements with
+// spAlreadyFound = pKF->GetMapPoints(), taken once before the loop as in the reference); one device search without the chi2 gate; the scatter
+// (:1975-1990) in index order, pKF->GetMapPoint(bestIdx) read at each point's turn (an earlier iteration may have filled the feature).
+int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const std::vector<MapPoint*> already(spAlreadyFound.begin(), spAlreadyFound.end());
+    const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, already, (int)th, th);
+    std::vector<uint8_t> occ;
+    const std::vector<MapPoint*> none(pKF->mvKeysUn.size(), (MapPoint*)NULL);
+    const orbslam3_hip::FrameView V = keyframe_view(pKF, occ, none);
+    std::vector<int> bestIdx, bestDist;
+    device_matcher(mfNNratio, mbCheckOrientation).Fuse(V, S.q, S.qd, nullptr, 0, bestIdx, bestDist);
+    int nFused = 0;
+    for (size_t k = 0; k < S.src.size(); k++) {
+        if (bestIdx[k] < 0) continue;                  // no candidate, or bestDist > TH_LOW (:1975)
+        const int iMP = S.src[k];
+        MapPoint* pMP = vpPoints[iMP];
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[k]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx[k]);
+            pKF->AddMapPoint(pMP, bestIdx[k]);
         }
         nFused++;
     }

@@ -21,6 +21,11 @@ int omo_search_by_projection(const void*, const uint8_t*, const float*, const ui
                              const uint8_t*, int, int, int, float, int, int32_t*, int32_t*);
 int omo_search_by_bow(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, const uint8_t*, const float*, int,
                       const int32_t*, const int32_t*, const int32_t*, int, float, int, int32_t*, int);
+int omo_search_for_initialization(const void* kps1, const uint8_t* desc1, int n1, const void* kps2, const uint8_t* desc2, int n2, float minX, float minY,
+                                  float gwInv, float ghInv, float* prev, int windowSize, float nnratio, int checkOri, int32_t* matches12);
+int omo_search_by_sim3(const void* kps1, const uint8_t* desc1, int n1, float minX1, float minY1, float gwInv1, float ghInv1, const void* kps2, const uint8_t* desc2,
+                       int n2, float minX2, float minY2, float gwInv2, float ghInv2, const void* q12, const uint8_t* q12desc, const void* q21, const uint8_t* q21desc,
+                       int32_t* matches12);
 int opo_pose_optimize(const double* pose_in, const void* edges, int n_edges, const void* cams, double* pose_out, uint8_t* outlier);
 int omo_search_by_bow_kf(const uint8_t*, const float*, const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, const uint8_t*, const float*,
                          const uint8_t*, const int32_t*, const int32_t*, const int32_t*, int, int, float, int, int32_t*);
@@ -403,6 +408,74 @@ int main() {
             KFa.mvpMapPoints = keepA; KFb.mvpMapPoints = keepB; KFa.mpCamera = camA0; KFb.mpCamera = camB0;
         }
     }
+    // ---- 7a'. SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) against the oracle's restatement of :838-979 ----
+    {
+        Frame F1 = fresh_frame(), F2 = fresh_frame();
+        F1.N = nA; F1.mvKeys = kA; F1.mvKeysUn = kA; F1.mDescriptors = descMat(dA); F1.mvuRight.assign(nA, -1.f); F1.mvpMapPoints.assign(nA, (MapPoint*)NULL);
+        std::vector<cv::Point2f> prev(nA);
+        std::vector<float> oprev(2 * (size_t)nA);
+        for (int i = 0; i < nA; i++) { prev[i] = cv::Point2f(kA[i].pt.x + 5.f, kA[i].pt.y - 3.f); oprev[2 * i] = prev[i].x; oprev[2 * i + 1] = prev[i].y; }
+        std::vector<int32_t> om(nA);
+        const int on = omo_search_for_initialization(kA.data(), dA.data(), nA, kB.data(), dB.data(), nB, Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv,
+                                                     Frame::mfGridElementHeightInv, oprev.data(), 30, 0.9f, 1, om.data());
+        ORBmatcher mi(0.9f, true);
+        std::vector<int> m12;
+        const int n = mi.SearchForInitialization(F1, F2, prev, m12, 30);
+        CHECK(n == on && n > 20 && (int)m12.size() == nA);
+        for (int i = 0; i < nA; i++) {
+            CHECK(m12[i] == om[i]);
+            CHECK(prev[i].x == oprev[2 * i] && prev[i].y == oprev[2 * i + 1]);
+        }
+        std::printf("glue SearchForInitialization: %d matches\n", n);
+    }
+    // ---- 7b'. SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): two key frames looking at the same points under a similarity; the
+    //           window queries are rebuilt here from the scene's construction and given to the oracle's restatement of :2044-2220 ----
+    {
+        KeyFrame K1(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2), K2(fx, fy, cx, cy, 40.f, -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+        K1.N = nA; K1.mvKeys = kA; K1.mvKeysUn = kA; K1.mDescriptors = descMat(dA); K1.mfLogScaleFactor = std::log(1.2f);
+        K2.N = nB; K2.mvKeys = kB; K2.mvKeysUn = kB; K2.mDescriptors = descMat(dB); K2.mfLogScaleFactor = std::log(1.2f);
+        cv::Mat I4 = cv::Mat::eye(4, 4, CV_32F);
+        K1.SetPose(I4); K2.SetPose(I4);
+        // Sim3 from camera 2 to camera 1: identity rotation, scale 1, translation 0 — every point projects to its own pixel in the other view, so the
+        // queries are known in closed form (and the frames are the shifted pair A / B: windows find the true partners)
+        const float s12 = 1.0f;
+        cv::Mat R12 = cv::Mat::eye(3, 3, CV_32F), t12(3, 1, CV_32F);
+        std::vector<MapPoint> p1(nA), p2(nB);
+        K1.mvpMapPoints.assign(nA, (MapPoint*)NULL); K2.mvpMapPoints.assign(nB, (MapPoint*)NULL);
+        struct Q { float u, v, radius, ur, angle; int16_t lo, hi; uint32_t flags; };
+        std::vector<Q> q12(nA), q21(nB);
+        std::vector<uint8_t> d12((size_t)nA * 32, 0), d21((size_t)nB * 32, 0);
+        auto lift = [&](MapPoint& p, const cv::KeyPoint& k, float du, float dv, const uint8_t* desc, Q& q, uint8_t* qd, KeyFrame* into) {
+            const float z = 4.f, u = k.pt.x + du, v = k.pt.y + dv;     // lands at (u, v) in the other view
+            p.mWorldPos = cv::Mat(3, 1, CV_32F);
+            p.mWorldPos.at<float>(0) = (u - cx) / fx * z; p.mWorldPos.at<float>(1) = (v - cy) / fy * z; p.mWorldPos.at<float>(2) = z;
+            const float d = (float)cv::norm(p.mWorldPos);
+            p.mfMaxDistance = d * sf[k.octave] * 0.999f; p.mfMinDistance = 0.01f;
+            p.mDescriptor = cv::Mat(1, 32, CV_8U);
+            std::memcpy(p.mDescriptor.data, desc, 32);
+            // the reference's projection of this point (:2056-2062): u = fx * (X / Z) + cx
+            const float invz = 1.0 / p.mWorldPos.at<float>(2), xx = p.mWorldPos.at<float>(0) * invz, yy = p.mWorldPos.at<float>(1) * invz;
+            const float uu = fx * xx + cx, vv = fy * yy + cy;
+            if (!into->IsInImage(uu, vv)) return;
+            const int L = p.PredictScale(d, into);
+            q = Q{uu, vv, 7.5f * sf[L], 0.f, 0.f, (int16_t)(L - 1), (int16_t)L, 1u};
+            std::memcpy(qd, desc, 32);
+        };
+        for (int i = 0; i < nA; i++) { q12[i] = Q{}; if (i % 4 != 3) { lift(p1[i], kA[i], 6.f, -4.f, &dA[(size_t)i * 32], q12[i], &d12[(size_t)i * 32], &K2); K1.mvpMapPoints[i] = &p1[i]; } }
+        for (int j = 0; j < nB; j++) { q21[j] = Q{}; if (j % 5 != 4) { lift(p2[j], kB[j], -6.f, 4.f, &dB[(size_t)j * 32], q21[j], &d21[(size_t)j * 32], &K1); K2.mvpMapPoints[j] = &p2[j]; } }
+        p1[8].mbBad = true; q12[8] = Q{}; std::memset(&d12[8 * 32], 0, 32);                       // a bad point takes no part
+        std::vector<MapPoint*> m12(nA, (MapPoint*)NULL);
+        m12[12] = &p2[20]; p2[20].mObservations[&K2] = std::make_tuple(20, -1);                     // an earlier match: both ends are taken
+        q12[12] = Q{}; std::memset(&d12[12 * 32], 0, 32); q21[20] = Q{}; std::memset(&d21[20 * 32], 0, 32);
+        std::vector<int32_t> om(nA);
+        const int on = omo_search_by_sim3(kA.data(), dA.data(), nA, 0.f, 0.f, 64.f / W, 48.f / H, kB.data(), dB.data(), nB, 0.f, 0.f, 64.f / W, 48.f / H, q12.data(),
+                                          d12.data(), q21.data(), d21.data(), om.data());
+        ORBmatcher ms(0.75f, true);
+        const int n = ms.SearchBySim3(&K1, &K2, m12, s12, R12, t12, 7.5f);
+        CHECK(n == on && n > 20);
+        for (int i = 0; i < nA; i++) CHECK(m12[i] == (i == 12 ? &p2[20] : om[i] >= 0 ? K2.mvpMapPoints[om[i]] : (MapPoint*)NULL));
+        std::printf("glue SearchBySim3: %d mutual matches\n", n);
+    }
     // ---- 7c. Fuse(pKF, vpMapPoints, th, bRight = false): map points built to land on chosen features of a key frame; every branch of the serial
     //          scatter (:1828-1855) and its order dependence — two points on one feature, a point already in the key frame, bad / null points ----
     {
@@ -485,6 +558,37 @@ int main() {
         for (size_t i = 0; i < cand.size(); i++) CHECK(cand[i].mbBad == (expBad[i] != 0) && cand[i].nObs == expObs[i]);
         for (int j = 0; j < nB; j++) CHECK(inKF[j].mbBad == (inBad[j] != 0));
         std::printf("glue Fuse: %zu candidates, %d fused\n", cand.size(), nf);
+        // the Sim3 overload on what is left: fresh points on features that are still free or already taken (-> vpReplacePoint), Scw = identity
+        {
+            std::vector<MapPoint> more;
+            more.reserve(200);
+            std::vector<int> tgt;
+            for (int j = 4; j < nB && (int)more.size() < 150; j += 5) {
+                if (kB[j].octave < 1) continue;
+                MapPoint p = make(j, 5.f, 2);
+                p.mfMaxDistance = (float)cv::norm(p.mWorldPos) * sf[kB[j].octave] * 0.999f;
+                if (more.size() % 7 == 3) p.mbBad = true;
+                more.push_back(p); tgt.push_back(j);
+            }
+            std::vector<MapPoint*> vq, repl(more.size(), (MapPoint*)NULL), expRepl(more.size(), (MapPoint*)NULL);
+            for (size_t i = 0; i < more.size(); i++) vq.push_back(&more[i]);
+            vq[5] = KF.mvpMapPoints[target[0]] ? KF.mvpMapPoints[target[0]] : vq[5];   // a point the key frame already has: skipped (spAlreadyFound)
+            std::vector<MapPoint*> expMP2 = KF.mvpMapPoints;
+            const std::set<MapPoint*> have = KF.GetMapPoints();
+            int expN = 0;
+            for (size_t i = 0; i < vq.size(); i++) {
+                if (vq[i]->mbBad || have.count(vq[i])) continue;
+                const int j = tgt[i];
+                if (expMP2[j]) { if (!expMP2[j]->mbBad) expRepl[i] = expMP2[j]; }
+                else expMP2[j] = vq[i];
+                expN++;
+            }
+            const int n2 = mf.Fuse(&KF, I4, vq, 3.0f, repl);
+            CHECK(n2 == expN && n2 > 60);
+            for (size_t i = 0; i < vq.size(); i++) CHECK(repl[i] == expRepl[i]);
+            for (int j = 0; j < nB; j++) CHECK(KF.mvpMapPoints[j] == expMP2[j]);
+            std::printf("glue Fuse (Sim3): %zu points, %d fused\n", vq.size(), n2);
+        }
     }
     // ---- 8. Optimizer::LocalBundleAdjustment on a small mock map, against the flattened LbaLinearizer path driven by hand ----
     {

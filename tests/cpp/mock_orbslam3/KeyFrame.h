@@ -2,6 +2,7 @@
 #pragma once
 #include <opencv2/core/core.hpp>
 #include <algorithm>
+#include <set>
 #include <vector>
 #include "GeometricCamera.h"
 #include "Map.h"
@@ -29,6 +30,7 @@ public:
     std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
     void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; nErased++; }
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }   // KeyFrame.cc:465-478
     MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }                  // KeyFrame.cc:437-441
     cv::Mat GetRightCameraCenter() { return -GetRightRotation().t() * GetRightTranslation(); }

@@ -19,6 +19,10 @@ public:
     int Observations() { return nObs; }
     std::map<KeyFrame*, std::tuple<int, int>> GetObservations() { return mObservations; }
     void EraseObservation(KeyFrame* pKF) { mObservations.erase(pKF); nErased++; }
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) {                                          // MapPoint.cc:393-403
+        std::map<KeyFrame*, std::tuple<int, int>>::iterator it = mObservations.find(pKF);
+        return it != mObservations.end() ? it->second : std::tuple<int, int>(-1, -1);
+    }
     bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }                       // MapPoint.cc:405-409
     void AddObservation(KeyFrame* pKF, int idx) { mObservations[pKF] = std::make_tuple(idx, -1); nObs++; }   // :123-148 (monocular count)
     void Replace(MapPoint* pMP) { if (pMP == this) return; mbBad = true; mpReplaced = pMP; pMP->nObs += nObs; }   // :281-338, as far as Fuse can observe it

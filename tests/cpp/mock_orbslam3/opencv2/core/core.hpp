@@ -77,6 +77,7 @@ inline Mat operator*(const Mat& a, const Mat& b) {
 inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) + b.at<float>(i); return m; }
 inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) - b.at<float>(i); return m; }
 inline Mat operator-(const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = -a.at<float>(i); return m; }
+inline Mat operator*(double s, const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = (float)(s * (double)a.at<float>(i)); return m; }
 inline Mat operator/(const Mat& a, float s) { Mat m(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) m.at<float>(i) = a.at<float>(i) / s; return m; }
 inline double norm(const Mat& a) { return std::sqrt(a.dot(a)); }
 // InputArray / OutputArray as the extractor's operator() uses them: a view of one Mat (getMat() of the output proxy hands out the Mat itself)

@@ -1,6 +1,7 @@
 """The reference-signature glue (integration/ORBmatcher_hip.cc, integration/Optimizer_hip.cc) compiled with -DORBHIP_WITH_ORBSLAM3 against the
 minimal mock declarations in tests/cpp/mock_orbslam3 (boundary test infrastructure, see its README) and run: the 5 SearchByProjection overloads,
-both SearchByBoW overloads, SearchForTriangulation (pinhole / fisheye / rig), Fuse, LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) and
+both SearchByBoW overloads, SearchForInitialization, SearchForTriangulation (pinhole / fisheye / rig), SearchBySim3, both Fuse overloads,
+LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) and
 PoseOptimization(Frame*) must reproduce the oracle / the flattened path / the outcome the scene was built for.
 CPU tier = emulated library, GPU tier = the real liborbhip.so."""
 import os
