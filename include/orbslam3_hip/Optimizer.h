@@ -225,6 +225,7 @@ private:
 class InertialBA {
 public:
     void setRig(const liba_rig& rig) { rig_ = rig; }
+    void clear() { kfs_.clear(); pts_.clear(); edges_.clear(); imu_.clear(); chi2_.clear(); depth_.clear(); }   // a new window; the device buffers stay
     // Rwb / twb: pKF->GetImuRotation / GetImuPosition; Rcw / tcw of camera 0: pKF->GetRotation / GetTranslation (row-major doubles widened from
     // the float cv::Mat); camera 1 (if any) is derived like G2oTypes.cc:55-63 by the caller and passed in Rcw1 / tcw1 (may be null)
     int addKeyFrame(const double Rwb[9], const double twb[3], const double Rcw0[9], const double tcw0[3], const double* Rcw1, const double* tcw1,

@@ -1,5 +1,6 @@
 // integration/Optimizer_hip.cc — Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) (reference include/Optimizer.h:58,
-// src/Optimizer.cc:1811-2523) and Optimizer::PoseOptimization(Frame*) (include/Optimizer.h:53, src/Optimizer.cc:907-1273) over liborbhip.so.
+// src/Optimizer.cc:1811-2523), Optimizer::PoseOptimization(Frame*) (include/Optimizer.h:53, src/Optimizer.cc:907-1273) and
+// Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, bool, bool) (include/Optimizer.h:99, src/Optimizer.cc:4753-5365) over liborbhip.so.
 //
 // Drop-in for the same-named function of src/Optimizer.cc: compile this file INSIDE the ORB-SLAM3 tree instead of that body
 // (integration/README.md), with -DORBHIP_WITH_ORBSLAM3.  LocalMapping calls it unchanged (LocalMapping.cc:236).
@@ -12,7 +13,9 @@
 // Not taken over: the Verbose / file-dump diagnostics of the reference (bRedrawError is dead code there: the function returns before it).
 #ifdef ORBHIP_WITH_ORBSLAM3
 #include "Optimizer.h"
+#include "G2oTypes.h"
 
+#include <algorithm>
 #include <cmath>
 #include <list>
 #include <map>
@@ -277,6 +280,281 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
     for (size_t k = 0; k < vnIndexEdge.size(); k++) pFrame->mvbOutlier[vnIndexEdge[k]] = outl[k];
     pFrame->SetPose(pose_to_cvmat(p7));              // :1255-1258
     return nGood;                                    // nInitialCorrespondences - nBad
+}
+
+// Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, bool bLarge, bool bRecInit) (reference include/Optimizer.h:99, src/Optimizer.cc:4753-5365;
+// LocalMapping.cc:196 calls it in the inertial modes instead of LocalBundleAdjustment).
+//   * the temporal window (:4769-4787), its map points (:4791-4811), the fixed key frames (:4813-4876), the outlier pass (:5237-5275), the
+//     rejection test (:5280-5285), the erase loop and the write-back (:5289-5350) are the reference's statements;
+//   * the g2o graph (:4899-5215) becomes one window of orbslam3_hip::InertialBA: key frames in ascending mnId (g2o's Hessian block order), one
+//     liba_imu_edge per EdgeInertial + EdgeGyroRW + EdgeAccRW triple in the reference's insertion order, visual edges landmark-major in
+//     GetObservations() order; optimizer.optimize(opt_it) with setUserLambdaInit is InertialBA::optimize (one launch on the device).
+//   * EdgeInertial's information matrix is taken from the reference's own EdgeInertial constructor (G2oTypes.cc:706-725), so the eigenvalue
+//     clean-up is the reference's code, not a restatement.
+// pbStopFlag: the reference hands it to the optimizer only AFTER optimize() returned (:5228-5229), so it has no effect there either.
+void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool bLarge, bool bRecInit) {
+    (void)pbStopFlag;
+    Map* pCurrentMap = pKF->GetMap();
+    int maxOpt = 10, opt_it = 10;
+    if (bLarge) { maxOpt = 25; opt_it = 4; }
+    const int Nd = std::min((int)pCurrentMap->KeyFramesInMap() - 2, maxOpt);
+    // ---- optimisable key frames: the temporal chain behind pKF (:4769-4787) ----
+    std::vector<KeyFrame*> vpOptimizableKFs;
+    const std::vector<KeyFrame*> vpNeighsKFs = pKF->GetVectorCovisibleKeyFrames();
+    std::list<KeyFrame*> lpOptVisKFs;
+    vpOptimizableKFs.reserve(Nd);
+    vpOptimizableKFs.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (int i = 1; i < Nd; i++) {
+        if (vpOptimizableKFs.back()->mPrevKF) {
+            vpOptimizableKFs.push_back(vpOptimizableKFs.back()->mPrevKF);
+            vpOptimizableKFs.back()->mnBALocalForKF = pKF->mnId;
+        } else
+            break;
+    }
+    int N = vpOptimizableKFs.size();
+    // ---- their map points (:4791-4811) ----
+    std::list<MapPoint*> lLocalMapPoints;
+    for (int i = 0; i < N; i++) {
+        std::vector<MapPoint*> vpMPs = vpOptimizableKFs[i]->GetMapPointMatches();
+        for (std::vector<MapPoint*>::iterator vit = vpMPs.begin(), vend = vpMPs.end(); vit != vend; vit++) {
+            MapPoint* pMP = *vit;
+            if (pMP)
+                if (!pMP->isBad())
+                    if (pMP->mnBALocalForKF != pKF->mnId) { lLocalMapPoints.push_back(pMP); pMP->mnBALocalForKF = pKF->mnId; }
+        }
+    }
+    // ---- the key frame before the chain is fixed; without one the oldest of the chain is (:4813-4826) ----
+    std::list<KeyFrame*> lFixedKeyFrames;
+    if (vpOptimizableKFs.back()->mPrevKF) {
+        lFixedKeyFrames.push_back(vpOptimizableKFs.back()->mPrevKF);
+        vpOptimizableKFs.back()->mPrevKF->mnBAFixedForKF = pKF->mnId;
+    } else {
+        vpOptimizableKFs.back()->mnBALocalForKF = 0;
+        vpOptimizableKFs.back()->mnBAFixedForKF = pKF->mnId;
+        lFixedKeyFrames.push_back(vpOptimizableKFs.back());
+        vpOptimizableKFs.pop_back();
+    }
+    // ---- optimisable covisible key frames (maxCovKF = 0 in the reference: the list stays empty, :4829-4860) ----
+    const size_t maxCovKF = 0;
+    for (int i = 0, iend = vpNeighsKFs.size(); i < iend; i++) {
+        if (lpOptVisKFs.size() >= maxCovKF) break;
+        KeyFrame* pKFi = vpNeighsKFs[i];
+        if (pKFi->mnBALocalForKF == pKF->mnId || pKFi->mnBAFixedForKF == pKF->mnId) continue;
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) {
+            lpOptVisKFs.push_back(pKFi);
+            std::vector<MapPoint*> vpMPs = pKFi->GetMapPointMatches();
+            for (std::vector<MapPoint*>::iterator vit = vpMPs.begin(), vend = vpMPs.end(); vit != vend; vit++) {
+                MapPoint* pMP = *vit;
+                if (pMP)
+                    if (!pMP->isBad())
+                        if (pMP->mnBALocalForKF != pKF->mnId) { lLocalMapPoints.push_back(pMP); pMP->mnBALocalForKF = pKF->mnId; }
+            }
+        }
+    }
+    // ---- fixed key frames: the first unmarked observer of each local map point, at most 200 (:4863-4882) ----
+    const size_t maxFixKF = 200;
+    for (std::list<MapPoint*>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+        std::map<KeyFrame*, std::tuple<int, int>> observations = (*lit)->GetObservations();
+        for (std::map<KeyFrame*, std::tuple<int, int>>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+            KeyFrame* pKFi = mit->first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad()) { lFixedKeyFrames.push_back(pKFi); break; }
+            }
+        }
+        if (lFixedKeyFrames.size() >= maxFixKF) break;
+    }
+    N = vpOptimizableKFs.size();
+
+    // ---- the graph (:4899-5215) as one window of orbslam3_hip::InertialBA ----
+    thread_local orbslam3_hip::InertialBA IB;   // device buffers are reused from call to call
+    IB.clear();
+    auto widen = [](const cv::Mat& m, double* out) { for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.cols; c++) out[r * m.cols + c] = (double)m.at<float>(r, c); };
+    auto mul33 = [](const double* A, const double* B, double* C) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c]; };
+    auto mul31 = [](const double* A, const double* x, const double* t, double* y) { for (int r = 0; r < 3; r++) y[r] = A[r * 3] * x[0] + A[r * 3 + 1] * x[1] + A[r * 3 + 2] * x[2] + (t ? t[r] : 0.0); };
+    double Rrl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, trl[3] = {0, 0, 0};
+    const bool bRig = pKF->mpCamera2 != nullptr;
+    if (bRig) { widen(pKF->mTrl.rowRange(0, 3).colRange(0, 3), Rrl); widen(pKF->mTrl.rowRange(0, 3).col(3), trl); }   // Converter::toMatrix4d(pKF->mTrl)
+    {   // the calibration members of ImuCamPose (G2oTypes.cc:44-66): the same for every key frame of the map
+        liba_rig rig{};
+        rig.n_cams = bRig ? 2 : 1;
+        widen(pKF->mImuCalib.Tcb.rowRange(0, 3).colRange(0, 3), rig.Rcb[0]);
+        widen(pKF->mImuCalib.Tcb.rowRange(0, 3).col(3), rig.tcb[0]);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rig.Rbc[0][r * 3 + c] = rig.Rcb[0][c * 3 + r];
+        widen(pKF->mImuCalib.Tbc.rowRange(0, 3).col(3), rig.tbc[0]);
+        rig.bf = (double)pKF->mbf;
+        GeometricCamera* cams[2] = {pKF->mpCamera, pKF->mpCamera2};
+        for (int k = 0; k < rig.n_cams; k++) {
+            rig.model[k] = cams[k]->GetType() == cams[k]->CAM_FISHEYE ? LBA_CAM_KB8 : LBA_CAM_PINHOLE;
+            for (size_t i = 0; i < cams[k]->size() && i < 8; i++) rig.p[k][i] = (double)cams[k]->getParameter((int)i);
+        }
+        if (bRig) {
+            mul31(Rrl, rig.tcb[0], trl, rig.tcb[1]);
+            mul33(Rrl, rig.Rcb[0], rig.Rcb[1]);
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rig.Rbc[1][r * 3 + c] = rig.Rcb[1][c * 3 + r];
+            double nt[3] = {-rig.tcb[1][0], -rig.tcb[1][1], -rig.tcb[1][2]};
+            mul31(rig.Rbc[1], nt, nullptr, rig.tbc[1]);
+        }
+        IB.setRig(rig);
+    }
+    // vertices: VertexPose id = mnId, V / G / A ids above every pose id -> key frames in ascending mnId
+    struct KfRole { KeyFrame* kf; bool poseFixed, hasImu, imuFixed; };
+    std::map<long unsigned int, KfRole> kfById;
+    for (int i = 0; i < N; i++) kfById[vpOptimizableKFs[i]->mnId] = KfRole{vpOptimizableKFs[i], false, vpOptimizableKFs[i]->bImu, false};              // :4899-4925
+    for (KeyFrame* pKFi : lpOptVisKFs) kfById[pKFi->mnId] = KfRole{pKFi, false, false, false};                                                        // :4928-4935
+    for (KeyFrame* pKFi : lFixedKeyFrames) kfById[pKFi->mnId] = KfRole{pKFi, true, pKFi->bImu, true};                                                 // :4938-4962
+    std::map<KeyFrame*, int> kfIdx;
+    for (auto& kv : kfById) {
+        KeyFrame* pKFi = kv.second.kf;
+        double Rwb[9], twb[3], Rcw0[9], tcw0[3], Rcw1[9], tcw1[3], v[3] = {0, 0, 0}, bg[3] = {0, 0, 0}, ba[3] = {0, 0, 0};
+        widen(pKFi->GetImuRotation(), Rwb); widen(pKFi->GetImuPosition(), twb);      // ImuCamPose(KeyFrame*) (G2oTypes.cc:24-70)
+        widen(pKFi->GetRotation(), Rcw0); widen(pKFi->GetTranslation(), tcw0);
+        if (bRig) { mul33(Rrl, Rcw0, Rcw1); mul31(Rrl, tcw0, trl, tcw1); }
+        if (kv.second.hasImu) { widen(pKFi->GetVelocity(), v); widen(pKFi->GetGyroBias(), bg); widen(pKFi->GetAccBias(), ba); }   // G2oTypes.cc:671-696
+        kfIdx[pKFi] = IB.addKeyFrame(Rwb, twb, Rcw0, tcw0, bRig ? Rcw1 : nullptr, bRig ? tcw1 : nullptr, v, bg, ba, kv.second.poseFixed, kv.second.hasImu, kv.second.imuFixed);
+    }
+    // inertial edges, newest first (:4964-5062)
+    for (int i = 0; i < N; i++) {
+        KeyFrame* pKFi = vpOptimizableKFs[i];
+        if (!pKFi->mPrevKF) continue;   // "NOT INERTIAL LINK TO PREVIOUS FRAME"
+        if (pKFi->bImu && pKFi->mPrevKF->bImu && pKFi->mpImuPreintegrated) {
+            IMU::Preintegrated* pInt = pKFi->mpImuPreintegrated;
+            pInt->SetNewBias(pKFi->mPrevKF->GetImuBias());
+            if (!kfIdx.count(pKFi->mPrevKF)) continue;   // a vertex of the previous key frame is missing (:4982-4987)
+            liba_imu_edge e{};
+            e.kf1 = kfIdx[pKFi->mPrevKF]; e.kf2 = kfIdx[pKFi];
+            auto narrow = [](const cv::Mat& m, float* out) { for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.cols; c++) out[r * m.cols + c] = m.at<float>(r, c); };
+            narrow(pInt->dR, e.dR); narrow(pInt->dV, e.dV); narrow(pInt->dP, e.dP);
+            narrow(pInt->JRg, e.JRg); narrow(pInt->JVg, e.JVg); narrow(pInt->JVa, e.JVa); narrow(pInt->JPg, e.JPg); narrow(pInt->JPa, e.JPa);
+            e.b[0] = pInt->b.bax; e.b[1] = pInt->b.bay; e.b[2] = pInt->b.baz; e.b[3] = pInt->b.bwx; e.b[4] = pInt->b.bwy; e.b[5] = pInt->b.bwz;
+            e.dT = pInt->dT;
+            EdgeInertial ei(pInt);   // the reference's constructor builds the information matrix
+            const double scale = (i == N - 1) ? 1e-2 : 1.0;                       // vei[i]->setInformation(vei[i]->information()*1e-2) (:5009)
+            for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) e.info[r * 9 + c] = ei.information()(r, c) * scale;
+            e.huber = (i == N - 1 || bRecInit) ? std::sqrt(16.92) : 0.0;          // rki->setDelta(sqrt(16.92)) (:5005-5012)
+            const cv::Mat cvInfoG = pInt->C.rowRange(9, 12).colRange(9, 12).inv(cv::DECOMP_SVD);     // :5024-5029
+            const cv::Mat cvInfoA = pInt->C.rowRange(12, 15).colRange(12, 15).inv(cv::DECOMP_SVD);   // :5036-5041
+            widen(cvInfoG, e.info_g); widen(cvInfoA, e.info_a);
+            IB.addInertial(e);
+        }
+    }
+    // map points and their observations (:5078-5215)
+    struct VisRef { KeyFrame* kf; MapPoint* mp; bool stereo; };
+    std::vector<VisRef> vis;   // in InertialBA edge order
+    std::vector<MapPoint*> vpPoints;
+    for (std::list<MapPoint*>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+        MapPoint* pMP = *lit;
+        const cv::Mat Xwm = pMP->GetWorldPos();
+        const float Xw[3] = {Xwm.at<float>(0), Xwm.at<float>(1), Xwm.at<float>(2)};
+        const int l = IB.addPoint(Xw);
+        vpPoints.push_back(pMP);
+        const std::map<KeyFrame*, std::tuple<int, int>> observations = pMP->GetObservations();
+        for (std::map<KeyFrame*, std::tuple<int, int>>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+            KeyFrame* pKFi = mit->first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) continue;
+            if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) {
+                if (!kfIdx.count(pKFi)) continue;   // marked but without a vertex (the reference would dereference a null vertex here)
+                const int leftIndex = std::get<0>(mit->second);
+                cv::KeyPoint kpUn;
+                Eigen::Matrix<double, 2, 1> obs;
+                if (leftIndex != -1 && pKFi->mvuRight[leftIndex] < 0) {   // Monocular observation (:5103-5126)
+                    kpUn = pKFi->mvKeysUn[leftIndex];
+                    obs(0, 0) = kpUn.pt.x; obs(1, 0) = kpUn.pt.y;
+                    const float unc2 = pKFi->mpCamera->uncertainty2(obs);
+                    IB.addMono(kfIdx[pKFi], l, kpUn.pt.x, kpUn.pt.y, pKFi->mvInvLevelSigma2[kpUn.octave] / unc2, 0);
+                    vis.push_back(VisRef{pKFi, pMP, false});
+                } else if (leftIndex != -1) {                             // Stereo observation (:5128-5156)
+                    kpUn = pKFi->mvKeysUn[leftIndex];
+                    obs(0, 0) = kpUn.pt.x; obs(1, 0) = kpUn.pt.y;
+                    const float unc2 = pKFi->mpCamera->uncertainty2(obs);
+                    IB.addStereo(kfIdx[pKFi], l, kpUn.pt.x, kpUn.pt.y, pKFi->mvuRight[leftIndex], pKFi->mvInvLevelSigma2[kpUn.octave] / unc2);
+                    vis.push_back(VisRef{pKFi, pMP, true});
+                }
+                if (pKFi->mpCamera2) {                                    // right camera of the rig (:5159-5192)
+                    int rightIndex = std::get<1>(mit->second);
+                    if (rightIndex != -1) {
+                        rightIndex -= pKFi->NLeft;
+                        const cv::KeyPoint kp = pKFi->mvKeysRight[rightIndex];
+                        obs(0, 0) = kp.pt.x; obs(1, 0) = kp.pt.y;
+                        const float unc2 = pKFi->mpCamera->uncertainty2(obs);
+                        // the reference weights this edge with the LEFT key point's octave (kpUn; octave 0 when there is no left observation)
+                        IB.addMono(kfIdx[pKFi], l, kp.pt.x, kp.pt.y, pKFi->mvInvLevelSigma2[kpUn.octave] / unc2, 1);
+                        vis.push_back(VisRef{pKFi, pMP, false});
+                    }
+                }
+            }
+        }
+    }
+
+    double dErr = 0, dErrEnd = 0;
+    const int its = IB.optimize(bLarge ? 1e-2 : 1e0, opt_it, &dErr, &dErrEnd);   // setUserLambdaInit (:4884-4896), optimizer.optimize(opt_it) (:5225)
+    if (its < 0 || vis.empty()) return;   // nothing to optimise, or the window was rejected (more than LIBA_MAX_FREE optimisable key frames)
+    const float err = (float)dErr, err_end = (float)dErrEnd;
+
+    // ---- outlier observations (:5237-5275): monocular edges (left and right camera) first, then stereo ----
+    const float chi2Mono2 = 5.991f, chi2Stereo2 = 7.815f;
+    std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;
+    vToErase.reserve(vis.size());
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t i = 0; i < vis.size(); i++) {
+            if (vis[i].stereo != (pass == 1)) continue;
+            MapPoint* pMP = vis[i].mp;
+            if (pMP->isBad()) continue;
+            const double chi2 = IB.visualChi2((int)i);
+            if (pass == 0) {
+                const bool bClose = pMP->mTrackDepth < 10.f;
+                if ((chi2 > chi2Mono2 && !bClose) || (chi2 > 1.5f * chi2Mono2 && bClose) || !IB.depthPositive((int)i)) vToErase.push_back(std::make_pair(vis[i].kf, pMP));
+            } else if (chi2 > chi2Stereo2)
+                vToErase.push_back(std::make_pair(vis[i].kf, pMP));
+        }
+
+    // Get Map Mutex and erase outliers
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !bLarge) return;   // "FAIL LOCAL-INERTIAL BA" (:5280-5285)
+    if (!vToErase.empty())
+        for (size_t i = 0; i < vToErase.size(); i++) {
+            KeyFrame* pKFi = vToErase[i].first;
+            MapPoint* pMPi = vToErase[i].second;
+            pKFi->EraseMapPointMatch(pMPi);
+            pMPi->EraseObservation(pKFi);
+        }
+    for (std::list<KeyFrame*>::iterator lit = lFixedKeyFrames.begin(), lend = lFixedKeyFrames.end(); lit != lend; lit++) (*lit)->mnBAFixedForKF = 0;
+
+    // ---- recover optimized data (:5306-5350) ----
+    auto toCvSE3 = [](const liba_keyframe& k) {   // Converter::toCvSE3(VP->estimate().Rcw[0], VP->estimate().tcw[0])
+        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.at<float>(r, c) = (float)k.Rcw[0][r * 3 + c]; T.at<float>(r, 3) = (float)k.tcw[0][r]; }
+        return T;
+    };
+    N = vpOptimizableKFs.size();
+    for (int i = 0; i < N; i++) {
+        KeyFrame* pKFi = vpOptimizableKFs[i];
+        const liba_keyframe& k = IB.keyFrame(kfIdx[pKFi]);
+        pKFi->SetPose(toCvSE3(k));
+        pKFi->mnBALocalForKF = 0;
+        if (pKFi->bImu) {
+            cv::Mat Vw(3, 1, CV_32F);
+            for (int r = 0; r < 3; r++) Vw.at<float>(r) = (float)k.v[r];   // Converter::toCvMat(VV->estimate())
+            pKFi->SetVelocity(Vw);
+            pKFi->SetNewBias(IMU::Bias(k.ba[0], k.ba[1], k.ba[2], k.bg[0], k.bg[1], k.bg[2]));   // IMU::Bias(b[3],b[4],b[5],b[0],b[1],b[2]) with b = (bg, ba)
+        }
+    }
+    for (std::list<KeyFrame*>::iterator it = lpOptVisKFs.begin(), itEnd = lpOptVisKFs.end(); it != itEnd; it++) {
+        KeyFrame* pKFi = *it;
+        pKFi->SetPose(toCvSE3(IB.keyFrame(kfIdx[pKFi])));
+        pKFi->mnBALocalForKF = 0;
+    }
+    for (size_t l = 0; l < vpPoints.size(); l++) {
+        MapPoint* pMP = vpPoints[l];
+        const double* X = IB.point((int)l);
+        cv::Mat Xw(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) Xw.at<float>(i) = (float)X[i];
+        pMP->SetWorldPos(Xw);
+        pMP->UpdateNormalAndDepth();
+    }
+    pMap->IncreaseChangeIndex();
 }
 
 }  // namespace ORB_SLAM3

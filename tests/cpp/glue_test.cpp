@@ -11,6 +11,7 @@
 
 #include "ORBmatcher.h"
 #include "Optimizer.h"
+#include "G2oTypes.h"
 #include <orbslam3_hip/Optimizer.h>
 
 extern "C" {
@@ -745,6 +746,221 @@ int main() {
         for (int j = 0; j < 7; j++) CHECK(std::fabs(q7[j] - pref[j]) < 2e-6);
         for (int r = 0; r < 3; r++) CHECK(std::fabs(F.mTcw.at<float>(r, 3) - tt[r]) < 0.02f);   // and it found the true pose
         std::printf("glue PoseOptimization: %zu observations, %d inliers, %d outliers\n", flat.size(), good, nOutl);
+    }
+    // ---- 10. Optimizer::LocalInertialBA(pKF, pbStopFlag, pMap, bLarge, bRecInit) on a mock inertial map (a temporal chain of key frames with
+    //          preintegrations, monocular + stereo observations, gross outliers, near and far points), against InertialBA driven by hand in the
+    //          order the glue must produce.  Scene A: the chain is longer than the window (the key frame before it is fixed with its V / G / A
+    //          vertices, an older observer is fixed by the observation walk).  Scene B: the chain ends inside the window (its oldest key frame
+    //          is popped and fixed), bLarge + bRecInit. ----
+    KannalaBrandt8 fishL(std::vector<float>{190.f, 190.f, 240.f, 180.f, 0.003f, 0.0007f, -0.002f, 0.0002f}), fishR(std::vector<float>{191.f, 189.f, 238.f, 181.f, 0.002f, 0.0009f, -0.001f, 0.0001f});
+    for (int scene = 0; scene < 3; scene++) {
+        const bool bLarge = scene == 1, bRecInit = scene == 1, rigScene = scene == 2;   // scene C: scene A's window on a fisheye rig (right-camera edges)
+        const int NK = scene == 0 ? 8 : (scene == 1 ? 5 : 6), NP = 140;
+        cv::Mat Trl = cv::Mat::eye(4, 4, CV_32F);   // x_right = Rrl x_left + trl
+        Trl.at<float>(0, 0) = std::cos(0.02f); Trl.at<float>(0, 2) = std::sin(0.02f); Trl.at<float>(2, 0) = -std::sin(0.02f); Trl.at<float>(2, 2) = std::cos(0.02f);
+        Trl.at<float>(0, 3) = -0.1f; Trl.at<float>(1, 3) = 0.001f; Trl.at<float>(2, 3) = 0.002f;
+        const float dtk = 0.3f;
+        Map map; map.mnInitKFid = 0; map.mbIsInertial = true; map.nKeyFrames = scene == 1 ? 20 : NK;
+        std::vector<KeyFrame*> kfs;
+        std::vector<IMU::Preintegrated*> pre;
+        std::vector<MapPoint> pts(NP);
+        std::vector<cv::Mat> Xtrue(NP);
+        for (int j = 0; j < NP; j++) {
+            Xtrue[j] = cv::Mat(3, 1, CV_32F);
+            Xtrue[j].at<float>(0) = frand(-2.f, 4.f); Xtrue[j].at<float>(1) = frand(-2.f, 2.f); Xtrue[j].at<float>(2) = frand(4.f, 14.f);
+            pts[j].mnId = j; pts[j].mpMap = &map; pts[j].mWorldPos = Xtrue[j].clone();
+            for (int k = 0; k < 3; k++) pts[j].mWorldPos.at<float>(k) += frand(-0.03f, 0.03f);
+            pts[j].mTrackDepth = Xtrue[j].at<float>(2);   // near (< 10: the 1.5x chi2 rule) and far points
+        }
+        cv::Mat Tcb = cv::Mat::eye(4, 4, CV_32F), Tbc = cv::Mat::eye(4, 4, CV_32F);
+        Tcb.at<float>(0, 3) = 0.05f; Tbc.at<float>(0, 3) = -0.05f;
+        for (int k = 0; k < NK; k++) {
+            cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+            T.at<float>(0, 3) = 0.05f - 0.3f * k;              // truth: body at (0.3 k, 0, 0), Rwb = I, camera 5 cm beside it
+            std::vector<cv::KeyPoint> keysL, keysR;
+            std::vector<float> uR;
+            std::vector<MapPoint*> mpL, mpR;
+            std::vector<int> jl, jr;
+            for (int j = 0; j < NP; j++) {
+                if ((j + 2 * k) % 5 == 0) continue;
+                cv::Mat Xc = T.rowRange(0, 3).colRange(0, 3) * Xtrue[j] + T.rowRange(0, 3).col(3);
+                const float z = Xc.at<float>(2);
+                const cv::Point2f pl = rigScene ? fishL.project(Xc) : cam.project(Xc);
+                const float u = pl.x, v = pl.y;
+                const bool inL = !(u < 5 || u > W - 5 || v < 5 || v > H - 5) && !(rigScene && j % 7 == 3);   // rig: some points are seen by the right camera only
+                if (inL) {
+                    cv::KeyPoint kp; kp.pt = cv::Point2f(u + frand(-0.5f, 0.5f), v + frand(-0.5f, 0.5f)); kp.octave = (int)(rnd() % 3);
+                    if ((j * 5 + k) % 37 == 0) kp.pt.y += 30.f;   // a gross outlier observation
+                    else if ((j * 3 + k) % 7 == 0 && j % 2 == 0) { kp.pt.y += 2.75f; kp.octave = 0; }   // a monocular residual between chi2Mono2 and 1.5 x chi2Mono2
+                    keysL.push_back(kp); uR.push_back((j % 2 && !rigScene) ? kp.pt.x - 40.f / z : -1.f); mpL.push_back(&pts[j]); jl.push_back(j);
+                }
+                if (rigScene && j % 3 != 1) {
+                    cv::Mat Xr = Trl.rowRange(0, 3).colRange(0, 3) * Xc + Trl.rowRange(0, 3).col(3);
+                    const cv::Point2f pr = fishR.project(Xr);
+                    if (pr.x < 5 || pr.x > W - 5 || pr.y < 5 || pr.y > H - 5) continue;
+                    cv::KeyPoint kp; kp.pt = cv::Point2f(pr.x + frand(-0.5f, 0.5f), pr.y + frand(-0.5f, 0.5f)); kp.octave = (int)(rnd() % 3);
+                    if ((j * 3 + k) % 41 == 0) kp.pt.x -= 25.f;
+                    keysR.push_back(kp); mpR.push_back(&pts[j]); jr.push_back(j);
+                }
+            }
+            KeyFrame* kf = new KeyFrame(fx, fy, cx, cy, 40.f, rigScene ? (int)keysL.size() : -1, 0, 0, W, H, 64.f / W, 48.f / H, sf, invSig2);
+            kf->mnId = k; kf->mpMap = &map; kf->bImu = true;
+            kf->mpCamera = rigScene ? (GeometricCamera*)&fishL : (GeometricCamera*)&cam;
+            if (rigScene) { kf->mpCamera2 = &fishR; kf->mTrl = Trl; }
+            kf->mImuCalib.Tcb = Tcb; kf->mImuCalib.Tbc = Tbc;
+            kf->mvKeys = keysL; kf->mvKeysUn = keysL; kf->mvuRight = uR; kf->mvKeysRight = keysR; kf->mvpMapPoints = mpL;
+            for (MapPoint* p : mpR) kf->mvpMapPoints.push_back(p);
+            for (size_t i = 0; i < jl.size(); i++) pts[jl[i]].mObservations[kf] = std::make_tuple((int)i, -1);
+            for (size_t i = 0; i < jr.size(); i++) {
+                auto it = pts[jr[i]].mObservations.find(kf);
+                const int li = it == pts[jr[i]].mObservations.end() ? -1 : std::get<0>(it->second);
+                pts[jr[i]].mObservations[kf] = std::make_tuple(li, (int)(keysL.size() + i));
+            }
+            kf->N = (int)kf->mvKeysUn.size();
+            const bool moved = scene == 1 ? k >= 1 : k >= 2;   // the key frames that will be optimised start off the truth
+            if (moved) { T.at<float>(0, 3) += frand(-0.02f, 0.02f); T.at<float>(1, 3) += frand(-0.02f, 0.02f); T.at<float>(2, 3) += frand(-0.02f, 0.02f); }
+            kf->Tcw = T;
+            kf->Vw = cv::Mat(3, 1, CV_32F);
+            kf->Vw.at<float>(0) = 1.f + (moved ? frand(-0.05f, 0.05f) : 0.f); kf->Vw.at<float>(1) = moved ? frand(-0.05f, 0.05f) : 0.f; kf->Vw.at<float>(2) = 0.f;
+            kf->mImuBias = IMU::Bias(frand(-0.01f, 0.01f), frand(-0.01f, 0.01f), frand(-0.01f, 0.01f), frand(-0.001f, 0.001f), frand(-0.001f, 0.001f), frand(-0.001f, 0.001f));
+            if (k > 0) {
+                kf->mPrevKF = kfs[k - 1]; kfs[k - 1]->mNextKF = kf;
+                IMU::Preintegrated* pi = new IMU::Preintegrated();
+                pi->dT = dtk;
+                pi->dR = cv::Mat::eye(3, 3, CV_32F); pi->dV = cv::Mat(3, 1, CV_32F); pi->dP = cv::Mat(3, 1, CV_32F);
+                pi->dV.at<float>(2) = 9.81f * dtk; pi->dP.at<float>(2) = 0.5f * 9.81f * dtk * dtk;   // the exact deltas of the constant-velocity truth
+                pi->JRg = -(double)dtk * cv::Mat::eye(3, 3, CV_32F); pi->JVa = -(double)dtk * cv::Mat::eye(3, 3, CV_32F);
+                pi->JPa = -0.5 * dtk * dtk * cv::Mat::eye(3, 3, CV_32F);
+                pi->JVg = cv::Mat(3, 3, CV_32F); pi->JPg = cv::Mat(3, 3, CV_32F);
+                pi->JVg.at<float>(0, 1) = 0.01f; pi->JPg.at<float>(1, 0) = -0.002f;
+                pi->C = cv::Mat(15, 15, CV_32F);
+                for (int q = 0; q < 15; q++) pi->C.at<float>(q, q) = q < 3 ? 1.f / 3e4f : (q < 6 ? 1.f / 2e3f : (q < 9 ? 1.f / 8e3f : (q < 12 ? 1.f / 4e5f : 1.f / 2e3f)));
+                pi->C.at<float>(0, 3) = pi->C.at<float>(3, 0) = 2e-5f; pi->C.at<float>(4, 7) = pi->C.at<float>(7, 4) = -3e-5f;
+                pi->C.at<float>(9, 10) = pi->C.at<float>(10, 9) = 4e-7f;
+                pi->b = kfs[k - 1]->mImuBias;   // integrated with the previous key frame's bias
+                kf->mpImuPreintegrated = pi;
+                pre.push_back(pi);
+            }
+            kfs.push_back(kf);
+        }
+        KeyFrame* cur = kfs[NK - 1];
+        // ---- by hand ----
+        const int firstFree = scene == 1 ? 1 : 2;   // A: Nd = min(8 - 2, 10) = 6 -> key frames 7..2, 1 fixed (before the chain), 0 fixed (observer);
+                                                    // B: Nd = 18 > chain -> 4..0 collected, 0 has no mPrevKF: popped and fixed
+        orbslam3_hip::InertialBA IB2;
+        liba_rig rig{};
+        rig.n_cams = 1; rig.bf = 40.0; rig.model[0] = LBA_CAM_PINHOLE;
+        for (int i = 0; i < 3; i++) { rig.Rcb[0][i * 4] = 1; rig.Rbc[0][i * 4] = 1; }
+        rig.tcb[0][0] = (double)0.05f; rig.tbc[0][0] = (double)-0.05f;
+        rig.p[0][0] = fx; rig.p[0][1] = fy; rig.p[0][2] = cx; rig.p[0][3] = cy;
+        double Rrl[3][3], trl[3];
+        for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) Rrl[a][c] = (double)Trl.at<float>(a, c); trl[a] = (double)Trl.at<float>(a, 3); }
+        if (rigScene) {   // ImuCamPose's second camera (G2oTypes.cc:55-66): Rcb1 = Rrl Rcb0 = Rrl, tcb1 = Rrl tcb0 + trl, Rbc1 = Rcb1^T, tbc1 = -Rbc1 tcb1
+            rig.n_cams = 2; rig.model[0] = rig.model[1] = LBA_CAM_KB8;
+            for (int i = 0; i < 8; i++) { rig.p[0][i] = (double)fishL.mvParameters[i]; rig.p[1][i] = (double)fishR.mvParameters[i]; }
+            for (int a = 0; a < 3; a++) {
+                rig.tcb[1][a] = Rrl[a][0] * rig.tcb[0][0] + Rrl[a][1] * rig.tcb[0][1] + Rrl[a][2] * rig.tcb[0][2] + trl[a];
+                for (int c = 0; c < 3; c++) { rig.Rcb[1][a * 3 + c] = Rrl[a][c]; rig.Rbc[1][c * 3 + a] = Rrl[a][c]; }
+            }
+            for (int a = 0; a < 3; a++) rig.tbc[1][a] = -(rig.Rbc[1][a * 3] * rig.tcb[1][0] + rig.Rbc[1][a * 3 + 1] * rig.tcb[1][1] + rig.Rbc[1][a * 3 + 2] * rig.tcb[1][2]);
+        }
+        IB2.setRig(rig);
+        auto w = [](const cv::Mat& m, double* o) { for (int i = 0; i < m.rows * m.cols; i++) o[i] = (double)m.at<float>(i); };
+        for (int k = 0; k < NK; k++) {
+            double Rwb[9], twb[3], Rcw[9], tcw[3], v[3], bg[3], ba[3];
+            w(kfs[k]->GetImuRotation(), Rwb); w(kfs[k]->GetImuPosition(), twb); w(kfs[k]->GetRotation(), Rcw); w(kfs[k]->GetTranslation(), tcw);
+            w(kfs[k]->Vw, v); w(kfs[k]->GetGyroBias(), bg); w(kfs[k]->GetAccBias(), ba);
+            double Rcw1[9], tcw1[3];
+            for (int a = 0; a < 3; a++) {
+                tcw1[a] = Rrl[a][0] * tcw[0] + Rrl[a][1] * tcw[1] + Rrl[a][2] * tcw[2] + trl[a];
+                for (int c = 0; c < 3; c++) Rcw1[a * 3 + c] = Rrl[a][0] * Rcw[c] + Rrl[a][1] * Rcw[3 + c] + Rrl[a][2] * Rcw[6 + c];
+            }
+            CHECK(IB2.addKeyFrame(Rwb, twb, Rcw, tcw, rigScene ? Rcw1 : nullptr, rigScene ? tcw1 : nullptr, v, bg, ba, k < firstFree, true, k < firstFree) == k);
+        }
+        for (int k = NK - 1; k >= firstFree; k--) {   // newest first
+            IMU::Preintegrated* pi = kfs[k]->mpImuPreintegrated;
+            liba_imu_edge e{};
+            e.kf1 = k - 1; e.kf2 = k; e.dT = pi->dT;
+            std::memcpy(e.dR, pi->dR.data, 36); std::memcpy(e.dV, pi->dV.data, 12); std::memcpy(e.dP, pi->dP.data, 12);
+            std::memcpy(e.JRg, pi->JRg.data, 36); std::memcpy(e.JVg, pi->JVg.data, 36); std::memcpy(e.JVa, pi->JVa.data, 36);
+            std::memcpy(e.JPg, pi->JPg.data, 36); std::memcpy(e.JPa, pi->JPa.data, 36);
+            const float bb[6] = {pi->b.bax, pi->b.bay, pi->b.baz, pi->b.bwx, pi->b.bwy, pi->b.bwz};
+            std::memcpy(e.b, bb, 24);
+            EdgeInertial ei(pi);
+            const bool last = k == firstFree;
+            for (int q = 0; q < 81; q++) e.info[q] = ei.information().v[q] * (last ? 1e-2 : 1.0);
+            e.huber = (last || bRecInit) ? std::sqrt(16.92) : 0.0;
+            w(pi->C.rowRange(9, 12).colRange(9, 12).inv(cv::DECOMP_SVD), e.info_g); w(pi->C.rowRange(12, 15).colRange(12, 15).inv(cv::DECOMP_SVD), e.info_a);
+            CHECK(e.info[0] > 1e2 && e.info_g[0] > 1e5 && e.info_g[1] != 0.0);
+            IB2.addInertial(e);
+        }
+        std::vector<MapPoint*> order; std::set<MapPoint*> seen;
+        for (int k = NK - 1; k >= (scene == 1 ? 0 : firstFree); k--)   // B: the popped key frame's points were collected before it was popped
+            for (MapPoint* p : kfs[k]->mvpMapPoints) if (p && !seen.count(p)) { seen.insert(p); order.push_back(p); }
+        struct ER { KeyFrame* kf; MapPoint* mp; bool st; };
+        std::vector<ER> eref;
+        int nRightEdges = 0;
+        for (size_t l = 0; l < order.size(); l++) {
+            MapPoint* p = order[l];
+            const float X[3] = {p->mWorldPos.at<float>(0), p->mWorldPos.at<float>(1), p->mWorldPos.at<float>(2)};
+            CHECK(IB2.addPoint(X) == (int)l);
+            for (auto& ob : p->mObservations) {
+                KeyFrame* k = ob.first; const int i = std::get<0>(ob.second), ir = std::get<1>(ob.second);
+                int leftOctave = 0;   // the reference weights the right-camera edge with the LEFT key point's octave (0 without a left observation)
+                if (i >= 0) {
+                    const cv::KeyPoint& kp = k->mvKeysUn[i];
+                    leftOctave = kp.octave;
+                    if (k->mvuRight[i] >= 0) IB2.addStereo((int)k->mnId, (int)l, kp.pt.x, kp.pt.y, k->mvuRight[i], invSig2[kp.octave]);
+                    else IB2.addMono((int)k->mnId, (int)l, kp.pt.x, kp.pt.y, invSig2[kp.octave]);
+                    eref.push_back(ER{k, p, k->mvuRight[i] >= 0});
+                }
+                if (ir >= 0) {
+                    const cv::KeyPoint& kp = k->mvKeysRight[ir - k->NLeft];
+                    IB2.addMono((int)k->mnId, (int)l, kp.pt.x, kp.pt.y, invSig2[leftOctave], 1);
+                    eref.push_back(ER{k, p, false});
+                    nRightEdges++;
+                }
+            }
+        }
+        double err = 0, errEnd = 0;
+        const int its = IB2.optimize(bLarge ? 1e-2 : 1.0, bLarge ? 4 : 10, &err, &errEnd);
+        CHECK(its >= 2 && errEnd < 0.9 * err);   // it really optimised (the gross outliers keep their Huber cost)
+        int nOut = 0, nClose = 0;
+        for (size_t i = 0; i < eref.size(); i++) {
+            const double c2 = IB2.visualChi2((int)i);
+            const bool close = eref[i].mp->mTrackDepth < 10.f;
+            nClose += close && !eref[i].st && c2 > 5.991f && !(c2 > 1.5f * 5.991f);   // kept by the near-point rule only
+            if (eref[i].st ? c2 > 7.815f : ((c2 > 5.991f && !close) || (c2 > 1.5f * 5.991f && close) || !IB2.depthPositive((int)i))) nOut++;
+        }
+        // ---- the glue ----
+        Optimizer::LocalInertialBA(cur, nullptr, &map, bLarge, bRecInit);
+        int erased = 0;
+        for (KeyFrame* k : kfs) erased += k->nErased;
+        CHECK(erased == nOut && nOut > 3 && nOut < (int)eref.size() / 5 && (scene == 1 || nClose > 0));
+        for (int k = 0; k < NK; k++) {
+            const liba_keyframe& r = IB2.keyFrame(k);
+            CHECK(kfs[k]->mnBALocalForKF == 0 && kfs[k]->mnBAFixedForKF == 0);
+            if (k < firstFree) { CHECK(kfs[k]->nPoseSets == 0 && kfs[k]->nVelSets == 0 && kfs[k]->nBiasSets == 0); continue; }
+            CHECK(kfs[k]->nPoseSets == 1 && kfs[k]->nVelSets == 1 && kfs[k]->nBiasSets == 1);
+            for (int a = 0; a < 3; a++) {   // identical to the flattened path, bit for bit
+                CHECK(kfs[k]->Tcw.at<float>(a, 3) == (float)r.tcw[0][a]);
+                for (int c = 0; c < 3; c++) CHECK(kfs[k]->Tcw.at<float>(a, c) == (float)r.Rcw[0][a * 3 + c]);
+                CHECK(kfs[k]->Vw.at<float>(a) == (float)r.v[a]);
+            }
+            CHECK(kfs[k]->mImuBias.bwx == (float)r.bg[0] && kfs[k]->mImuBias.bwz == (float)r.bg[2] && kfs[k]->mImuBias.bax == (float)r.ba[0] && kfs[k]->mImuBias.bay == (float)r.ba[1]);
+            CHECK(kfs[k]->mpImuPreintegrated->nSetNewBias == 2);   // SetNewBias(prev bias) before the edge (:4972) + KeyFrame::SetNewBias of the write-back
+            CHECK(std::fabs(r.twb[0] - 0.3 * k) < 0.04 && std::fabs(r.twb[1]) < 0.04 && std::fabs(r.v[0] - 1.0) < 0.1);   // pulled towards the truth
+        }
+        for (size_t l = 0; l < order.size(); l++) {
+            const double* X = IB2.point((int)l);
+            for (int a = 0; a < 3; a++) CHECK(order[l]->mWorldPos.at<float>(a) == (float)X[a]);
+            CHECK(order[l]->nNormalUpdates == 1);
+        }
+        CHECK(order.size() > 100 && map.mnMapChange == 1 && (nRightEdges > 150) == rigScene);
+        std::printf("glue LocalInertialBA (%s): %d iterations, %zu edges, %d erased (%d kept by the near-point rule), chi2 %.1f -> %.1f\n",
+                    scene == 0 ? "window inside the chain" : (scene == 1 ? "short chain, bLarge + bRecInit" : "fisheye rig"), its, eref.size(), nOut, nClose, err, errEnd);
+        for (KeyFrame* k : kfs) delete k;
+        for (IMU::Preintegrated* q : pre) delete q;
     }
     std::printf("glue_test OK\n");
     return 0;

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE (see README.md): CameraModels/GeometricCamera.h — the members the glue uses; `Pinhole` as the concrete model.
 #pragma once
 #include <opencv2/core/core.hpp>
+#include <Eigen/Core>
 #include <vector>
 namespace ORB_SLAM3 {
 class GeometricCamera {
@@ -9,6 +10,7 @@ public:
     virtual cv::Point2f project(const cv::Point3f& p3D) = 0;
     virtual cv::Point2f project(const cv::Mat& m3D) = 0;
     virtual cv::Mat toK() = 0;
+    virtual float uncertainty2(const Eigen::Matrix<double, 2, 1>& p2D) { (void)p2D; return 1.0f; }   // Pinhole.cpp:56-59, KannalaBrandt8.cpp:86-95
     float getParameter(const int i) { return mvParameters[i]; }
     size_t size() { return mvParameters.size(); }
     unsigned int GetType() { return mnType; }

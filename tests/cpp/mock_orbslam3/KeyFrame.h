@@ -5,6 +5,7 @@
 #include <set>
 #include <vector>
 #include "GeometricCamera.h"
+#include "ImuTypes.h"
 #include "Map.h"
 #include "MapPoint.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
@@ -27,6 +28,23 @@ public:
         cv::Mat Rrl = mTlr.rowRange(0, 3).colRange(0, 3).t();
         return Rrl * GetTranslation() + (-Rrl * mTlr.rowRange(0, 3).col(3));
     }
+    // inertial state (KeyFrame.cc:161-165, 192-208, 222-226, 916-940)
+    cv::Mat GetImuPosition() { cv::Mat Rwc = GetRotation().t(); return Rwc * mImuCalib.Tcb.rowRange(0, 3).col(3) + GetCameraCenter(); }   // Owb (:100-108)
+    cv::Mat GetImuRotation() { return GetRotation().t() * mImuCalib.Tcb.rowRange(0, 3).colRange(0, 3); }
+    cv::Mat GetVelocity() { return Vw.clone(); }
+    void SetVelocity(const cv::Mat& Vw_) { Vw = Vw_.clone(); nVelSets++; }
+    void SetNewBias(const IMU::Bias& b) { mImuBias = b; if (mpImuPreintegrated) mpImuPreintegrated->SetNewBias(b); nBiasSets++; }
+    cv::Mat GetGyroBias() { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = mImuBias.bwx; m.at<float>(1) = mImuBias.bwy; m.at<float>(2) = mImuBias.bwz; return m; }
+    cv::Mat GetAccBias() { cv::Mat m(3, 1, CV_32F); m.at<float>(0) = mImuBias.bax; m.at<float>(1) = mImuBias.bay; m.at<float>(2) = mImuBias.baz; return m; }
+    IMU::Bias GetImuBias() { return mImuBias; }
+    KeyFrame* mPrevKF = nullptr;
+    KeyFrame* mNextKF = nullptr;
+    IMU::Preintegrated* mpImuPreintegrated = nullptr;
+    IMU::Calib mImuCalib;
+    bool bImu = false;
+    cv::Mat Vw;
+    IMU::Bias mImuBias;
+    int nVelSets = 0, nBiasSets = 0;
     std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
     void EraseMapPointMatch(MapPoint* pMP) { for (auto& p : mvpMapPoints) if (p == pMP) p = nullptr; nErased++; }
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }

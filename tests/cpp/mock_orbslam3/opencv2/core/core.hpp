@@ -6,11 +6,13 @@
 #include <cstring>
 #include <vector>
 #include <cstdlib>
+#include <utility>
 #define CV_8U 0
 #define CV_8UC1 0
 #define CV_32F 5
 #define CV_Assert(expr) do { if (!(expr)) std::abort(); } while (0)
 namespace cv {
+enum { DECOMP_LU = 0, DECOMP_SVD = 1 };
 struct Rect { int x, y, width, height; Rect(int x_ = 0, int y_ = 0, int w_ = 0, int h_ = 0) : x(x_), y(y_), width(w_), height(h_) {} };
 struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
 struct Point3f { float x, y, z; Point3f(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {} };
@@ -44,6 +46,28 @@ public:
     Mat col(int c) const { return block(0, rows, c, c + 1); }
     Mat t() const { Mat m(cols, rows, CV_32F); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.at<float>(c, r) = at<float>(r, c); return m; }
     double dot(const Mat& o) const { double s = 0; for (int i = 0; i < rows * cols; i++) s += (double)at<float>(i) * (double)o.at<float>(i); return s; }
+    Mat inv(int method) const {   // inv(cv::DECOMP_SVD) of a well-conditioned n x n block: Gauss-Jordan with partial pivoting in double, rounded once
+        (void)method;
+        if (rows == 3 && cols == 3) return inv();
+        const int n = rows;
+        std::vector<double> a((size_t)n * 2 * n, 0.0);
+        for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) a[(size_t)r * 2 * n + c] = at<float>(r, c); a[(size_t)r * 2 * n + n + r] = 1.0; }
+        for (int c = 0; c < n; c++) {
+            int piv = c;
+            for (int r = c + 1; r < n; r++) if (std::fabs(a[(size_t)r * 2 * n + c]) > std::fabs(a[(size_t)piv * 2 * n + c])) piv = r;
+            if (piv != c) for (int k = 0; k < 2 * n; k++) std::swap(a[(size_t)c * 2 * n + k], a[(size_t)piv * 2 * n + k]);
+            const double d = a[(size_t)c * 2 * n + c];
+            for (int k = 0; k < 2 * n; k++) a[(size_t)c * 2 * n + k] /= d;
+            for (int r = 0; r < n; r++) {
+                if (r == c) continue;
+                const double f = a[(size_t)r * 2 * n + c];
+                if (f != 0.0) for (int k = 0; k < 2 * n; k++) a[(size_t)r * 2 * n + k] -= f * a[(size_t)c * 2 * n + k];
+            }
+        }
+        Mat m(n, n, CV_32F);
+        for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) m.at<float>(r, c) = (float)a[(size_t)r * 2 * n + n + c];
+        return m;
+    }
     Mat inv() const {   // 3x3 (cofactors in double, rounded once) or a rigid 4x4 [R t; 0 1] (Converter / write-back use)
         if (rows == 3 && cols == 3) {
             const double a = at<float>(0, 0), b = at<float>(0, 1), c = at<float>(0, 2), d = at<float>(1, 0), e = at<float>(1, 1), f = at<float>(1, 2),

@@ -1,8 +1,8 @@
 """The reference-signature glue (integration/ORBmatcher_hip.cc, integration/Optimizer_hip.cc) compiled with -DORBHIP_WITH_ORBSLAM3 against the
 minimal mock declarations in tests/cpp/mock_orbslam3 (boundary test infrastructure, see its README) and run: the 5 SearchByProjection overloads,
 both SearchByBoW overloads, SearchForInitialization, SearchForTriangulation (pinhole / fisheye / rig), SearchBySim3, both Fuse overloads,
-LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&) and
-PoseOptimization(Frame*) must reproduce the oracle / the flattened path / the outcome the scene was built for.
+LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&), PoseOptimization(Frame*) and
+LocalInertialBA(KeyFrame*, bool*, Map*, bool, bool) (three scenes) must reproduce the oracle / the flattened path / the outcome the scene was built for.
 CPU tier = emulated library, GPU tier = the real liborbhip.so."""
 import os
 import subprocess
