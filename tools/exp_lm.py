@@ -19,11 +19,17 @@ ap.add_argument("--kf", type=int, default=100)
 ap.add_argument("--fixed", type=int, default=20)
 ap.add_argument("--points", type=int, default=20000)
 ap.add_argument("--kind", default="mono", help="mono | stereo | kb8 | body | mixed (synth_window)")
+ap.add_argument("--sorted", action="store_true", help="order every landmark's observations by pose index (what std::map<KeyFrame*> iteration "
+                "gives when key frames are allocated in id order) instead of synth_window's random order")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 wins, cams = [], None
 for i in range(2):
     w, cams = synth_window(100 + i, args.kf, args.fixed, args.points, 8, args.kind)
+    if args.sorted:
+        o = np.lexsort((w["edges"]["pose"], w["edges"]["point"]))
+        assert (w["edges"]["point"][o] == w["edges"]["point"]).all()   # still landmark-major
+        w["edges"] = w["edges"][o]
     wins.append(w)
 Lw = LbaWindows([wins[i % 2] for i in range(args.windows)], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
 p0, x0 = Lw.d["poses"].clone(), Lw.d["points"].clone()
