@@ -31,7 +31,7 @@ public:
         orbx_handle h = nullptr;
         if (orbx_create(&cfg_, 752, 480, 1, device_, &h) == ORB_OK) { loadTables(h); orbx_destroy(h); }
     }
-    ~ORBextractor() { if (h_) orbx_destroy(h_); }
+    ~ORBextractor() { if (h_) orbx_destroy(h_); if (stereoBuf_) orb_dev_free(stereoBuf_); }
     ORBextractor(const ORBextractor&) = delete;
     ORBextractor& operator=(const ORBextractor&) = delete;
 
@@ -88,6 +88,42 @@ public:
     std::vector<cv::Mat> mvImagePyramid;  // ORBextractor.h:83
 #endif
 
+    // Frame::ComputeStereoMatches (reference src/Frame.cc:955-1134) for the rectified pair THIS extractor (left image) and `right` just extracted:
+    // the SAD refinement reads both extractors' pyramids where the last extract() left them on the device (the reference reads mvImagePyramid of
+    // both, Frame.cc:1052,1071).  kps / desc: what the two extract() calls returned.  mvuRight / mvDepth come back sized N with -1 = no match.
+    void ComputeStereoMatches(ORBextractor& right, const orb_keypoint* kpsL, const uint8_t* descL, int nL, const orb_keypoint* kpsR, const uint8_t* descR, int nR,
+                              float mb, float mbf, std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+        mvuRight.assign(nL, -1.0f); mvDepth.assign(nL, -1.0f);
+        if (nL == 0 || nR == 0) return;
+        if (!h_ || !right.h_) throw std::runtime_error("ComputeStereoMatches: both extractors must have extracted their image first");
+        const int cap = nL > nR ? nL : nR;
+        const size_t kb = (size_t)cap * sizeof(orb_keypoint), db = (size_t)cap * 32;
+        // one device block: [kps L | kps R | desc L | desc R | counts L, R (2 x int32 each) | u_right | depth | work]
+        const size_t need = 2 * kb + 2 * db + 16 + 3 * (size_t)cap * 4;
+        if (need > stereoBytes_) {
+            if (stereoBuf_) orb_dev_free(stereoBuf_);
+            stereoBuf_ = nullptr; stereoBytes_ = 0;
+            if (orb_dev_alloc(device_, need, &stereoBuf_) != ORB_OK) throw std::runtime_error("ComputeStereoMatches: device allocation failed");
+            stereoBytes_ = need;
+        }
+        unsigned char* d = (unsigned char*)stereoBuf_;
+        orb_keypoint *dkl = (orb_keypoint*)d, *dkr = (orb_keypoint*)(d + kb);
+        uint8_t *ddl = d + 2 * kb, *ddr = d + 2 * kb + db;
+        int32_t* dc = (int32_t*)(d + 2 * kb + 2 * db);
+        float *dur = (float*)(dc + 4), *ddp = dur + cap;
+        int32_t* dwork = (int32_t*)(ddp + cap);
+        const int32_t cnt[4] = {nL, 0, nR, 0};
+        bool ok = orb_memcpy_h2d(dkl, kpsL, (size_t)nL * sizeof(orb_keypoint), nullptr) == ORB_OK && orb_memcpy_h2d(dkr, kpsR, (size_t)nR * sizeof(orb_keypoint), nullptr) == ORB_OK &&
+                  orb_memcpy_h2d(ddl, descL, (size_t)nL * 32, nullptr) == ORB_OK && orb_memcpy_h2d(ddr, descR, (size_t)nR * 32, nullptr) == ORB_OK &&
+                  orb_memcpy_h2d(dc, cnt, sizeof(cnt), nullptr) == ORB_OK;
+        if (!ok) throw std::runtime_error("ComputeStereoMatches: upload failed");
+        if (orbx_stereo_matches(h_, right.h_, dkl, ddl, dc, dkr, ddr, dc + 2, cap, 1, mb, mbf, dur, ddp, dwork, nullptr) != ORB_OK)
+            throw std::runtime_error(std::string("orbx_stereo_matches: ") + orbx_last_error(h_));
+        if (orb_memcpy_d2h(mvuRight.data(), dur, (size_t)nL * 4, nullptr) != ORB_OK || orb_memcpy_d2h(mvDepth.data(), ddp, (size_t)nL * 4, nullptr) != ORB_OK ||
+            orb_stream_sync(nullptr) != ORB_OK)
+            throw std::runtime_error("ComputeStereoMatches: copy back failed");
+    }
+
     // host copy of pyramid level `level` of the last call; border = 0 or 19 (reference layout)
     std::vector<uint8_t> pyramidLevel(int level, int border, int& w, int& h) {
         if (!h_ || orbx_pyramid_level(h_, 0, level, nullptr, &w, &h, nullptr) != ORB_OK) throw std::runtime_error("no pyramid");
@@ -122,6 +158,8 @@ private:
     int device_;
     orbx_handle h_ = nullptr;
     int w_ = 0, hgt_ = 0;
+    void* stereoBuf_ = nullptr;
+    size_t stereoBytes_ = 0;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 

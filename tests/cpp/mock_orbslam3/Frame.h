@@ -3,6 +3,7 @@
 #include <opencv2/core/core.hpp>
 #include <vector>
 #include "GeometricCamera.h"
+#include "ORBextractor.h"
 #include "MapPoint.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 namespace ORB_SLAM3 {
@@ -30,5 +31,15 @@ public:
     int Nleft = -1, Nright = -1;
     std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;
     cv::Mat mTlr, mRlr, mtlr, mTrl;
+    // the Frame-constructor steps integration/Frame_hip.cc defines (include/Frame.h:104-118, 264-270) and what they touch
+    void ComputeStereoMatches();
+    void UndistortKeyPoints();
+    void ComputeStereoFishEyeMatches();
+    ORBextractor *mpORBextractorLeft = nullptr, *mpORBextractorRight = nullptr;
+    cv::Mat mK, mDistCoef;
+    std::vector<float> mvLevelSigma2;
+    int monoLeft = -1, monoRight = -1;
+    std::vector<cv::Mat> mvStereo3Dpoints;
+    int mnCloseMPs = 0;
 };
 }  // namespace ORB_SLAM3

@@ -59,3 +59,30 @@ def test_extractor_opencv_signature_on_emulated_library(emu_lib, tmp_path):
 def test_extractor_opencv_signature_on_hip_library(hip_lib, tmp_path):
     from orbhip import _lib
     _build_and_run_extractor_cv(_lib.LIB_PATH, "hip", tmp_path)
+
+
+def _build_and_run_frame_glue(libpath, tag, tmp_path):
+    """integration/Frame_hip.cc (Frame::ComputeStereoMatches / UndistortKeyPoints / ComputeStereoFishEyeMatches) with the extractor adapter's
+    OpenCV-signature branch standing in for ORB_SLAM3::ORBextractor, against the oracle's restatements of the three loops."""
+    exe = str(tmp_path / ("frame_glue_test_" + tag))
+    libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)[3:-3]
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir], stdout=subprocess.DEVNULL)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-DORBHIP_WITH_ORBSLAM3", "-DORBHIP_WITH_OPENCV", "-I", os.path.join(ROOT, "tests", "cpp", "mock_orbslam3"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "frame_glue_test.cpp"), os.path.join(ROOT, "integration", "Frame_hip.cc"),
+           "-L", libdir, "-l" + libname, "-L", odir, "-loracle", "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+           "-lpthread", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "frame_glue_test OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_frame_glue_on_emulated_library(emu_lib, tmp_path):
+    import build_emu
+    _build_and_run_frame_glue(build_emu.OUT, "emu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_frame_glue_on_hip_library(hip_lib, tmp_path):
+    from orbhip import _lib
+    _build_and_run_frame_glue(_lib.LIB_PATH, "hip", tmp_path)
