@@ -550,6 +550,7 @@ struct LmArgs {
     double* Dinv; double* db;               // [cap_l][9], [cap_l][3]
     double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
     double* panExt;                         // [np6][CH_LD] per window: Cholesky panel of systems too large for LDS, else nullptr
+    double* cholScratch;                    // [LM_CHOLS_SCRATCH] per window: the per-phase factorisation's diagonal block between two launches
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
     int4* rowMeta;                          // [batch][cap_e] per entry of the pose-major edge lists: (edge, landmark, first / end edge of the landmark's run)
@@ -850,6 +851,10 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
 }
 
 #include "dense_chol.inc"
+#ifndef LM_CHOL_SPLIT_MAX_BATCH
+#define LM_CHOL_SPLIT_MAX_BATCH 128   // windows per call up to which the per-phase launches beat one workgroup per window (MI355X, 480 unknowns:
+                                      // 4.7 vs 6.8 ms per optimize(5) at 1 window, 11.4 vs 12.9 at 32, 32.7 vs 33.0 at 128, 60.7 vs 58.5 at 256)
+#endif
 #ifndef LM_CHOL_NT
 #define LM_CHOL_NT 512    // 8 waves per window: the factorisation is one workgroup per window, its trailing update a global-memory latency problem
 #endif
@@ -862,6 +867,120 @@ static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const i
     if (!wg_chol_solve<LM_CHOL_NT, NB>(A.Hs + (size_t)b * ld * ld, n, ld, A.xp + (size_t)b * ld, orb_smem, A.panExt ? A.panExt + (size_t)b * ld * (NB + 1) : nullptr) &&
         threadIdx.x == 0)
         A.st[b].ok = 0;
+}
+
+// The factorisation as one launch per phase (dense_chol.inc): batches that leave most compute units idle.  kb = first column of the panel.
+//   k_lm_chol_panel   one wave per 64 rows of the panel: every wave factors the 32 x 32 diagonal block for itself (registers, the same steps
+//                     as wg_chol_solve: identical values everywhere), then solves its rows against it and takes their share of the forward
+//                     substitution.  The factored block and its 32 right-hand-side entries go to a scratch slab — other waves are still
+//                     reading the unfactored block from Hs — and are committed by the next launch.
+//   k_lm_chol_update  commit + the rank-32 update of the trailing triangle, a wave per 16 x 16 tile (fp64 matrix core, operands from Hs)
+//   k_lm_chol_back    L^T x = y, one workgroup per window
+#define LM_CHOLS_NB 32
+#define LM_CHOLS_SCRATCH (LM_CHOLS_NB * (LM_CHOLS_NB + 1) + LM_CHOLS_NB)   // doubles per window: [32][33] block + 32 y
+static __global__ __launch_bounds__(64) void k_lm_chol_panel(LmArgs A, const int32_t* nfreeArr, int kb) {
+    constexpr int NB = LM_CHOLS_NB, LD = NB + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    double* blk = (double*)orb_smem;      // [NB][LD] factored diagonal block
+    double* ys = blk + NB * LD;           // [NB] forward-substituted right-hand side of the block, then [NB] reciprocal pivots
+    const int b = blockIdx.y, lane = threadIdx.x;
+    if (!A.st[b].needTrial || !A.st[b].ok) return;    // a window whose earlier panel was not positive definite stays failed
+    const int n = nfreeArr[b] * 6, ld = A.np6;
+    if (kb >= n) return;
+    const int nb = min(NB, n - kb), m = n - kb;
+    const int r = (int)blockIdx.x * 64 + lane;        // this lane's panel row
+    if ((int)blockIdx.x * 64 >= m) return;
+    double* S = A.Hs + (size_t)b * ld * ld;
+    double* x = A.xp + (size_t)b * ld;
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) a[c] = (lane < nb && c <= lane) ? S[(size_t)(kb + c) * ld + kb + lane] : (c == lane ? 1.0 : 0.0);
+    double y = lane < nb ? x[kb + lane] : 0.0;
+    // this lane's row below the block, loaded before the dependent chain of the block starts
+    const bool below = r >= nb && r < m;
+    double v[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) v[c] = below ? S[(size_t)(kb + c) * ld + kb + r] : 0.0;
+    double acc = below ? x[kb + r] : 0.0;
+    // The launch is one dependent chain per wave (nothing else of the window can run): pivots as reciprocal square roots — one short
+    // operation per column instead of a square root and two divisions — and every division of the row solves a multiplication by them.
+    // (k_lm_chol<NB>, which shares a compute unit's time with other windows' workgroups, keeps sqrt / divide; the two agree to rounding.)
+    double rinv = 0.0;                                // lane c: 1 / L(c, c)
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+        const double dkk = wg_chol_bcast(a[c], c);
+        ok = ok && (dkk > 0) && (dkk < 1.7e308);
+#ifdef HIP_EMULATED
+        const double ri = 1.0 / sqrt(dkk);
+#else
+        const double ri = rsqrt(dkk);
+#endif
+        const double lrc = (lane == c) ? dkk * ri : a[c] * ri;
+        a[c] = lrc;
+        rinv = (lane == c) ? ri : rinv;
+#pragma unroll
+        for (int c2 = c + 1; c2 < NB; c2++) {
+            const double l2 = wg_chol_bcast(lrc, c2);
+            a[c2] -= (lane >= c2) ? lrc * l2 : 0.0;
+        }
+        const double yc = wg_chol_bcast(y, c) * ri;
+        y = (lane == c) ? yc : (lane > c ? y - lrc * yc : y);
+    }
+    if (!ok) { if (blockIdx.x == 0 && lane == 0) A.st[b].ok = 0; return; }   // uniform over the window's waves: the same values everywhere
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) blk[lane * LD + c] = (lane < nb && c <= lane) ? a[c] : (c == lane ? 1.0 : 0.0);
+        ys[lane] = y;
+        ys[NB + lane] = rinv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (blockIdx.x == 0 && lane < NB) {               // block + y -> scratch (committed by k_lm_chol_update)
+        double* sc = A.cholScratch + (size_t)b * LM_CHOLS_SCRATCH;
+#pragma unroll
+        for (int c = 0; c < NB; c++) sc[lane * LD + c] = blk[lane * LD + c];
+        sc[NB * LD + lane] = y;
+    }
+    if (below) {                                      // nb == NB here: rows below a short last block do not exist
+        // right-looking over the row's 32 entries: entry c is final once columns < c have been taken off it; the updates of the later
+        // entries are independent of each other (a left-looking sum would be a chain of c dependent operations per entry)
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            v[c] *= ys[NB + c];
+            acc -= v[c] * ys[c];
+#pragma unroll
+            for (int c2 = c + 1; c2 < NB; c2++) v[c2] -= v[c] * blk[c2 * LD + c];
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) S[(size_t)(kb + c) * ld + kb + r] = v[c];
+        x[kb + r] = acc;
+    }
+}
+static __global__ __launch_bounds__(256) void k_lm_chol_update(LmArgs A, const int32_t* nfreeArr, int kb) {
+    constexpr int NB = LM_CHOLS_NB, LD = NB + 1;
+    const int b = blockIdx.y;
+    if (!A.st[b].needTrial || !A.st[b].ok) return;
+    const int n = nfreeArr[b] * 6, ld = A.np6;
+    if (kb >= n) return;
+    double* S = A.Hs + (size_t)b * ld * ld;
+    if (blockIdx.x == 0) {                            // commit the factored diagonal block and its right-hand side
+        const int nb = min(NB, n - kb);
+        const double* sc = A.cholScratch + (size_t)b * LM_CHOLS_SCRATCH;
+        for (int t = threadIdx.x; t < NB * NB; t += 256) { const int rr = t % NB, c = t / NB; if (rr < nb && c <= rr) S[(size_t)(kb + c) * ld + kb + rr] = sc[rr * LD + c]; }
+        if ((int)threadIdx.x < nb) A.xp[(size_t)b * ld + kb + threadIdx.x] = sc[NB * LD + threadIdx.x];
+    }
+    if (kb + NB >= n) return;
+    wg_chol_update_tile<NB>(S, n, ld, kb, (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
+}
+template <int NB>
+static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol_back(LmArgs A, const int32_t* nfreeArr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x;
+    if (!A.st[b].needTrial || !A.st[b].ok) return;
+    const int ld = A.np6;
+    wg_chol_backward<LM_CHOL_NT, NB>(A.Hs + (size_t)b * ld * ld, nfreeArr[b] * 6, ld, A.xp + (size_t)b * ld, orb_smem);
 }
 
 #ifdef CHOL_PROF
@@ -1094,6 +1213,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
     s += lm_align(B * p->cap_e * 16) + lm_align(B * ((size_t)p->cap_e + 8) * 4);     // Schur row metadata
+    s += lm_align(B * 1088 * 8);                                                      // cholScratch (LM_CHOLS_SCRATCH doubles per window)
     if (np6 > WG_CHOL_LDS_MAX_LD) s += lm_align(B * np6 * CH_LD * 8);                 // out-of-LDS Cholesky panel (only if ALL poses could be free)
     return s;
 }
@@ -1138,6 +1258,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
     A.rowMeta = (int4*)take(B * P.cap_e * 16); A.edgeH = (int32_t*)take(B * ((size_t)P.cap_e + 8) * 4);
+    A.cholScratch = (double*)take(B * 1088 * 8);
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
@@ -1163,6 +1284,11 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)
     if (cholSmem > 64 * 1024 &&
         hipFuncSetAttribute(nb32 ? (const void*)k_lm_chol<32> : (const void*)k_lm_chol<CH_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
+        return ORB_E_HIP;
+    // few windows: the factorisation as one launch per phase, its trailing updates spread over the machine (k_lm_chol_panel / _update / _back)
+    const bool cholSplit = nb32 && batch <= LM_CHOL_SPLIT_MAX_BATCH;
+    if (cholSplit && cholSmem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)k_lm_chol_back<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
         return ORB_E_HIP;
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
@@ -1209,7 +1335,14 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
                 else if (schurNW == 2) hipLaunchKernelGGL(k_lm_schur_rows<2>, gS, dim3(128), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
                 else hipLaunchKernelGGL(k_lm_schur_rows<1>, gS, dim3(64), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
             }
-            if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
+            if (cholSplit) {
+                for (int kb = 0; kb < (int)np6; kb += LM_CHOLS_NB) {
+                    hipLaunchKernelGGL(k_lm_chol_panel, dim3(((int)np6 - kb + 63) / 64, batch), dim3(64), (LM_CHOLS_SCRATCH + LM_CHOLS_NB) * 8, st, A, (const int32_t*)nfree, kb);
+                    const int T = std::max(0, ((int)np6 - kb - LM_CHOLS_NB + 15) >> 4);
+                    hipLaunchKernelGGL(k_lm_chol_update, dim3(std::max(1, (T * (T + 1) / 2 + 3) / 4), batch), dim3(256), 0, st, A, (const int32_t*)nfree, kb);
+                }
+                hipLaunchKernelGGL(k_lm_chol_back<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
+            } else if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);

@@ -405,6 +405,18 @@ def main():
         extra["lba"]["lm_ms_per_optimize5_batch"] = round(dto / osteps * 1e3, 3)
         extra["lba"]["lm_trials_per_window"] = float(stats[:, 3].mean())
         extra["lba"]["lm_windows_per_step"] = args.lm_windows
+        # one window per call: what LocalMapping's single LocalBundleAdjustment sees (latency: the dense Cholesky runs as one launch per phase)
+        L1 = LbaWindows([wins[0]], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+        q0, y0 = L1.d["poses"].clone(), L1.d["points"].clone()
+        L1.optimize(5)
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(5):
+            L1.d["poses"].copy_(q0); L1.d["points"].copy_(y0)
+            L1.optimize(5)
+        barrier()
+        extra["lba"]["lm_single_window_ms_per_optimize5"] = round((time.perf_counter() - t4) / 5 * 1e3, 3)
+        del L1
         # the same LM on windows of the other edge families (the monocular windows above run the monocular-pinhole kernel instantiation):
         # stereo / RGB-D pinhole maps (monocular + stereo edges: the pinhole instantiation) and fisheye maps (the generic kernels)
         for fam, kind in (("stereo_pinhole", "stereo"), ("fisheye", "kb8")):

@@ -300,7 +300,38 @@ def test_emu_lba_optimize_wide_panel():
     import build_emu
     from orbhip import _lib
     lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MIN_LD=0",), tag="cholnb32")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)   # few windows per call: the factorisation as one launch per phase (k_lm_chol_panel / _update / _back)
+
+
+def test_emu_lba_optimize_wide_panel_one_workgroup():
+    """The same with LM_CHOL_SPLIT_MAX_BATCH=0: the 32-column panel inside ONE workgroup per window (k_lm_chol<32>, what a batch of more than 128
+    windows takes)."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MIN_LD=0", "LM_CHOL_SPLIT_MAX_BATCH=0"), tag="cholnb32mono")))
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+@pytest.mark.gpu
+def test_hip_cholesky_per_phase_launches_agree_with_one_workgroup(hip_lib):
+    """60 free key frames = 360 unknowns (32-column panel).  One window per call takes the per-phase launches (reciprocal pivots), 129 windows per
+    call one workgroup per window (sqrt / divide): the same factorisation to rounding — poses within 1e-9 of each other, both within 1e-6 of the
+    oracle — and the 129 copies of the batch bit-identical among themselves."""
+    w, cams = synth_window(5, 70, 10, 5000, 8, "mono")
+    assert (w["pose_hidx"] >= 0).sum() == 60
+    L1 = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=HUBER)
+    s1 = L1.optimize(3)
+    L33 = LbaWindows([w] * 129, cams, to_dev("hip"), lib=hip_lib, huber=HUBER)
+    s33 = L33.optimize(3)
+    p1, p33 = to_host(L1.d["poses"])[0], to_host(L33.d["poses"])
+    assert s1[0, 0] == s33[0, 0] and s1[0, 3] == s33[0, 3] and abs(s1[0, 1] - s33[0, 1]) < 1e-9 * s33[0, 1]
+    assert np.abs(p1 - p33[0]).max() < 1e-9
+    assert np.array_equal(p33[0], p33[128]) and np.array_equal(s33[0], s33[128])
+    assert np.array_equal(to_host(L33.d["points"])[3], to_host(L33.d["points"])[17])
+    op, ox, ost = O.lba_optimize(w, cams, HUBER, 3)
+    assert s1[0, 0] == ost[0] and s1[0, 3] == ost[3]
+    assert np.abs(p1[:70] - op).max() < 1e-6 and np.abs(p33[0, :70] - op).max() < 1e-6
 
 
 @pytest.mark.gpu
