@@ -1534,11 +1534,15 @@ struct PoseOptArgs {
 };
 
 // block-wide sum of NV doubles per thread, result broadcast to every thread (fixed order: butterfly inside a wave, waves 0..3)
-template <int NV>
-#ifndef POSE_T
-#define POSE_T 64    // threads per frame: a frame has a few hundred edges, and at 256 VGPRs one wave per SIMD is all that fits — one-wave
-                     // workgroups put four frames on a CU instead of one and need no cross-wave reduction step
+#ifndef POSE_T_MANY
+#define POSE_T_MANY 64    // threads per frame of a batch that fills the machine: a frame has a few hundred edges, and at 256 VGPRs one wave per SIMD is
+                     // all that fits — one-wave workgroups put four frames on a CU instead of one and need no cross-wave reduction step
 #endif
+#ifndef POSE_T_FEW
+#define POSE_T_FEW 256   // threads per frame when there are fewer frames than SIMDs to put them on (Tracking optimises ONE frame per call: 1-2
+                         // edges per lane instead of 5; MI355X, one 300-edge frame: 0.60 -> 0.41 ms with the redundant error pass below gone too)
+#endif
+template <int NV, int POSE_T>
 static __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1561,7 +1565,7 @@ static __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratc
     }
 }
 
-template <bool PH>
+template <bool PH, int POSE_T>
 static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1583,7 +1587,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
             T = T0;
             double na[1] = {0};
             for (int e = tid; e < ne; e += POSE_T) na[0] += level[e] == 0 ? 1.0 : 0.0;
-            block_sum<1>(na, scratch);
+            block_sum<1, POSE_T>(na, scratch);
             auto evalErrors = [&](const SE3& Tc) {   // computeActiveErrors + activeRobustChi2
                 double s[1] = {0};
                 for (int e = tid; e < ne; e += POSE_T) {
@@ -1596,14 +1600,18 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
                     if (robust) { const double d = E.kind == LBA_EDGE_STEREO ? deltaStereo : deltaMono, dsq = d * d; if (!(L.chi2 <= dsq)) r0 = 2 * sqrt(L.chi2) * d - dsq; }
                     s[0] += r0;
                 }
-                block_sum<1>(s, scratch);
+                block_sum<1, POSE_T>(s, scratch);
                 return s[0];
             };
             if (na[0] > 0) {
                 double lambda = -1, ni = 2;
                 int nBadLM = 0;
+                double currentChi = 0;
                 for (int iter = 0; iter < 10; iter++) {
-                    double currentChi = evalErrors(T), tempChi = currentChi;
+                    // computeActiveErrors at the head of an iteration: after the first one the state is the one the last (accepted) trial
+                    // evaluated — a rejected last trial leaves the loop below — so its errors and their sum are already there, bit for bit
+                    if (iter == 0) currentChi = evalErrors(T);
+                    double tempChi = currentChi;
                     const double iniChi = currentChi;
                     double acc[27];   // 21 lower-triangle entries of H (column-major order c2 <= c) + 6 of b
 #pragma unroll
@@ -1634,7 +1642,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
                             acc[21 + c] -= rho1 * a;
                         }
                     }
-                    block_sum<27>(acc, scratch);
+                    block_sum<27, POSE_T>(acc, scratch);
                     double H[36], bvec[6];
                     {
                         int t = 0;
@@ -1694,7 +1702,7 @@ static __global__ __launch_bounds__(POSE_T) void k_pose_opt(PoseOptArgs A) {
                 if (chi2 > (E.kind == LBA_EDGE_STEREO ? th3 : th2)) { outl[e] = 1; level[e] = 1; nb[0] += 1.0; }
                 else { outl[e] = 0; level[e] = 0; }
             }
-            block_sum<1>(nb, scratch);
+            block_sum<1, POSE_T>(nb, scratch);
             nBad = (int)nb[0];
             if (it == 2) robust = false;
             if (ne < 10) break;
@@ -1716,8 +1724,11 @@ static int pose_optimize_impl(const double* d_poses_in, const pose_edge* d_edges
     const size_t smem = (size_t)4 * 28 * 8 + (size_t)cap_e * 8 + 2 * (((size_t)cap_e + 15) & ~(size_t)15);
     if (smem > 64 * 1024) return ORB_E_INVALID;
     PoseOptArgs A{d_poses_in, d_edges, d_n_edges, cap_e, d_cameras, d_poses_out, d_outlier, d_n_good};
-    if (pinhole) hipLaunchKernelGGL(k_pose_opt<true>, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
-    else hipLaunchKernelGGL(k_pose_opt<false>, dim3(batch), dim3(POSE_T), smem, (hipStream_t)stream, A);
+    if (batch * (POSE_T_FEW / 64) <= 1024) {   // four waves per frame while every wave still gets a SIMD of its own (256 CUs x 4)
+        if (pinhole) hipLaunchKernelGGL((k_pose_opt<true, POSE_T_FEW>), dim3(batch), dim3(POSE_T_FEW), smem, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL((k_pose_opt<false, POSE_T_FEW>), dim3(batch), dim3(POSE_T_FEW), smem, (hipStream_t)stream, A);
+    } else if (pinhole) hipLaunchKernelGGL((k_pose_opt<true, POSE_T_MANY>), dim3(batch), dim3(POSE_T_MANY), smem, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL((k_pose_opt<false, POSE_T_MANY>), dim3(batch), dim3(POSE_T_MANY), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
 

@@ -85,6 +85,17 @@ def test_emu_pose_optimization_matches_oracle(emu_lib, kind, seed, n_pts):
     check(emu_lib, "emu", kind, seed, n_pts, batch=4, tol=KB8_TOL if kind == "body" else 1e-7)
 
 
+def test_emu_pose_optimization_one_wave_per_frame():
+    """POSE_T_FEW=64: the one-wave-per-frame instantiation that batches of more than 256 frames take (the default build gives the small test
+    batches four waves per frame)."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("POSE_T_FEW=64",), tag="posewave")))
+    check(lib, "emu", "stereo", 7, 40, batch=4, tol=1e-7)
+    check(lib, "emu", "mono", 0, 300, batch=2, tol=1e-7)
+
+
 def test_emu_pose_optimization_small_frames(emu_lib):
     f = synth_pose_frames(seed=9, batch=4, n_pts=12, kind="mono", outlier_frac=0.0)
     f["n_edges"][:] = [2, 3, 9, 12]
