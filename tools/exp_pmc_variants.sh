@@ -1,0 +1,19 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+for so in $R/exp_so/*.so; do
+  n=$(basename $so .so)
+  ORBHIP_LIB=$so rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --headline-only --streams 1 > /tmp/pmc_$n.log 2>&1
+  f=$(find /tmp/pmc_$n -name "*counter_collection.csv" | head -1)
+  python - "$f" "$n" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0]
+    if k.startswith("k_describe"):
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    print(sys.argv[2], k, {c: "%.4g" % x for c, x in m.items()}, "valu/wave %.1f" % (m["SQ_INSTS_VALU"] / m["SQ_WAVES"]))
+PY
+done
