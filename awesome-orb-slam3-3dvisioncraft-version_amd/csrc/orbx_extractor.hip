@@ -1752,6 +1752,11 @@ struct orbx_extractor {
     FastTile* d_tiles = nullptr;
     // single-image staging
     uint8_t* d_img = nullptr; int imgStride = 0; orb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int32_t* d_counts1 = nullptr;
+    // single-frame host call: the three outputs share ONE device block ([counts | keypoints | descriptors]; the pointers above point into it) so that
+    // one copy brings them back, and both directions go through pinned staging buffers — the whole call is one graph launch (H2D, kernels, D2H) and
+    // one synchronisation, with plain memcpy on the host side (a pageable-memory copy is staged and synchronous inside the runtime: three of them
+    // and two synchronisations were half of the call's 205 us)
+    uint8_t* d_out1 = nullptr; uint8_t* h_img = nullptr; uint8_t* h_out = nullptr; size_t out1Bytes = 0, kps1Off = 0, desc1Off = 0;
     // last call (debug taps / pyramid views)
     const uint8_t* lastImages = nullptr; size_t lastFrameStride = 0; int lastRowStride = 0, lastBatch = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed = false;
@@ -1785,8 +1790,10 @@ static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* bufs[] = {h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
-                    h->d_lapCount, h->d_tiles, h->d_img, h->d_kps1, h->d_desc1, h->d_counts1};
+                    h->d_lapCount, h->d_tiles, h->d_img, h->d_out1};
     for (void* p : bufs) if (p) (void)hipFree(p);
+    if (h->h_img) (void)hipHostFree(h->h_img);
+    if (h->h_out) (void)hipHostFree(h->h_out);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1913,9 +1920,13 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
     h->imgStride = (width + 63) & ~63;
     CK(hipMalloc((void**)&h->d_img, (size_t)h->imgStride * height));
-    CK(hipMalloc((void**)&h->d_kps1, (size_t)maxKp * sizeof(orb_keypoint)));
-    CK(hipMalloc((void**)&h->d_desc1, (size_t)maxKp * 32));
-    CK(hipMalloc((void**)&h->d_counts1, 2 * sizeof(int32_t)));
+    h->kps1Off = 64;
+    h->desc1Off = (h->kps1Off + (size_t)maxKp * sizeof(orb_keypoint) + 63) & ~(size_t)63;
+    h->out1Bytes = h->desc1Off + (size_t)maxKp * 32;
+    CK(hipMalloc((void**)&h->d_out1, h->out1Bytes));
+    h->d_counts1 = (int32_t*)h->d_out1; h->d_kps1 = (orb_keypoint*)(h->d_out1 + h->kps1Off); h->d_desc1 = h->d_out1 + h->desc1Off;
+    CK(hipHostMalloc((void**)&h->h_img, (size_t)h->imgStride * height, hipHostMallocDefault));
+    CK(hipHostMalloc((void**)&h->h_out, h->out1Bytes, hipHostMallocDefault));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
     {
         float pf[1024];
@@ -2064,18 +2075,22 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
     if (!image || width <= 0 || height <= 0) return orbx_fail(h, ORB_E_EMPTY_IMAGE, "empty image");
     if (width != h->W || height != h->H || stride < width) return orbx_fail(h, ORB_E_INVALID, "image size differs from the handle's");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpy2DAsync(h->d_img, h->imgStride, image, stride, width, height, hipMemcpyHostToDevice, h->stream));
+    // the image into the pinned staging buffer (device pitch), then H2D + kernels + D2H as one graph launch and ONE synchronisation
+    if (stride == h->imgStride) memcpy(h->h_img, image, (size_t)stride * (height - 1) + width);
+    else for (int y = 0; y < height; y++) memcpy(h->h_img + (size_t)y * h->imgStride, image + (size_t)y * stride, (size_t)width);
+    const size_t imgBytes = (size_t)h->imgStride * height;
     int rc = ORB_OK;
     if (h->graphState >= 0 && (!h->graphExec || h->graphLap0 != lap0 || h->graphLap1 != lap1)) {
         if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             h->capturing = true;
-            rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp,
-                                        h->d_counts1, h->stream);
+            hipError_t em = hipMemcpyAsync(h->d_img, h->h_img, imgBytes, hipMemcpyHostToDevice, h->stream);
+            rc = orbx_extract_batch_dev(h, h->d_img, 1, imgBytes, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp, h->d_counts1, h->stream);
+            if (em == hipSuccess) em = hipMemcpyAsync(h->h_out, h->d_out1, h->out1Bytes, hipMemcpyDeviceToHost, h->stream);
             h->capturing = false;
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(h->stream, &g);
-            if (rc == ORB_OK && ec == hipSuccess && g && hipGraphInstantiate(&h->graphExec, g, nullptr, nullptr, 0) == hipSuccess) {
+            if (rc == ORB_OK && em == hipSuccess && ec == hipSuccess && g && hipGraphInstantiate(&h->graphExec, g, nullptr, nullptr, 0) == hipSuccess) {
                 h->graphLap0 = lap0; h->graphLap1 = lap1; h->graphState = 1;
             } else { h->graphExec = nullptr; h->graphState = -1; }
             if (g) (void)hipGraphDestroy(g);
@@ -2087,21 +2102,21 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
         h->timed = false;   // per-kernel events are not part of the graph
         HIPCHK(h, hipGraphLaunch(h->graphExec, h->stream));
     } else {
-        rc = orbx_extract_batch_dev(h, h->d_img, 1, (size_t)h->imgStride * height, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp,
-                                    h->d_counts1, h->stream);
+        HIPCHK(h, hipMemcpyAsync(h->d_img, h->h_img, imgBytes, hipMemcpyHostToDevice, h->stream));
+        rc = orbx_extract_batch_dev(h, h->d_img, 1, imgBytes, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp, h->d_counts1, h->stream);
         if (rc != ORB_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->h_out, h->d_out1, h->out1Bytes, hipMemcpyDeviceToHost, h->stream));
     }
-    int32_t counts[2];
-    HIPCHK(h, hipMemcpyAsync(counts, h->d_counts1, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    int32_t counts[2];
+    memcpy(counts, h->h_out, sizeof(counts));
     if (n_out) *n_out = counts[0];
     if (mono_index) *mono_index = counts[1];
     if (counts[0] > cap) return orbx_fail(h, ORB_E_CAPACITY, "output capacity too small");
     if (counts[0] > 0) {
         if (!kps || !desc) return orbx_fail(h, ORB_E_INVALID, "null output");
-        HIPCHK(h, hipMemcpyAsync(kps, h->d_kps1, (size_t)counts[0] * sizeof(orb_keypoint), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(desc, h->d_desc1, (size_t)counts[0] * 32, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        memcpy(kps, h->h_out + h->kps1Off, (size_t)counts[0] * sizeof(orb_keypoint));
+        memcpy(desc, h->h_out + h->desc1Off, (size_t)counts[0] * 32);
     }
     return ORB_OK;
 }
