@@ -16,6 +16,8 @@ extern "C" int orb_dev_alloc(int device, size_t bytes, void** d_ptr) {
     return rc(hipMalloc(d_ptr, bytes ? bytes : 1));
 }
 extern "C" int orb_dev_free(void* d_ptr) { return d_ptr ? rc(hipFree(d_ptr)) : ORB_OK; }
+extern "C" int orb_host_alloc(size_t bytes, void** h_ptr) { return h_ptr ? rc(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault)) : ORB_E_INVALID; }
+extern "C" int orb_host_free(void* h_ptr) { return h_ptr ? rc(hipHostFree(h_ptr)) : ORB_OK; }
 extern "C" int orb_memcpy_h2d(void* d, const void* h, size_t n, void* st) { return rc(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
 extern "C" int orb_memcpy_d2h(void* h, const void* d, size_t n, void* st) { return rc(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
 extern "C" int orb_memset(void* d, int v, size_t n, void* st) { return rc(hipMemsetAsync(d, v, n, (hipStream_t)st)); }

@@ -588,6 +588,9 @@ int liba_pose_inertial_lastframe(liba_keyframe* d_frames, liba_keyframe* d_prev_
 int orb_device_count(void);
 int orb_dev_alloc(int device, size_t bytes, void** d_ptr);
 int orb_dev_free(void* d_ptr);
+int orb_host_alloc(size_t bytes, void** h_ptr);   /* page-locked host memory: copies from / to it are real asynchronous DMA (a pageable copy is staged and
+                                                     synchronous inside the runtime); the adapters' packed staging blocks live in it */
+int orb_host_free(void* h_ptr);
 int orb_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);   /* asynchronous on stream */
 int orb_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);   /* asynchronous on stream */
 int orb_memset(void* d_dst, int value, size_t bytes, void* stream);

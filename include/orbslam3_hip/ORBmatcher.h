@@ -31,6 +31,24 @@ struct DevBuf {
         return d;
     }
 };
+// page-locked host block that only ever grows (orb_host_alloc): the packed staging blocks of the per-frame searches
+struct HostBuf {
+    uint8_t* p = nullptr; size_t cap = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    ~HostBuf() { if (p) orb_host_free(p); }
+    uint8_t* ensure(size_t n) {
+        if (n > cap) {
+            if (p) orb_host_free(p);
+            p = nullptr; void* q = nullptr;
+            const size_t want = n + n / 2;
+            if (orb_host_alloc(want, &q) != ORB_OK) throw std::runtime_error("orb_host_alloc");
+            p = (uint8_t*)q; cap = want;
+        }
+        return p;
+    }
+};
 }  // namespace detail
 
 // What the matcher reads from an ORB_SLAM3::Frame (Nleft == -1): N, mvKeysUn, mDescriptors, mvuRight, and the static
@@ -86,17 +104,17 @@ public:
         const size_t oK = sec((size_t)n * sizeof(orb_keypoint)), oD = sec((size_t)n * 32), oU = sec(F.uRight ? (size_t)n * 4 : 0),
                      oO = sec(F.occupied ? (size_t)n : 0), oQ = sec((size_t)nq * sizeof(orbm_query)), oQD = sec((size_t)nq * 32), oC = sec(16),
                      oL = sec((F.Nleft != -1 && F.kpLink) ? (size_t)n * 4 : 0);
-        stage_.resize(off);
-        std::memcpy(&stage_[oK], F.keysUn, (size_t)n * sizeof(orb_keypoint));
-        std::memcpy(&stage_[oD], F.descriptors, (size_t)n * 32);
-        if (F.uRight) std::memcpy(&stage_[oU], F.uRight, (size_t)n * 4);
-        if (F.occupied) std::memcpy(&stage_[oO], F.occupied, (size_t)n);
-        std::memcpy(&stage_[oQ], queries.data(), (size_t)nq * sizeof(orbm_query));
-        std::memcpy(&stage_[oQD], qdesc.data(), (size_t)nq * 32);
+        uint8_t* stage = stage_.ensure(off);
+        std::memcpy(stage + oK, F.keysUn, (size_t)n * sizeof(orb_keypoint));
+        std::memcpy(stage + oD, F.descriptors, (size_t)n * 32);
+        if (F.uRight) std::memcpy(stage + oU, F.uRight, (size_t)n * 4);
+        if (F.occupied) std::memcpy(stage + oO, F.occupied, (size_t)n);
+        std::memcpy(stage + oQ, queries.data(), (size_t)nq * sizeof(orbm_query));
+        std::memcpy(stage + oQD, qdesc.data(), (size_t)nq * 32);
         const int32_t counts[3] = {n, nq, F.Nleft};
-        std::memcpy(&stage_[oC], counts, sizeof(counts));
-        if (F.Nleft != -1 && F.kpLink) std::memcpy(&stage_[oL], F.kpLink, (size_t)n * 4);
-        uint8_t* dIn = in_.upload(stage_.data(), off);
+        std::memcpy(stage + oC, counts, sizeof(counts));
+        if (F.Nleft != -1 && F.kpLink) std::memcpy(stage + oL, F.kpLink, (size_t)n * 4);
+        uint8_t* dIn = in_.upload(stage, off);
         const orb_keypoint* dk = (const orb_keypoint*)(dIn + oK);
         const uint8_t* dd = dIn + oD;
         const float* dur = F.uRight ? (const float*)(dIn + oU) : nullptr;
@@ -121,13 +139,13 @@ public:
             if (orbm_search_by_projection_rig(dk, dd, docc, dlk, dc, 1, n, gs, gi, dq, dqd, dc + 1, nq, 1, &prm, dqm, dkm, dnm, work, nullptr) != ORB_OK)
                 throw std::runtime_error("orbm_search_by_projection_rig");
         }
-        back_.resize(oNM + 4);
-        orb_memcpy_d2h(back_.data(), dOut, oNM + 4, nullptr);
+        const uint8_t* back = back_.ensure(oNM + 4);
+        orb_memcpy_d2h(back_.p, dOut, oNM + 4, nullptr);
         if (orb_stream_sync(nullptr) != ORB_OK) throw std::runtime_error("orb_stream_sync");
-        std::memcpy(queryMatch.data(), &back_[oQM], (size_t)nq * 4);
-        std::memcpy(kpMatch.data(), &back_[oKM], (size_t)n * 4);
+        std::memcpy(queryMatch.data(), back + oQM, (size_t)nq * 4);
+        std::memcpy(kpMatch.data(), back + oKM, (size_t)n * 4);
         int nmatches = 0;
-        std::memcpy(&nmatches, &back_[oNM], 4);
+        std::memcpy(&nmatches, back + oNM, 4);
         return nmatches;
     }
 
@@ -393,7 +411,7 @@ public:
 
 private:
     detail::DevBuf kps_, desc_, ur_, occ_, q_, qd_, cnt_, gs_, gi_, qm_, km_, nm_, work_, in_, out_;
-    std::vector<uint8_t> stage_, back_;   // host mirrors of the packed input / output blocks of SearchByProjection
+    detail::HostBuf stage_, back_;   // page-locked host mirrors of the packed input / output blocks of SearchByProjection
     detail::DevBuf tk_[2], td_[2], tu_[2], tm_[2], tn_[2], ts_[2], tf_[2], nl_, lk_, ta_[2];
 };
 
