@@ -73,3 +73,38 @@ def test_emu_empty_and_degenerate_inputs(emu_lib):
 @pytest.mark.gpu
 def test_hip_empty_and_degenerate_inputs(hip_lib):
     _run(hip_lib, "hip")
+
+
+def _host_alloc_round_trip(lib):
+    """orb_host_alloc / orb_host_free (include/orbhip.h): a page-locked host block is written, sent to the device and read back through the helpers."""
+    import ctypes as C
+    import numpy as np
+    for f in (lib.orb_host_alloc, lib.orb_host_free, lib.orb_dev_alloc, lib.orb_dev_free, lib.orb_memcpy_h2d, lib.orb_memcpy_d2h, lib.orb_stream_sync):
+        f.restype = C.c_int
+    lib.orb_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.orb_host_free.argtypes = [C.c_void_p]
+    lib.orb_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.orb_dev_free.argtypes = [C.c_void_p]
+    lib.orb_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.orb_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.orb_stream_sync.argtypes = [C.c_void_p]
+    n = 100000
+    hp, hq, dp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.orb_host_alloc(n, C.byref(hp)) == 0 and lib.orb_host_alloc(n, C.byref(hq)) == 0 and lib.orb_dev_alloc(0, n, C.byref(dp)) == 0
+    assert lib.orb_host_alloc(n, None) == -3                     # ORB_E_INVALID
+    src = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), (n,))
+    dst = np.ctypeslib.as_array(C.cast(hq, C.POINTER(C.c_uint8)), (n,))
+    src[:] = np.random.default_rng(3).integers(0, 256, n, dtype=np.uint8)
+    dst[:] = 0
+    assert lib.orb_memcpy_h2d(dp, hp, n, None) == 0 and lib.orb_memcpy_d2h(hq, dp, n, None) == 0 and lib.orb_stream_sync(None) == 0
+    assert np.array_equal(src, dst)
+    assert lib.orb_host_free(hp) == 0 and lib.orb_host_free(hq) == 0 and lib.orb_dev_free(dp) == 0 and lib.orb_host_free(None) == 0
+
+
+def test_emu_host_alloc_round_trip(emu_lib):
+    _host_alloc_round_trip(emu_lib)
+
+
+@pytest.mark.gpu
+def test_hip_host_alloc_round_trip(hip_lib):
+    _host_alloc_round_trip(hip_lib)
