@@ -276,7 +276,9 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
         const int ty = (tid >> 4) + 16 * k;
         if (by0 + ty >= P.dh) break;
         const uint4 rt = rowt[ty];
-        const uint32_t b0 = rt.z, b1 = rt.w;
+        // both factors are below 2^24 (weights << 7 <= 2^18, H-pass sums << 5 < 2^24); saying so on BOTH lets the compiler pick the full-rate
+        // v_mul_hi_u32_u24 — with only one side masked it emitted v_mul_hi_u32 plus the sixteen v_and of the masks
+        const uint32_t b0 = rt.z & 0xFFFFFFu, b1 = rt.w & 0xFFFFFFu;
         const uint4 T0 = *(const uint4*)((const uint8_t*)hbuf + rt.x + xg * 16);
         const uint4 T1 = *(const uint4*)((const uint8_t*)hbuf + rt.y + xg * 16);
 #define R2_PIX(t0, t1) (((uint32_t)(((uint64_t)b0 * ((t0) & 0xFFFFFFu)) >> 32) + (uint32_t)(((uint64_t)b1 * ((t1) & 0xFFFFFFu)) >> 32) + 2u) >> 2)
