@@ -69,6 +69,7 @@ struct ResizeParams {
     uint8_t* dst; size_t dFrame; int dStride, dw, dh;
     double scale_x, scale_y;   // 1 / ((double)dw / sw), 1 / ((double)dh / sh)  — cv::resize's scale_x / scale_y
     const int* coef;           // k_resize2: per-level tables xs[dw] | xw[dw] | ys[dh] | yw[dh] (resize_coef of every column / row)
+    const int* tileTab;        // k_resize2: per-level staging footprints {xal, ndw} x tilesX | {ylo, nrows} x tilesY (resize2_footprint, built at orbx_create)
     int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
 };
 
@@ -183,6 +184,17 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 #define R2_ROWS 46        // 32 * 1.3 + 2 taps + 2 slack (estimated footprint)
 #define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks, 16-byte aligned)
 #define R2_SMEM ((RS_TW * 2 + R2_TH * 4) * 4 + R2_ROWS * R2_HP * 4 + R2_ROWS * RS_PITCH)
+// Staging footprint of a k_resize2 tile along one axis: first staged source coordinate (dword-aligned for x) and the staged extent, from a FLOAT
+// estimate of the first / last coefficient widened by one on each side (the exact indices come from the double-precision tables and can differ
+// by one).  Workgroup-uniform float arithmetic — 30 VALU instructions that every lane of every tile repeated (there is no scalar float unit) —
+// so it is evaluated once per level at orbx_create and read back through the scalar cache.
+static inline void resize2_footprint(int t0, int tlen, int dlen, int slen, double scale, bool alignX, int& lo, int& ext) {
+    const float fs = (float)scale;
+    const int a = std::max((int)floorf(((float)t0 + 0.5f) * fs - 0.5f) - 1, 0);
+    const int e = std::min((int)floorf(((float)(std::min(t0 + tlen, dlen) - 1) + 0.5f) * fs - 0.5f) + 2, slen - 1);
+    if (alignX) { lo = a & ~3; ext = ((e - lo) >> 2) + 1; }   // dwords
+    else { lo = a; ext = e - a + 1; }                          // rows
+}
 static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     typedef unsigned short u16x2 __attribute__((vector_size(4)));
@@ -199,20 +211,15 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     const int bx0 = txI * RS_TW, by0 = tyI * R2_TH;
 #else
     const int frameZ = blockIdx.z;
+    const int txI = blockIdx.x, tyI = blockIdx.y;
     const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * R2_TH;
 #endif
     const uint8_t* S = P.src + (size_t)frameZ * P.sFrame;
     const int* xs = P.coef; const int* xw = xs + P.dw; const int* ys = xw + P.dw; const int* yw = ys + P.dh;
-    // Source footprint of the tile from a float estimate of the first / last coefficient, widened by one column / row on each
-    // side (the exact indices come from the double-precision tables and can differ by one): the staging loads then do not wait
-    // for the table loads — both global round trips are in flight together.
-    const float fsx = (float)P.scale_x, fsy = (float)P.scale_y;
-    const int xlo = max((int)floorf(((float)bx0 + 0.5f) * fsx - 0.5f) - 1, 0);
-    const int xal = xlo & ~3;
-    const int xend = min((int)floorf(((float)(min(bx0 + RS_TW, P.dw) - 1) + 0.5f) * fsx - 0.5f) + 2, P.sw - 1);
-    const int ylo = max((int)floorf(((float)by0 + 0.5f) * fsy - 0.5f) - 1, 0);
-    const int yhi = min((int)floorf(((float)(min(by0 + R2_TH, P.dh) - 1) + 0.5f) * fsy - 0.5f) + 2, P.sh - 1);
-    const int ndw = ((xend - xal) >> 2) + 1, nrows = yhi - ylo + 1;       // <= RS_PITCH/4, <= R2_ROWS for scale <= 1.3
+    // Source footprint of the tile (resize2_footprint, tabulated per level): two scalar loads from a table the scalar cache holds, instead of
+    // float arithmetic on workgroup-uniform values in every lane; the staging loads still do not wait for the coefficient-table (vector) loads.
+    const int2 fx = ((const int2*)P.tileTab)[txI], fy = ((const int2*)P.tileTab)[P.tilesX + tyI];
+    const int xal = fx.x, ndw = fx.y, ylo = fy.x, nrows = fy.y;           // <= RS_PITCH/4, <= R2_ROWS for scale <= 1.3
     {   // stage the source footprint: lane = dword column, 8 rows per pass (coalesced aligned row segments)
         const int c = tid & 31, r0 = tid >> 5;
         uint32_t v[(R2_ROWS + 7) / 8];
@@ -1749,6 +1756,7 @@ struct orbx_extractor {
     hipStream_t stream = nullptr;
     int32_t* d_rowStart = nullptr; int32_t* d_rowIdx = nullptr; int rowCapAlloc = 0;   // ComputeStereoMatches row buckets (lazy)
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
+    size_t tileTabOff[ORBX_MAX_LEVELS] = {0};                        // k_resize2 staging footprints of every level >= 1 (inside d_coef)
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
     FastTile* d_tiles = nullptr;
@@ -1907,6 +1915,12 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
             int* xs = tab.data() + h->coefOff[l]; int* xw = xs + dw; int* ys = xw + dw; int* yw = ys + dh;
             for (int x = 0; x < dw; x++) { int s0, w0, w1; resize_coef(x, sx, sw, true, s0, w0, w1); xs[x] = s0; xw[x] = (w0 & 0xFFFF) | (w1 << 16); }
             for (int y = 0; y < dh; y++) { int s0, w0, w1; resize_coef(y, sy, sh, false, s0, w0, w1); ys[y] = s0; yw[y] = (w0 & 0xFFFF) | (w1 << 16); }
+            // staging footprints of the 64 x 32 destination tiles (8-byte aligned pairs)
+            if (tab.size() & 1) tab.push_back(0);
+            h->tileTabOff[l] = tab.size();
+            const int tX = (dw + RS_TW - 1) / RS_TW, tY = (dh + R2_TH - 1) / R2_TH;
+            for (int t = 0; t < tX; t++) { int lo, ext; resize2_footprint(t * RS_TW, RS_TW, dw, sw, sx, true, lo, ext); tab.push_back(lo); tab.push_back(ext); }
+            for (int t = 0; t < tY; t++) { int lo, ext; resize2_footprint(t * R2_TH, R2_TH, dh, sh, sy, false, lo, ext); tab.push_back(lo); tab.push_back(ext); }
         }
         CK(hipMalloc((void**)&h->d_coef, std::max<size_t>(tab.size() * 4, 256)));
         if (!tab.empty()) CK(hipMemcpy(h->d_coef, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
@@ -1994,6 +2008,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.dw = h->lv[l].w; R.dh = h->lv[l].h;
         R.scale_x = 1. / ((double)R.dw / R.sw); R.scale_y = 1. / ((double)R.dh / R.sh);
         R.coef = h->d_coef + h->coefOff[l];
+        R.tileTab = h->d_coef + h->tileTabOff[l];
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
 #if R2_XCD
