@@ -492,14 +492,15 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         // dword instead (those columns are never tested).
         const bool edge = gq * 16 + 4 > safe;
         const int lastOff = (safe - 4) & ~3;
+        // byte offsets inside the frame are 32-bit (src is workgroup-uniform): scalar base + vector offset addressing, no 64-bit VALU arithmetic
         auto fetch = [&](const int r, const int c, uint32_t* w) {
-            const uint8_t* g = src + (size_t)r * L.rowStride;
+            const uint32_t o = (uint32_t)(r * L.rowStride);
             if (!edge) {
-                const uint32_t* gw = (const uint32_t*)(g + 16 * c);
+                const uint32_t* gw = (const uint32_t*)(src + (o + 16u * (uint32_t)c));
                 w[0] = gw[0]; w[1] = gw[1]; w[2] = gw[2]; w[3] = gw[3]; w[4] = gw[4];
             } else {
 #pragma unroll
-                for (int k = 0; k < 5; k++) w[k] = *(const uint32_t*)(g + min(16 * c + 4 * k, lastOff));
+                for (int k = 0; k < 5; k++) w[k] = *(const uint32_t*)(src + (o + (uint32_t)min(16 * c + 4 * k, lastOff)));
             }
         };
         auto put = [&](const int r, const int c, const uint32_t* w) {
@@ -510,12 +511,27 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         uint32_t w[NS][5];
         int rr[NS], cc[NS];
         int r = tid / gq, c = tid - r * gq;
+        // interior and right-border tiles take separate code copies of the request loop: merged behind one set of load instructions, the
+        // interior case lost its dwordx4 + dword form (five single-dword loads with an address computation each)
+        if (!edge) {
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
-            rr[k] = r; cc[k] = c;
-            if (tid + 256 * k < ng) fetch(r, c, w[k]);
-            r += dr; c += dc;
-            if (c >= gq) { c -= gq; r++; }
+            for (int k = 0; k < NS; k++) {
+                rr[k] = r; cc[k] = c;
+                if (tid + 256 * k < ng) {
+                    const uint32_t* gw = (const uint32_t*)(src + ((uint32_t)(r * L.rowStride) + 16u * (uint32_t)c));
+                    w[k][0] = gw[0]; w[k][1] = gw[1]; w[k][2] = gw[2]; w[k][3] = gw[3]; w[k][4] = gw[4];
+                }
+                r += dr; c += dc;
+                if (c >= gq) { c -= gq; r++; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                rr[k] = r; cc[k] = c;
+                if (tid + 256 * k < ng) fetch(r, c, w[k]);
+                r += dr; c += dc;
+                if (c >= gq) { c -= gq; r++; }
+            }
         }
         for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll

@@ -10,7 +10,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"].split("(")[0]
-    if k.startswith("k_describe"):
+    if k.startswith("k_fast") or k.startswith("k_resize2") or k.startswith("k_describe"):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
