@@ -1931,12 +1931,33 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
             int* xs = tab.data() + h->coefOff[l]; int* xw = xs + dw; int* ys = xw + dw; int* yw = ys + dh;
             for (int x = 0; x < dw; x++) { int s0, w0, w1; resize_coef(x, sx, sw, true, s0, w0, w1); xs[x] = s0; xw[x] = (w0 & 0xFFFF) | (w1 << 16); }
             for (int y = 0; y < dh; y++) { int s0, w0, w1; resize_coef(y, sy, sh, false, s0, w0, w1); ys[y] = s0; yw[y] = (w0 & 0xFFFF) | (w1 << 16); }
-            // staging footprints of the 64 x 32 destination tiles (8-byte aligned pairs)
+            // staging footprints of the 64 x 32 destination tiles (8-byte aligned pairs).  For the levels k_resize2 serves (scale <= 1.3) every
+            // footprint is checked here, once, against the exact tables: it must cover both taps of every column / row of its tile and fit the
+            // kernel's LDS tile — what the kernel otherwise takes on trust (a miss would read, an overflow would write, outside the staged tile)
+            const int tX = (dw + RS_TW - 1) / RS_TW, tY = (dh + R2_TH - 1) / R2_TH;
+            std::vector<int> fp;
+            bool covered = true;
+            for (int t = 0; t < tX; t++) {
+                int lo, ext; resize2_footprint(t * RS_TW, RS_TW, dw, sw, sx, true, lo, ext); fp.push_back(lo); fp.push_back(ext);
+                for (int x = t * RS_TW; x < std::min(t * RS_TW + RS_TW, dw); x++)
+                    covered = covered && xs[x] >= lo && std::min(xs[x] + 1, sw - 1) < lo + 4 * ext;
+                covered = covered && ext >= 1 && 4 * ext <= RS_PITCH;
+            }
+            for (int t = 0; t < tY; t++) {
+                int lo, ext; resize2_footprint(t * R2_TH, R2_TH, dh, sh, sy, false, lo, ext); fp.push_back(lo); fp.push_back(ext);
+                for (int y = t * R2_TH; y < std::min(t * R2_TH + R2_TH, dh); y++) {
+                    const int y0 = std::min(std::max(ys[y], 0), sh - 1), y1 = std::min(std::max(ys[y] + 1, 0), sh - 1);
+                    covered = covered && y0 >= lo && y1 < lo + ext;
+                }
+                covered = covered && ext >= 1 && ext <= R2_ROWS;
+            }
+            if (!covered && sx <= 1.3 && sy <= 1.3) {
+                orbx_free(h);
+                return orbx_fail(nullptr, ORB_E_INVALID, "k_resize2: a staging footprint does not cover its tile (level " + std::to_string(l) + ")");
+            }
             if (tab.size() & 1) tab.push_back(0);
             h->tileTabOff[l] = tab.size();
-            const int tX = (dw + RS_TW - 1) / RS_TW, tY = (dh + R2_TH - 1) / R2_TH;
-            for (int t = 0; t < tX; t++) { int lo, ext; resize2_footprint(t * RS_TW, RS_TW, dw, sw, sx, true, lo, ext); tab.push_back(lo); tab.push_back(ext); }
-            for (int t = 0; t < tY; t++) { int lo, ext; resize2_footprint(t * R2_TH, R2_TH, dh, sh, sy, false, lo, ext); tab.push_back(lo); tab.push_back(ext); }
+            tab.insert(tab.end(), fp.begin(), fp.end());
         }
         CK(hipMalloc((void**)&h->d_coef, std::max<size_t>(tab.size() * 4, 256)));
         if (!tab.empty()) CK(hipMemcpy(h->d_coef, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));

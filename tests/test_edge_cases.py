@@ -108,3 +108,24 @@ def test_emu_host_alloc_round_trip(emu_lib):
 @pytest.mark.gpu
 def test_hip_host_alloc_round_trip(hip_lib):
     _host_alloc_round_trip(hip_lib)
+
+
+def test_emu_resize_staging_footprints_cover_their_tiles(emu_lib):
+    """orbx_create checks every tabulated k_resize2 staging footprint against the exact cv::resize index tables (coverage of both taps of every column / row of the
+    tile, LDS tile capacity) and refuses the configuration otherwise.  Host code only: a sweep over image sizes, scale factors and level counts must never hit it."""
+    import ctypes as C
+    from orbhip._lib import OrbxConfig
+    rng = np.random.default_rng(2024)
+    created = 0
+    for i in range(3000):
+        W, H = int(rng.integers(80, 2600)), int(rng.integers(80, 1700))
+        sf = float(rng.uniform(1.01, 1.3)) if i % 3 == 0 else float(rng.choice([1.1, 1.2, 1.25, 1.3])) if i % 3 == 1 else float(rng.uniform(1.3, 1.6))
+        cfg = OrbxConfig(1000, sf, int(rng.integers(2, 11)), 20, 7)
+        h = C.c_void_p()
+        rc = emu_lib.orbx_create(C.byref(cfg), W, H, 1, 0, C.byref(h))
+        if rc == 0:
+            created += 1
+            emu_lib.orbx_destroy(h)
+        else:
+            assert "footprint" not in (emu_lib.orbx_last_error(None) or b"").decode(), (W, H, sf)
+    assert created > 1500
