@@ -1253,7 +1253,9 @@ static int launch_status() { return hipGetLastError() == hipSuccess ? ORB_OK : O
 
 // ---- optional per-kernel device timing of the projection search (bench.py's roofline legs): HIP events recorded on the launch stream
 // around k_grid_build / k_sbp_candidates2 / k_sbp_resolve while enabled.  Process-wide and not re-entrant: a measurement facility only.
-static struct { bool on = false, made = false, have_grid = false, have_sbp = false; hipEvent_t ev[5]; } g_mt;
+// per calling thread: Tracking, LocalMapping and LoopClosing each drive their own matcher calls on their own streams; a thread that enables the
+// timing gets events of its own and reads back its own last call, whatever the others do
+static thread_local struct { bool on = false, made = false, have_grid = false, have_sbp = false; hipEvent_t ev[5]; } g_mt;
 static bool mt_ready() {
     if (!g_mt.on) return false;
     if (!g_mt.made) {

@@ -231,7 +231,8 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
 
 /* Measurement facility (bench.py's roofline legs), the stage-2 counterpart of orbx_last_timing: while enabled, HIP events are recorded on the launch
  * stream around the kernels of orbm_grid_build and orbm_search_by_projection; orbm_last_timing synchronises on them and returns the device time of the
- * last call's kernels: ms[0] = grid build, ms[1] = candidate enumeration + Hamming, ms[2] = serial-order resolution.  Process-wide, not re-entrant. */
+ * last call's kernels: ms[0] = grid build, ms[1] = candidate enumeration + Hamming, ms[2] = serial-order resolution.  The switch and the events are per calling thread: a thread times its own calls only, concurrent matcher
+ * calls of other threads neither record into nor disturb them. */
 int orbm_enable_timing(int on);
 int orbm_last_timing(float* ms3);
 
@@ -474,7 +475,8 @@ int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_wor
 int lba_optimize_stopflag(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
                           const volatile unsigned char* pb_stop_flag, void* stream);
 /* lba_optimize returns ORB_E_CAPACITY when the reduced camera system (6 unknowns per FREE key frame; fixed key frames do not count) no
- * longer fits the solver's LDS budget (> ~3 300 free key frames): callers fall back to their CPU solver for such a map. */
+ * longer fits the solver's LDS budget (> ~3 300 free key frames): nothing was changed, the window stays as it was.  A host that must optimise such a map
+ * keeps its own CPU solver for it (integration/Optimizer_hip.cc REPLACES the g2o body and therefore leaves the map untouched instead — GlueGuard.h). */
 
 /* SURVEY.md N3 — Optimizer::PoseOptimization(Frame*) (reference src/Optimizer.cc:907-1273): the motion-only BA that follows
  * every matcher call in Tracking (Tracking.cc:2210,2395,2468).  One pose vertex, unary reprojection edges

@@ -97,9 +97,14 @@ public:
         if (nL == 0 || nR == 0) return;
         if (!h_ || !right.h_) throw std::runtime_error("ComputeStereoMatches: both extractors must have extracted their image first");
         const int cap = nL > nR ? nL : nR;
-        const size_t kb = (size_t)cap * sizeof(orb_keypoint), db = (size_t)cap * 32;
-        // one device block: [kps L | kps R | desc L | desc R | counts L, R (2 x int32 each) | u_right | depth | work]
-        const size_t need = 2 * kb + 2 * db + 16 + 3 * (size_t)cap * 4;
+        // one device block: [kps L | kps R | desc L | desc R | counts L, R (2 x int32 each) | u_right | depth | work], every section on a 256-byte
+        // boundary (the kernels read descriptors with 16-byte vector loads; 28-byte key point records would leave them 8-byte aligned at best)
+        size_t off = 0;
+        auto sec = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t oKL = sec((size_t)cap * sizeof(orb_keypoint)), oKR = sec((size_t)cap * sizeof(orb_keypoint)), oDL = sec((size_t)cap * 32), oDR = sec((size_t)cap * 32),
+                     oC = sec(16), oU = sec((size_t)cap * 4), oP = sec((size_t)cap * 4), oW = sec((size_t)cap * 4);
+        (void)oKL;
+        const size_t need = off;
         if (need > stereoBytes_) {
             if (stereoBuf_) orb_dev_free(stereoBuf_);
             stereoBuf_ = nullptr; stereoBytes_ = 0;
@@ -107,11 +112,11 @@ public:
             stereoBytes_ = need;
         }
         unsigned char* d = (unsigned char*)stereoBuf_;
-        orb_keypoint *dkl = (orb_keypoint*)d, *dkr = (orb_keypoint*)(d + kb);
-        uint8_t *ddl = d + 2 * kb, *ddr = d + 2 * kb + db;
-        int32_t* dc = (int32_t*)(d + 2 * kb + 2 * db);
-        float *dur = (float*)(dc + 4), *ddp = dur + cap;
-        int32_t* dwork = (int32_t*)(ddp + cap);
+        orb_keypoint *dkl = (orb_keypoint*)d, *dkr = (orb_keypoint*)(d + oKR);
+        uint8_t *ddl = d + oDL, *ddr = d + oDR;
+        int32_t* dc = (int32_t*)(d + oC);
+        float *dur = (float*)(d + oU), *ddp = (float*)(d + oP);
+        int32_t* dwork = (int32_t*)(d + oW);
         const int32_t cnt[4] = {nL, 0, nR, 0};
         bool ok = orb_memcpy_h2d(dkl, kpsL, (size_t)nL * sizeof(orb_keypoint), nullptr) == ORB_OK && orb_memcpy_h2d(dkr, kpsR, (size_t)nR * sizeof(orb_keypoint), nullptr) == ORB_OK &&
                   orb_memcpy_h2d(ddl, descL, (size_t)nL * 32, nullptr) == ORB_OK && orb_memcpy_h2d(ddr, descR, (size_t)nR * 32, nullptr) == ORB_OK &&

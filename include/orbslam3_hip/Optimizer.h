@@ -81,7 +81,7 @@ public:
         static_assert(sizeof(bool) == 1, "the reference's bool* pbStopFlag is polled as one byte");
         const int rc = pbStopFlagBool ? lba_optimize_stopflag(&P, 1, iterations, ws, stats, (const volatile unsigned char*)pbStopFlagBool, nullptr)
                                       : lba_optimize(&P, 1, iterations, ws, stats, pbStopFlag, nullptr);
-        if (rc == ORB_E_CAPACITY) throw std::length_error("lba_optimize: reduced camera system too large for the device solver (fall back to g2o)");
+        if (rc == ORB_E_CAPACITY) throw std::length_error("lba_optimize: ORB_E_CAPACITY, the reduced camera system of this window does not fit the device solver (> ~3 300 free key frames)");
         if (rc != ORB_OK && rc != ORB_E_ABORTED) throw std::runtime_error("lba_optimize failed");
         orb_memcpy_d2h(poses_.data(), dPoses_, poses_.size() * 8, nullptr);
         orb_memcpy_d2h(points_.data(), dPoints_, points_.size() * 8, nullptr);

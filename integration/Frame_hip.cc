@@ -19,19 +19,20 @@
 #include <vector>
 
 #include <orbslam3_hip/Frame.h>
+#include <orbslam3_hip/GlueGuard.h>
 
 namespace ORB_SLAM3 {
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint is read as orb_keypoint (pt.x, pt.y, size, angle, response, octave, class_id)");
 
-void Frame::ComputeStereoMatches() {
+void Frame::ComputeStereoMatches() try {
     // mvuRight / mvDepth sized N, -1 = no match (:957-958); everything between :960 and :1133 runs on the device
     const int nR = (int)mvKeysRight.size();
     mpORBextractorLeft->ComputeStereoMatches(*mpORBextractorRight, reinterpret_cast<const orb_keypoint*>(mvKeys.data()), mDescriptors.data, N,
                                              reinterpret_cast<const orb_keypoint*>(mvKeysRight.data()), mDescriptorsRight.data, nR, mb, mbf, mvuRight, mvDepth);
-}
+} ORBHIP_GLUE_CATCH("Frame::ComputeStereoMatches", { mvuRight = std::vector<float>(N, -1.0f); mvDepth = std::vector<float>(N, -1.0f); return; })   // "no stereo match" (:957-958): the constructor indexes both
 
-void Frame::UndistortKeyPoints() {
+void Frame::UndistortKeyPoints() try {
     if (mDistCoef.at<float>(0) == 0.0) {   // :879-883
         mvKeysUn = mvKeys;
         return;
@@ -53,9 +54,9 @@ void Frame::UndistortKeyPoints() {
     C.ops->UndistortKeyPoints(in, out);
     mvKeysUn.resize(N);   // every other attribute of the key point is the distorted one's (:913-921)
     if (N) std::memcpy((void*)mvKeysUn.data(), out.data(), (size_t)N * sizeof(orb_keypoint));
-}
+} ORBHIP_GLUE_CATCH("Frame::UndistortKeyPoints", { mvKeysUn = mvKeys; return; })   // sized like mvKeys, as every later step assumes
 
-void Frame::ComputeStereoFishEyeMatches() {
+void Frame::ComputeStereoFishEyeMatches() try {
     orbf_fisheye_rig rig{};
     for (int i = 0; i < 8; i++) { rig.k_left[i] = mpCamera->getParameter(i); rig.k_right[i] = mpCamera2->getParameter(i); }
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) rig.R_lr[r * 3 + c] = mRlr.at<float>(r, c); rig.t_lr[r] = mtlr.at<float>(r); }
@@ -82,7 +83,9 @@ void Frame::ComputeStereoFishEyeMatches() {
             for (int c = 0; c < 3; c++) p.at<float>(c) = p3d[(size_t)i * 3 + c];
             mvStereo3Dpoints[i] = p;
         }
-}
+} ORBHIP_GLUE_CATCH("Frame::ComputeStereoFishEyeMatches", {   // "nothing matched", sized as :1292-1297 leave them
+    mvLeftToRightMatch = std::vector<int>(Nleft, -1); mvRightToLeftMatch = std::vector<int>(Nright, -1); mvDepth = std::vector<float>(Nleft, -1.0f);
+    mvuRight = std::vector<float>(Nleft, -1); mvStereo3Dpoints = std::vector<cv::Mat>(Nleft); mnCloseMPs = 0; return; })
 
 }  // namespace ORB_SLAM3
 #endif  // ORBHIP_WITH_ORBSLAM3

@@ -18,6 +18,7 @@
 #include <set>
 #include <vector>
 
+#include <orbslam3_hip/GlueGuard.h>
 #include <orbslam3_hip/ORBmatcher.h>
 
 namespace ORB_SLAM3 {
@@ -74,7 +75,7 @@ void flatten_featvec(const DBoW2::FeatureVector& fv, orbslam3_hip::ORBmatcher::K
 }  // namespace
 
 // ---- SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)   ORBmatcher.cc:59-255, Tracking.cc:2964 ------
-int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) {
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints) try {
     FrameGather G(F, [](MapPoint* p) { return p && p->Observations() > 0; }, true);   // :125-127 (left), :212-214 (right)
     const bool rig = F.Nleft != -1;
     std::vector<orbm_query> q;
@@ -116,10 +117,10 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     for (int idx = 0; idx < F.N; idx++)   // F.mvpMapPoints[bestIdx] = pMP (:171, :174, :241, :246): the holder after the serial loop
         if (kpMatch[idx] >= 0) F.mvpMapPoints[idx] = owner[kpMatch[idx]];
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByProjection", return 0;)
 
 // ---- SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)   ORBmatcher.cc:2244-2509, Tracking.cc:2363-2378 --------
-int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) try {
     FrameGather G(CurrentFrame, [](MapPoint* p) { return p && p->Observations() > 0; }, true);   // :2347-2349
     const bool rig = CurrentFrame.Nleft != -1;
     const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
@@ -173,10 +174,10 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         else if (kpMatch[idx] == -2) CurrentFrame.mvpMapPoints[idx] = static_cast<MapPoint*>(NULL);
     }
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByProjection", return 0;)
 
 // ---- SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   ORBmatcher.cc:2520-2652, Tracking.cc:3403,3417 (relocalisation) ----
-int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) try {
     FrameGather G(CurrentFrame, [](MapPoint* p) { return p != NULL; }, false);   // `if(CurrentFrame.mvpMapPoints[i2]) continue;` :2586
     const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
     const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
@@ -214,7 +215,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
         else if (kpMatch[idx] == -2) CurrentFrame.mvpMapPoints[idx] = NULL;   // :2637
     }
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByProjection", return 0;)
 
 // ---- the two Sim3 projection searches of loop closing / merging   ORBmatcher.cc:593-706 and :708-824 ------------------------------------
 namespace {
@@ -273,7 +274,7 @@ orbslam3_hip::FrameView keyframe_view(KeyFrame* pKF, std::vector<uint8_t>& occ, 
 }
 }  // namespace
 
-int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th, float ratioHamming) {
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th, float ratioHamming) try {
     const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, vpMatched, th);
     std::vector<uint8_t> occ;
     const orbslam3_hip::FrameView V = keyframe_view(pKF, occ, vpMatched);
@@ -284,10 +285,10 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector
     for (int idx = 0; idx < V.N; idx++)
         if (kpMatch[idx] >= 0) vpMatched[idx] = vpPoints[S.src[kpMatch[idx]]];   // :688
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByProjection", return 0;)
 
 int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<KeyFrame*>& vpPointsKFs,
-                                   std::vector<MapPoint*>& vpMatched, std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming) {
+                                   std::vector<MapPoint*>& vpMatched, std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming) try {
     const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, vpMatched, th);
     std::vector<uint8_t> occ;
     const orbslam3_hip::FrameView V = keyframe_view(pKF, occ, vpMatched);
@@ -297,10 +298,10 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector
     for (int idx = 0; idx < V.N; idx++)
         if (kpMatch[idx] >= 0) { vpMatched[idx] = vpPoints[S.src[kpMatch[idx]]]; vpMatchedKF[idx] = vpPointsKFs[S.src[kpMatch[idx]]]; }   // :806-807
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByProjection", return 0;)
 
 // ---- SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   ORBmatcher.cc:323-587, Tracking.cc:2185 / :3340 ------------------------------------
-int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) try {
     const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
     vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
     const int nKF = (int)vpMapPointsKF.size();
@@ -321,10 +322,10 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     for (int j = 0; j < F.N; j++)
         if (fMatch[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[fMatch[j]];   // :473, :513
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByBoW", return 0;)
 
 // ---- SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)   ORBmatcher.cc:984-1124, LoopClosing.cc:697 --------------------------------------------
-int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) try {
     const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
     const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
     vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
@@ -350,10 +351,11 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
     for (size_t i = 0; i < m12.size(); i++)
         if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];   // :1076
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchByBoW", return 0;)
 
 // ---- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)   ORBmatcher.cc:838-979, Tracking.cc (monocular initialisation) ----
-int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) {
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) try {
+    vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1);   // :842 (sized before the device call: the caller indexes it whatever happens)
     FrameGather G1(F1, [](MapPoint*) { return false; }, false), G2(F2, [](MapPoint*) { return false; }, false);
     G1.V.N = (int)F1.mvKeysUn.size(); G2.V.N = (int)F2.mvKeysUn.size();   // the function indexes mvKeysUn (:844, :856-859)
     std::vector<float> prev(2 * (size_t)G1.V.N);
@@ -362,14 +364,14 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
     for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)   // Update prev matched (:972-975)
         if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
     return nmatches;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchForInitialization", return 0;)
 
 // ---- SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo, bCoarse)   ORBmatcher.cc:1138-1428, LocalMapping.cc:628 ------
 // The statements before the loops (:1144-1193: epipole, R12 / t12 or the four left / right combinations of a rig) are the reference's cv::Mat
 // expressions; the vocabulary-node walk with the epipolar gate runs on the device.  `F12` is not read — as in the reference, whose
 // GeometricCamera::epipolarConstrain recomputes what it needs from R12, t12 and the calibrations (Pinhole.cpp:155-160, KannalaBrandt8.cpp:235-330).
 int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
-                                       const bool bOnlyStereo, const bool bCoarse) {
+                                       const bool bOnlyStereo, const bool bCoarse) try {
     (void)F12;
     // Compute epipole in second image (:1144-1152)
     cv::Mat Cw = pKF1->GetCameraCenter();
@@ -457,13 +459,13 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F
         if (i < nLevels) P.scale_factors_2[i] = pKF2->mvScaleFactors[i];
     }
     return M.SearchForTriangulationKB8(K[0], pKF1->NLeft, K[1], pKF2->NLeft, P, vMatchedPairs, bOnlyStereo, bCoarse);
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchForTriangulation", return 0;)
 
 // ---- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)   ORBmatcher.cc:2008-2232 (loop closing: more matches under a known Sim3) ------
 // The two projection passes (:2044-2080 key frame 1's points into key frame 2, :2131-2167 the other way) are the reference's statements up to
 // GetFeaturesInArea; both window searches and the mutual-agreement test (:2206-2220) run on the device.
 int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12,
-                             const float th) {
+                             const float th) try {
     const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;
     cv::Mat R1w = pKF1->GetRotation(), t1w = pKF1->GetTranslation();   // Camera 1 from world
     cv::Mat R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();   // Camera 2 from world
@@ -523,7 +525,7 @@ int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoin
     for (int i1 = 0; i1 < N1; i1++)
         if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];   // :2214
     return nFound;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::SearchBySim3", return 0;)
 
 // ---- Fuse(pKF, vpMapPoints, th, bRight)   ORBmatcher.cc:1630-1879, LocalMapping.cc:1006-1042 (every key frame, every neighbour) -----------
 // Per map point the gates and the projection (:1666-1765) are the reference's statements; the window search with the chi2 gate and the
@@ -531,7 +533,7 @@ int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoin
 // order afterwards.  The map changes while the reference's loop runs — a point that an earlier iteration replaced is bad when its own turn
 // comes, a feature that an earlier iteration gave a map point has one — so isBad() / IsInKeyFrame() are read again at each point's turn and
 // pKF->GetMapPoint(bestIdx) is read at that moment, exactly as the serial loop sees them; the search itself reads nothing that changes.
-int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) try {
     cv::Mat Rcw, tcw, Ow;
     GeometricCamera* pCamera;
     if (bRight) { Rcw = pKF->GetRightRotation(); tcw = pKF->GetRightTranslation(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
@@ -610,13 +612,13 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
         nFused++;
     }
     return nFused;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::Fuse", return 0;)
 
 // ---- Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)   ORBmatcher.cc:1881-2006 (loop closing / map merging: fuse the points seen from the other side) ----
 // Gates and projection (:1883-1935) are the loop the Sim3 SearchByProjection overloads share (gather_sim3: the same statements with
 // spAlreadyFound = pKF->GetMapPoints(), taken once before the loop as in the reference); one device search without the chi2 gate; the scatter
 // (:1975-1990) in index order, pKF->GetMapPoint(bestIdx) read at each point's turn (an earlier iteration may have filled the feature).
-int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) try {
     const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
     const std::vector<MapPoint*> already(spAlreadyFound.begin(), spAlreadyFound.end());
     const Sim3Gather S = gather_sim3(pKF, Scw, vpPoints, already, (int)th, th);
@@ -640,7 +642,7 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& v
         nFused++;
     }
     return nFused;
-}
+} ORBHIP_GLUE_CATCH("ORBmatcher::Fuse", return 0;)
 
 }  // namespace ORB_SLAM3
 #endif  // ORBHIP_WITH_ORBSLAM3

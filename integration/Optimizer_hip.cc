@@ -23,6 +23,7 @@
 #include <set>
 #include <vector>
 
+#include <orbslam3_hip/GlueGuard.h>
 #include <orbslam3_hip/Optimizer.h>
 
 namespace ORB_SLAM3 {
@@ -54,7 +55,7 @@ cv::Mat pose_to_cvmat(const double* p7) {
 }
 }  // namespace
 
-void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF) {
+void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF) try {
     // ---- Local KeyFrames: First Breath Search from Current Keyframe (:1813-1829) ----
     std::list<KeyFrame*> lLocalKeyFrames;
     lLocalKeyFrames.push_back(pKF);
@@ -178,6 +179,9 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
 
     if (pbStopFlag)
         if (*pbStopFlag) return;
+    // a window without a single observation edge: the reference's optimize() calls do nothing on the empty graph and the function then leaves
+    // through `vToErase.size() >= 0` (:2349-2352) with the map untouched
+    if (edges.empty()) return;
 
     L.optimize(5, nullptr, nullptr, pbStopFlag);   // optimizer.optimize(5) :2205; pbStopFlag is polled between lambda trials like g2o's terminate()
 
@@ -229,13 +233,13 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
         pMP->UpdateNormalAndDepth();
     }
     pMap->IncreaseChangeIndex();
-}
+} ORBHIP_GLUE_CATCH("Optimizer::LocalBundleAdjustment", return;)
 
 // Optimizer::PoseOptimization(Frame*) (reference include/Optimizer.h:53, src/Optimizer.cc:907-1273; called after every matcher call in Tracking:
 // Tracking.cc:2210, 2395, 2468).  The observation walk (:966-1127) is the reference's, one PoseOptimizer observation per g2o edge in the same
 // order; the four optimise / classify rounds (:1133-1252) are the single call PoseOptimizer::optimize (one launch on the device); pose
 // recovery and return value as :1255-1270.
-int Optimizer::PoseOptimization(Frame* pFrame) {
+int Optimizer::PoseOptimization(Frame* pFrame) try {
     thread_local orbslam3_hip::PoseOptimizer PO;     // device buffers are reused from frame to frame
     PO.reset();
     int nInitialCorrespondences = 0;
@@ -253,14 +257,12 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
             const float Xw[3] = {Xwm.at<float>(0), Xwm.at<float>(1), Xwm.at<float>(2)};
             if (!pFrame->mpCamera2) {                // Conventional SLAM (:971-1050)
                 nInitialCorrespondences++;
-                pFrame->mvbOutlier[i] = false;
                 const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
                 const float invSigma2 = pFrame->mvInvLevelSigma2[kpUn.octave];
                 if (pFrame->mvuRight[i] < 0) PO.addMono(Xw, kpUn.pt.x, kpUn.pt.y, invSigma2, camL);                      // :979-1011
                 else PO.addStereo(Xw, kpUn.pt.x, kpUn.pt.y, pFrame->mvuRight[i], invSigma2, camL);                        // :1013-1049
             } else {                                 // fisheye rig (:1052-1125): left camera on mvKeys, right camera through mTrl
                 nInitialCorrespondences++;
-                pFrame->mvbOutlier[i] = false;
                 if (i < pFrame->Nleft) {
                     const cv::KeyPoint kpUn = pFrame->mvKeys[i];
                     PO.addMono(Xw, kpUn.pt.x, kpUn.pt.y, pFrame->mvInvLevelSigma2[kpUn.octave], camL);
@@ -272,7 +274,12 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
             vnIndexEdge.push_back((size_t)i);
         }
     }
-    if (nInitialCorrespondences < 3) return 0;       // :1130-1131
+    // pFrame->mvbOutlier[i] = false of the graph build (:977, :1057) is applied after the device call (the classification overwrites every
+    // one of these entries anyway), so that a failing call leaves the frame as it was
+    if (nInitialCorrespondences < 3) {               // :1130-1131
+        for (size_t k = 0; k < vnIndexEdge.size(); k++) pFrame->mvbOutlier[vnIndexEdge[k]] = false;
+        return 0;
+    }
     double p7[7];
     orbslam3_hip::LbaLinearizer::poseFromTcw(pFrame->mTcw.ptr<float>(), pFrame->mTcw.cols, p7);   // Converter::toSE3Quat(pFrame->mTcw)
     std::vector<bool> outl;
@@ -280,7 +287,7 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
     for (size_t k = 0; k < vnIndexEdge.size(); k++) pFrame->mvbOutlier[vnIndexEdge[k]] = outl[k];
     pFrame->SetPose(pose_to_cvmat(p7));              // :1255-1258
     return nGood;                                    // nInitialCorrespondences - nBad
-}
+} ORBHIP_GLUE_CATCH("Optimizer::PoseOptimization", return 0;)
 
 // Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, bool bLarge, bool bRecInit) (reference include/Optimizer.h:99, src/Optimizer.cc:4753-5365;
 // LocalMapping.cc:196 calls it in the inertial modes instead of LocalBundleAdjustment).
@@ -292,7 +299,7 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
 //   * EdgeInertial's information matrix is taken from the reference's own EdgeInertial constructor (G2oTypes.cc:706-725), so the eigenvalue
 //     clean-up is the reference's code, not a restatement.
 // pbStopFlag: the reference hands it to the optimizer only AFTER optimize() returned (:5228-5229), so it has no effect there either.
-void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool bLarge, bool bRecInit) {
+void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool bLarge, bool bRecInit) try {
     (void)pbStopFlag;
     Map* pCurrentMap = pKF->GetMap();
     int maxOpt = 10, opt_it = 10;
@@ -488,9 +495,10 @@ void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool
         }
     }
 
+    if (vis.empty()) return;   // no visual edge: nothing to erase and nothing the optimisation could move against
     double dErr = 0, dErrEnd = 0;
     const int its = IB.optimize(bLarge ? 1e-2 : 1e0, opt_it, &dErr, &dErrEnd);   // setUserLambdaInit (:4884-4896), optimizer.optimize(opt_it) (:5225)
-    if (its < 0 || vis.empty()) return;   // nothing to optimise, or the window was rejected (more than LIBA_MAX_FREE optimisable key frames)
+    if (its < 0) return;   // the window was rejected (more than LIBA_MAX_FREE optimisable key frames)
     const float err = (float)dErr, err_end = (float)dErrEnd;
 
     // ---- outlier observations (:5237-5275): monocular edges (left and right camera) first, then stereo ----
@@ -555,7 +563,7 @@ void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool
         pMP->UpdateNormalAndDepth();
     }
     pMap->IncreaseChangeIndex();
-}
+} ORBHIP_GLUE_CATCH("Optimizer::LocalInertialBA", return;)
 
 }  // namespace ORB_SLAM3
 #endif  // ORBHIP_WITH_ORBSLAM3

@@ -26,10 +26,9 @@ def extractor_case(seed, W, H, nf, lap):
                 cand_counts=np.array([len(o.level_candidates(l)) for l in range(8)]))
 
 
-def main():
-    np.savez_compressed(os.path.join(HERE, "extract_320x240.npz"), **extractor_case(1, 320, 240, 300, (0, 1000)))
-    np.savez_compressed(os.path.join(HERE, "extract_400x300_lap.npz"), **extractor_case(2, 400, 300, 400, (120, 260)))
-    # matcher: frame B = frame A moved by (6,-4); queries = A's keypoints projected into B (test_matcher_parity.scene)
+def matcher_scene():
+    # matcher: frame B = frame A moved by (6,-4); queries = A's keypoints projected into B (test_matcher_parity.scene).
+    # kp_match codes: >= 0 query index, -1 untouched, -2 claimed during the call and reset to NULL by the orientation cull (ORBmatcher.cc:2499)
     import test_matcher_parity as T
     S = T.scene()
     out = {}
@@ -40,6 +39,14 @@ def main():
         out[name + "_q_match"] = qm
         out[name + "_n"] = n
     np.savez_compressed(os.path.join(HERE, "matcher_scene.npz"), **out)
+
+
+def main():
+    if sys.argv[1:] == ["matcher"]:   # regenerate one fixture only (npz bytes carry zip timestamps: an untouched fixture stays untouched in git)
+        return matcher_scene()
+    np.savez_compressed(os.path.join(HERE, "extract_320x240.npz"), **extractor_case(1, 320, 240, 300, (0, 1000)))
+    np.savez_compressed(os.path.join(HERE, "extract_400x300_lap.npz"), **extractor_case(2, 400, 300, 400, (120, 260)))
+    matcher_scene()
     # LBA: 12-KF / 300-point mixed window: per-block checksums
     w, cams = synth_window(0, 12, 3, 300, 6, "mixed")
     o = O.lba_build_system(w, cams, (HUBER_MONO, HUBER_STEREO))

@@ -86,3 +86,30 @@ def test_frame_glue_on_emulated_library(emu_lib, tmp_path):
 def test_frame_glue_on_hip_library(hip_lib, tmp_path):
     from orbhip import _lib
     _build_and_run_frame_glue(_lib.LIB_PATH, "hip", tmp_path)
+
+
+def _build_and_run_glue_fault(libpath, tag, tmp_path):
+    """tests/cpp/glue_fault_test.cpp: the glue functions replace bodies that never throw — with one C-ABI entry point interposed to fail on demand
+    they must return quietly (0 matches / 0 inliers / void), leave frame and map untouched and count the failure; a LocalBundleAdjustment window
+    without edges leaves through the reference's own exit."""
+    exe = str(tmp_path / ("glue_fault_test_" + tag))
+    libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)[3:-3]
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-DORBHIP_WITH_ORBSLAM3", "-I", os.path.join(ROOT, "tests", "cpp", "mock_orbslam3"),
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "glue_fault_test.cpp"), os.path.join(ROOT, "integration", "ORBmatcher_hip.cc"),
+           os.path.join(ROOT, "integration", "Optimizer_hip.cc"), "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lpthread", "-ldl", "-o", exe]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "glue_fault_test OK" in out.stdout, out.stdout + out.stderr
+    assert out.stderr.count("[orbhip]") == 4, out.stderr   # one report per injected fault
+
+
+def test_glue_failure_policy_on_emulated_library(emu_lib, tmp_path):
+    import build_emu
+    _build_and_run_glue_fault(build_emu.OUT, "emu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_glue_failure_policy_on_hip_library(hip_lib, tmp_path):
+    from orbhip import _lib
+    _build_and_run_glue_fault(_lib.LIB_PATH, "hip", tmp_path)
