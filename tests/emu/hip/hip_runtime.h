@@ -285,6 +285,11 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
 inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
+inline unsigned __builtin_amdgcn_lerp(unsigned a, unsigned b, unsigned c) {   // v_lerp_u8: per byte (a + b + (c & 1)) >> 1
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) r |= ((((a >> (8 * i)) & 255u) + ((b >> (8 * i)) & 255u) + ((c >> (8 * i)) & 1u)) >> 1) << (8 * i);
+    return r;
+}
 inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {   // v_perm_b32 (selectors 0-7 and 0x0c only)
     const uint64_t src = ((uint64_t)s0 << 32) | s1;
     unsigned r = 0;

@@ -31,6 +31,9 @@ def case(rng):
     sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.4]))
     nl = int(rng.choice([3, 5, 8, 8, 8, 10]))
     ini = int(rng.choice([10, 20, 20, 30])); mn = int(rng.choice([3, 7, 7, 10]))
+    if rng.random() < 0.15:   # threshold extremes and parities: the byte-parallel pre-test of k_fast derives its compare constants from min(ini, mn)
+        mn = int(rng.choice([0, 1, 2, 4, 5, 6, 8, 9, 11, 16, 33, 64, 127, 128, 200, 253, 254, 255]))
+        ini = int(max(mn, rng.choice([0, 1, 12, 20, 40, 100, 254, 255])))
     lap = (int(rng.integers(0, W // 2)), int(rng.integers(W // 2, W + 50))) if rng.random() < 0.5 else (0, 0)
     return img, nf, sf, nl, ini, min(mn, ini), lap
 
