@@ -46,6 +46,9 @@ static const int8_t h_pattern[1024] = {
 };
 static __constant__ float4 c_patternf[256];   // the same pairs as floats (x0, y0, x1, y1): no per-keypoint int8 -> float conversions
 static __constant__ int c_umax[16];
+// n / g == (n * c_div16[g]) >> 16 for n * g < 65536: k_fast's index maps divide thread ids (< 256) by workgroup-uniform divisors (< 16) — a
+// 24-bit multiply and a shift instead of the ~20-instruction integer division sequence
+static __constant__ uint32_t c_div16[16] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370};
 static __constant__ uint32_t c_icmask[16][12];   // [|v|][dword k of the patch row]: 0xFF where |col - 21| <= umax[|v|] (IC_Angle's circular patch)
 
 // ============================================================================================================
@@ -308,6 +311,7 @@ struct FastTile { short level, cellRow, cell0, nCells; };
 struct FastLevel {
     const uint8_t* base; size_t frameStride; int rowStride;
     int w, h, nCols, nRows, wCell, hCell;
+    int wCellMagic;   // ceil(65536 / wCell): column / wCell == (column * wCellMagic) >> 16 for column < 256
     size_t candOff;   // offset (u32 units) of this level's candidate slab inside one frame's block
     int candCap;
 };
@@ -363,13 +367,10 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
 // only the passing side's "max over arcs of min" is needed — the other side's is <= 0 < S.  m = 0: ring brighter than the centre
 // (e = x - v), m = -1: darker (e = ~x - ~v = v - x); one v_xad_u32 per ring pixel.
 static __device__ __forceinline__ int fast_S_pol(const uint8_t* c, const int pitch, const int m) {
+#ifdef HIP_EMULATED
     const int nv = -((int)c[0] ^ m);
     int e[16];
-#ifdef HIP_EMULATED
 #define LD(k, dx, dy) e[k] = ((int)c[(dy) * pitch + (dx)] ^ m) + nv;
-#else   // (x ^ m) + nv is ONE v_xad_u32; left to itself the compiler hoists v ^ m and emits an xor and a subtract per ring pixel
-#define LD(k, dx, dy) asm("v_xad_u32 %0, %1, %2, %3" : "=v"(e[k]) : "v"((int)c[(dy) * pitch + (dx)]), "v"(m), "v"(nv));
-#endif
     RING16(LD)
 #undef LD
     int lo2[16], lo4[16];
@@ -381,6 +382,35 @@ static __device__ __forceinline__ int fast_S_pol(const uint8_t* c, const int pit
 #pragma unroll
     for (int i = 0; i < 16; i++) A = max(A, min(min(lo4[i], lo4[(i + 4) & 15]), e[(i + 8) & 15]));
     return A;
+#else
+    // the same min / max network on packed 16-bit pairs: register i holds ring positions (i, i + 8) — e fits 9 bits —, so one v_pk_min_i16
+    // is two of the scalar mins and the wrap-around neighbours (i + 8 of the last registers = i of the first) are the half swap every packed
+    // instruction has for free (op_sel): 57 instructions per corner instead of 96
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    int x[16];
+#define LD(k, dx, dy) x[k] = c[(dy) * pitch + (dx)];
+    RING16(LD)
+#undef LD
+    const int v = c[0];
+    const short sg = (short)(1 | m), cv = (short)(m ? v : -v);   // e = x * (+1) - v   or   x * (-1) + v: one v_pk_mad per pair
+    const s16x2 S = {sg, sg}, C = {cv, cv};
+    s16x2 P[8], L2[8], L4[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) P[i] = __builtin_bit_cast(s16x2, (uint32_t)x[i] | ((uint32_t)x[i + 8] << 16)) * S + C;
+#define SWP(a) __builtin_shufflevector(a, a, 1, 0)
+#pragma unroll
+    for (int i = 0; i < 8; i++) L2[i] = __builtin_elementwise_min(P[i], i < 7 ? P[(i + 1) & 7] : SWP(P[0]));          // min(e[j], e[j+1]), j = i and i + 8
+#pragma unroll
+    for (int i = 0; i < 8; i++) L4[i] = __builtin_elementwise_min(L2[i], i < 6 ? L2[(i + 2) & 7] : SWP(L2[(i + 2) & 7]));   // min over e[j .. j+3]
+    s16x2 A = {-256, -256};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const s16x2 t = __builtin_elementwise_min(L4[i], i < 4 ? L4[i + 4] : SWP(L4[i - 4]));                          // min over e[j .. j+7]
+        A = __builtin_elementwise_max(A, __builtin_elementwise_min(t, SWP(P[i])));                                      // ... and e[j+8]
+    }
+#undef SWP
+    return max((int)A.x, (int)A.y);
+#endif
 }
 
 // inclusive prefix sum over the 64 lanes of a wave, register-only: four row_shr steps inside each row of 16 lanes, then the two DPP row
@@ -485,7 +515,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         const int gq = wbytes >> 4;                      // 16-byte groups staged per LDS row
         const int ng = rows * gq;
         const int safe = L.w - (xal & ~3);               // bytes of an image row that may be read from src
-        const int dr = 256 / gq, dc = 256 - dr * gq;
+        const uint32_t gqm = c_div16[gq];                // gq <= FAST_PITCH / 16 = 9
+        const int dr = (int)((256u * gqm) >> 16), dc = 256 - dr * gq;
         // Only the tile at the right image border can reach past the end of an image row.  The test is workgroup-uniform: everywhere else
         // a step is dwordx4 + dword with no per-lane branch (a per-lane branch makes the compiler drain the outstanding loads at its join —
         // both sides write the same registers); in the border tile a dword that would start past the row's end re-reads the row's last
@@ -510,7 +541,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         constexpr int NS = 3;                            // steps held in registers: 768 groups = 85 rows of 144 bytes (a cell row is ~36 rows)
         uint32_t w[NS][5];
         int rr[NS], cc[NS];
-        int r = tid / gq, c = tid - r * gq;
+        int r = (int)(((uint32_t)tid * gqm) >> 16), c = tid - r * gq;
         // interior and right-border tiles take separate code copies of the request loop: merged behind one set of load instructions, the
         // interior case lost its dwordx4 + dword form (five single-dword loads with an address computation each)
         if (!edge) {
@@ -546,7 +577,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         }
         if (tid < 8 + FAST_MAXCELLS) sh[tid] = 0;
         if (tid < detW) {
-            const int cell = tid / L.wCell;
+            const int cell = (int)(((uint32_t)tid * (uint32_t)L.wCellMagic) >> 16);   // tid / L.wCell
             const int cx = tid - cell * L.wCell, cw = min(L.wCell, detW - cell * L.wCell);
             colTab[tid] = (uint8_t)(cell | (cx == 0 ? 0x40 : 0) | (cx + 1 >= cw ? 0x80 : 0));
         }
@@ -2063,6 +2094,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             FastLevel& fl = F.lv[l]; const LevelHost& L = h->lv[l];
             level_view(h, l, fl.base, fl.frameStride, fl.rowStride);
             fl.w = L.w; fl.h = L.h; fl.nCols = L.nCols; fl.nRows = L.nRows; fl.wCell = L.wCell; fl.hCell = L.hCell;
+            fl.wCellMagic = (65536 + L.wCell - 1) / L.wCell;   // wCell = ceil(fw / floor(fw / 30)) < 60
             fl.candOff = L.candOff; fl.candCap = L.candCap;
         }
         F.tiles = h->d_tiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
