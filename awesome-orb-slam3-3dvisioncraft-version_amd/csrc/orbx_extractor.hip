@@ -432,8 +432,9 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 // Queue entries are (row << 8 | col) inside the tile's detection region (<= 66 rows x <= 256 cols); q2 bit 15 = local maximum.
 // The emit list reuses q1 (FAST_QCAP/2 u32 entries).
 #ifndef FAST_Q2CAP
-#define FAST_Q2CAP 2016   // corners per tile kept in LDS (504 per wave); more -> whole-tile fallback (tests build with a tiny value to cover it).
-                          // 2016 rather than 2048: at 752x480 the kernel's LDS is then 20 480 B = 8 workgroups per CU instead of 7 (0.97 vs 1.00 ms)
+#define FAST_Q2CAP 1856   // corners per tile kept in LDS (464 per wave, 40 % of its pixels; the benchmark's densest tile has 6 %); more -> whole-tile
+                          // fallback (tests build with a tiny value to cover it).  1856: at 752x480 the kernel's LDS is then 20 448 B = 8 workgroups
+                          // per CU instead of 7 (0.857 vs 0.89 ms)
 #endif
 #ifndef FAST_XCD
 #define FAST_XCD 0   // 1: frame-per-XCD mapping (xcd_frame_unit) for k_fast too.  Measured on MI355X: 1.162 ms vs 1.137 ms with the plain (tile, frame)
@@ -441,11 +442,14 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
                      // 43x48-byte patches overlap heavily and gain 2-3 % from it.  Kept switchable.
 #endif
 #define FAST_TW 128               // detection columns per tile (threads 0..127 / 128..255 take alternate rows)
-#define FAST_PITCH 144            // LDS row pitch of every tile: 128 detection columns + 6 (ROI overlap) + 4 (dword alignment of the detection
-                                  // region) rounded up to 16-byte rows.  A compile-time constant, so the 7 ring rows of the classification and of
-                                  // the score are instruction offsets instead of address arithmetic (k_fast is VALU-issue bound).
-#define FAST_ROWS_PER_CHUNK (FAST_QCAP / FAST_TW)   // 16 rows: each of the 4 waves owns 8 rows x 64 columns = FAST_QCAP/4 pixels
-#define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice: one chunk's survivors + up to 63 carried over from the previous chunk
+#ifndef FAST_PITCH
+#define FAST_PITCH 148            // LDS row pitch of every tile: 128 detection columns + 6 (ROI overlap) + 4 (dword alignment of the detection
+#endif                            // region) = 138 -> 144 staged bytes, plus one dword: 37 dwords per row.  A compile-time constant, so the ring
+                                  // rows of pre-test, classification and score are instruction offsets; and ODD in dwords, so that the
+                                  // survivors of a vertical edge (one column, consecutive rows) spread over all 32 banks in the byte gathers of
+                                  // stage 2 / 3 (36 dwords put them on 8 banks: 46 % of the kernel's LDS cycles were bank conflicts, 26 % now;
+                                  // LDS busy 78 % -> 59 %, 0.885 -> 0.857 ms).  Rows are then only 4-byte aligned: staged with dword stores.
+#define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
@@ -489,7 +493,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     // LDS column 0 = image column iniX-1, so that the detection region starts at byte 4 of every LDS row: detection column c
     // lives in dword 1 + c/4, which lets stage 1 treat one dword = 4 pixels per lane (rows are staged with a byte shift).
     const int xal = iniX - 1;
-    constexpr int pitch = FAST_PITCH;               // 16-byte rows: staged and cleared with 128-bit LDS stores
+    constexpr int pitch = FAST_PITCH;
     const int wbytes = ((maxX - xal) + 15) & ~15;   // bytes of a row that are actually staged
     const int rows = maxY - iniY;
     // detection region of the tile, local coordinates (cv::FAST skips a 3-px frame of each ROI; ROIs overlap by 6)
@@ -535,8 +539,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             }
         };
         auto put = [&](const int r, const int c, const uint32_t* w) {
+#if FAST_PITCH % 16 == 0
             ((uint4*)img)[r * (FAST_PITCH / 16) + c] = make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], sh8), __builtin_amdgcn_alignbyte(w[2], w[1], sh8),
                                                                  __builtin_amdgcn_alignbyte(w[3], w[2], sh8), __builtin_amdgcn_alignbyte(w[4], w[3], sh8));
+#else
+            uint32_t* dq = (uint32_t*)(img + r * FAST_PITCH) + 4 * c;
+            dq[0] = __builtin_amdgcn_alignbyte(w[1], w[0], sh8); dq[1] = __builtin_amdgcn_alignbyte(w[2], w[1], sh8);
+            dq[2] = __builtin_amdgcn_alignbyte(w[3], w[2], sh8); dq[3] = __builtin_amdgcn_alignbyte(w[4], w[3], sh8);
+#endif
         };
         constexpr int NS = 3;                            // steps held in registers: 768 groups = 85 rows of 144 bytes (a cell row is ~36 rows)
         uint32_t w[NS][5];
@@ -587,14 +597,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     PROF_MARK(0, 1);   // staging wait
 
     const int t0 = min(P.iniTh, P.minTh);
-    // Stages 1-3 are wave-private: wave w owns columns (w&1)*64.. of the rows with parity (w>>1), compacts its own survivors
-    // and corners into its own slices of q1 / q2 and scores them itself -> no workgroup barrier and no LDS atomic until NMS.
+    // Stages 1-3 are wave-private: wave w owns the detection rows 2w, 2w+1 (mod 8), compacts its own survivors and corners into its own
+    // slices of q1 / q2 and scores them itself -> no workgroup barrier and no LDS atomic until NMS.
     const int wave = tid >> 6;
     const int dcol = lane & 31, rsub = lane >> 5;       // stage 1: lane = one LDS dword (4 detection columns) of one row
-    uint16_t* q1w = q1 + wave * FAST_Q1W;               // 512 entries (4 rows x 128 columns per chunk, exact bound) + the carried remainder
+    uint16_t* q1w = q1 + wave * FAST_Q1W;               // this wave's pre-test survivors
     uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);       // this wave's corner list: brighter-ring corners from the front, darker-ring ones from the back
     int n2b = 0, n2d = 0;                               // corners of this wave by polarity (wave-uniform)
-    int nq = 0;                                         // survivors carried over from the previous chunk (< 64, at the front of q1w)
     bool ovf = false;
     // stage 2 of one batch of 64 queue entries: full ring classification -> this wave's q2 slice
     auto classify = [&](const int i, const bool valid) {
@@ -628,76 +637,68 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const int tp = min(t0, 254);
     const uint32_t KB = 0x01010101u * (uint32_t)(256 - ((tp + 256) >> 1));   // bit 7 <=> D >= (t + 256) >> 1   (may be brighter than v + t)
     const uint32_t KG = 0x01010101u * (uint32_t)(255 - ((254 - tp) >> 1));    // bit 7 <=> D >  (254 - t) >> 1   (can NOT be darker than v - t)
-    for (int r0 = 0; r0 < detH; r0 += FAST_ROWS_PER_CHUNK) {
-        // ---- stage 1: pre-test on four antipodal pairs of the ring, {0,8} {2,10} {4,12} {6,14}.  A 9-arc of the 16-ring contains at least
-        //      one member of EVERY antipodal pair {i, i+8}, so a corner has a brighter (> v+t) member in each of them, or a darker one in
-        //      each (cv::FAST's own "high-speed test", fast.cpp, uses all eight pairs; the two compass pairs alone let 20 % of the benchmark's
-        //      pixels through, these four 11 %, all eight 7.5 %, against 3 % corners).  Byte-parallel: one dword = 4 pixels per lane, every
-        //      ring position is the same dword window shifted (v_alignbyte), every compare a v_lerp_u8 whose bit 7 per byte is the flag.
-        //      Wave w owns rows r0+4w .. r0+4w+3 of the chunk.  Survivors -> this wave's q1 slice.
-        const int rend = min(r0 + FAST_ROWS_PER_CHUNK, detH);
-        uint32_t mask = 0;   // bit 8*t + 7 - k: column 4*dcol + t of row r0 + 4*wave + rsub + 2k passed
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int ry = r0 + 4 * wave + rsub + 2 * k;
-            if (ry < rend && 4 * dcol < detW) {
-                // base = the dword left of the centre dword, three rows up: every operand is a non-negative instruction offset (ds_read2_b32)
-                constexpr int p4 = pitch >> 2;
-                const uint32_t* cw = (const uint32_t*)(img + ((dy0 - 3 + ry) & 0xFF) * pitch) + dcol;   // (& 0xFF: a 24-bit multiply)
-                const uint32_t U3 = cw[1], A0 = cw[p4], A1 = cw[p4 + 1], A2 = cw[p4 + 2];                // rows -3, -2
-                const uint32_t Cp = cw[3 * p4], C = cw[3 * p4 + 1], Cn = cw[3 * p4 + 2];                 // row 0
-                const uint32_t B0 = cw[5 * p4], B1 = cw[5 * p4 + 1], B2 = cw[5 * p4 + 2], D3 = cw[6 * p4 + 1];   // rows +2, +3
-                const uint32_t nV = ~C;
-                uint32_t accB, accG;   // bit 7 of a byte: every pair so far has a member that may be brighter / a pair so far has no member that may be darker
-#define PAIR(first, xa, xb) {                                                                                                                   \
-                    const uint32_t Da = __builtin_amdgcn_lerp(xa, nV, 0u), Db = __builtin_amdgcn_lerp(xb, nV, 0u);                              \
-                    const uint32_t b = __builtin_amdgcn_lerp(Da, KB, 0u) | __builtin_amdgcn_lerp(Db, KB, 0u);                                   \
-                    const uint32_t g = __builtin_amdgcn_lerp(Da, KG, 0u) & __builtin_amdgcn_lerp(Db, KG, 0u);                                   \
-                    if (first) { accB = b; accG = g; } else { accB &= b; accG |= g; } }
-                PAIR(true, D3, U3)                                                                                      // ring 0 (0, 3) and 8 (0, -3)
-                PAIR(false, __builtin_amdgcn_alignbyte(Cn, C, 3), __builtin_amdgcn_alignbyte(C, Cp, 1))                 // 4 (3, 0) and 12 (-3, 0)
-                PAIR(false, __builtin_amdgcn_alignbyte(B2, B1, 2), __builtin_amdgcn_alignbyte(A1, A0, 2))               // 2 (2, 2) and 10 (-2, -2)
-                PAIR(false, __builtin_amdgcn_alignbyte(A2, A1, 2), __builtin_amdgcn_alignbyte(B1, B0, 2))               // 6 (2, -2) and 14 (-2, 2)
+    // ---- stage 1: pre-test on four antipodal pairs of the ring, {0,8} {2,10} {4,12} {6,14}, over ALL rows of the tile.  A 9-arc of the
+    //      16-ring contains at least one member of EVERY antipodal pair {i, i+8}, so a corner has a brighter (> v+t) member in each of them,
+    //      or a darker one in each (cv::FAST's own "high-speed test", fast.cpp, uses all eight pairs; the two compass pairs alone let 20 % of
+    //      the benchmark's pixels through, these four 11 %, all eight 7.5 %, against 3 % corners).  Byte-parallel: one dword = 4 pixels per
+    //      lane, every ring position is the same dword window shifted (v_alignbyte), every compare a v_lerp_u8 whose bit 7 per byte is the flag.
+    //      Lane (rsub, dcol) of wave w takes the dword dcol of the rows 2w + rsub + 8k, k = 0 .. 7 (a tile has <= 64 detection rows).
+    const int K = (detH + 7) >> 3;
+    uint32_t mask = 0;   // bit 8*t + k: column 4*dcol + t of row 2*wave + rsub + 8k passed
+    for (int k = 0; k < K; k++) {
+        const int ry = 8 * k + 2 * wave + rsub;
+        if (ry < detH && 4 * dcol < detW) {
+            // base = the dword left of the centre dword, three rows up: every operand is a non-negative instruction offset (ds_read2_b32)
+            constexpr int p4 = pitch >> 2;
+            const uint32_t* cw = (const uint32_t*)(img + ((dy0 - 3 + ry) & 0xFF) * pitch) + dcol;   // (& 0xFF: a 24-bit multiply)
+            const uint32_t U3 = cw[1], A0 = cw[p4], A1 = cw[p4 + 1], A2 = cw[p4 + 2];                // rows -3, -2
+            const uint32_t Cp = cw[3 * p4], C = cw[3 * p4 + 1], Cn = cw[3 * p4 + 2];                 // row 0
+            const uint32_t B0 = cw[5 * p4], B1 = cw[5 * p4 + 1], B2 = cw[5 * p4 + 2], D3 = cw[6 * p4 + 1];   // rows +2, +3
+            const uint32_t nV = ~C;
+            uint32_t accB, accG;   // bit 7 of a byte: every pair so far has a member that may be brighter / a pair so far has no member that may be darker
+#define PAIR(first, xa, xb) {                                                                                                               \
+                const uint32_t Da = __builtin_amdgcn_lerp(xa, nV, 0u), Db = __builtin_amdgcn_lerp(xb, nV, 0u);                              \
+                const uint32_t b = __builtin_amdgcn_lerp(Da, KB, 0u) | __builtin_amdgcn_lerp(Db, KB, 0u);                                   \
+                const uint32_t g = __builtin_amdgcn_lerp(Da, KG, 0u) & __builtin_amdgcn_lerp(Db, KG, 0u);                                   \
+                if (first) { accB = b; accG = g; } else { accB &= b; accG |= g; } }
+            PAIR(true, D3, U3)                                                                                      // ring 0 (0, 3) and 8 (0, -3)
+            PAIR(false, __builtin_amdgcn_alignbyte(Cn, C, 3), __builtin_amdgcn_alignbyte(C, Cp, 1))                 // 4 (3, 0) and 12 (-3, 0)
+            PAIR(false, __builtin_amdgcn_alignbyte(B2, B1, 2), __builtin_amdgcn_alignbyte(A1, A0, 2))               // 2 (2, 2) and 10 (-2, -2)
+            PAIR(false, __builtin_amdgcn_alignbyte(A2, A1, 2), __builtin_amdgcn_alignbyte(B1, B0, 2))               // 6 (2, -2) and 14 (-2, 2)
 #undef PAIR
-                uint32_t bits = (accB | ~accG) & 0x80808080u;
-                const int nvalid = detW - 4 * dcol;                             // columns of this dword inside the detection region
-                if (nvalid < 4) bits &= (1u << (8 * nvalid)) - 1u;
-                mask |= bits >> k;
-            }
+            uint32_t bits = (accB | ~accG) & 0x80808080u;
+            const int nvalid = detW - 4 * dcol;                             // columns of this dword inside the detection region
+            if (nvalid < 4) bits &= (1u << (8 * nvalid)) - 1u;
+            mask |= bits >> (7 - k);
         }
-        const int cnt = __popc(mask);
-        const int incl = wave_scan_incl(cnt);
-        const int n1 = nq + __builtin_amdgcn_readlane(incl, 63);
-        {
-            int slot = nq + incl - cnt;
-            const int ent1 = ((r0 + 4 * wave + rsub + 2) << 8) | (4 * dcol);   // the entry of column t = 0 in the lane's second row (k = 1)
-            while (mask) {
-                const int j = __ffs((int)mask) - 1;                            // bit 8t + 7 - k
-                mask &= mask - 1;
-                q1w[slot++] = (uint16_t)(ent1 - ((j & 1) << 9) + (j >> 3));
+    }
+    // ---- compaction: ONE wave scan and one queue fill per tile (the survivors of all rows; ~11 % of the pixels), then stage 2 on batches of 64
+    //      dense lanes.  If a wave's survivors do not fit its queue slice (more than half of its pixels pass: noise images), it goes row
+    //      group by row group instead (a row group is at most 2 x 128 pixels).
+    {
+        const int total = __builtin_amdgcn_readlane(wave_scan_incl(__popc(mask)), 63);
+        const bool fits = total <= FAST_Q1W;
+        for (int kp = 0; kp < (fits ? 1 : K); kp++) {
+            uint32_t m = fits ? mask : mask & (0x01010101u << kp);
+            const int cnt = __popc(m);
+            const int incl = wave_scan_incl(cnt);
+            const int n1 = __builtin_amdgcn_readlane(incl, 63);
+            int slot = incl - cnt;
+            const int ent0 = ((2 * wave + rsub) << 8) | (4 * dcol);           // the entry of column t = 0 in the lane's first row (k = 0)
+            while (m) {
+                const int j = __ffs((int)m) - 1;                               // bit 8t + k
+                m &= m - 1;
+                q1w[slot++] = (uint16_t)(ent0 + ((j & 7) << 11) + (j >> 3));
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- stage 2 on the FULL batches of 64 survivors only (dense lanes); the remainder (< 64) is carried to the front of the queue
-        //      and classified together with the next chunk's survivors (~72 % -> ~90 % busy lanes in this stage)
-        const int full = n1 & ~63;
-        for (int i0 = 0; i0 < full; i0 += 64) classify(i0 + lane, true);
-        const int rem = n1 - full;
-        if (full > 0) {
-            const int carry = lane < rem ? (int)q1w[full + lane] : 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < rem) q1w[lane] = (uint16_t)carry;
+            for (int i0 = 0; i0 < n1; i0 += 64) classify(i0 + lane, i0 + lane < n1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // q1w is refilled by the next row group
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        nq = rem;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // q1w is appended to by the next chunk
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (nq > 0) classify(lane, lane < nq);
     PROF_MARK(0, 2);   // stage 1 + compaction + stage 2
     if (ovf) sh[4] = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1925,6 +1926,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
             }
         }
         maxRows = std::max(maxRows, L.hCell + 6);
+        if (L.hCell > 64) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell higher than 64 rows"); }   // k_fast's row mask: 8 rows per lane
     }
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size();

@@ -74,6 +74,18 @@ def test_emulated_fast_tile_fallback_path():
             _run_case(lib, case)
 
 
+def test_emulated_fast_row_group_compaction_path():
+    """k_fast fills a wave's pre-test queue once per tile; when a wave's survivors do not fit its queue slice it goes row group by row group.
+    FAST_QCAP=768 shrinks the slice to 256 entries (one row group's worst case), so ordinary tiles take that path too; results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_QCAP=768",), tag="qcap768")))
+    for case in CASES:
+        if case[0] in ("sparse_640x480", "noise_tile_overflow", "euroc_752x480"):
+            _run_case(lib, case)
+
+
 def test_emulated_octree_lds_key_cache_path():
     """The octree keeps a level's candidates in an LDS cache for small batches (OCT_KEYCAP keys; bigger levels and big batches read them from
     global memory).  A 1500-key cache is hit by the small levels and missed by the big ones, so both paths run inside one extraction.
