@@ -451,6 +451,16 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
                                   // LDS busy 78 % -> 59 %, 0.885 -> 0.857 ms).  Rows are then only 4-byte aligned: staged with dword stores.
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
+// a * b for operands below 2^24: ONE full-rate v_mul_u32_u24 (the compiler cannot prove the ranges of row indices, strides and table
+// multipliers and emits the quarter-rate v_mul_lo_u32)
+static __device__ __forceinline__ uint32_t mul24(const uint32_t a, const uint32_t b) {
+#ifdef HIP_EMULATED
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#else
+    return __umul24(a, b);
+#endif
+}
+
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
     const unsigned long long m = __ballot(pass);
@@ -529,7 +539,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         const int lastOff = (safe - 4) & ~3;
         // byte offsets inside the frame are 32-bit (src is workgroup-uniform): scalar base + vector offset addressing, no 64-bit VALU arithmetic
         auto fetch = [&](const int r, const int c, uint32_t* w) {
-            const uint32_t o = (uint32_t)(r * L.rowStride);
+            const uint32_t o = mul24((uint32_t)r, (uint32_t)L.rowStride);
             if (!edge) {
                 const uint32_t* gw = (const uint32_t*)(src + (o + 16u * (uint32_t)c));
                 w[0] = gw[0]; w[1] = gw[1]; w[2] = gw[2]; w[3] = gw[3]; w[4] = gw[4];
@@ -543,7 +553,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             ((uint4*)img)[r * (FAST_PITCH / 16) + c] = make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], sh8), __builtin_amdgcn_alignbyte(w[2], w[1], sh8),
                                                                  __builtin_amdgcn_alignbyte(w[3], w[2], sh8), __builtin_amdgcn_alignbyte(w[4], w[3], sh8));
 #else
-            uint32_t* dq = (uint32_t*)(img + r * FAST_PITCH) + 4 * c;
+            uint32_t* dq = (uint32_t*)(img + mul24((uint32_t)r, FAST_PITCH)) + 4 * c;
             dq[0] = __builtin_amdgcn_alignbyte(w[1], w[0], sh8); dq[1] = __builtin_amdgcn_alignbyte(w[2], w[1], sh8);
             dq[2] = __builtin_amdgcn_alignbyte(w[3], w[2], sh8); dq[3] = __builtin_amdgcn_alignbyte(w[4], w[3], sh8);
 #endif
@@ -551,7 +561,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         constexpr int NS = 3;                            // steps held in registers: 768 groups = 85 rows of 144 bytes (a cell row is ~36 rows)
         uint32_t w[NS][5];
         int rr[NS], cc[NS];
-        int r = (int)(((uint32_t)tid * gqm) >> 16), c = tid - r * gq;
+        int r = (int)(mul24((uint32_t)tid, gqm) >> 16), c = tid - (int)mul24((uint32_t)r, (uint32_t)gq);
         // interior and right-border tiles take separate code copies of the request loop: merged behind one set of load instructions, the
         // interior case lost its dwordx4 + dword form (five single-dword loads with an address computation each)
         if (!edge) {
@@ -559,7 +569,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             for (int k = 0; k < NS; k++) {
                 rr[k] = r; cc[k] = c;
                 if (tid + 256 * k < ng) {
-                    const uint32_t* gw = (const uint32_t*)(src + ((uint32_t)(r * L.rowStride) + 16u * (uint32_t)c));
+                    const uint32_t* gw = (const uint32_t*)(src + (mul24((uint32_t)r, (uint32_t)L.rowStride) + 16u * (uint32_t)c));
                     w[k][0] = gw[0]; w[k][1] = gw[1]; w[k][2] = gw[2]; w[k][3] = gw[3]; w[k][4] = gw[4];
                 }
                 r += dr; c += dc;
@@ -587,8 +597,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         }
         if (tid < 8 + FAST_MAXCELLS) sh[tid] = 0;
         if (tid < detW) {
-            const int cell = (int)(((uint32_t)tid * (uint32_t)L.wCellMagic) >> 16);   // tid / L.wCell
-            const int cx = tid - cell * L.wCell, cw = min(L.wCell, detW - cell * L.wCell);
+            const int cell = (int)(mul24((uint32_t)tid, (uint32_t)L.wCellMagic) >> 16);   // tid / L.wCell
+            const int cellx0 = (int)mul24((uint32_t)cell, (uint32_t)L.wCell);
+            const int cx = tid - cellx0, cw = min(L.wCell, detW - cellx0);
             colTab[tid] = (uint8_t)(cell | (cx == 0 ? 0x40 : 0) | (cx + 1 >= cw ? 0x80 : 0));
         }
     }
