@@ -427,14 +427,17 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 }
 
 // LDS layout of k_fast (dynamic region), sizes fixed per handle:
-//   img[imgBytes] | smap[imgBytes] | q1[FAST_QCAP] u16 | q2[FAST_Q2CAP] u16 | colTab[FAST_TW] u8 | sh[8 + FAST_MAXCELLS] int
-// q1: pixels that passed the 4-point cardinal pre-test in the current row chunk; q2: every corner (S > min(ini,min)) of the tile.
-// Queue entries are (row << 8 | col) inside the tile's detection region (<= 66 rows x <= 256 cols); q2 bit 15 = local maximum.
-// The emit list reuses q1 (FAST_QCAP/2 u32 entries).
+//   img[imgBytes] | q1[4 * FAST_Q1W] u16 | q2[FAST_Q2CAP] u16 | colTab[FAST_TW] u8 | sh[8 + FAST_MAXCELLS] int
+// q1: pixels that passed the pre-test; q2: every corner (S > min(ini,min)) of the tile.
+// Queue entries are (row << 8 | col) inside the tile's detection region (<= 64 rows x <= 256 cols); q2 bit 15 = local maximum.
+// The score map of the NMS is the img region itself: the image tile is dead once the last corner is scored, so a wave parks its scores in a byte
+// list (its own q1 slice, idle by then) until every wave is through, and they are scattered into the cleared region — with one blank map row
+// between the tile's cell rows, so that NMS never compares across a cell boundary.  (A second tile-sized array next to img would cost the
+// two-cell-row tiles their eighth workgroup per CU.)  The emit list reuses q1 (FAST_QCAP/2 u32 entries).
 #ifndef FAST_Q2CAP
-#define FAST_Q2CAP 1856   // corners per tile kept in LDS (464 per wave, 40 % of its pixels; the benchmark's densest tile has 6 %); more -> whole-tile
-                          // fallback (tests build with a tiny value to cover it).  1856: at 752x480 the kernel's LDS is then 20 448 B = 8 workgroups
-                          // per CU instead of 7 (0.857 vs 0.89 ms)
+#define FAST_Q2CAP 2176   // corners per tile kept in LDS (544 per wave: 23 % of the pixels of a two-cell-row tile, 46 % of a one-row tile; the benchmark's
+                          // densest tile has 6 %); more -> whole-tile fallback (tests build with a tiny value to cover it).  2176: at 752x480 the kernel's
+                          // LDS is then 19 904 B = 8 workgroups per CU (with 3584 entries and 7 workgroups 0.81 instead of 0.79 ms)
 #endif
 #ifndef FAST_XCD
 #define FAST_XCD 0   // 1: frame-per-XCD mapping (xcd_frame_unit) for k_fast too.  Measured on MI355X: 1.162 ms vs 1.137 ms with the plain (tile, frame)
@@ -449,6 +452,10 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
                                   // survivors of a vertical edge (one column, consecutive rows) spread over all 32 banks in the byte gathers of
                                   // stage 2 / 3 (36 dwords put them on 8 banks: 46 % of the kernel's LDS cycles were bank conflicts, 26 % now;
                                   // LDS busy 78 % -> 59 %, 0.885 -> 0.857 ms).  Rows are then only 4-byte aligned: staged with dword stores.
+#ifndef FAST_CROWS
+#define FAST_CROWS 2              // cell rows per tile where two of them fit the 64 detection rows of the pre-test's row mask (levels 0-3 at 752x480: 81 % of the
+#endif                            // pixels): prologue, staging set-up, barriers and the partly filled batches of score / NMS / emit are paid once per tile, the
+                                  // 6-row halo is shared — 5.4 % fewer VALU instructions per launch, 0.847 -> 0.792 ms per 512 frames at 8 workgroups per CU
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
 // a * b for operands below 2^24: ONE full-rate v_mul_u32_u24 (the compiler cannot prove the ranges of row indices, strides and table
@@ -494,10 +501,11 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const int frame = blockIdx.y;
 #endif
 #undef FAST_TILE_AT
-    const FastLevel& L = P.lv[T.level];
+    const int level = T.level & 0xFF, nCR = (int)T.level >> 8;   // the tile covers nCR whole cell rows, T.cellRow the first
+    const FastLevel& L = P.lv[level];
 
     const int iniY = ORBX_MINB + T.cellRow * L.hCell;
-    const int maxY = min(iniY + L.hCell + 6, L.h - ORBX_MINB);
+    const int maxY = min(iniY + nCR * L.hCell + 6, L.h - ORBX_MINB);
     const int iniX = ORBX_MINB + T.cell0 * L.wCell;
     const int maxX = min(ORBX_MINB + (T.cell0 + T.nCells) * L.wCell + 6, L.w - ORBX_MINB);
     // LDS column 0 = image column iniX-1, so that the detection region starts at byte 4 of every LDS row: detection column c
@@ -513,8 +521,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     if (detW <= 0 || detH <= 0) return;
 
     uint8_t* img = orb_smem;
-    uint8_t* smap = orb_smem + P.imgBytes;
-    uint16_t* q1 = (uint16_t*)(orb_smem + 2 * P.imgBytes);
+    uint8_t* smap = orb_smem;     // aliased onto the image tile once the last corner is scored
+    uint16_t* q1 = (uint16_t*)(orb_smem + P.imgBytes);
+    auto cellRowOf = [&](const int ry) {
+        int cr = 0;
+#pragma unroll
+        for (int j = 1; j < FAST_CROWS; j++) cr += (j < nCR && ry >= j * L.hCell) ? 1 : 0;
+        return cr;
+    };
     uint32_t* elist = (uint32_t*)q1;                  // reused after the scoring phase
     uint16_t* q2 = q1 + 4 * FAST_Q1W;
     uint8_t* colTab = (uint8_t*)(q2 + FAST_Q2CAP);    // per detection column: cell | leftEdge<<6 | rightEdge<<7
@@ -584,7 +598,6 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 if (c >= gq) { c -= gq; r++; }
             }
         }
-        for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int k = 0; k < NS; k++)
             if (tid + 256 * k < ng) put(rr[k], cc[k], w[k]);
@@ -719,10 +732,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     // entry i of the wave's corner list: the brighter-ring corners [0, n2b) sit at the front of the slice, the darker-ring ones at its back
 #define Q2SLOT(i) ((i) < n2b ? (i) : FAST_Q2CAP / 4 - 1 - ((i) - n2b))
     // ---- stage 3: exact score of this wave's corners (dense lanes; only the passing polarity's arcs are evaluated)
+    uint8_t* sbuf = (uint8_t*)q1w;   // the scores wait in the wave's own (now idle) queue slice until no wave needs the image any more
+    static_assert(FAST_Q2CAP / 4 <= 2 * FAST_Q1W, "a wave's scores are parked in its q1 slice");
+    static_assert(4 * FAST_PITCH <= 4 * FAST_Q1W * 2, "the fallback's four-row score ring lives in the q1 region");
     for (int i = lane; i < n2w; i += 64) {
-        const int ent = q2w[Q2SLOT(i)];
+        const int slot = Q2SLOT(i);
+        const int ent = q2w[slot];
         const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-        smap[pos] = (uint8_t)(fast_S_pol(img + pos, pitch, i < n2b ? 0 : -1) - 1);   // S > t0 >= 0 here
+        sbuf[slot] = (uint8_t)(fast_S_pol(img + pos, pitch, i < n2b ? 0 : -1) - 1);   // S > t0 >= 0 here
     }
     PROF_MARK(0, 3);   // stage 3
     __syncthreads();
@@ -730,19 +747,28 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
     if (!overflow) {
+        for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int i = lane; i < n2w; i += 64) {
+            const int slot = Q2SLOT(i);
+            const int ent = q2w[slot];
+            const int ry = ent >> 8;
+            smap[(dy0 + ry + cellRowOf(ry)) * pitch + dx0 + (ent & 255)] = sbuf[slot];
+        }
+        __syncthreads();
         // ---- NMS over the corner lists: strict maximum over the 8 neighbours inside the same cell's detection region.
         //      survive(T) = s >= T && localmax (threshold-independent localmax, DESIGN.md "FAST as set algebra").
         for (int i = lane; i < n2w; i += 64) {
             const int ent = q2w[Q2SLOT(i)];
-            const int rx = ent & 255;
-            const uint8_t* m = smap + (dy0 + (ent >> 8)) * pitch + dx0 + rx;
+            const int rx = ent & 255, ryn = ent >> 8, crn = cellRowOf(ryn);
+            const uint8_t* m = smap + (dy0 + ryn + crn) * pitch + dx0 + rx;
             const int s = m[0], ct = colTab[rx];
             bool ok = s > 0 && s > m[-pitch] && s > m[pitch];
             if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
             if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
             if (ok) {
                 q2w[Q2SLOT(i)] = (uint16_t)(ent | 0x8000);
-                if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
+                if (s >= P.iniTh) atomicAdd(&cellCnt[crn * T.nCells + (ct & 63)], 1);
             }
         }
         __syncthreads();
@@ -750,8 +776,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             const int ent = q2w[Q2SLOT(i)];
             if (!(ent & 0x8000)) continue;
             const int rx = ent & 255, ry = (ent >> 8) & 127;
-            const int s = smap[(dy0 + ry) * pitch + dx0 + rx];
-            const int Tth = cellCnt[colTab[rx] & 63] > 0 ? P.iniTh : P.minTh;   // per-cell retry, ORBextractor.cc:825-828
+            const int cr2 = cellRowOf(ry);
+            const int s = smap[(dy0 + ry + cr2) * pitch + dx0 + rx];
+            const int Tth = cellCnt[cr2 * T.nCells + (colTab[rx] & 63)] > 0 ? P.iniTh : P.minTh;   // per-cell retry, ORBextractor.cc:825-828
             if (s >= Tth) {
                 // coordinates relative to minBorder, as vToDistributeKeys holds them (ORBextractor.cc:845-850)
                 const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
@@ -759,56 +786,61 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                 const int slot = atomicAdd(&sh[1], 1);
                 if (slot < FAST_QCAP / 2) elist[slot] = packed;
                 else {
-                    const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, 1);
+                    const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + level, 1);
                     if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
                 }
             }
         }
         __syncthreads();
     } else {
-        // ---- fallback (more than FAST_Q2CAP corners in one tile): score every pixel of the tile in place and scan the
-        //      whole score map.  Same results, no queue bound.
-        const int npix = detW * detH;
-        for (int p = tid; p < npix; p += 256) {
-            const int ry = p / detW, rx = p - ry * detW;
-            const int pos = (dy0 + ry) * pitch + dx0 + rx;
-            const int S = fast_S(img + pos, pitch);
-            smap[pos] = (uint8_t)(S > t0 ? S - 1 : 0);
+        // ---- fallback (a wave met more corners than its list holds: noise images, thresholds near 0): score EVERY pixel of the tile, in
+        //      place.  The tile has one LDS image and the score map takes its place, so the scores of a row wait in a four-row ring (the q1
+        //      region) until the rows that still read its pixels (ring radius 3) are scored; then NMS and the per-cell retry over the whole
+        //      map with explicit cell-row bounds, and every survivor goes straight to global memory.  Same results, no list bound; slow.
+        uint8_t* ring = (uint8_t*)q1;                    // [4][pitch]
+        for (int ry = 0; ry < detH + 3; ry++) {
+            if (ry < detH && tid < detW) {
+                const int S = fast_S(img + (dy0 + ry) * pitch + dx0 + tid, pitch);
+                ring[(ry & 3) * pitch + tid] = (uint8_t)(S > t0 ? S - 1 : 0);
+            }
+            __syncthreads();
+            const int rf = ry - 3;                       // rows <= rf + 3 are scored: nothing reads the pixels of row rf any more
+            if (rf >= 0 && tid < detW) smap[(dy0 + rf) * pitch + dx0 + tid] = ring[(rf & 3) * pitch + tid];
+            __syncthreads();
         }
-        __syncthreads();
+        const int npix = detW * detH;
         for (int pass = 0; pass < 2; pass++) {
             for (int p = tid; p < npix; p += 256) {
-                const int ry = p / detW, rx = p - ry * detW;
+                const int ry = p / detW, rx = p - ry * detW, cr = cellRowOf(ry);
                 const uint8_t* m = smap + (dy0 + ry) * pitch + dx0 + rx;
                 const int s = m[0], ct = colTab[rx];
                 if (s == 0) continue;
-                bool ok = s > m[-pitch] && s > m[pitch];
-                if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
-                if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
+                const int ryc = ry - cr * L.hCell;
+                const bool top = ryc == 0, bot = ryc == L.hCell - 1 || ry == detH - 1, lft = (ct & 0x40) != 0, rgt = (ct & 0x80) != 0;
+                bool ok = (lft || s > m[-1]) && (rgt || s > m[1]);
+                if (!top) ok = ok && s > m[-pitch] && (lft || s > m[-pitch - 1]) && (rgt || s > m[-pitch + 1]);
+                if (!bot) ok = ok && s > m[pitch] && (lft || s > m[pitch - 1]) && (rgt || s > m[pitch + 1]);
                 if (!ok) continue;
                 if (pass == 0) {
-                    if (s >= P.iniTh) atomicAdd(&cellCnt[ct & 63], 1);
+                    if (s >= P.iniTh) atomicAdd(&cellCnt[cr * T.nCells + (ct & 63)], 1);
                 } else {
-                    const int Tth = cellCnt[ct & 63] > 0 ? P.iniTh : P.minTh;
+                    const int Tth = cellCnt[cr * T.nCells + (ct & 63)] > 0 ? P.iniTh : P.minTh;
                     if (s >= Tth) {
                         const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
-                        const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
-                        const int slot = atomicAdd(&sh[1], 1);
-                        if (slot < FAST_QCAP / 2) elist[slot] = packed;
-                        else {
-                            const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, 1);
-                            if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = packed;
-                        }
+                        const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + level, 1);
+                        if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = xr | (yr << 12) | ((uint32_t)s << 24);
                     }
                 }
             }
             __syncthreads();
         }
+        PROF_FLUSH(0);
+        return;
     }
     PROF_MARK(0, 5);   // NMS + per-cell retry + list
     const int ne = min(sh[1], FAST_QCAP / 2);
     if (ne == 0) { PROF_FLUSH(0); return; }
-    if (tid == 0) sh[2] = atomicAdd(P.candCount + (size_t)frame * P.nlevels + T.level, ne);
+    if (tid == 0) sh[2] = atomicAdd(P.candCount + (size_t)frame * P.nlevels + level, ne);
     __syncthreads();
     const int gbase = sh[2];
     uint32_t* out = P.cand + (size_t)frame * P.candFrame + L.candOff;
@@ -1923,27 +1955,29 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
         L.selCap = std::max(h->nfeat[l], 4 * L.nIni) + 4; L.selOff = selOff; selOff += L.selCap;
         nodeCap = std::max(nodeCap, L.selCap); maxKp += L.selCap;
         if (L.selCap > 60000) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "nfeatures per level too large"); }
-        // FAST tiles: groups of whole cells of one cell row, <= 256 px wide
-        const int cpt = std::max(1, std::min(FAST_MAXCELLS, FAST_TW / L.wCell));
+        // FAST tiles: whole cells, <= FAST_TW px wide, FAST_CROWS cell rows high (the last tile of a level takes what is left)
+        const int cpt = std::max(1, std::min(FAST_MAXCELLS / FAST_CROWS, FAST_TW / L.wCell));
         const int nT = (L.nCols + cpt - 1) / cpt, per = (L.nCols + nT - 1) / nT;
-        for (int i = 0; i < L.nRows; i++) {
-            const int iniY = ORBX_MINB + i * L.hCell;
-            if (iniY >= L.maxBY - 3) continue;
+        int validRows = 0;
+        for (int i = 0; i < L.nRows; i++) if (ORBX_MINB + i * L.hCell < L.maxBY - 3) validRows = i + 1;
+        const int crows = (FAST_CROWS * L.hCell <= 64) ? FAST_CROWS : 1;   // k_fast's row mask holds 8 rows per lane = 64 detection rows per tile
+        for (int i = 0; i < validRows; i += crows) {
+            const int ncr = std::min(crows, validRows - i);
             for (int c0 = 0; c0 < L.nCols; c0 += per) {
                 const int n = std::min(per, L.nCols - c0);
                 if (ORBX_MINB + c0 * L.wCell >= L.maxBX - 6) continue;
-                tiles.push_back(FastTile{(short)l, (short)i, (short)c0, (short)n});
+                tiles.push_back(FastTile{(short)(l | (ncr << 8)), (short)i, (short)c0, (short)n});
                 maxPitch = std::max(maxPitch, ((n * L.wCell + 6 + 3) + 15) & ~15);
             }
         }
-        maxRows = std::max(maxRows, L.hCell + 6);
-        if (L.hCell > 64) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell higher than 64 rows"); }   // k_fast's row mask: 8 rows per lane
+        maxRows = std::max(maxRows, crows * L.hCell + 6 + crows);
+        if (L.hCell > 64) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell higher than 64 rows"); }
     }
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size();
     if (maxPitch > FAST_PITCH) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST tile wider than FAST_PITCH"); }
     h->fastImgBytes = (maxRows * FAST_PITCH + 15) & ~15;
-    h->fastSmem = (size_t)2 * h->fastImgBytes + 4 * FAST_Q1W * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
+    h->fastSmem = (size_t)h->fastImgBytes + 4 * FAST_Q1W * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
     // 92 B per node with the second child-count buffer, 76 without: very large nFeatures fall back to two key walks per round
     h->octMerge = (size_t)(256 + 16) * 4 + (size_t)nodeCap * 92 + 15 <= 150 * 1024 ? 1 : 0;
     h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (h->octMerge ? 92 : 76) + 15) & ~(size_t)15);
