@@ -456,6 +456,9 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 #define FAST_CROWS 2              // cell rows per tile where two of them fit the 64 detection rows of the pre-test's row mask (levels 0-3 at 752x480: 81 % of the
 #endif                            // pixels): prologue, staging set-up, barriers and the partly filled batches of score / NMS / emit are paid once per tile, the
                                   // 6-row halo is shared — 5.4 % fewer VALU instructions per launch, 0.847 -> 0.792 ms per 512 frames at 8 workgroups per CU
+#ifndef FAST_TALL_MIN_BATCH
+#define FAST_TALL_MIN_BATCH 8     // frames per call from which the two-cell-row tiles are used
+#endif
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
 // a * b for operands below 2^24: ONE full-rate v_mul_u32_u24 (the compiler cannot prove the ranges of row indices, strides and table
@@ -1838,7 +1841,7 @@ struct orbx_extractor {
     std::vector<float> scale, invScale, sigma2, invSigma2; std::vector<int> nfeat; int umax[16];
     LevelHost lv[ORBX_MAX_LEVELS];
     size_t pyrFrame = 0, candFrame = 0; int selFrame = 0, nodeCap = 0, maxKp = 0;
-    int nTiles = 0, fastImgBytes = 0, octKeyOff = 0, octMerge = 0; size_t fastSmem = 0, octSmem = 0;
+    int nTiles = 0, nTiles1 = 0, fastImgBytes = 0, octKeyOff = 0, octMerge = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
     int32_t* d_rowStart = nullptr; int32_t* d_rowIdx = nullptr; int rowCapAlloc = 0;   // ComputeStereoMatches row buckets (lazy)
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
@@ -1922,7 +1925,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
         for (v = 15, v0 = 0; v >= vmin; --v) { while (h->umax[v0] == h->umax[v0 + 1]) ++v0; h->umax[v] = v0; ++v0; }
     }
     // ---- per-level geometry: ORBextractor.cc:1162-1163 (sizes), :769-785 (cells), :541-543 (octree roots)
-    std::vector<FastTile> tiles;
+    std::vector<FastTile> tiles, tiles1;   // two-cell-row tiles (batches) / one-cell-row tiles (few frames)
     size_t pyrOff = 0, candOff = 0; int selOff = 0, maxRows = 0, maxPitch = 0, nodeCap = 0, maxKp = 0;
     for (int l = 0; l < nl; l++) {
         LevelHost& L = h->lv[l];
@@ -1970,11 +1973,18 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
                 maxPitch = std::max(maxPitch, ((n * L.wCell + 6 + 3) + 15) & ~15);
             }
         }
+        // the same level as one-cell-row tiles: calls with few frames (the single-frame drop-in call) want many short workgroups — with one
+        // frame the 134 two-row tiles are one round of workgroups that live twice as long (host API: 192 -> 204 us per 752x480 frame)
+        for (int i = 0; i < validRows; i++)
+            for (int c0 = 0; c0 < L.nCols; c0 += per) {
+                if (ORBX_MINB + c0 * L.wCell >= L.maxBX - 6) continue;
+                tiles1.push_back(FastTile{(short)(l | (1 << 8)), (short)i, (short)c0, (short)std::min(per, L.nCols - c0)});
+            }
         maxRows = std::max(maxRows, crows * L.hCell + 6 + crows);
         if (L.hCell > 64) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell higher than 64 rows"); }
     }
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
-    h->nTiles = (int)tiles.size();
+    h->nTiles = (int)tiles.size(); h->nTiles1 = (int)tiles1.size();
     if (maxPitch > FAST_PITCH) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST tile wider than FAST_PITCH"); }
     h->fastImgBytes = (maxRows * FAST_PITCH + 15) & ~15;
     h->fastSmem = (size_t)h->fastImgBytes + 4 * FAST_Q1W * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
@@ -2042,6 +2052,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_selAux, B * h->selFrame * 4));
     CK(hipMalloc((void**)&h->d_selCount, B * nl * 4));
     CK(hipMalloc((void**)&h->d_lapCount, B * nl * 4));
+    tiles.insert(tiles.end(), tiles1.begin(), tiles1.end());   // one allocation: [two-row list | one-row list]
     CK(hipMalloc((void**)&h->d_tiles, tiles.size() * sizeof(FastTile)));
     CK(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
     h->imgStride = (width + 63) & ~63;
@@ -2144,14 +2155,16 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             fl.wCellMagic = (65536 + L.wCell - 1) / L.wCell;   // wCell = ceil(fw / floor(fw / 30)) < 60
             fl.candOff = L.candOff; fl.candCap = L.candCap;
         }
-        F.tiles = h->d_tiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
+        const bool tall = batch >= FAST_TALL_MIN_BATCH;
+        const int nTiles = tall ? h->nTiles : h->nTiles1;
+        F.tiles = tall ? h->d_tiles : h->d_tiles + h->nTiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
         F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
         F.imgBytes = h->fastImgBytes;
-        F.nTiles = h->nTiles; F.batch = batch;
+        F.nTiles = nTiles; F.batch = batch;
 #if FAST_XCD
-        hipLaunchKernelGGL(k_fast, dim3(h->nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
+        hipLaunchKernelGGL(k_fast, dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
-        hipLaunchKernelGGL(k_fast, dim3(h->nTiles, batch), dim3(256), h->fastSmem, st, F);
+        hipLaunchKernelGGL(k_fast, dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
 #endif
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[2], st));

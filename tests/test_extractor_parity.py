@@ -86,6 +86,23 @@ def test_emulated_fast_row_group_compaction_path():
             _run_case(lib, case)
 
 
+def test_emulated_fast_two_cell_row_tiles():
+    """Calls with >= 8 frames run k_fast on tiles of two cell rows (score map aliased onto the image tile, one blank map row between the cell rows,
+    per-cell retry counters per (cell row, cell)); FAST_TALL_MIN_BATCH=1 sends the single-frame cases through them on the emulator — also combined
+    with the whole-tile fallback (FAST_Q2CAP=48: the in-place score ring) and the row-group compaction (FAST_QCAP=768).  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1",), tag="tall1")))
+    for case in CASES:
+        if case[0] in EMU_CASES:
+            _run_case(lib, case)
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=48", "FAST_QCAP=768"), tag="tall1_q2cap48_qcap768")))
+    for case in CASES:
+        if case[0] in ("sparse_640x480", "noise_tile_overflow", "euroc_752x480"):
+            _run_case(lib, case)
+
+
 def test_emulated_octree_lds_key_cache_path():
     """The octree keeps a level's candidates in an LDS cache for small batches (OCT_KEYCAP keys; bigger levels and big batches read them from
     global memory).  A 1500-key cache is hit by the small levels and missed by the big ones, so both paths run inside one extraction.
@@ -131,9 +148,9 @@ def test_bordered_pyramid_matches_reference_layout(emu_lib):
 
 
 @pytest.mark.gpu
-def test_hip_batch_matches_oracle_and_is_deterministic(hip_lib):
+@pytest.mark.parametrize("B", [6, 10])   # below / above the batch size from which k_fast runs on two-cell-row tiles
+def test_hip_batch_matches_oracle_and_is_deterministic(hip_lib, B):
     import torch
-    B = 6
     imgs = np.stack([synth_image(20 + i) for i in range(B - 2)] + [flat_image(), low_contrast_image(31)])
     e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=hip_lib)
     dev = torch.from_numpy(imgs).cuda()

@@ -16,6 +16,7 @@ from orbhip.synth import synth_image  # noqa: E402
 
 def case(rng):
     W = int(rng.integers(200, 1400)); H = int(rng.integers(160, 800))
+    if rng.random() < 0.4: W &= ~3   # dense batches (the two-cell-row tile path of k_fast) need 4-byte row strides
     kind = rng.integers(0, 4)
     if kind == 0:
         img = synth_image(int(rng.integers(1 << 30)), W, H, n_rect=int(rng.integers(5, 500)), n_disc=int(rng.integers(0, 300)),
@@ -66,6 +67,14 @@ def main():
                 ok = rejected == prod_rejected
             else:
                 ok = m2 == mono and len(k) == len(k2) and np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2)
+                if ok and img.shape[1] % 4 == 0:   # (dense batches need 4-byte row strides) also as a batch of 8 copies: batches run k_fast on two-cell-row tiles, single frames on one-row tiles
+                    import torch
+                    kb, db, cb = e.extract_batch(torch.from_numpy(np.ascontiguousarray(np.stack([img] * 8))).cuda(), lap)
+                    kb, db, cb = kb.cpu().numpy(), db.cpu().numpy(), cb.cpu().numpy()
+                    for f in (0, 7):
+                        nb = int(cb[f, 0])
+                        ok = ok and nb == len(k) and int(cb[f, 1]) == mono and np.array_equal(kb[f, :nb].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) \
+                            and np.array_equal(db[f, :nb], d)
         except Exception as ex:  # noqa: BLE001
             ok = False
             print("case %d raised %r" % (seed0 + i, ex))
