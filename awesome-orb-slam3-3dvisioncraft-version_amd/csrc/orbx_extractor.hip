@@ -1317,13 +1317,21 @@ static __device__ __forceinline__ void det_sincos(float angle, float* s_out, flo
 #ifndef DESC_ALIAS
 #define DESC_ALIAS 1
 #endif
+#ifndef DESC_SPARSE
+#define DESC_SPARSE 1   // 1: the Gaussian column pass is evaluated only where rBRIEF samples (512 points per key point, 7 taps each) instead of on all
+#endif                  //    37 x 37 pixels of the blurred neighbourhood (9 583 taps) — no blurred tile is materialised at all (round 3: 701 -> 642 VALU
+                        //    instructions per key point, 0.665 -> 0.625 ms per 512 frames, 3 408 instead of 4 896 B of LDS per wave)
 #if DESC_ALIAS
 // LDS per keypoint: [ region A: the 43x52 source patch, overwritten IN PLACE by the 37x46 u16 row-pass buffer (3404 B) | 37x40 blurred tile ].
 // A lane reads its whole patch row into registers before any lane of the wave writes a row-pass value (same wave, program order, fenced),
 // so the two can share storage: 4896 B per wave instead of 5648 -> 8 workgroups per CU instead of 7.
 #define DESC_ROWP_OFF 0
 #define DESC_BLUR_OFF 3408
+#if DESC_SPARSE
+#define DESC_WAVE_STRIDE 3408   // no blurred tile
+#else
 #define DESC_WAVE_STRIDE 4896
+#endif
 #else
 #define DESC_ROWP_OFF (DP * DPP)
 #define DESC_BLUR_OFF 0
@@ -1360,7 +1368,7 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
     PROF_DECL;
     uint8_t* patch = orb_smem + wave * DESC_WAVE_STRIDE;
     uint16_t* rowp = (uint16_t*)(patch + DESC_ROWP_OFF);
-    uint8_t* blur = patch + DESC_BLUR_OFF;
+    uint8_t* blur = patch + DESC_BLUR_OFF; (void)blur;
 
     // The workgroup's level and position follow from its index alone (a constant table), so the keypoint record is fetched in the FIRST
     // global round trip, together with the per-level counts that are only needed for `valid` and, at the very end, for the output slot;
@@ -1506,6 +1514,7 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
         det_sincos(ang * (float)(3.1415926535897932384626433832795 / 180.f), &sn, &cs);
         trig[3 * threadIdx.x] = ang; trig[3 * threadIdx.x + 1] = sn; trig[3 * threadIdx.x + 2] = cs;
     }
+#if !DESC_SPARSE
     // column pass: a task filters DESC_CLEN rows of one column with v_dot2_u32_u16 on vertical pairs (segments start on even rows so that the
     // pair loads stay dword aligned; the row shared by two segments is written twice with the same value); out = (sum + 32768) >> 16, saturated.
     //   4 keypoints per block: 4 x 37 columns x 2 segments of 19 rows = 296 tasks over 256 threads (1.16 rounds of 19 rows);
@@ -1544,6 +1553,7 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
             bl[j * DBP] = (uint8_t)min(acc >> 16, 255u);
         }
     }
+#endif
     PROF_MARK(1, 5);   // trig (wave 0) + column pass
     DESC_SYNC();
     PROF_MARK(1, 6);   // barrier 3
@@ -1562,7 +1572,27 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
         const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
         const int r0 = __float2int_rn(R[0]), q0 = __float2int_rn(Q[0]);
         const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
+#if DESC_SPARSE
+        // blurred(r, c) = sat8((sum_k g[k] * rowpass(r + k, c) + 32768) >> 16): seven u16 of one column of the transposed row-pass buffer.  The run
+        // starts on either parity: five ALIGNED dwords from the even row below it, realigned by a per-lane v_alignbyte shift of 0 or 2 bytes
+        // (a 14-byte load at 2-byte alignment is what the compiler makes of seven u16 reads: ds_read_b96 at odd offsets, 0.78 instead of 0.66 ms)
+        typedef unsigned short u16x2 __attribute__((vector_size(4)));
+        const u16x2 Wa = {18, 34}, Wb = {49, 55}, Wc = {49, 34}, Wd = {18, 0};
+        auto blurred = [&](const int r, const int c) {
+            const int rr = 18 + r;
+            const uint32_t* cq = (const uint32_t*)(rowp + (18 + c) * DRP + (rr & ~1));   // DRP is even: dword aligned
+            const uint32_t sh = (uint32_t)(rr & 1) * 2u;
+            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];   // (row 45 at most: inside the column's 46 entries)
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d1, d0, sh)), Wa, 32768u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d2, d1, sh)), Wb, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d2, sh)), Wc, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d4, d3, sh)), Wd, acc, false);   // (the eighth value has weight 0)
+            return (int)min(acc >> 16, 255u);
+        };
+        const int t0 = blurred(r0, q0), t1 = blurred(r1, q1);
+#else
         const int t0 = blur[(18 + r0) * DBP + 18 + q0], t1 = blur[(18 + r1) * DBP + 18 + q1];
+#endif
         nib |= (uint32_t)(t0 < t1) << j;
     }
     // pack: byte = nibble(even lane) | nibble(odd lane) << 4 ; dword = 4 consecutive bytes
