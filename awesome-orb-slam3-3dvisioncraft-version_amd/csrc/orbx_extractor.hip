@@ -1385,14 +1385,44 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
     const DescLevel& L = P.lv[level];
     const bool inSlab = pos < L.selCap;
     uint32_t key = 0, aux = 0;
+    if (inSlab) {
+        key = P.sel[(size_t)frame * P.selFrame + L.selOff + pos];
+        aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
+    }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED) && !defined(DESC_COUNTS_VECTOR)
+    // The per-level counts and their prefix sums are wave-uniform (frame and level are): scalar loads through the constant address space —
+    // adjacent dwords, merged into wide s_loads, ONE round trip next to the key point record — and scalar adds, instead of two vector loads,
+    // two wave scans and four v_readlane per key point (~35 VALU instructions of 640).  (The scalar cache is invalidated at kernel boundaries:
+    // k_octree's counts are visible.)
+    int nTotal = 0, monoTotal = 0, nLevel = 0, monoBase = 0, lapBase = 0;
+    {
+        const int __attribute__((address_space(4)))* cN = (const int __attribute__((address_space(4)))*)(unsigned long long)(P.selCount + (size_t)frame * P.nlevels);
+        const int __attribute__((address_space(4)))* cL = (const int __attribute__((address_space(4)))*)(unsigned long long)(P.lapCount + (size_t)frame * P.nlevels);
+        // eight levels per block, each block's sixteen entries loaded unconditionally (the arrays are padded) — loads behind a uniform
+        // branch per level are one round trip per level, and all sixteen levels at once spill scalar registers; the second block only runs for
+        // pyramids of more than eight levels
+#pragma unroll
+        for (int blk = 0; blk < ORBX_MAX_LEVELS; blk += 8) {
+            if (blk < P.nlevels) {
+                int nn[8], ll[8];
+#pragma unroll
+                for (int l = 0; l < 8; l++) { nn[l] = cN[blk + l]; ll[l] = cL[blk + l]; }
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const int n = blk + l < P.nlevels ? nn[l] : 0, lp = blk + l < P.nlevels ? ll[l] : 0;
+                    nTotal += n; monoTotal += n - lp;
+                    monoBase += blk + l < level ? n - lp : 0;          // monocular / lapping-area keypoints of the levels before this one
+                    lapBase += blk + l < level ? lp : 0;
+                    nLevel = blk + l == level ? n : nLevel;
+                }
+            }
+        }
+    }
+#else
     int myN = 0, myL = 0;
     if (lane < P.nlevels) {
         myN = P.selCount[(size_t)frame * P.nlevels + lane];
         myL = P.lapCount[(size_t)frame * P.nlevels + lane];
-    }
-    if (inSlab) {
-        key = P.sel[(size_t)frame * P.selFrame + L.selOff + pos];
-        aux = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos];
     }
     const int myM = myN - myL;                                  // monocular keypoints of level `lane`
     const int inclN = wave_scan_incl(myN), inclM = wave_scan_incl(myM);
@@ -1400,6 +1430,7 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
     const int nLevel = __builtin_amdgcn_readlane(myN, level);
     const int monoBase = __builtin_amdgcn_readlane(inclM - myM, level);               // monocular keypoints of the levels before this one
     const int lapBase = __builtin_amdgcn_readlane(inclN - myN, level) - monoBase;     // lapping-area keypoints of the levels before this one
+#endif
     if (grp == 0 && kwave == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
     const bool valid = inSlab && pos < nLevel;
     PROF_MARK(1, 0);   // record + counts (first global round trip)
@@ -2080,8 +2111,11 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_candCount, B * nl * 4));
     CK(hipMalloc((void**)&h->d_sel, B * h->selFrame * 4));
     CK(hipMalloc((void**)&h->d_selAux, B * h->selFrame * 4));
-    CK(hipMalloc((void**)&h->d_selCount, B * nl * 4));
-    CK(hipMalloc((void**)&h->d_lapCount, B * nl * 4));
+    // (+ ORBX_MAX_LEVELS entries: k_describe reads a frame's counts as one fixed-size block, whatever nlevels is)
+    CK(hipMalloc((void**)&h->d_selCount, (B * nl + ORBX_MAX_LEVELS) * 4));
+    CK(hipMalloc((void**)&h->d_lapCount, (B * nl + ORBX_MAX_LEVELS) * 4));
+    CK(hipMemset(h->d_selCount, 0, (B * nl + ORBX_MAX_LEVELS) * 4));
+    CK(hipMemset(h->d_lapCount, 0, (B * nl + ORBX_MAX_LEVELS) * 4));
     tiles.insert(tiles.end(), tiles1.begin(), tiles1.end());   // one allocation: [two-row list | one-row list]
     CK(hipMalloc((void**)&h->d_tiles, tiles.size() * sizeof(FastTile)));
     CK(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
