@@ -1655,6 +1655,223 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
     PROF_FLUSH(1);
 }
 
+// Two key points per wave (round 3).  The ~130 wave-uniform instructions of fastAtan2 + the double-precision sin / cos are a fifth of a key point's
+// instructions and occupy ONE lane; here lanes 0 and 1 evaluate them for the wave's two key points at once.  Everything else runs one key point
+// after the other on all lanes: both 43 x 48 patches are staged side by side, every lane reads its row of BOTH into registers (IC_Angle moments on
+// the way), and only then the row pass of the first key point overwrites the patch region with its transposed row-pass buffer — the second one
+// follows from registers after the first has been sampled.  LDS per wave: two patches = 4 472 B (the round-2 attempt at several key points per wave
+// carried a blurred tile per key point and lost its instruction saving to occupancy; there is no blurred tile any more), 8 waves per SIMD.
+#ifndef DESC_KPW
+#define DESC_KPW 2   // key points per wave: 2 (k_describe2) or 1 (k_describe)
+#endif
+#define DESC2_PATCH (DP * DPP)                       // 2 236 B
+#define DESC2_WAVE_BYTES (2 * DESC2_PATCH + 8)       // region A: two patches, later the 3 404-byte row-pass buffer
+static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int lane = threadIdx.x & 63;
+    int frame, grp;
+    if (!xcd_frame_unit(P.groups * 2, P.batch, &frame, &grp)) return;
+    const int kpair = grp & 1;
+    grp >>= 1;
+    uint8_t* patch = orb_smem;
+    uint16_t* rowp = (uint16_t*)orb_smem;
+    int* mom = (int*)(orb_smem + DESC2_WAVE_BYTES);          // [2][2] m01, m10
+    float* trig = (float*)(mom + 4);                         // [2][3] angle (degrees), sin, cos
+    int level = 0, ustart = 0;
+#pragma unroll
+    for (int l = 1; l < ORBX_MAX_LEVELS; l++) { const int us = P.unitStart[l]; if (grp >= us) { level = l; ustart = us; } }
+    const int pos0 = (grp - ustart) * 4 + 2 * kpair;         // the wave's key points are pos0 and pos0 + 1 of the level's slab
+    const DescLevel& L = P.lv[level];
+    uint32_t key[2] = {0, 0}, aux[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+        if (pos0 + s < L.selCap) {
+            key[s] = P.sel[(size_t)frame * P.selFrame + L.selOff + pos0 + s];
+            aux[s] = P.selAux[(size_t)frame * P.selFrame + L.selOff + pos0 + s];
+        }
+    // per-level counts and their prefix sums: wave-uniform (see k_describe)
+    int nTotal = 0, monoTotal = 0, nLevel = 0, monoBase = 0, lapBase = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+    {
+        const int __attribute__((address_space(4)))* cN = (const int __attribute__((address_space(4)))*)(unsigned long long)(P.selCount + (size_t)frame * P.nlevels);
+        const int __attribute__((address_space(4)))* cL = (const int __attribute__((address_space(4)))*)(unsigned long long)(P.lapCount + (size_t)frame * P.nlevels);
+#pragma unroll
+        for (int blk = 0; blk < ORBX_MAX_LEVELS; blk += 8) {
+            if (blk < P.nlevels) {
+                int nn[8], ll[8];
+#pragma unroll
+                for (int l = 0; l < 8; l++) { nn[l] = cN[blk + l]; ll[l] = cL[blk + l]; }
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const int n = blk + l < P.nlevels ? nn[l] : 0, lp = blk + l < P.nlevels ? ll[l] : 0;
+                    nTotal += n; monoTotal += n - lp;
+                    monoBase += blk + l < level ? n - lp : 0;
+                    lapBase += blk + l < level ? lp : 0;
+                    nLevel = blk + l == level ? n : nLevel;
+                }
+            }
+        }
+    }
+#else
+    for (int l = 0; l < P.nlevels; l++) {
+        const int n = P.selCount[(size_t)frame * P.nlevels + l], lp = P.lapCount[(size_t)frame * P.nlevels + l];
+        nTotal += n; monoTotal += n - lp;
+        if (l < level) { monoBase += n - lp; lapBase += lp; }
+        if (l == level) nLevel = n;
+    }
+#endif
+    if (grp == 0 && kpair == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
+    const bool valid[2] = {pos0 < L.selCap && pos0 < nLevel, pos0 + 1 < L.selCap && pos0 + 1 < nLevel};
+    if (!valid[0]) return;                                   // (positions fill from the front: no second key point without a first)
+    int cx[2], cy[2], ox[2] = {0, 0};
+    const uint8_t* img = L.base + (size_t)frame * L.frameStride;
+    // ---- both patches -> LDS (all loads of a key point in flight before its first store; the second key point's follow the first's stores)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        cx[s] = (int)(key[s] & 0xFFF) + ORBX_MINB; cy[s] = (int)((key[s] >> 12) & 0xFFF) + ORBX_MINB;
+        if (!valid[s]) continue;
+        uint8_t* pt = patch + s * DESC2_PATCH;
+        const int xs = cx[s] - 21, ys = cy[s] - 21;
+        if (xs >= 0 && ys >= 0 && cy[s] + 21 < L.h && cx[s] + 27 <= L.w) {
+            const int x0 = xs & ~3;
+            ox[s] = xs - x0;
+            const int c = lane % 12, r5 = lane / 12;       // lanes 0..59 = 5 rows x 12 dwords per pass, 9 passes
+            const uint8_t* src = img + (size_t)(ys + r5) * L.rowStride + x0 + 4 * c;
+            uint8_t* dstp = pt + r5 * DPP + 4 * c;
+            uint32_t v[9];
+            if (lane < 60) {
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < 8 || r5 < 3) v[k] = *(const uint32_t*)(src + (size_t)(5 * k) * L.rowStride);
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if (k < 8 || r5 < 3) *(uint32_t*)(dstp + 5 * k * DPP) = v[k];
+            }
+        } else {   // the 7x7 blur taps may cross the image border: BORDER_REFLECT_101 at load
+            for (int i = lane; i < DP * DP; i += 64) {
+                const int r = i / DP, c = i - r * DP;
+                pt[r * DPP + c] = img[(size_t)reflect101(ys + r, L.h) * L.rowStride + reflect101(xs + c, L.w)];
+            }
+        }
+    }
+    DESC_SYNC();
+    // ---- lane r owns patch row r of both key points: packed rows into registers, IC_Angle moments (ORBextractor.cc:75-102) on the way
+    uint32_t e[2][11];
+    int m10[2] = {0, 0}, m01[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int k = 0; k < 11; k++) e[s][k] = 0;
+        if (valid[s] && lane < DP) {
+            const uint32_t* rw = (const uint32_t*)(patch + s * DESC2_PATCH + lane * DPP);
+            uint32_t d[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) d[k] = rw[k];
+#pragma unroll
+            for (int k = 0; k < 11; k++) e[s][k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ox[s]);
+            const int v = lane - 21;
+            const int av = v < 0 ? -v : v;
+            if (av <= 15) {
+                const uint32_t* mk = c_icmask[av];
+                uint32_t s1 = 0, sw = 0;
+#pragma unroll
+                for (int k = 1; k <= 9; k++) {
+                    uint32_t W = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { const int j = 4 * k + t; if (j >= 6 && j <= 36) W |= (uint32_t)(j - 6) << (8 * t); }
+                    const uint32_t m = e[s][k] & mk[k];
+                    s1 = __builtin_amdgcn_udot4(m, 0x01010101u, s1, false);
+                    sw = __builtin_amdgcn_udot4(m, W, sw, false);
+                }
+                m10[s] = (int)sw - 15 * (int)s1;
+                m01[s] = v * (int)s1;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) { m10[s] += __shfl_xor(m10[s], off); m01[s] += __shfl_xor(m01[s], off); }
+    }
+    // fastAtan2 + sin / cos once for both key points: lane s serves key point s
+    if (lane < 2) {
+        const int my01 = lane == 0 ? m01[0] : m01[1], my10 = lane == 0 ? m10[0] : m10[1];
+        const float ang = fast_atan2_deg((float)my01, (float)my10);
+        float sn, cs;
+        det_sincos(ang * (float)(3.1415926535897932384626433832795 / 180.f), &sn, &cs);
+        trig[3 * lane] = ang; trig[3 * lane + 1] = sn; trig[3 * lane + 2] = cs;
+    }
+    DESC_SYNC();   // every lane's patch rows are in registers (the row-pass buffer may overwrite the patches), and trig[] is visible
+    typedef unsigned short u16x2 __attribute__((vector_size(4)));
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (!valid[s]) break;
+        if (s == 1) DESC_SYNC();   // the first key point's samples are read
+        if (lane < DP) {
+            // Gaussian row pass: k = {18,34,49,55,49,34,18}; out(c) = dot4(bytes c..c+3, k[0..3]) + dot4(bytes c+4..c+7, {k[4..6],0}); stored
+            // transposed, rowp[c][r] (u16, pitch DRP)
+            const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+            uint32_t A[41];
+#pragma unroll
+            for (int c = 0; c < 41; c++) A[c] = (c & 3) == 0 ? e[s][c >> 2] : __builtin_amdgcn_alignbyte(e[s][(c >> 2) + 1], e[s][c >> 2], (uint32_t)(c & 3));
+            uint16_t* o = rowp + lane;
+#pragma unroll
+            for (int c = 0; c < DB; c++)
+                o[c * DRP] = (uint16_t)__builtin_amdgcn_udot4(A[c], K0, __builtin_amdgcn_udot4(A[c + 4], K1, 0u, false), false);
+        }
+        DESC_SYNC();
+        // rBRIEF (ORBextractor.cc:106-145): lane i evaluates pairs 4i..4i+3; the blur's column pass only where it samples (see k_describe)
+        const float angle = trig[3 * s], b = trig[3 * s + 1], a = trig[3 * s + 2];
+        uint32_t nib = 0;
+        const u16x2 Wa = {18, 34}, Wb = {49, 55}, Wc = {49, 34}, Wd = {18, 0};
+        auto blurred = [&](const int r, const int c) {
+            const int rr = 18 + r;
+            const uint32_t* cq = (const uint32_t*)(rowp + (18 + c) * DRP + (rr & ~1));
+            const uint32_t sh = (uint32_t)(rr & 1) * 2u;
+            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];
+            uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d1, d0, sh)), Wa, 32768u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d2, d1, sh)), Wb, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d2, sh)), Wc, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d4, d3, sh)), Wd, acc, false);
+            return (int)min(acc >> 16, 255u);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            typedef float f32x2 __attribute__((vector_size(8)));
+            const float4 pt = c_patternf[lane * 4 + j];
+            const f32x2 X = {pt.x, pt.z}, Y = {pt.y, pt.w}, Bv = {b, b}, Av = {a, a};
+            const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
+            const int r0 = __float2int_rn(R[0]), q0 = __float2int_rn(Q[0]);
+            const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
+            nib |= (uint32_t)(blurred(r0, q0) < blurred(r1, q1)) << j;
+        }
+        uint32_t v = nib | (__shfl_xor(nib, 1) << 4);           // valid on even lanes
+        const uint32_t b1 = __shfl_down(v, 2), b2 = __shfl_down(v, 4), b3 = __shfl_down(v, 6);
+        const uint32_t dw = (v & 255) | ((b1 & 255) << 8) | ((b2 & 255) << 16) | ((b3 & 255) << 24);
+        // output slot (ORBextractor.cc:1141-1152)
+        const int rank = (int)(aux[s] & 0x7FFFFFFF);
+        const int idx = (aux[s] >> 31) ? (nTotal - 1 - (lapBase + rank)) : (monoBase + rank);
+        if (idx >= 0 && idx < P.cap) {
+            uint32_t* dout = (uint32_t*)(P.desc + ((size_t)frame * P.cap + idx) * 32);
+            if ((lane & 7) == 0) dout[lane >> 3] = dw;
+            if (lane < 7) {
+                float fx = (float)cx[s], fy = (float)cy[s];
+                if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+                uint32_t w;
+                switch (lane) {
+                    case 0: w = __float_as_uint(fx); break;
+                    case 1: w = __float_as_uint(fy); break;
+                    case 2: w = __float_as_uint(L.size); break;
+                    case 3: w = __float_as_uint(angle); break;
+                    case 4: w = __float_as_uint((float)(key[s] >> 24)); break;
+                    case 5: w = (uint32_t)level; break;
+                    default: w = 0xFFFFFFFFu; break;
+                }
+                ((uint32_t*)(P.kps + (size_t)frame * P.cap + idx))[lane] = w;
+            }
+        }
+    }
+}
+
 struct Desc { uint32_t w[8]; };
 static __device__ __forceinline__ Desc load_desc16(const uint8_t* p) {
     Desc d;
@@ -2264,7 +2481,11 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         for (int l = 0; l < nl; l++) D.unitStart[l + 1] = D.unitStart[l] + (h->lv[l].selCap + 3) / 4;
         for (int l = nl + 1; l <= ORBX_MAX_LEVELS; l++) D.unitStart[l] = INT_MAX;
         D.groups = D.unitStart[nl]; D.batch = batch;
+#if DESC_KPW == 2
+        hipLaunchKernelGGL(k_describe2, dim3(D.groups * 2 * 8 * ((batch + 7) / 8)), dim3(64), DESC2_WAVE_BYTES + 48, st, D);
+#else
         hipLaunchKernelGGL(k_describe, dim3(D.groups * (4 / DESC_WPB) * 8 * ((batch + 7) / 8)), dim3(64 * DESC_WPB), DESC_WPB * DESC_WAVE_STRIDE + 96, st, D);
+#endif
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
     if (!h->capturing) h->timed = true;
