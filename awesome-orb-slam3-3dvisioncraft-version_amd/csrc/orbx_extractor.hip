@@ -177,8 +177,8 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 // Separable form of the same arithmetic for scale factors <= 1.3 (every ORB-SLAM3 configuration: 1.2): one workgroup = one 64 x 32
 // destination tile.  The per-column / per-row coefficients come from per-level tables built once at orbx_create with the same
 // resize_coef() (host side, same IEEE operations).  H pass: every staged source row is filtered once per destination column
-// (t = p0*a0 + p1*a1 as one v_dot2_u32_u16 on a byte pair picked by v_perm from an 8-byte window; cv::resize's ">> 4" applied,
-// stored << 9 so that the V pass is one v_mul_hi_u32_u24 per tap: ((b << 7) * ((t >> 4) << 9)) >> 32 == (b * (t >> 4)) >> 16).
+// (t = p0*a0 + p1*a1 as one v_dot2_u32_u16 on a byte pair picked by v_perm from an 8-byte window; cv::resize's ">> 4" is the one v_and that
+// clears the low four bits — the V pass is one v_mul_hi_u32_u24 per tap with the weight pre-shifted: ((b << 12) * (16 * (t >> 4))) >> 32 == (b * (t >> 4)) >> 16).
 // V pass: 4 adjacent pixels per thread from two 16-byte LDS reads.
 #ifndef R2_XCD
 #define R2_XCD 1
@@ -204,7 +204,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     int* cxs = (int*)orb_smem;                 // [64] source column of each destination column of the tile
     int* cxw = cxs + RS_TW;                    // [64] a0 | a1 << 16
     uint4* rowt = (uint4*)(cxw + RS_TW);       // [32] {hbuf byte offset of source row 0, of source row 1, b0 << 7, b1 << 7}
-    uint32_t* hbuf = (uint32_t*)(rowt + R2_TH);   // [R2_ROWS][R2_HP]  ((p0*a0 + p1*a1) >> 4) << 9
+    uint32_t* hbuf = (uint32_t*)(rowt + R2_TH);   // [R2_ROWS][R2_HP]  16 * ((p0*a0 + p1*a1) >> 4)
     uint8_t* tile = (uint8_t*)(hbuf + R2_ROWS * R2_HP);   // [R2_ROWS][RS_PITCH]
     const int tid = threadIdx.x;
 #if R2_XCD
@@ -241,7 +241,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
             int sy1 = sy0 + 1;
             sy0 = sy0 < 0 ? 0 : (sy0 < P.sh ? sy0 : P.sh - 1);   // rows are clipped after the weights are fixed (resize.cpp)
             sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
-            rowt[t] = make_uint4((uint32_t)((sy0 - ylo) * R2_HP * 4), (uint32_t)((sy1 - ylo) * R2_HP * 4), (bw & 0xFFFFu) << 7, (bw >> 16) << 7);
+            rowt[t] = make_uint4((uint32_t)((sy0 - ylo) * R2_HP * 4), (uint32_t)((sy1 - ylo) * R2_HP * 4), (bw & 0xFFFFu) << 12, (bw >> 16) << 12);
         }
         uint8_t* t = tile + r0 * RS_PITCH + 4 * c;
 #pragma unroll
@@ -271,7 +271,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
             for (int j = 0; j < 4; j++) {
                 const uint32_t pp = __builtin_amdgcn_perm(W1, W0, sel[j]);
                 const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), aw[j], 0u, false);
-                Tp[j] = (t & ~15u) << 5;
+                Tp[j] = t & ~15u;   // 16 * (t >> 4)
             }
             *(uint4*)(hbuf + r * R2_HP + x0) = T;
         }
@@ -286,14 +286,14 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
         const int ty = (tid >> 4) + 16 * k;
         if (by0 + ty >= P.dh) break;
         const uint4 rt = rowt[ty];
-        // both factors are below 2^24 (weights << 7 <= 2^18, H-pass sums << 5 < 2^24); saying so on BOTH lets the compiler pick the full-rate
+        // both factors are below 2^24 (weights << 12 <= 2^23, H-pass sums < 2^19); saying so on BOTH lets the compiler pick the full-rate
         // v_mul_hi_u32_u24 — with only one side masked it emitted v_mul_hi_u32 plus the sixteen v_and of the masks
         const uint32_t b0 = rt.z & 0xFFFFFFu, b1 = rt.w & 0xFFFFFFu;
         const uint4 T0 = *(const uint4*)((const uint8_t*)hbuf + rt.x + xg * 16);
         const uint4 T1 = *(const uint4*)((const uint8_t*)hbuf + rt.y + xg * 16);
 #define R2_PIX(t0, t1) (((uint32_t)(((uint64_t)b0 * ((t0) & 0xFFFFFFu)) >> 32) + (uint32_t)(((uint64_t)b1 * ((t1) & 0xFFFFFFu)) >> 32) + 2u) >> 2)
-        const uint32_t out = (R2_PIX(T0.x, T1.x) & 255u) | ((R2_PIX(T0.y, T1.y) & 255u) << 8) | ((R2_PIX(T0.z, T1.z) & 255u) << 16) |
-                             (R2_PIX(T0.w, T1.w) << 24);
+        // a pixel is <= 255 without a clamp: the two weights add up to 2048 (+-1), the H sums are <= 255 * 2048, so the two products sum to <= 1020
+        const uint32_t out = R2_PIX(T0.x, T1.x) | (R2_PIX(T0.y, T1.y) << 8) | (R2_PIX(T0.z, T1.z) << 16) | (R2_PIX(T0.w, T1.w) << 24);
 #undef R2_PIX
         uint8_t* Dk = D + (size_t)(16 * k) * P.dStride;
         if (dx0 + 3 < P.dw) {
