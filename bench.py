@@ -706,7 +706,7 @@ def main():
         whole_ext, pk = algorithmic_bytes(W, H, NFEAT)
         whole_match, pkm = match_algorithmic_bytes(NFEAT, NFEAT)    # SURVEY §8(d) figures are quoted at N = N_q = nFeatures
         pk.update(pkm)
-        names = {"pyramid": "k_resize2", "fast": "k_fast", "octree": "k_octree", "describe": "k_describe", "undistort": "k_undistort",
+        names = {"pyramid": "k_resize2", "fast": "k_fast", "octree": "k_octree", "describe": "k_describe2", "undistort": "k_undistort",
                  "grid_build": "k_grid_build", "sbp_candidates": "k_sbp_candidates2", "sbp_resolve": "k_sbp_resolve"}
         dom = max(names, key=lambda k: kern.get(k, 0.0))
         ach = pk[dom] * B / (kern[dom] * 1e-3) / 1e9 if kern.get(dom, 0) > 0 else 0.0
