@@ -1613,11 +1613,11 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
             const int rr = 18 + r;
             const uint32_t* cq = (const uint32_t*)(rowp + (18 + c) * DRP + (rr & ~1));   // DRP is even: dword aligned
             const uint32_t sh = (uint32_t)(rr & 1) * 2u;
-            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];   // (row 45 at most: inside the column's 46 entries)
+            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3];   // (the run's seventh value is the low or the high half of d3)
             uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d1, d0, sh)), Wa, 32768u, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d2, d1, sh)), Wb, acc, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d2, sh)), Wc, acc, false);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d4, d3, sh)), Wd, acc, false);   // (the eighth value has weight 0)
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d3, sh)), Wd, acc, false);   // (the other half has weight 0)
             return (int)min(acc >> 16, 255u);
         };
         const int t0 = blurred(r0, q0), t1 = blurred(r1, q1);
@@ -1809,14 +1809,23 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
         if (lane < DP) {
             // Gaussian row pass: k = {18,34,49,55,49,34,18}; out(c) = dot4(bytes c..c+3, k[0..3]) + dot4(bytes c+4..c+7, {k[4..6],0}); stored
             // transposed, rowp[c][r] (u16, pitch DRP)
-            const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
-            uint32_t A[41];
-#pragma unroll
-            for (int c = 0; c < 41; c++) A[c] = (c & 3) == 0 ? e[s][c >> 2] : __builtin_amdgcn_alignbyte(e[s][(c >> 2) + 1], e[s][c >> 2], (uint32_t)(c & 3));
+            // on the ALIGNED dwords of the row, with the seven weights shifted to the column's byte phase instead of the bytes shifted to the
+            // weights: 2 v_dot4 for phases 0 and 1 (the taps span two dwords), 3 for phases 2 and 3 — 92 per row instead of 74 + 30 v_alignbyte
             uint16_t* o = rowp + lane;
 #pragma unroll
-            for (int c = 0; c < DB; c++)
-                o[c * DRP] = (uint16_t)__builtin_amdgcn_udot4(A[c], K0, __builtin_amdgcn_udot4(A[c + 4], K1, 0u, false), false);
+            for (int c = 0; c < DB; c++) {
+                constexpr uint32_t g[7] = {18, 34, 49, 55, 49, 34, 18};
+                const int q = c >> 2, ph = c & 3;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int dwi = 0; dwi < 3; dwi++) {
+                    uint32_t Wd = 0;   // weights of the bytes of dword q + dwi: byte t is tap 4 * dwi + t - ph
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { const int tap = 4 * dwi + t - ph; if (tap >= 0 && tap < 7) Wd |= g[tap] << (8 * t); }
+                    if (Wd != 0) acc = __builtin_amdgcn_udot4(e[s][q + dwi], Wd, acc, false);
+                }
+                o[c * DRP] = (uint16_t)acc;
+            }
         }
         DESC_SYNC();
         // rBRIEF (ORBextractor.cc:106-145): lane i evaluates pairs 4i..4i+3; the blur's column pass only where it samples (see k_describe)
@@ -1827,11 +1836,11 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             const int rr = 18 + r;
             const uint32_t* cq = (const uint32_t*)(rowp + (18 + c) * DRP + (rr & ~1));
             const uint32_t sh = (uint32_t)(rr & 1) * 2u;
-            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3], d4 = cq[4];
+            const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3];   // (the run's seventh value is the low or the high half of d3)
             uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d1, d0, sh)), Wa, 32768u, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d2, d1, sh)), Wb, acc, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d2, sh)), Wc, acc, false);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d4, d3, sh)), Wd, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d3, d3, sh)), Wd, acc, false);   // (the other half has weight 0)
             return (int)min(acc >> 16, 255u);
         };
 #pragma unroll
