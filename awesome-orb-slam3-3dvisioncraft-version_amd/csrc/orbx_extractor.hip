@@ -363,6 +363,46 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
     return max(A, -B);
 }
 
+// fast_S on packed 16-bit pairs (device builds): register i holds d = v - x of ring positions (i, i + 8); the min network gives the darker-ring
+// score A = max over arcs of min(d), the max network the brighter-ring one -B = -min over arcs of max(d); wrap-around neighbours are the half
+// swap every packed instruction has for free (op_sel).  ~100 instructions for BOTH polarities (the scalar form above: ~190).
+static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitch) {
+#ifdef HIP_EMULATED
+    return fast_S(c, pitch);
+#else
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    int x[16];
+#define LD(k, dx, dy) x[k] = c[(dy) * pitch + (dx)];
+    RING16(LD)
+#undef LD
+    const short v = (short)c[0];
+    const s16x2 V = {v, v};
+    s16x2 P[8], L2[8], L4[8], H2[8], H4[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) P[i] = V - __builtin_bit_cast(s16x2, (uint32_t)x[i] | ((uint32_t)x[i + 8] << 16));
+#define SWP(a) __builtin_shufflevector(a, a, 1, 0)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const s16x2 nx = i < 7 ? P[(i + 1) & 7] : SWP(P[0]);
+        L2[i] = __builtin_elementwise_min(P[i], nx); H2[i] = __builtin_elementwise_max(P[i], nx);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        L4[i] = __builtin_elementwise_min(L2[i], i < 6 ? L2[(i + 2) & 7] : SWP(L2[(i + 2) & 7]));
+        H4[i] = __builtin_elementwise_max(H2[i], i < 6 ? H2[(i + 2) & 7] : SWP(H2[(i + 2) & 7]));
+    }
+    s16x2 A = {-256, -256}, B = {256, 256};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const s16x2 o = SWP(P[i]);   // e[j + 8]
+        A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(L4[i], i < 4 ? L4[i + 4] : SWP(L4[i - 4])), o));
+        B = __builtin_elementwise_min(B, __builtin_elementwise_max(__builtin_elementwise_max(H4[i], i < 4 ? H4[i + 4] : SWP(H4[i - 4])), o));
+    }
+#undef SWP
+    return max(max((int)A.x, (int)A.y), -min((int)B.x, (int)B.y));
+#endif
+}
+
 // The same score when the corner's polarity is known (a FAST-9 corner cannot have both a brighter and a darker 9-arc: 9 + 9 > 16):
 // only the passing side's "max over arcs of min" is needed — the other side's is <= 0 < S.  m = 0: ring brighter than the centre
 // (e = x - v), m = -1: darker (e = ~x - ~v = v - x); one v_xad_u32 per ring pixel.
@@ -458,6 +498,9 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
                                   // 6-row halo is shared — 5.4 % fewer VALU instructions per launch, 0.847 -> 0.792 ms per 512 frames at 8 workgroups per CU
 #ifndef FAST_TALL_MIN_BATCH
 #define FAST_TALL_MIN_BATCH 8     // frames per call from which the two-cell-row tiles are used
+#endif
+#ifndef FAST_FITS_MAX
+#define FAST_FITS_MAX (FAST_QCAP / 4 + 64)   // survivors a wave queues in one go (tests build with a small value to send ordinary tiles row group by row group)
 #endif
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
@@ -629,33 +672,35 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     const int wave = tid >> 6;
     const int dcol = lane & 31, rsub = lane >> 5;       // stage 1: lane = one LDS dword (4 detection columns) of one row
     uint16_t* q1w = q1 + wave * FAST_Q1W;               // this wave's pre-test survivors
-    uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);       // this wave's corner list: brighter-ring corners from the front, darker-ring ones from the back
-    int n2b = 0, n2d = 0;                               // corners of this wave by polarity (wave-uniform)
+    uint16_t* q2w = q2 + wave * (FAST_Q2CAP / 4);       // this wave's corner list
+    uint8_t* sbuf = (uint8_t*)q1w;                      // ... and the corners' scores, parked at the FRONT of the wave's own queue slice: entry i of the
+                                                        // queue is read before the i-th score byte can be written (a batch reads its 64 entries, then
+                                                        // writes at most 64 bytes below them), so the list eats its way into consumed entries only
+    static_assert(FAST_Q2CAP / 4 <= 2 * FAST_Q1W, "a wave's scores are parked in its q1 slice");
+    static_assert((FAST_Q2CAP / 4 + 1) / 2 + 256 <= FAST_Q1W && FAST_FITS_MAX <= FAST_Q1W, "a row group (<= 256 survivors) queues behind the parked scores");
+    static_assert(4 * FAST_PITCH <= 4 * FAST_Q1W * 2, "the fallback's four-row score ring lives in the q1 region");
+    int n2w = 0;                                        // corners of this wave (wave-uniform)
     bool ovf = false;
-    // stage 2 of one batch of 64 queue entries: full ring classification -> this wave's q2 slice
+    // stage 2 of one batch of 64 queue entries: the EXACT score decides (S > t <=> FAST-9 corner at threshold t, S - 1 is cv's score) and is kept —
+    // on the benchmark's pyramid 22 % of the pixels pass the pre-test and 10 % are corners (a third of the pixels on the coarsest levels), so a
+    // classification by ring bit masks followed by a score pass over the corners computed the ring differences of almost every second survivor
+    // twice; the packed score costs little more than the classification did.
     auto classify = [&](const int i, const bool valid) {
-        bool corner = false, bright = false;
-        int ent = 0;
+        int ent = 0, S = 0;
         if (valid) {
             ent = q1w[i];
-            const uint8_t* cc = img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-            const int v = cc[0];
-            // z = ((v+t - x) << 16) + (x - (v-t)) in one v_mad_i32_i24: bit 31 = brighter than v+t, bit 15 = darker than v-t (a
-            // negative low half borrows 1 from a high half that is then >= 2t, so the two signs never disturb each other)
-            const int K = ((v + t0) << 16) - (v - t0);
-            uint32_t acc = 0;   // after 16 steps: bits 31..16 = brighter mask, bits 15..0 = darker mask (ring position 0 in the LSB)
-#define CL(k_, dx, dy) { const int x = cc[(dy) * pitch + (dx)]; const uint32_t z = (uint32_t)(x * -65535 + K); acc = (acc >> 1) | (z & 0x80008000u); }
-            RING16(CL)
-#undef CL
-            bright = ring_has9(acc >> 16);
-            corner = bright || ring_has9(acc & 0xFFFFu);
+            S = fast_S_pk(img + (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255), pitch);
         }
-        const unsigned long long mc = __ballot(corner), mb = __ballot(bright);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int nb = __popcll(mb), nd = __popcll(mc) - nb;
-        if (n2b + n2d + nb + nd <= FAST_Q2CAP / 4) {
-            if (corner) q2w[bright ? n2b + __popcll(mb & below) : FAST_Q2CAP / 4 - 1 - n2d - __popcll(mc & ~mb & below)] = (uint16_t)ent;
-            n2b += nb; n2d += nd;
+        const bool corner = valid && S > t0;
+        const unsigned long long mc = __ballot(corner);   // (also orders every lane's queue read before the score writes below: the emulator
+        const int nc = __popcll(mc);                      // runs the lanes one after the other between such points)
+        if (n2w + nc <= FAST_Q2CAP / 4) {
+            if (corner) {
+                const int slot = n2w + __popcll(mc & ((1ull << lane) - 1ull));
+                q2w[slot] = (uint16_t)ent;
+                sbuf[slot] = (uint8_t)(S - 1);            // S > t0 >= 0 here
+            }
+            n2w += nc;
         } else if (mc) ovf = true;
     };
     // stage-1 thresholds on D = (x + 255 - v) >> 1 (one v_lerp_u8 per ring position: four pixels per instruction).  x - v > t implies
@@ -704,13 +749,14 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     //      group by row group instead (a row group is at most 2 x 128 pixels).
     {
         const int total = __builtin_amdgcn_readlane(wave_scan_incl(__popc(mask)), 63);
-        const bool fits = total <= FAST_Q1W;
+        const bool fits = total <= FAST_FITS_MAX;
         for (int kp = 0; kp < (fits ? 1 : K); kp++) {
             uint32_t m = fits ? mask : mask & (0x01010101u << kp);
             const int cnt = __popc(m);
             const int incl = wave_scan_incl(cnt);
             const int n1 = __builtin_amdgcn_readlane(incl, 63);
-            int slot = incl - cnt;
+            const int qb = fits ? 0 : (n2w + 1) >> 1;                           // a later row group queues behind the score bytes parked so far
+            int slot = qb + incl - cnt;
             const int ent0 = ((2 * wave + rsub) << 8) | (4 * dcol);           // the entry of column t = 0 in the lane's first row (k = 0)
             while (m) {
                 const int j = __ffs((int)m) - 1;                               // bit 8t + k
@@ -720,7 +766,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int i0 = 0; i0 < n1; i0 += 64) classify(i0 + lane, i0 + lane < n1);
+            for (int i0 = 0; i0 < n1; i0 += 64) classify(qb + i0 + lane, i0 + lane < n1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // q1w is refilled by the next row group
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -731,19 +777,6 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n2w = n2b + n2d;                          // <= FAST_Q2CAP / 4 (a batch that would not fit sets the overflow flag instead)
-    // entry i of the wave's corner list: the brighter-ring corners [0, n2b) sit at the front of the slice, the darker-ring ones at its back
-#define Q2SLOT(i) ((i) < n2b ? (i) : FAST_Q2CAP / 4 - 1 - ((i) - n2b))
-    // ---- stage 3: exact score of this wave's corners (dense lanes; only the passing polarity's arcs are evaluated)
-    uint8_t* sbuf = (uint8_t*)q1w;   // the scores wait in the wave's own (now idle) queue slice until no wave needs the image any more
-    static_assert(FAST_Q2CAP / 4 <= 2 * FAST_Q1W, "a wave's scores are parked in its q1 slice");
-    static_assert(4 * FAST_PITCH <= 4 * FAST_Q1W * 2, "the fallback's four-row score ring lives in the q1 region");
-    for (int i = lane; i < n2w; i += 64) {
-        const int slot = Q2SLOT(i);
-        const int ent = q2w[slot];
-        const int pos = (dy0 + (ent >> 8)) * pitch + dx0 + (ent & 255);
-        sbuf[slot] = (uint8_t)(fast_S_pol(img + pos, pitch, i < n2b ? 0 : -1) - 1);   // S > t0 >= 0 here
-    }
     PROF_MARK(0, 3);   // stage 3
     __syncthreads();
     PROF_MARK(0, 4);   // barrier after stage 3
@@ -753,7 +786,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         for (int i = lane; i < n2w; i += 64) {
-            const int slot = Q2SLOT(i);
+            const int slot = i;
             const int ent = q2w[slot];
             const int ry = ent >> 8;
             smap[(dy0 + ry + cellRowOf(ry)) * pitch + dx0 + (ent & 255)] = sbuf[slot];
@@ -762,7 +795,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         // ---- NMS over the corner lists: strict maximum over the 8 neighbours inside the same cell's detection region.
         //      survive(T) = s >= T && localmax (threshold-independent localmax, DESIGN.md "FAST as set algebra").
         for (int i = lane; i < n2w; i += 64) {
-            const int ent = q2w[Q2SLOT(i)];
+            const int ent = q2w[i];
             const int rx = ent & 255, ryn = ent >> 8, crn = cellRowOf(ryn);
             const uint8_t* m = smap + (dy0 + ryn + crn) * pitch + dx0 + rx;
             const int s = m[0], ct = colTab[rx];
@@ -770,13 +803,13 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             if (!(ct & 0x40)) ok = ok && s > m[-1] && s > m[-pitch - 1] && s > m[pitch - 1];
             if (!(ct & 0x80)) ok = ok && s > m[1] && s > m[-pitch + 1] && s > m[pitch + 1];
             if (ok) {
-                q2w[Q2SLOT(i)] = (uint16_t)(ent | 0x8000);
+                q2w[i] = (uint16_t)(ent | 0x8000);
                 if (s >= P.iniTh) atomicAdd(&cellCnt[crn * T.nCells + (ct & 63)], 1);
             }
         }
         __syncthreads();
         for (int i = lane; i < n2w; i += 64) {
-            const int ent = q2w[Q2SLOT(i)];
+            const int ent = q2w[i];
             if (!(ent & 0x8000)) continue;
             const int rx = ent & 255, ry = (ent >> 8) & 127;
             const int cr2 = cellRowOf(ry);
@@ -851,7 +884,6 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         if (gbase + i < L.candCap) out[gbase + i] = elist[i];
     PROF_MARK(0, 6);   // emit
     PROF_FLUSH(0);
-#undef Q2SLOT
 }
 
 // ============================================================================================================

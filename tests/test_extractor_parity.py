@@ -76,11 +76,12 @@ def test_emulated_fast_tile_fallback_path():
 
 def test_emulated_fast_row_group_compaction_path():
     """k_fast fills a wave's pre-test queue once per tile; when a wave's survivors do not fit its queue slice it goes row group by row group.
-    FAST_QCAP=768 shrinks the slice to 256 entries (one row group's worst case), so ordinary tiles take that path too; results must not change."""
+    FAST_FITS_MAX=96 sends every wave with more than 96 survivors that way (each group queues behind the score bytes parked so far), so ordinary
+    tiles take that path too; results must not change."""
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_QCAP=768",), tag="qcap768")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_FITS_MAX=96",), tag="fits96")))
     for case in CASES:
         if case[0] in ("sparse_640x480", "noise_tile_overflow", "euroc_752x480"):
             _run_case(lib, case)
@@ -89,7 +90,7 @@ def test_emulated_fast_row_group_compaction_path():
 def test_emulated_fast_two_cell_row_tiles():
     """Calls with >= 8 frames run k_fast on tiles of two cell rows (score map aliased onto the image tile, one blank map row between the cell rows,
     per-cell retry counters per (cell row, cell)); FAST_TALL_MIN_BATCH=1 sends the single-frame cases through them on the emulator — also combined
-    with the whole-tile fallback (FAST_Q2CAP=48: the in-place score ring) and the row-group compaction (FAST_QCAP=768).  Results must not change."""
+    with the whole-tile fallback (FAST_Q2CAP=48: the in-place score ring) and the row-group compaction (FAST_FITS_MAX=96).  Results must not change."""
     import ctypes
     import build_emu
     from orbhip import _lib
@@ -97,7 +98,7 @@ def test_emulated_fast_two_cell_row_tiles():
     for case in CASES:
         if case[0] in EMU_CASES:
             _run_case(lib, case)
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=48", "FAST_QCAP=768"), tag="tall1_q2cap48_qcap768")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=48", "FAST_FITS_MAX=96"), tag="tall1_q2cap48_fits96")))
     for case in CASES:
         if case[0] in ("sparse_640x480", "noise_tile_overflow", "euroc_752x480"):
             _run_case(lib, case)
