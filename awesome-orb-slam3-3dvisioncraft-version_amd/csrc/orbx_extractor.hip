@@ -325,16 +325,6 @@ struct FastParams {
     int nTiles, batch;                  // tiles per frame, frames: the XCD-aware 1-D grid
 };
 
-// circular 16-bit mask has a run of >= 9 ones
-static __device__ __forceinline__ bool ring_has9(uint32_t m) {
-    uint32_t M = m | (m << 16);
-    uint32_t r = M & (M >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= M >> 8;
-    return (r & 0xFFFFu) != 0;
-}
-
 #define RING16(F)                                                                                         \
     F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3)             \
     F(8, 0, -3) F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
@@ -400,56 +390,6 @@ static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitc
     }
 #undef SWP
     return max(max((int)A.x, (int)A.y), -min((int)B.x, (int)B.y));
-#endif
-}
-
-// The same score when the corner's polarity is known (a FAST-9 corner cannot have both a brighter and a darker 9-arc: 9 + 9 > 16):
-// only the passing side's "max over arcs of min" is needed — the other side's is <= 0 < S.  m = 0: ring brighter than the centre
-// (e = x - v), m = -1: darker (e = ~x - ~v = v - x); one v_xad_u32 per ring pixel.
-static __device__ __forceinline__ int fast_S_pol(const uint8_t* c, const int pitch, const int m) {
-#ifdef HIP_EMULATED
-    const int nv = -((int)c[0] ^ m);
-    int e[16];
-#define LD(k, dx, dy) e[k] = ((int)c[(dy) * pitch + (dx)] ^ m) + nv;
-    RING16(LD)
-#undef LD
-    int lo2[16], lo4[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) lo2[i] = min(e[i], e[(i + 1) & 15]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) lo4[i] = min(lo2[i], lo2[(i + 2) & 15]);
-    int A = -256;
-#pragma unroll
-    for (int i = 0; i < 16; i++) A = max(A, min(min(lo4[i], lo4[(i + 4) & 15]), e[(i + 8) & 15]));
-    return A;
-#else
-    // the same min / max network on packed 16-bit pairs: register i holds ring positions (i, i + 8) — e fits 9 bits —, so one v_pk_min_i16
-    // is two of the scalar mins and the wrap-around neighbours (i + 8 of the last registers = i of the first) are the half swap every packed
-    // instruction has for free (op_sel): 57 instructions per corner instead of 96
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    int x[16];
-#define LD(k, dx, dy) x[k] = c[(dy) * pitch + (dx)];
-    RING16(LD)
-#undef LD
-    const int v = c[0];
-    const short sg = (short)(1 | m), cv = (short)(m ? v : -v);   // e = x * (+1) - v   or   x * (-1) + v: one v_pk_mad per pair
-    const s16x2 S = {sg, sg}, C = {cv, cv};
-    s16x2 P[8], L2[8], L4[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) P[i] = __builtin_bit_cast(s16x2, (uint32_t)x[i] | ((uint32_t)x[i + 8] << 16)) * S + C;
-#define SWP(a) __builtin_shufflevector(a, a, 1, 0)
-#pragma unroll
-    for (int i = 0; i < 8; i++) L2[i] = __builtin_elementwise_min(P[i], i < 7 ? P[(i + 1) & 7] : SWP(P[0]));          // min(e[j], e[j+1]), j = i and i + 8
-#pragma unroll
-    for (int i = 0; i < 8; i++) L4[i] = __builtin_elementwise_min(L2[i], i < 6 ? L2[(i + 2) & 7] : SWP(L2[(i + 2) & 7]));   // min over e[j .. j+3]
-    s16x2 A = {-256, -256};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const s16x2 t = __builtin_elementwise_min(L4[i], i < 4 ? L4[i + 4] : SWP(L4[i - 4]));                          // min over e[j .. j+7]
-        A = __builtin_elementwise_max(A, __builtin_elementwise_min(t, SWP(P[i])));                                      // ... and e[j+8]
-    }
-#undef SWP
-    return max((int)A.x, (int)A.y);
 #endif
 }
 
