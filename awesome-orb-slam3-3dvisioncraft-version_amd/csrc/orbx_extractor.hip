@@ -1,10 +1,11 @@
 // orbx_extractor.hip — stage 1 of the hot path on gfx950: ORBextractor (reference src/ORBextractor.cc).
 //
 // One handle = one (image size, config).  A call processes a batch of independent frames with
-//   k_resize   x (nlevels-1)   E1  ComputePyramid            ORBextractor.cc:1158-1183 (cv::resize INTER_LINEAR, fixed point)
+//   k_resize2  x (nlevels-1)   E1  ComputePyramid            ORBextractor.cc:1158-1183 (cv::resize INTER_LINEAR, fixed point; k_resize for scale factors > 1.3)
 //   k_fast                     E2  per-cell FAST-9/16 + NMS   ORBextractor.cc:763-855   (cv::FAST semantics per 30-px cell ROI)
 //   k_octree                   E3  DistributeOctTree          ORBextractor.cc:537-761   (+ E4/E8 ordering ranks)
-//   k_describe                 E5-E8 IC_Angle, 7x7 blur (patch-local), rBRIEF, output assembly  :75-145, 1093-1155
+//   k_describe2                E5-E8 IC_Angle, 7x7 blur (at the sampled points), rBRIEF, output assembly  :75-145, 1093-1155
+//                              (two key points per wave; k_describe is the one-key-point-per-wave form, -DDESC_KPW=1)
 // All integer/fixed-point work is bit-exact w.r.t. the oracle; float expressions are written so that they
 // round exactly as the reference's (compile with -ffp-contract=off and correctly rounded fp32 division).
 //
@@ -38,7 +39,7 @@ __device__ unsigned long long g_prof[2][8][256];   // [kernel][phase][shard]: sh
 #endif
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:72
 #define ORBX_MINB 16          // EDGE_THRESHOLD-3, ORBextractor.cc:769
-#define FAST_QCAP 2048        // corner queue entries (u16) per chunk
+#define FAST_QCAP 2048        // sizes k_fast's queues: a wave's pre-test queue holds FAST_QCAP / 4 + 64 entries, the staged emit list FAST_QCAP / 2
 #define FAST_MAXCELLS 32
 
 static const int8_t h_pattern[1024] = {
@@ -518,7 +519,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     uint32_t* elist = (uint32_t*)q1;                  // reused after the scoring phase
     uint16_t* q2 = q1 + 4 * FAST_Q1W;
     uint8_t* colTab = (uint8_t*)(q2 + FAST_Q2CAP);    // per detection column: cell | leftEdge<<6 | rightEdge<<7
-    int* sh = (int*)(colTab + FAST_TW);                   // [0],[5]=q1 counts (chunk parity) [1]=emit count [2]=emit base [3]=q2 count [4]=q2 overflow [8..]=cell counts
+    int* sh = (int*)(colTab + FAST_TW);                   // [1]=emit count [2]=emit base [4]=corner-list overflow [8..]=per-cell counts of local maxima >= iniTh
 
     {   // stage the tile, 16 bytes per lane and step: five consecutive aligned dwords of the row (the compiler merges them into dwordx4 +
         // dword) -> four funnel shifts -> one 128-bit LDS store.  ALL global loads of the tile are issued before the first one is consumed
@@ -717,9 +718,9 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    PROF_MARK(0, 3);   // stage 3
+    PROF_MARK(0, 3);   // (stage 3 of earlier builds: the score is stage 2's by-product now)
     __syncthreads();
-    PROF_MARK(0, 4);   // barrier after stage 3
+    PROF_MARK(0, 4);   // barrier: every wave is through with the image tile
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
     if (!overflow) {
