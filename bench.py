@@ -18,6 +18,7 @@ headline line.
 import argparse
 import json
 import os
+import re
 import sys
 import traceback
 import time
@@ -61,13 +62,21 @@ def algorithmic_bytes(W, H, N):
     return whole, per_kernel
 
 
+_C_TOKEN = re.compile(r'"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'|//[^\n]*|/\*.*?\*/', re.S)
+
+
 def source_sha():
-    """sha256 over the kernel sources a PMC pass belongs to (profiles/pmc_latest.json carries the same figure)."""
+    """sha256 over the kernel sources a PMC pass belongs to (profiles/pmc_latest.json carries the same figure).  Comments and white space
+    are taken out first (string / character literals are kept as they are), so a comment-only edit of a kernel file does not orphan the
+    counters that were measured on the same code."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "csrc")
     for f in ("orbx_extractor.hip", "orbm_matcher.hip", "orbf_frame.hip"):
-        h.update(open(os.path.join(d, f), "rb").read())
+        src = open(os.path.join(d, f), "r", encoding="utf-8", errors="replace").read()
+        src = _C_TOKEN.sub(lambda m: " " if m.group(0)[0] == "/" else m.group(0), src)
+        h.update(" ".join(src.split()).encode())
+        h.update(b"\0")
     return h.hexdigest()[:16]
 
 

@@ -75,3 +75,29 @@ def test_bench_cli_parses_without_gpu():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_source_sha_ignores_comments_only(tmp_path, monkeypatch):
+    """profiles/pmc_latest.json is tied to the kernel sources by bench.source_sha(): a comment / white-space edit keeps the tie, a code
+    edit (or an edit inside a string literal) breaks it."""
+    import json
+    import bench
+    d = tmp_path / "awesome-orb-slam3-3dvisioncraft-version_amd" / "csrc"
+    d.mkdir(parents=True)
+    base = 'int f(int a) { return a / 2; }  // halves\nconst char* s = "a // b";\n'
+    for f in ("orbx_extractor.hip", "orbm_matcher.hip", "orbf_frame.hip"):
+        (d / f).write_text(base)
+    real_root = bench.ROOT
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h0 = bench.source_sha()
+    (d / "orbm_matcher.hip").write_text('/* block\n comment */ int f(int a)\n{\n    return a / 2;   // other words\n}\nconst char* s = "a // b";\n')
+    assert bench.source_sha() == h0
+    (d / "orbm_matcher.hip").write_text(base.replace("a / 2", "a / 3"))
+    assert bench.source_sha() != h0
+    (d / "orbm_matcher.hip").write_text(base.replace('"a // b"', '"a // c"'))
+    assert bench.source_sha() != h0
+    monkeypatch.setattr(bench, "ROOT", real_root)
+    pm = json.load(open(os.path.join(real_root, "profiles", "pmc_latest.json")))
+    if pm["source_sha"] != bench.source_sha():   # a kernel under development: bench.py then reports roofline.traffic as null, which is the honest line
+        import warnings
+        warnings.warn("profiles/pmc_latest.json belongs to other kernel sources: re-run tools/gpu_profile.sh + tools/summarize_prof.py")
