@@ -354,44 +354,52 @@ static __device__ __forceinline__ int fast_S(const uint8_t* c, int pitch) {
     return max(A, -B);
 }
 
-// fast_S on packed 16-bit pairs (device builds): register i holds d = v - x of ring positions (i, i + 8); the min network gives the darker-ring
-// score A = max over arcs of min(d), the max network the brighter-ring one -B = -min over arcs of max(d); wrap-around neighbours are the half
-// swap every packed instruction has for free (op_sel).  ~100 instructions for BOTH polarities (the scalar form above: ~190).
-static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitch) {
+// Two 16-bit lanes per register.  Device builds: clang vector types (v_pk_min_u16 / v_pk_max_u16, the half swap is the op_sel every packed
+// instruction has for free); the emulator: the same operations written out, so that the CPU tier runs fast_S_pk's logic as it stands.
 #ifdef HIP_EMULATED
-    return fast_S(c, pitch);
+struct pk16 { uint16_t x, y; };
+static inline pk16 pk_from(uint32_t u) { return pk16{(uint16_t)u, (uint16_t)(u >> 16)}; }
+static inline pk16 pk_min(pk16 a, pk16 b) { return pk16{a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y}; }
+static inline pk16 pk_max(pk16 a, pk16 b) { return pk16{a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y}; }
+static inline pk16 pk_swp(pk16 a) { return pk16{a.y, a.x}; }
 #else
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    int x[16];
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ pk16 pk_from(uint32_t u) { return __builtin_bit_cast(pk16, u); }
+static __device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+static __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+static __device__ __forceinline__ pk16 pk_swp(pk16 a) { return __builtin_shufflevector(a, a, 1, 0); }
+#endif
+
+// fast_S for the pixels that are candidates: S exact where S > 0, some value <= 0 where fast_S is <= 0 (nobody looks at those: thresholds are >= 0).
+// Ring positions (i, i + 8) share a register.  ONE polarity is evaluated, the only one that can hold a 9-arc: G = 255 + x - v per 16-bit lane
+// (one 32-bit add on the pair: no carry leaves a lane) has (x > v) as its second byte, a v_dot4 per register counts them, and a 9-arc of brighter
+// ring pixels needs nine of them — with fewer, only a darker arc can exist (both polarities would need 18 ring pixels), and 511 - G = G ^ 0x1FF =
+// 256 + v - x is that polarity on the same min network: max over the sixteen arcs of the minimum of nine.  ~80 instructions (both networks: ~100).
+static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitch) {
+    uint32_t x[16];
 #define LD(k, dx, dy) x[k] = c[(dy) * pitch + (dx)];
     RING16(LD)
 #undef LD
-    const short v = (short)c[0];
-    const s16x2 V = {v, v};
-    s16x2 P[8], L2[8], L4[8], H2[8], H4[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) P[i] = V - __builtin_bit_cast(s16x2, (uint32_t)x[i] | ((uint32_t)x[i + 8] << 16));
-#define SWP(a) __builtin_shufflevector(a, a, 1, 0)
+    const uint32_t C = (255u - (uint32_t)c[0]) * 0x00010001u;
+    uint32_t G[8], nB = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const s16x2 nx = i < 7 ? P[(i + 1) & 7] : SWP(P[0]);
-        L2[i] = __builtin_elementwise_min(P[i], nx); H2[i] = __builtin_elementwise_max(P[i], nx);
+        G[i] = (x[i] | (x[i + 8] << 16)) + C;
+        nB = __builtin_amdgcn_udot4(G[i], 0x01000100u, nB, false);
     }
+    const bool bright = nB >= 9;
+    const uint32_t flip = bright ? 0u : 0x01FF01FFu;
+    pk16 P[8], L2[8], L4[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        L4[i] = __builtin_elementwise_min(L2[i], i < 6 ? L2[(i + 2) & 7] : SWP(L2[(i + 2) & 7]));
-        H4[i] = __builtin_elementwise_max(H2[i], i < 6 ? H2[(i + 2) & 7] : SWP(H2[(i + 2) & 7]));
-    }
-    s16x2 A = {-256, -256}, B = {256, 256};
+    for (int i = 0; i < 8; i++) P[i] = pk_from(G[i] ^ flip);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const s16x2 o = SWP(P[i]);   // e[j + 8]
-        A = __builtin_elementwise_max(A, __builtin_elementwise_min(__builtin_elementwise_min(L4[i], i < 4 ? L4[i + 4] : SWP(L4[i - 4])), o));
-        B = __builtin_elementwise_min(B, __builtin_elementwise_max(__builtin_elementwise_max(H4[i], i < 4 ? H4[i + 4] : SWP(H4[i - 4])), o));
-    }
-#undef SWP
-    return max(max((int)A.x, (int)A.y), -min((int)B.x, (int)B.y));
-#endif
+    for (int i = 0; i < 8; i++) L2[i] = pk_min(P[i], i < 7 ? P[(i + 1) & 7] : pk_swp(P[0]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) L4[i] = pk_min(L2[i], i < 6 ? L2[(i + 2) & 7] : pk_swp(L2[(i + 2) & 7]));
+    pk16 A = pk_from(0u);
+#pragma unroll
+    for (int i = 0; i < 8; i++) A = pk_max(A, pk_min(pk_min(L4[i], i < 4 ? L4[i + 4] : pk_swp(L4[i - 4])), pk_swp(P[i])));   // pk_swp(P[i]) = ring position j + 8
+    return (int)max((uint32_t)A.x, (uint32_t)A.y) - (bright ? 255 : 256);
 }
 
 // inclusive prefix sum over the 64 lanes of a wave, register-only: four row_shr steps inside each row of 16 lanes, then the two DPP row
