@@ -374,7 +374,8 @@ static __device__ __forceinline__ pk16 pk_swp(pk16 a) { return __builtin_shuffle
 // Ring positions (i, i + 8) share a register.  ONE polarity is evaluated, the only one that can hold a 9-arc: G = 255 + x - v per 16-bit lane
 // (one 32-bit add on the pair: no carry leaves a lane) has (x > v) as its second byte, a v_dot4 per register counts them, and a 9-arc of brighter
 // ring pixels needs nine of them — with fewer, only a darker arc can exist (both polarities would need 18 ring pixels), and 511 - G = G ^ 0x1FF =
-// 256 + v - x is that polarity on the same min network: max over the sixteen arcs of the minimum of nine.  ~80 instructions (both networks: ~100).
+// 256 + v - x is that polarity on the same min network: max over the sixteen arcs of the minimum of nine.  ~70 instructions (both polarities on the
+// doubling network of rounds 2-3: ~100).
 static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitch) {
     uint32_t x[16];
 #define LD(k, dx, dy) x[k] = c[(dy) * pitch + (dx)];
@@ -389,16 +390,18 @@ static __device__ __forceinline__ int fast_S_pk(const uint8_t* c, const int pitc
     }
     const bool bright = nB >= 9;
     const uint32_t flip = bright ? 0u : 0x01FF01FFu;
-    pk16 P[8], L2[8], L4[8];
+    // The sixteen arc minima by running minima (van Herk / Gil-Werman): the low lanes are ring positions 0-7, the high lanes 8-15, and the arc that
+    // starts at position j is [j..7] of its own block (a suffix minimum) followed by [0..j] of the other block (a prefix minimum, half-swapped):
+    // 7 + 7 + 8 packed minima and 7 maxima (the doubling network L2 / L4 / L8 + one took 32 + 8).
+    pk16 pre[8], suf[8];
+    pre[0] = pk_from(G[0] ^ flip); suf[7] = pk_from(G[7] ^ flip);
 #pragma unroll
-    for (int i = 0; i < 8; i++) P[i] = pk_from(G[i] ^ flip);
+    for (int i = 1; i < 8; i++) pre[i] = pk_min(pre[i - 1], pk_from(G[i] ^ flip));
 #pragma unroll
-    for (int i = 0; i < 8; i++) L2[i] = pk_min(P[i], i < 7 ? P[(i + 1) & 7] : pk_swp(P[0]));
+    for (int i = 6; i >= 0; i--) suf[i] = pk_min(suf[i + 1], pk_from(G[i] ^ flip));
+    pk16 A = pk_min(suf[0], pk_swp(pre[0]));
 #pragma unroll
-    for (int i = 0; i < 8; i++) L4[i] = pk_min(L2[i], i < 6 ? L2[(i + 2) & 7] : pk_swp(L2[(i + 2) & 7]));
-    pk16 A = pk_from(0u);
-#pragma unroll
-    for (int i = 0; i < 8; i++) A = pk_max(A, pk_min(pk_min(L4[i], i < 4 ? L4[i + 4] : pk_swp(L4[i - 4])), pk_swp(P[i])));   // pk_swp(P[i]) = ring position j + 8
+    for (int i = 1; i < 8; i++) A = pk_max(A, pk_min(suf[i], pk_swp(pre[i])));
     return (int)max((uint32_t)A.x, (uint32_t)A.y) - (bright ? 255 : 256);
 }
 
