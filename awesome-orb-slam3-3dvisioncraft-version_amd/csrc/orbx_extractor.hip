@@ -324,6 +324,7 @@ struct FastParams {
     int iniTh, minTh;
     int imgBytes;                       // LDS bytes reserved for the image tile (== score-map bytes)
     int nTiles, batch;                  // tiles per frame, frames: the XCD-aware 1-D grid
+    uint32_t* retry;                    // [0] tiles listed, then {tile | frame << 16, mask of its cells to detect again: bit 16 * cell row + cell}
 };
 
 #define RING16(F)                                                                                         \
@@ -451,6 +452,9 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 #ifndef FAST_TALL_MIN_BATCH
 #define FAST_TALL_MIN_BATCH 8     // frames per call from which the two-cell-row tiles are used
 #endif
+#ifndef FAST_TWO_PASS
+#define FAST_TWO_PASS 1   // 1: batches detect at iniThFAST first and only the tiles with an empty cell again at min(ini, min) (k_fast, second launch)
+#endif
 #ifndef FAST_FITS_MAX
 #define FAST_FITS_MAX (FAST_QCAP / 4 + 64)   // survivors a wave queues in one go (tests build with a small value to send ordinary tiles row group by row group)
 #endif
@@ -478,6 +482,7 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+template <int PASS>   // 0: first pass at iniThFAST, 1: the listed tiles at min(ini, min), 2: one pass at min(ini, min) (see below)
 static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -494,9 +499,43 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     int frame, tileIdx;
     if (!xcd_frame_unit(P.nTiles, P.batch, &frame, &tileIdx)) return;
     const FastTile T = FAST_TILE_AT(tileIdx);
+    const uint32_t emitMask = 0xFFFFFFFFu;   // (one pass only in this mapping)
 #else
-    const FastTile T = FAST_TILE_AT(blockIdx.x);
-    const int frame = blockIdx.y;
+    // Two thresholds, two launches (PASS).  The reference runs cv::FAST at iniThFAST on every cell and again at minThFAST only on the cells that came
+    // back empty (ORBextractor.cc:812-828).  Detecting at the lower threshold and filtering by score gives the same key points ("FAST as set
+    // algebra") but scores every corner between the two thresholds for nothing wherever iniThFAST finds something: on the benchmark's frames 98 % of
+    // the cells, while 35 % of the pre-test's survivors and 41 % of the corners at 7 are below 20.  Pass 0 therefore detects at iniThFAST and emits what it
+    // finds — final for every cell that holds a local maximum — and a tile with cells that hold none (flat ones; a third of the benchmark's level-0
+    // tiles have one) lists itself with their mask; a tile whose corner list overflows lists all of its cells and emits nothing.  Pass 1 (the same grid,
+    // launched behind pass 0) takes a listed tile at min(ini, min) exactly as the one-pass form (pass 2) does — as a one-cell tile if one cell is
+    // asked for — and reports the listed cells only.
+    int tileIdx = blockIdx.x, frame = blockIdx.y;
+    FastTile T;
+    uint32_t emitMask = 0xFFFFFFFFu;   // cells (bit 16 * cell row + cell) this workgroup reports
+    if (PASS == 1) {
+        // The retry list is read through the scalar cache, like the tile record: most workgroups of this launch only find out that they have nothing
+        // to do, and each holds its slot for as long as that takes.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+        const uint32_t __attribute__((address_space(4)))* rl = (const uint32_t __attribute__((address_space(4)))*)(unsigned long long)P.retry;
+#else
+        const uint32_t* rl = P.retry;
+#endif
+        const int id = blockIdx.x + gridDim.x * blockIdx.y;
+        if (id >= (int)rl[0]) return;
+        const uint32_t e = rl[2 + 2 * id];
+        emitMask = rl[3 + 2 * id];
+        tileIdx = (int)(e & 0xFFFFu); frame = (int)(e >> 16);
+        T = FAST_TILE_AT(tileIdx);
+        if (__popc(emitMask) == 1) {   // one empty cell (the usual case): a tile of its own
+            const int b = __ffs((int)emitMask) - 1;
+            T.level = (short)((T.level & 0xFF) | 0x100); T.cellRow = (short)(T.cellRow + (b >> 4)); T.cell0 = (short)(T.cell0 + (b & 15)); T.nCells = 1;
+            emitMask = 1u;
+        }
+    } else {
+        T = FAST_TILE_AT(tileIdx);
+    }
+    frame = __builtin_amdgcn_readfirstlane(frame);
+    emitMask = (uint32_t)__builtin_amdgcn_readfirstlane((int)emitMask);
 #endif
 #undef FAST_TILE_AT
     const int level = T.level & 0xFF, nCR = (int)T.level >> 8;   // the tile covers nCR whole cell rows, T.cellRow the first
@@ -618,7 +657,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     __syncthreads();
     PROF_MARK(0, 1);   // staging wait
 
-    const int t0 = min(P.iniTh, P.minTh);
+    const int t0 = PASS == 0 ? P.iniTh : min(P.iniTh, P.minTh);
     // Stages 1-3 are wave-private: wave w owns the detection rows 2w, 2w+1 (mod 8), compacts its own survivors and corners into its own
     // slices of q1 / q2 and scores them itself -> no workgroup barrier and no LDS atomic until NMS.
     const int wave = tid >> 6;
@@ -631,6 +670,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     static_assert(FAST_Q2CAP / 4 <= 2 * FAST_Q1W, "a wave's scores are parked in its q1 slice");
     static_assert((FAST_Q2CAP / 4 + 1) / 2 + 256 <= FAST_Q1W && FAST_FITS_MAX <= FAST_Q1W, "a row group (<= 256 survivors) queues behind the parked scores");
     static_assert(4 * FAST_PITCH <= 4 * FAST_Q1W * 2, "the fallback's four-row score ring lives in the q1 region");
+    static_assert(FAST_CROWS <= 2 && FAST_MAXCELLS / FAST_CROWS <= 16, "a tile's cells are bit 16 * cell row + cell of a 32-bit mask (retry list)");
     int n2w = 0;                                        // corners of this wave (wave-uniform)
     bool ovf = false;
     // stage 2 of one batch of 64 queue entries: the EXACT score decides (S > t <=> FAST-9 corner at threshold t, S - 1 is cv's score) and is kept —
@@ -734,6 +774,12 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     PROF_MARK(0, 4);   // barrier: every wave is through with the image tile
     const bool overflow = sh[4] != 0;
     int* cellCnt = sh + 8;
+    auto retry_later = [&](const uint32_t cells) {   // (thread 0) these cells again in pass 1
+        const uint32_t i = atomicAdd(P.retry, 1u);
+        P.retry[2 + 2 * i] = (uint32_t)tileIdx | ((uint32_t)frame << 16);
+        P.retry[3 + 2 * i] = cells;
+    };
+    if (overflow && PASS == 0) { if (tid == 0) retry_later(0xFFFFFFFFu); PROF_FLUSH(0); return; }   // more corners at iniThFAST than the lists hold: the second pass has the fallback
     if (!overflow) {
         for (int i = tid; i < (P.imgBytes >> 4); i += 256) ((uint4*)smap)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
@@ -760,14 +806,23 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             }
         }
         __syncthreads();
+        if (PASS == 0) {   // first pass: the cells (with pixels) that hold no local maximum — all of them are >= iniThFAST here — go on the list
+            const int ncx = min((int)T.nCells, (int)(mul24((uint32_t)(detW + L.wCell - 1), (uint32_t)L.wCellMagic) >> 16));
+            uint32_t emptyCells = 0;
+            for (int cr = 0; cr < nCR; cr++)
+                if (cr * L.hCell < detH)
+                    for (int c = 0; c < ncx; c++) emptyCells |= cellCnt[cr * T.nCells + c] > 0 ? 0u : 1u << (16 * cr + c);
+            if (emptyCells && tid == 0) retry_later(emptyCells);
+        }
         for (int i = lane; i < n2w; i += 64) {
             const int ent = q2w[i];
             if (!(ent & 0x8000)) continue;
             const int rx = ent & 255, ry = (ent >> 8) & 127;
             const int cr2 = cellRowOf(ry);
             const int s = smap[(dy0 + ry + cr2) * pitch + dx0 + rx];
-            const int Tth = cellCnt[cr2 * T.nCells + (colTab[rx] & 63)] > 0 ? P.iniTh : P.minTh;   // per-cell retry, ORBextractor.cc:825-828
-            if (s >= Tth) {
+            const int cell2 = colTab[rx] & 63;
+            const int Tth = cellCnt[cr2 * T.nCells + cell2] > 0 ? P.iniTh : P.minTh;   // per-cell retry, ORBextractor.cc:825-828
+            if (s >= Tth && (emitMask >> (16 * cr2 + cell2) & 1u)) {
                 // coordinates relative to minBorder, as vToDistributeKeys holds them (ORBextractor.cc:845-850)
                 const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
                 const uint32_t packed = xr | (yr << 12) | ((uint32_t)s << 24);
@@ -813,7 +868,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
                     if (s >= P.iniTh) atomicAdd(&cellCnt[cr * T.nCells + (ct & 63)], 1);
                 } else {
                     const int Tth = cellCnt[cr * T.nCells + (ct & 63)] > 0 ? P.iniTh : P.minTh;
-                    if (s >= Tth) {
+                    if (s >= Tth && (emitMask >> (16 * cr + (ct & 63)) & 1u)) {
                         const uint32_t xr = (uint32_t)(xal + dx0 + rx - ORBX_MINB), yr = (uint32_t)(iniY + dy0 + ry - ORBX_MINB);
                         const int g = atomicAdd(P.candCount + (size_t)frame * P.nlevels + level, 1);
                         if (g < L.candCap) P.cand[(size_t)frame * P.candFrame + L.candOff + g] = xr | (yr << 12) | ((uint32_t)s << 24);
@@ -2129,7 +2184,7 @@ struct orbx_extractor {
     size_t tileTabOff[ORBX_MAX_LEVELS] = {0};                        // k_resize2 staging footprints of every level >= 1 (inside d_coef)
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
-    FastTile* d_tiles = nullptr;
+    FastTile* d_tiles = nullptr; uint32_t* d_retry = nullptr;
     // single-image staging
     uint8_t* d_img = nullptr; int imgStride = 0; orb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int32_t* d_counts1 = nullptr;
     // single-frame host call: the three outputs share ONE device block ([counts | keypoints | descriptors]; the pointers above point into it) so that
@@ -2170,7 +2225,7 @@ static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* bufs[] = {h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
-                    h->d_lapCount, h->d_tiles, h->d_img, h->d_out1};
+                    h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_out) (void)hipHostFree(h->h_out);
@@ -2333,6 +2388,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_cand, B * h->candFrame * 4));
     CK(hipMalloc((void**)&h->d_keyNode, B * h->candFrame * 2));
     CK(hipMalloc((void**)&h->d_candCount, B * nl * 4));
+    CK(hipMalloc((void**)&h->d_retry, ((size_t)B * tiles.size() * 2 + 2) * 4));   // k_fast's retry list: count, then two words per (frame, two-row tile) at most
     CK(hipMalloc((void**)&h->d_sel, B * h->selFrame * 4));
     CK(hipMalloc((void**)&h->d_selAux, B * h->selFrame * 4));
     // (+ ORBX_MAX_LEVELS entries: k_describe reads a frame's counts as one fixed-size block, whatever nlevels is)
@@ -2448,11 +2504,18 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         F.tiles = tall ? h->d_tiles : h->d_tiles + h->nTiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
         F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
         F.imgBytes = h->fastImgBytes;
-        F.nTiles = nTiles; F.batch = batch;
+        F.nTiles = nTiles; F.batch = batch; F.retry = h->d_retry;
 #if FAST_XCD
-        hipLaunchKernelGGL(k_fast, dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
+        hipLaunchKernelGGL((k_fast<2>), dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
-        hipLaunchKernelGGL(k_fast, dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+        // two passes for batches (the same frame count from which the two-row tiles are used: a single frame wants one short launch, not two)
+        if (FAST_TWO_PASS && tall && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535) {
+            HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
+            hipLaunchKernelGGL((k_fast<0>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+            hipLaunchKernelGGL((k_fast<1>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+        } else {
+            hipLaunchKernelGGL((k_fast<2>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+        }
 #endif
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[2], st));

@@ -265,6 +265,7 @@ inline emu_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_v4
     return c;
 }
 inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l, 64); }   // lane index must be wave-uniform
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // the kernels use it on wave-uniform values only (to tell the compiler so)
 // v_mov_b32_dpp as __builtin_amdgcn_update_dpp: the controls the kernels use — row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
 // A lane whose row / bank is masked out, or whose source lane lies outside its row, keeps `old` (bound_ctrl = false) or gets 0 (true).
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
