@@ -761,6 +761,10 @@ def main():
                          # SIMDs issue VALU back to back: the kernel is instruction-issue bound and its HBM fraction follows from its instruction count)
                          "occupancy_and_issue": sq_info or None,
                          "algorithmic_bytes_per_launch": pk[dom] * B, "kernel_ms": round(kern[dom], 4),
+                         # a batch runs k_fast as two launches — instance <0> detects at iniThFAST, instance <1> again the cells that came back empty
+                         # (ORBextractor.cc:812-828) —, pyramid = the 7 k_resize2 launches: kernel_ms, the rocprofv3 figure (profiles/*_kernel_stats.csv,
+                         # "sum of instances per batch") and traffic are per batch = the sum over the stage's launches
+                         "launches_per_batch": {"k_fast": "k_fast<0> + k_fast<1>", "k_resize2": 7}.get(names[dom], 1),
                          "whole_step_algorithmic_bytes_per_frame": whole_ext + whole_match,
                          "whole_step_frac": round((whole_ext + whole_match) * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                          "whole_extract_frac": round(whole_ext * fps_extract / world / 1e9 / HBM_PEAK_GBS, 5),

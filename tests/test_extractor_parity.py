@@ -104,6 +104,29 @@ def test_emulated_fast_two_cell_row_tiles():
             _run_case(lib, case)
 
 
+def test_emulated_fast_two_threshold_passes():
+    """Batches run k_fast twice: instance <0> detects at iniThFAST and lists, per tile, the cells that hold no local maximum; instance <1> detects the
+    listed cells again at min(ini, min) — as a one-cell tile when one cell is listed, else the whole tile reporting the listed cells only.
+    FAST_TALL_MIN_BATCH=1 sends single frames that way on the emulator; a corner list of 192 / 96 entries makes tiles that pass at 20 overflow at 7
+    (the in-place fallback under a partial cell mask) or overflow already at 20 (every cell listed, nothing emitted by the first pass).  Thresholds
+    20/7 (the reference's), 40/5 (many empty cells) and 7/7, 5/9 (ini <= min: one pass).  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    imgs = [synth_image(31, 400, 300, n_rect=25, n_disc=10, noise=1.0), synth_image(32, 333, 251, n_rect=120, n_disc=60, noise=3.0, contrast=0.5)]
+    for defines, tag in ((("FAST_TALL_MIN_BATCH=1",), "tall1"), (("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=192"), "tall1_q2cap192"),
+                         (("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=96"), "tall1_q2cap96")):
+        lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=defines, tag=tag)))
+        for ini, mn in ((20, 7), (40, 5), (7, 7), (5, 9)):
+            for img in imgs:
+                o = O.OrbOracle(500, 1.2, 6, ini, mn)
+                mono, k, d = o.extract(img)
+                e = orbhip.ORBextractor(500, 1.2, 6, ini, mn, lib=lib)
+                m2, k2, d2 = e(img)
+                assert m2 == mono and len(k) == len(k2), (tag, ini, mn, len(k), len(k2))
+                assert np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2), (tag, ini, mn)
+
+
 def test_emulated_octree_lds_key_cache_path():
     """The octree keeps a level's candidates in an LDS cache for small batches (OCT_KEYCAP keys; bigger levels and big batches read them from
     global memory).  A 1500-key cache is hit by the small levels and missed by the big ones, so both paths run inside one extraction.

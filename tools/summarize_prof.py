@@ -10,6 +10,15 @@ import os
 import sqlite3
 import sys
 
+import re
+
+
+def base(name):
+    """'void k_fast<0>(FastParams)' -> 'k_fast': the instances of a template kernel (k_fast's two passes run once per batch each) are summed per batch"""
+    b = re.sub(r"^void\s+", "", name).split("(")[0]
+    return re.sub(r"<.*>$", "", b) if b.startswith("k_") else name.split("(")[0]   # (this library's kernels only)
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
@@ -20,8 +29,14 @@ c = sqlite3.connect(os.path.join(src, "stats", "trace_results.db"))
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --streams 1  (durations in us)\n")
     f.write("kernel,calls,total_us,average_us,percentage\n")
+    inst = {}
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         f.write("%s,%d,%.1f,%.3f,%.2f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
+        inst.setdefault(base(r[0]), []).append(r)
+    for b, rs in inst.items():
+        if len(rs) > 1:   # a template kernel's instances, once per batch each: the stage is their sum
+            calls = max(r[1] for r in rs)
+            f.write("%s (sum of %d instances per batch),%d,%.1f,%.3f,%.2f\n" % (b, len(rs), calls, sum(r[2] for r in rs), sum(r[2] for r in rs) / calls, sum(r[4] for r in rs)))
     f.write("# launch geometry / registers (first dispatch of each kernel)\n")
     f.write("kernel,grid,workgroup,lds_bytes,vgpr,sgpr\n")
     for r in c.execute("select name,grid_x,grid_y,grid_z,workgroup_x,lds_size,vgpr_count,sgpr_count from kernels group by name"):
@@ -34,7 +49,7 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
         d = sqlite3.connect(os.path.join(src, kind, "pmc_results.db"))
         for name, ctr, n, mean in d.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection group by kernel_name,counter_name"):
             f.write("%s,%s,%d,%.1f\n" % (name.replace(",", ";"), ctr, n, mean))
-            pmc.setdefault(name.split("(")[0], {})[ctr] = mean * 1024.0
+            pmc.setdefault(base(name), {})[ctr] = pmc.get(base(name), {}).get(ctr, 0.0) + mean * 1024.0
 out = {"tag": tag, "note": "bytes per launch; FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide coalesced reads "
        "(MI355X_MICROARCH.md §HBM): 'corrected' doubles the read side; other widths are uncalibrated, so raw <= true <= corrected",
        "kernels": {}}
@@ -55,10 +70,12 @@ for kind in ("sq1", "sq2"):
         continue
     d = sqlite3.connect(fdb)
     for name, ctr, n, mean in d.execute("select kernel_name,counter_name,count(*),avg(value) from counters_collection group by kernel_name,counter_name"):
-        if name.startswith("k_"):
-            sq.setdefault(name.split("(")[0], {})[ctr] = mean
+        if base(name).startswith("k_"):
+            sq.setdefault(base(name), {})[ctr] = sq.get(base(name), {}).get(ctr, 0.0) + mean
 if sq:
-    dur = {r[0].split("(")[0]: r[1] for r in c.execute("select name,average from top_kernels")}
+    dur = {}
+    for r in c.execute("select name,average from top_kernels"):
+        dur[base(r[0])] = dur.get(base(r[0]), 0.0) + r[1]
     cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
             "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY",
             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
