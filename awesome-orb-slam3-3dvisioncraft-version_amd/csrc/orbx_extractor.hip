@@ -455,6 +455,12 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 #ifndef FAST_TWO_PASS
 #define FAST_TWO_PASS 1   // 1: batches detect at iniThFAST first and only the tiles with an empty cell again at min(ini, min) (k_fast, second launch)
 #endif
+#ifndef FAST_TWO_PASS_MAX_LISTED
+#define FAST_TWO_PASS_MAX_LISTED 0.22   // listed share of the tiles up to which the two passes are kept (measured: -9 % of k_fast at 0.14, +15 % at 0.42)
+#endif
+#ifndef FAST_PROBE_EVERY
+#define FAST_PROBE_EVERY 16         // calls between two-pass probes while a handle runs one pass
+#endif
 #ifndef FAST_FITS_MAX
 #define FAST_FITS_MAX (FAST_QCAP / 4 + 64)   // survivors a wave queues in one go (tests build with a small value to send ordinary tiles row group by row group)
 #endif
@@ -526,10 +532,18 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         emitMask = rl[3 + 2 * id];
         tileIdx = (int)(e & 0xFFFFu); frame = (int)(e >> 16);
         T = FAST_TILE_AT(tileIdx);
-        if (__popc(emitMask) == 1) {   // one empty cell (the usual case): a tile of its own
-            const int b = __ffs((int)emitMask) - 1;
-            T.level = (short)((T.level & 0xFF) | 0x100); T.cellRow = (short)(T.cellRow + (b >> 4)); T.cell0 = (short)(T.cell0 + (b & 15)); T.nCells = 1;
-            emitMask = 1u;
+        if (emitMask != 0xFFFFFFFFu) {   // (all ones: the first pass's corner list overflowed, the whole tile again)
+            // the tile shrinks to the bounding box of the listed cells — one cell in the usual case —, and inside the box the pre-test below looks at
+            // the listed cells' columns only: what the second pass costs follows the area that came back empty, not the tile
+            uint32_t r0 = emitMask & 0xFFFFu, r1 = emitMask >> 16;
+            int rows = (int)T.level >> 8;
+            if (r1 == 0) rows = 1;
+            else if (r0 == 0) { T.cellRow = (short)(T.cellRow + 1); rows = 1; r0 = r1; r1 = 0; }
+            const uint32_t u = r0 | r1;
+            const int cmin = __ffs((int)u) - 1, cmax = 31 - __clz((int)u);
+            T.cell0 = (short)(T.cell0 + cmin); T.nCells = (short)(cmax - cmin + 1);
+            T.level = (short)((T.level & 0xFF) | (rows << 8));
+            emitMask = (r0 >> cmin) | ((r1 >> cmin) << 16);
         }
     } else {
         T = FAST_TILE_AT(tileIdx);
@@ -709,6 +723,16 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
     //      Lane (rsub, dcol) of wave w takes the dword dcol of the rows 2w + rsub + 8k, k = 0 .. 7 (a tile has <= 64 detection rows).
     const int K = (detH + 7) >> 3;
     uint32_t mask = 0;   // bit 8*t + k: column 4*dcol + t of row 2*wave + rsub + 8k passed
+    uint32_t colMask[FAST_CROWS];   // second pass: bit 7 of byte t = column 4*dcol + t belongs to a listed cell of that cell row
+    if (PASS == 1) {
+#pragma unroll
+        for (int cr = 0; cr < FAST_CROWS; cr++) {
+            colMask[cr] = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                colMask[cr] |= (emitMask >> (16 * cr + (colTab[min(4 * dcol + t, detW - 1)] & 63)) & 1u) << (8 * t + 7);
+        }
+    }
     for (int k = 0; k < K; k++) {
         const int ry = 8 * k + 2 * wave + rsub;
         if (ry < detH && 4 * dcol < detW) {
@@ -731,6 +755,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             PAIR(false, __builtin_amdgcn_alignbyte(A2, A1, 2), __builtin_amdgcn_alignbyte(B1, B0, 2))               // 6 (2, -2) and 14 (-2, 2)
 #undef PAIR
             uint32_t bits = (accB | ~accG) & 0x80808080u;
+            if (PASS == 1) bits &= colMask[cellRowOf(ry)];
             const int nvalid = detW - 4 * dcol;                             // columns of this dword inside the detection region
             if (nvalid < 4) bits &= (1u << (8 * nvalid)) - 1u;
             mask |= bits >> (7 - k);
@@ -2185,6 +2210,8 @@ struct orbx_extractor {
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
     FastTile* d_tiles = nullptr; uint32_t* d_retry = nullptr;
+    uint32_t* h_retry = nullptr;   // pinned: [0] tiles the last two-pass FAST call listed for its second pass (copied back asynchronously), [1] tiles of that call
+    uint32_t fastCalls = 0; int fastLastTwoPass = 0;
     // single-image staging
     uint8_t* d_img = nullptr; int imgStride = 0; orb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int32_t* d_counts1 = nullptr;
     // single-frame host call: the three outputs share ONE device block ([counts | keypoints | descriptors]; the pointers above point into it) so that
@@ -2228,6 +2255,7 @@ static void orbx_free(orbx_extractor* h) {
                     h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
+    if (h->h_retry) (void)hipHostFree(h->h_retry);
     if (h->h_out) (void)hipHostFree(h->h_out);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
@@ -2407,6 +2435,8 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_out1, h->out1Bytes));
     h->d_counts1 = (int32_t*)h->d_out1; h->d_kps1 = (orb_keypoint*)(h->d_out1 + h->kps1Off); h->d_desc1 = h->d_out1 + h->desc1Off;
     CK(hipHostMalloc((void**)&h->h_img, (size_t)h->imgStride * height, hipHostMallocDefault));
+    CK(hipHostMalloc((void**)&h->h_retry, 8, hipHostMallocDefault));
+    h->h_retry[0] = 0; h->h_retry[1] = 1;
     CK(hipHostMalloc((void**)&h->h_out, h->out1Bytes, hipHostMallocDefault));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
     {
@@ -2508,11 +2538,28 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #if FAST_XCD
         hipLaunchKernelGGL((k_fast<2>), dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
-        // two passes for batches (the same frame count from which the two-row tiles are used: a single frame wants one short launch, not two)
-        if (FAST_TWO_PASS && tall && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535) {
+        // Two passes for batches (the same frame count from which the two-row tiles are used: a single frame wants one short launch, not two) — while
+        // they pay.  Both forms give the same key points; which is faster depends on the frames: the first pass saves the corners between the two
+        // thresholds, every listed tile pays staging and pre-test a second time.  On the benchmark's frames 13 % of the tiles are listed (k_fast
+        // 0.70 -> 0.63 ms per 512 frames), on sparsely textured ones (the same synthetic scene at 1280x720) most are (0.78 -> 0.90 ms).  The listed
+        // share of the handle's previous two-pass call (copied back asynchronously, read here without waiting: a stale figure only delays the
+        // switch) decides; in one-pass mode every FAST_PROBE_EVERY-th call takes the two passes to measure again.
+        bool two = FAST_TWO_PASS && tall && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535;
+        if (two) {
+            const volatile uint32_t* hr = h->h_retry;
+            const bool pays = (double)hr[0] <= FAST_TWO_PASS_MAX_LISTED * (double)hr[1];
+            two = pays || (h->fastCalls % FAST_PROBE_EVERY) == 0;
+            h->fastCalls++;
+        }
+        h->fastLastTwoPass = two;
+        if (two) {
             HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
             hipLaunchKernelGGL((k_fast<0>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
             hipLaunchKernelGGL((k_fast<1>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+            if (!h->capturing) {
+                h->h_retry[1] = (uint32_t)nTiles * (uint32_t)batch;
+                HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 4, hipMemcpyDeviceToHost, st));
+            }
         } else {
             hipLaunchKernelGGL((k_fast<2>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
         }
@@ -2729,6 +2776,15 @@ extern "C" int orbx_debug_prof(unsigned long long* out32, int clear) {
     return ORB_OK;
 }
 #endif
+
+extern "C" int orbx_last_fast_passes(orbx_handle h, int* two_pass, uint32_t* listed, uint32_t* tiles) {
+    if (!h) return ORB_E_INVALID;
+    const volatile uint32_t* hr = h->h_retry;
+    if (two_pass) *two_pass = h->fastLastTwoPass;
+    if (listed) *listed = hr[0];
+    if (tiles) *tiles = hr[1];
+    return ORB_OK;
+}
 
 extern "C" int orbx_last_timing(orbx_handle h, float* ms5) {
     if (!h || !ms5 || !h->timed) return ORB_E_INVALID;

@@ -94,6 +94,13 @@ class ORBextractor:
         self._check(self._L.orbx_last_timing(self._h, ptr(ms)))
         return dict(pyramid=float(ms[0]), fast=float(ms[1]), octree=float(ms[2]), describe=float(ms[3]), total=float(ms[4]))
 
+    def last_fast_passes(self):
+        """How the last batch call ran FAST (orbhip.h: orbx_last_fast_passes): dict(two_pass, listed, tiles) — a scheduling detail, never the result."""
+        v = np.zeros(3, np.uint32)
+        a = v.ctypes.data
+        self._check(self._L.orbx_last_fast_passes(self._h, C.c_void_p(a), C.c_void_p(a + 4), C.c_void_p(a + 8)))
+        return dict(two_pass=int(v[0]), listed=int(v[1]), tiles=int(v[2]))
+
     # -- getters, ORBextractor.h:61-81
     def _tables(self):
         W, H = self._size if self._size else (752, 480)

@@ -103,6 +103,12 @@ int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int c
  * ms[0]=pyramid ms[1]=FAST ms[2]=octree ms[3]=orient+blur+rBRIEF ms[4]=total.  Synchronises the stream. */
 int orbx_last_timing(orbx_handle h, float* ms5);
 
+/* How the last batch call ran FAST (a scheduling decision only: the key points do not depend on it).  two_pass: 1 = detection at iniThFAST followed by a
+ * second launch on the cells that came back empty (ORBextractor.cc:812-828), 0 = one pass at min(ini, min).  listed / tiles: the tiles the handle's
+ * most recent two-pass call sent to its second pass, of how many — the share that decides whether the next call takes two passes again (copied back
+ * asynchronously: synchronise the stream first for the figure of the call just made).  Any pointer may be NULL. */
+int orbx_last_fast_passes(orbx_handle h, int* two_pass, uint32_t* listed, uint32_t* tiles);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Stage 2 — ORBmatcher  (reference include/ORBmatcher.h:39-94, src/ORBmatcher.cc) + the Frame grid helpers it
  * depends on (src/Frame.cc:444-478, 755-862).  The reference functions walk pointer graphs (Frame&, KeyFrame*,

@@ -127,6 +127,29 @@ def test_emulated_fast_two_threshold_passes():
                 assert np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2), (tag, ini, mn)
 
 
+def test_emulated_fast_pass_policy_never_changes_results():
+    """Which form a batch call takes is decided from the listed share of the handle's previous two-pass call: a sparsely textured frame (most tiles
+    have an empty cell) sends the second call down the one-pass form, a textured one keeps the two passes — and the key points are the same either
+    way (orbx_last_fast_passes reports the decision)."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1",), tag="tall1")))
+    sparse = synth_image(41, 400, 300, n_rect=6, n_disc=2, noise=0.5)
+    dense = synth_image(42, 400, 300, n_rect=400, n_disc=200, noise=2.0)
+    for img, expect_second in ((sparse, 0), (dense, 1)):
+        o = O.OrbOracle(400, 1.2, 5, 20, 7)
+        mono, k, d = o.extract(img)
+        e = orbhip.ORBextractor(400, 1.2, 5, 20, 7, lib=lib)
+        modes = []
+        for _ in range(3):
+            m2, k2, d2 = e(img)
+            modes.append(e.last_fast_passes())
+            assert m2 == mono and np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2)
+        assert modes[0]["two_pass"] == 1 and 0 < modes[0]["tiles"]
+        assert modes[1]["two_pass"] == expect_second, modes
+
+
 def test_emulated_octree_lds_key_cache_path():
     """The octree keeps a level's candidates in an LDS cache for small batches (OCT_KEYCAP keys; bigger levels and big batches read them from
     global memory).  A 1500-key cache is hit by the small levels and missed by the big ones, so both paths run inside one extraction.
