@@ -217,6 +217,38 @@ def test_hip_batch_matches_oracle_and_is_deterministic(hip_lib, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sparse_1280x720", "textured_752x480"])
+def test_hip_fast_pass_policy_never_changes_results(hip_lib, kind):
+    """A handle keeps the two-pass form of k_fast while few tiles are listed for the second pass and drops to one pass otherwise (probing again every
+    16th call).  Twenty consecutive batch calls on the same frames: every call's output is the oracle's, whatever form it ran in; sparse frames end up
+    in the one-pass form, textured ones keep the two passes."""
+    import torch
+    if kind == "sparse_1280x720":
+        W, H, nf = 1280, 720, 1500
+        imgs = np.stack([synth_image(300 + i, W, H, n_rect=40, n_disc=10) for i in range(8)])
+    else:
+        W, H, nf = 752, 480, 1000
+        imgs = np.stack([synth_image(310 + i, W, H, n_rect=900, n_disc=400) for i in range(8)])
+    e = orbhip.ORBextractor(nf, 1.2, 8, 20, 7, lib=hip_lib)
+    dev = torch.from_numpy(imgs).cuda()
+    o = O.OrbOracle(nf)
+    ref = [o.extract(imgs[b]) for b in (0, 7)]
+    modes = []
+    for call in range(20):
+        kps, desc, counts = [t.cpu().numpy() for t in e.extract_batch(dev, (0, 0))]
+        modes.append(e.last_fast_passes()["two_pass"])
+        for b, (mono, k, d) in zip((0, 7), ref):
+            n = counts[b, 0]
+            assert n == len(k) and counts[b, 1] == mono, (call, b)
+            assert np.array_equal(kps[b, :n].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) and np.array_equal(desc[b, :n], d), (call, b)
+    assert modes[0] == 1
+    if kind == "sparse_1280x720":
+        assert modes[2] == 0 and modes[16] == 1, modes   # one pass once the listed share is known; the 17th call probes
+    else:
+        assert all(modes), modes
+
+
+@pytest.mark.gpu
 def test_hip_full_size_batch_properties(hip_lib):
     """BASELINE-size batch: size-independent properties (counts, bounds, frame independence under permutation)."""
     import torch
