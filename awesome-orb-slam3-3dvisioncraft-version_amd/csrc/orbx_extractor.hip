@@ -2,7 +2,8 @@
 //
 // One handle = one (image size, config).  A call processes a batch of independent frames with
 //   k_resize2  x (nlevels-1)   E1  ComputePyramid            ORBextractor.cc:1158-1183 (cv::resize INTER_LINEAR, fixed point; k_resize for scale factors > 1.3)
-//   k_fast                     E2  per-cell FAST-9/16 + NMS   ORBextractor.cc:763-855   (cv::FAST semantics per 30-px cell ROI)
+//   k_fast<0>, k_fast<1>       E2  per-cell FAST-9/16 + NMS   ORBextractor.cc:763-855   (cv::FAST semantics per 30-px cell ROI): batches detect at iniThFAST,
+//                              then again the cells that came back empty at minThFAST (second launch); k_fast<2> = one pass (single frames, sparse scenes)
 //   k_octree                   E3  DistributeOctTree          ORBextractor.cc:537-761   (+ E4/E8 ordering ranks)
 //   k_describe2                E5-E8 IC_Angle, 7x7 blur (at the sampled points), rBRIEF, output assembly  :75-145, 1093-1155
 //                              (two key points per wave; k_describe is the one-key-point-per-wave form, -DDESC_KPW=1)
