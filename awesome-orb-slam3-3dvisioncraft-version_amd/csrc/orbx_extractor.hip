@@ -456,6 +456,9 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 #ifndef FAST_TWO_PASS
 #define FAST_TWO_PASS 1   // 1: batches detect at iniThFAST first and only the tiles with an empty cell again at min(ini, min) (k_fast, second launch)
 #endif
+#ifndef FAST_TWO_PASS_MIN_BATCH
+#define FAST_TWO_PASS_MIN_BATCH 64   // frames per call from which the two-pass form is considered
+#endif
 #ifndef FAST_TWO_PASS_MAX_LISTED
 #define FAST_TWO_PASS_MAX_LISTED 0.22   // listed share of the tiles up to which the two passes are kept (measured: -9 % of k_fast at 0.14, +15 % at 0.42)
 #endif
@@ -2539,13 +2542,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #if FAST_XCD
         hipLaunchKernelGGL((k_fast<2>), dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
-        // Two passes for batches (the same frame count from which the two-row tiles are used: a single frame wants one short launch, not two) — while
-        // they pay.  Both forms give the same key points; which is faster depends on the frames: the first pass saves the corners between the two
+        // Two passes for batches of FAST_TWO_PASS_MIN_BATCH frames or more (two dependent launches cost a small batch more than the first pass saves:
+        // k_fast 0.036 vs 0.030 ms at 8 frames, 0.046 vs 0.042 at 16, 0.065 vs 0.063 at 32, 0.102 vs 0.105 at 64, 0.171 vs 0.184 at 128) — while they pay.  Both forms give the same key points; which is faster depends on the frames: the first pass saves the corners between the two
         // thresholds, every listed tile pays staging and pre-test a second time.  On the benchmark's frames 13 % of the tiles are listed (k_fast
         // 0.70 -> 0.63 ms per 512 frames), on sparsely textured ones (the same synthetic scene at 1280x720) most are (0.78 -> 0.90 ms).  The listed
         // share of the handle's previous two-pass call (copied back asynchronously, read here without waiting: a stale figure only delays the
         // switch) decides; in one-pass mode every FAST_PROBE_EVERY-th call takes the two passes to measure again.
-        bool two = FAST_TWO_PASS && tall && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535;
+        bool two = FAST_TWO_PASS && tall && batch >= FAST_TWO_PASS_MIN_BATCH && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535;
         if (two) {
             const volatile uint32_t* hr = h->h_retry;
             const bool pays = (double)hr[0] <= FAST_TWO_PASS_MAX_LISTED * (double)hr[1];

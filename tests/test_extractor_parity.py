@@ -94,11 +94,11 @@ def test_emulated_fast_two_cell_row_tiles():
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1",), tag="tall1")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1"), tag="tall1")))
     for case in CASES:
         if case[0] in EMU_CASES:
             _run_case(lib, case)
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=48", "FAST_FITS_MAX=96"), tag="tall1_q2cap48_fits96")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1", "FAST_Q2CAP=48", "FAST_FITS_MAX=96"), tag="tall1_q2cap48_fits96")))
     for case in CASES:
         if case[0] in ("sparse_640x480", "noise_tile_overflow", "euroc_752x480"):
             _run_case(lib, case)
@@ -107,15 +107,16 @@ def test_emulated_fast_two_cell_row_tiles():
 def test_emulated_fast_two_threshold_passes():
     """Batches run k_fast twice: instance <0> detects at iniThFAST and lists, per tile, the cells that hold no local maximum; instance <1> detects the
     listed cells again at min(ini, min) — as a one-cell tile when one cell is listed, else the whole tile reporting the listed cells only.
-    FAST_TALL_MIN_BATCH=1 sends single frames that way on the emulator; a corner list of 192 / 96 entries makes tiles that pass at 20 overflow at 7
+    FAST_TALL_MIN_BATCH=1 FAST_TWO_PASS_MIN_BATCH=1 send single frames that way on the emulator; a corner list of 192 / 96 entries makes tiles that pass at 20 overflow at 7
     (the in-place fallback under a partial cell mask) or overflow already at 20 (every cell listed, nothing emitted by the first pass).  Thresholds
     20/7 (the reference's), 40/5 (many empty cells) and 7/7, 5/9 (ini <= min: one pass).  Results must not change."""
     import ctypes
     import build_emu
     from orbhip import _lib
     imgs = [synth_image(31, 400, 300, n_rect=25, n_disc=10, noise=1.0), synth_image(32, 333, 251, n_rect=120, n_disc=60, noise=3.0, contrast=0.5)]
-    for defines, tag in ((("FAST_TALL_MIN_BATCH=1",), "tall1"), (("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=192"), "tall1_q2cap192"),
-                         (("FAST_TALL_MIN_BATCH=1", "FAST_Q2CAP=96"), "tall1_q2cap96")):
+    for defines, tag in ((("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1"), "tall1"),
+                         (("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1", "FAST_Q2CAP=192"), "tall1_q2cap192"),
+                         (("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1", "FAST_Q2CAP=96"), "tall1_q2cap96")):
         lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=defines, tag=tag)))
         for ini, mn in ((20, 7), (40, 5), (7, 7), (5, 9)):
             for img in imgs:
@@ -134,7 +135,7 @@ def test_emulated_fast_pass_policy_never_changes_results():
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1",), tag="tall1")))
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1"), tag="tall1")))
     sparse = synth_image(41, 400, 300, n_rect=6, n_disc=2, noise=0.5)
     dense = synth_image(42, 400, 300, n_rect=400, n_disc=200, noise=2.0)
     for img, expect_second in ((sparse, 0), (dense, 1)):
@@ -195,7 +196,7 @@ def test_bordered_pyramid_matches_reference_layout(emu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [6, 10])   # below / above the batch size from which k_fast runs on two-cell-row tiles
+@pytest.mark.parametrize("B", [6, 10, 66])   # one-row tiles / two-row tiles in one pass / two-row tiles in two passes (k_fast)
 def test_hip_batch_matches_oracle_and_is_deterministic(hip_lib, B):
     import torch
     imgs = np.stack([synth_image(20 + i) for i in range(B - 2)] + [flat_image(), low_contrast_image(31)])
@@ -225,19 +226,19 @@ def test_hip_fast_pass_policy_never_changes_results(hip_lib, kind):
     import torch
     if kind == "sparse_1280x720":
         W, H, nf = 1280, 720, 1500
-        imgs = np.stack([synth_image(300 + i, W, H, n_rect=40, n_disc=10) for i in range(8)])
+        imgs = np.stack([synth_image(300 + i, W, H, n_rect=40, n_disc=10) for i in range(8)] * 8)   # 64 frames: the two-pass form starts there
     else:
         W, H, nf = 752, 480, 1000
-        imgs = np.stack([synth_image(310 + i, W, H, n_rect=900, n_disc=400) for i in range(8)])
+        imgs = np.stack([synth_image(310 + i, W, H, n_rect=900, n_disc=400) for i in range(8)] * 8)
     e = orbhip.ORBextractor(nf, 1.2, 8, 20, 7, lib=hip_lib)
     dev = torch.from_numpy(imgs).cuda()
     o = O.OrbOracle(nf)
-    ref = [o.extract(imgs[b]) for b in (0, 7)]
+    ref = [o.extract(imgs[b]) for b in (0, 63)]
     modes = []
     for call in range(20):
         kps, desc, counts = [t.cpu().numpy() for t in e.extract_batch(dev, (0, 0))]
         modes.append(e.last_fast_passes()["two_pass"])
-        for b, (mono, k, d) in zip((0, 7), ref):
+        for b, (mono, k, d) in zip((0, 63), ref):
             n = counts[b, 0]
             assert n == len(k) and counts[b, 1] == mono, (call, b)
             assert np.array_equal(kps[b, :n].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) and np.array_equal(desc[b, :n], d), (call, b)

@@ -67,11 +67,11 @@ def main():
                 ok = rejected == prod_rejected
             else:
                 ok = m2 == mono and len(k) == len(k2) and np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2)
-                if ok and img.shape[1] % 4 == 0:   # (dense batches need 4-byte row strides) also as a batch of 8 copies: batches run k_fast on two-cell-row tiles, single frames on one-row tiles
+                if ok and img.shape[1] % 4 == 0:   # (dense batches need 4-byte row strides) also as a batch of 64 copies: batches run k_fast on two-cell-row tiles and, from 64 frames, in two passes; single frames on one-row tiles in one
                     import torch
-                    kb, db, cb = e.extract_batch(torch.from_numpy(np.ascontiguousarray(np.stack([img] * 8))).cuda(), lap)
+                    kb, db, cb = e.extract_batch(torch.from_numpy(np.ascontiguousarray(np.stack([img] * 64))).cuda(), lap)
                     kb, db, cb = kb.cpu().numpy(), db.cpu().numpy(), cb.cpu().numpy()
-                    for f in (0, 7):
+                    for f in (0, 63):
                         nb = int(cb[f, 0])
                         ok = ok and nb == len(k) and int(cb[f, 1]) == mono and np.array_equal(kb[f, :nb].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) \
                             and np.array_equal(db[f, :nb], d)
