@@ -185,8 +185,10 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 #ifndef R2_XCD
 #define R2_XCD 1
 #endif
+#ifndef R2_TH
 #define R2_TH 32
-#define R2_ROWS 46        // 32 * 1.3 + 2 taps + 2 slack (estimated footprint)
+#endif
+#define R2_ROWS (R2_TH * 13 / 10 + 5)   // R2_TH * 1.3 + 2 taps + 2 slack (estimated footprint): 46 rows for 32
 #define R2_HP 68          // H-buffer pitch in u32 (64 + 4: rows skewed across banks, 16-byte aligned)
 #define R2_SMEM ((RS_TW * 2 + R2_TH * 4) * 4 + R2_ROWS * R2_HP * 4 + R2_ROWS * RS_PITCH)
 // Staging footprint of a k_resize2 tile along one axis: first staged source coordinate (dword-aligned for x) and the staged extent, from a FLOAT
@@ -284,7 +286,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     if (dx0 >= P.dw) return;
     uint8_t* D = P.dst + (size_t)frameZ * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < R2_TH / 16; k++) {
         const int ty = (tid >> 4) + 16 * k;
         if (by0 + ty >= P.dh) break;
         const uint4 rt = rowt[ty];
