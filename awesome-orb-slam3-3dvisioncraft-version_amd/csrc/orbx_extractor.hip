@@ -421,6 +421,16 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return x;
 }
+// wave-wide sum / minimum through the same DPP steps (the result forms in lane 63 and is broadcast with one v_readlane): seven register-only
+// instructions where a __shfl_xor butterfly is six dependent ds_bpermute round trips.  All 64 lanes must be active.
+static __device__ __forceinline__ int wave_sum(int x) { return __builtin_amdgcn_readlane(wave_scan_incl(x), 63); }
+static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+#define WMIN_STEP(ctrl, rows) x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ctrl, rows, 0xF, false))
+    WMIN_STEP(0x111, 0xF); WMIN_STEP(0x112, 0xF); WMIN_STEP(0x114, 0xF); WMIN_STEP(0x118, 0xF);   // row_shr:1, 2, 4, 8
+    WMIN_STEP(0x142, 0xA); WMIN_STEP(0x143, 0xC);                                                 // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3
+#undef WMIN_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 
 // LDS layout of k_fast (dynamic region), sizes fixed per handle:
 //   img[imgBytes] | q1[4 * FAST_Q1W] u16 | q2[FAST_Q2CAP] u16 | colTab[FAST_TW] u8 | sh[8 + FAST_MAXCELLS] int
@@ -1991,11 +2001,13 @@ static __device__ __forceinline__ int stereo_pix(const DescLevel& L, int frame, 
 
 // vRowIndices (Frame.cc:972-982): every right keypoint is listed in the rows [floor(y - r), ceil(y + r)], r = 2 * scale[octave], in
 // increasing keypoint index.  One workgroup per frame: LDS counting sort over the image rows, insertion order restored per row.
-static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P) {
+static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P, const int ldsCap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     int* cnt = (int*)orb_smem;             // [nRows] counts -> starts
     int* fill = cnt + P.nRows;             // [nRows]
     int* scratch = fill + P.nRows;         // [256]
+    int* lbuf = scratch + 256;             // [ldsCap] the frame's row lists while they are filled and ordered (round 3): the per-row insertion sort
+                                           // was a chain of dependent global loads and stores (0.21 ms per 512 frames, one workgroup per frame)
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int Nr = min(P.cntR[2 * frame], P.cap);
     const orb_keypoint* kps = P.kpsR + (size_t)frame * P.cap;
@@ -2010,6 +2022,7 @@ static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P) {
         for (int y = minr; y <= maxr; y++) atomicAdd(&cnt[y], 1);
     }
     __syncthreads();
+    int total;
     {
         const int per = (P.nRows + 255) / 256, s0 = tid * per, s1 = min(s0 + per, P.nRows);
         int sum = 0;
@@ -2022,28 +2035,39 @@ static __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams P) {
             scratch[tid] += v;
             __syncthreads();
         }
+        total = scratch[255];
         int run = scratch[tid] - sum;
         for (int k = s0; k < s1; k++) { const int c = cnt[k]; cnt[k] = run; run += c; }
         if (tid == 255) rs[P.nRows] = min(run, P.rowCap);
     }
     __syncthreads();
     for (int r = tid; r < P.nRows; r += 256) rs[r] = min(cnt[r], P.rowCap);
-    for (int i = tid; i < Nr; i += 256) {
-        const orb_keypoint kp = kps[i];
-        const float r = 2.0f * P.lvL[kp.octave].scale;
-        const int maxr = min((int)ceilf(kp.y + r), P.nRows - 1), minr = max((int)floorf(kp.y - r), 0);
-        for (int y = minr; y <= maxr; y++) { const int p = cnt[y] + atomicAdd(&fill[y], 1); if (p < P.rowCap) ri[p] = i; }
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int r = tid; r < P.nRows; r += 256) {   // restore ascending keypoint order inside each row (rows hold a few dozen entries)
-        const int s = cnt[r], m = min(fill[r], max(P.rowCap - s, 0));
-        for (int a = 1; a < m; a++) {
-            const int v = ri[s + a];
-            int p = a - 1;
-            while (p >= 0 && ri[s + p] > v) { ri[s + p + 1] = ri[s + p]; p--; }
-            ri[s + p + 1] = v;
+    const bool staged = total <= ldsCap && total <= P.rowCap;   // (workgroup-uniform)
+    auto fill_and_order = [&](int* buf) {
+        for (int i = tid; i < Nr; i += 256) {
+            const orb_keypoint kp = kps[i];
+            const float r = 2.0f * P.lvL[kp.octave].scale;
+            const int maxr = min((int)ceilf(kp.y + r), P.nRows - 1), minr = max((int)floorf(kp.y - r), 0);
+            for (int y = minr; y <= maxr; y++) { const int p = cnt[y] + atomicAdd(&fill[y], 1); if (p < P.rowCap) buf[p] = i; }
         }
+        __threadfence_block();
+        __syncthreads();
+        for (int r = tid; r < P.nRows; r += 256) {   // restore ascending keypoint order inside each row (rows hold a few dozen entries)
+            const int s = cnt[r], m = min(fill[r], max(P.rowCap - s, 0));
+            for (int a = 1; a < m; a++) {
+                const int v = buf[s + a];
+                int p = a - 1;
+                while (p >= 0 && buf[s + p] > v) { buf[s + p + 1] = buf[s + p]; p--; }
+                buf[s + p + 1] = v;
+            }
+        }
+    };
+    if (staged) {
+        fill_and_order(lbuf);
+        __syncthreads();
+        for (int p = tid; p < total; p += 256) ri[p] = lbuf[p];
+    } else {
+        fill_and_order(ri);
     }
 }
 
@@ -2085,8 +2109,7 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+    best = wave_min_u32(best);
     const int bestDist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);
     if (bestDist < ORBM_TH_HIGH && bestDist < (ORBM_TH_HIGH + ORBM_TH_LOW) / 2) {
         const int bestIdxR = (int)(best & 0xFFFF);
@@ -2121,9 +2144,11 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float vDists[11];
             int bestSad = 2147483647, bestincR = 0;
+            // a lane's contributions to the eleven SADs first, two per register (a SAD is at most 121 * 255 < 2^16, so the halves never carry), then six
+            // wave sums (rounds 1-2: eleven butterflies of six dependent ds_bpermute each — the kernel was that chain)
+            uint32_t part[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int inc = 0; inc < 11; inc++) {
-                const int incR = inc - Lw;
                 const int cRv = strip[w * 24 + inc + w];
                 int sum = 0;
 #pragma unroll
@@ -2135,8 +2160,14 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
                         sum += dd < 0 ? -dd : dd;
                     }
                 }
-                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-                const float dist = (float)sum;
+                part[inc >> 1] |= (uint32_t)sum << (16 * (inc & 1));
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) part[k] = (uint32_t)wave_sum((int)part[k]);
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++) {
+                const int incR = inc - Lw;
+                const float dist = (float)(int)((part[inc >> 1] >> (16 * (inc & 1))) & 0xFFFFu);
                 if (dist < (float)bestSad) { bestSad = (int)dist; bestincR = incR; }
                 vDists[inc] = dist;
             }
@@ -2162,34 +2193,59 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
 }
 
 // median SAD cull (Frame.cc:1119-1132): sort (dist, iL); median = element size/2; drop everything with dist >= 1.5*1.4*median
+#define STEREO_CULL_BINS 1024   // SAD >> 5: an 11 x 11 patch of bytes sums to at most 121 * 255 = 30 855
 static __global__ __launch_bounds__(256) void k_stereo_cull(StereoParams P) {
+    // median of the valid SADs = the value at rank size / 2 of the ascending order (Frame.cc:1120-1123: sort of (dist, index) pairs — ties do not change
+    // the VALUE at a rank), by a two-level histogram: 1 024 bins of 32 values, then the 32 values of the bin that holds the rank.  (Rounds 1-2 ranked
+    // every value against every other from an LDS copy: 4 000 turns per thread at 1 000 key points, 0.18 ms per 512 frames — and cap + 2 words of LDS.)
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    int* sd = (int*)orb_smem;   // [cap]
-    int* ctl = sd + P.cap;      // [2]
+    int* hist = (int*)orb_smem;               // [STEREO_CULL_BINS]
+    int* sub = hist + STEREO_CULL_BINS;       // [32]
+    int* scratch = sub + 32;                  // [256]
+    int* ctl = scratch + 256;                 // [0] bin of the rank, [1] rank inside the bin, [2] the median
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int N = min(P.cntL[2 * frame], P.cap);
     const int32_t* sad = P.sad + (size_t)frame * P.cap;
-    if (tid == 0) { ctl[0] = 0; ctl[1] = -1; }
+    for (int k = tid; k < STEREO_CULL_BINS + 32; k += 256) hist[k] = 0;
     __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < N; i += 256) { const int s = sad[i]; sd[i] = s; mine += s >= 0; }
-    if (mine) atomicAdd(&ctl[0], mine);
+    for (int i = tid; i < N; i += 256) { const int s = sad[i]; if (s >= 0) atomicAdd(&hist[min(s >> 5, STEREO_CULL_BINS - 1)], 1); }
     __syncthreads();
-    const int size = ctl[0];
-    if (size == 0) return;   // (the reference reads vDistIdx[0] unconditionally; nothing to cull here)
-    const int target = size / 2;
-    for (int i = tid; i < N; i += 256) {
-        const int s = sd[i];
-        if (s < 0) continue;
-        int rank = 0;
-        for (int j = 0; j < N; j++) { const int t = sd[j]; rank += (t >= 0) && (t < s || (t == s && j < i)); }
-        if (rank == target) ctl[1] = s;
+    {
+        constexpr int per = STEREO_CULL_BINS / 256;
+        int sum = 0;
+        for (int k = 0; k < per; k++) sum += hist[tid * per + k];
+        scratch[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? scratch[tid - off] : 0;
+            __syncthreads();
+            scratch[tid] += v;
+            __syncthreads();
+        }
+        const int size = scratch[255];
+        if (size == 0) return;   // (the reference reads vDistIdx[0] unconditionally; nothing to cull here)  — workgroup-uniform
+        const int target = size / 2;
+        int run = scratch[tid] - sum;
+        for (int k = 0; k < per; k++) {
+            const int c = hist[tid * per + k];
+            if (target >= run && target < run + c) { ctl[0] = tid * per + k; ctl[1] = target - run; }
+            run += c;
+        }
     }
     __syncthreads();
-    const float median = (float)ctl[1];
+    const int bin = ctl[0];
+    for (int i = tid; i < N; i += 256) { const int s = sad[i]; if (s >= 0 && min(s >> 5, STEREO_CULL_BINS - 1) == bin) atomicAdd(&sub[s & 31], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, v = 0;
+        for (int k = 0; k < 32; k++) { if (ctl[1] >= run && ctl[1] < run + sub[k]) v = k; run += sub[k]; }
+        ctl[2] = (bin << 5) | v;
+    }
+    __syncthreads();
+    const float median = (float)ctl[2];
     const float thDist = 1.5f * 1.4f * median;
     for (int i = tid; i < N; i += 256) {
-        const int s = sd[i];
+        const int s = sad[i];
         if (s >= 0 && !((float)s < thDist)) { P.uRight[(size_t)frame * P.cap + i] = -1.0f; P.depth[(size_t)frame * P.cap + i] = -1.0f; }
     }
 }
@@ -2704,9 +2760,10 @@ extern "C" int orbx_stereo_matches(orbx_handle left, orbx_handle right, const or
     }
     S.rowStart = h->d_rowStart; S.rowIdx = h->d_rowIdx; S.rowCap = rowCap;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stereo_rows, dim3(batch), dim3(256), (size_t)(2 * h->H + 256) * 4, st, S);
+    const int rowsLds = std::max(0, std::min(rowCap, (64 * 1024 - (2 * h->H + 256) * 4) / 4));   // row lists staged in LDS if a frame's fit (they do: ~5 per key point)
+    hipLaunchKernelGGL(k_stereo_rows, dim3(batch), dim3(256), (size_t)(2 * h->H + 256 + rowsLds) * 4, st, S, rowsLds);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 4 * 11 * 24, st, S);
-    hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(cap_per_frame + 2) * 4, st, S);
+    hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(STEREO_CULL_BINS + 32 + 256 + 4) * 4, st, S);
     HIPCHK(h, hipGetLastError());
     return ORB_OK;
 }
