@@ -395,11 +395,13 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
     int cs = 0, ce = 0;
     if (hl < ncol) { cs = gs[(nMinCellX + hl) * ORBM_GRID_ROWS + nMinCellY]; ce = gs[(nMinCellX + hl) * ORBM_GRID_ROWS + nMaxCellY + 1]; }
     int incl = ce - cs;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (hl >= off) incl += t;
-    }
+    // inclusive scan inside each 32-lane half, register-only: row_shr:1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast:15 carries a half's first
+    // row into its second (rows 1 and 3) — five DPP adds where five __shfl_up steps are five dependent ds_bpermute round trips.  All 64 lanes are active.
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
     const int excl = incl - (ce - cs);
     const int total = __shfl(incl, half * 32 + 31);     // lanes >= ncol carry the last column's inclusive sum
     int count = 0;

@@ -1878,10 +1878,8 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int s = 0; s < 2; s++) { m10[s] += __shfl_xor(m10[s], off); m01[s] += __shfl_xor(m01[s], off); }
-    }
+    for (int s = 0; s < 2; s++) { m10[s] = wave_sum(m10[s]); m01[s] = wave_sum(m01[s]); }   // (register-only DPP steps: no LDS round trips)
     // fastAtan2 + sin / cos once for both key points: lane s serves key point s
     if (lane < 2) {
         const int my01 = lane == 0 ? m01[0] : m01[1], my10 = lane == 0 ? m10[0] : m10[1];
@@ -1943,8 +1941,10 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
             nib |= (uint32_t)(blurred(r0, q0) < blurred(r1, q1)) << j;
         }
-        uint32_t v = nib | (__shfl_xor(nib, 1) << 4);           // valid on even lanes
-        const uint32_t b1 = __shfl_down(v, 2), b2 = __shfl_down(v, 4), b3 = __shfl_down(v, 6);
+        // eight lanes' nibbles -> one descriptor dword in the first of them, by DPP moves inside the row (quad_perm [1,0,3,2], row_shl:2 / 4 / 6)
+        const uint32_t v = nib | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, false) << 4);           // valid on even lanes
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, false), b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, false),
+                       b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x106, 0xF, 0xF, false);
         const uint32_t dw = (v & 255) | ((b1 & 255) << 8) | ((b2 & 255) << 16) | ((b3 & 255) << 24);
         // output slot (ORBextractor.cc:1141-1152)
         const int rank = (int)(aux[s] & 0x7FFFFFFF);

@@ -266,12 +266,15 @@ inline emu_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_v4
 }
 inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l, 64); }   // lane index must be wave-uniform
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // the kernels use it on wave-uniform values only (to tell the compiler so)
-// v_mov_b32_dpp as __builtin_amdgcn_update_dpp: the controls the kernels use — row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
+// v_mov_b32_dpp as __builtin_amdgcn_update_dpp: the controls the kernels use — quad_perm (0x00-0xFF), row_shl:n (0x100 + n), row_shr:n (0x110 + n),
+// row_bcast:15 (0x142), row_bcast:31 (0x143).
 // A lane whose row / bank is masked out, or whose source lane lies outside its row, keeps `old` (bound_ctrl = false) or gets 0 (true).
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const int l = emu::lane(), row = l >> 4, pos = l & 15;
     int from = -1;
     if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (pos - n >= 0) from = l - n; }
+    else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; if (pos + n <= 15) from = l + n; }   // row_shl:n
+    else if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);                          // quad_perm
     else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }
     else if (ctrl == 0x143) { if (row >= 2) from = 31; }
     else { fprintf(stderr, "hip_emu: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
