@@ -961,7 +961,7 @@ struct OctParams {
 };
 
 // In-place exclusive scan of a[0..n) (LDS) by the whole OCT_T-thread block; returns the total.  Thread-serial chunks, one
-// shuffle scan per wave, wave totals through LDS: two workgroup barriers per call (the octree calls this ~5 times per round).
+// DPP scan per wave, wave totals through LDS: two workgroup barriers per call (the octree calls this ~5 times per round).
 #ifndef OCT_T
 #define OCT_T 256   // threads per (frame, level) octree problem
 #endif
@@ -971,12 +971,7 @@ static __device__ int block_scan_excl(int* a, int n, int* scratch) {
     const int s0 = tid * chunk, s1 = min(s0 + chunk, n);
     int sum = 0;
     for (int i = s0; i < s1; i++) sum += a[i];
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
+    const int incl = wave_scan_incl(sum);   // (register-only DPP steps; every thread of the block is here)
     if (lane == 63) scratch[wave] = incl;
     __syncthreads();
     int base = 0, total = 0;
