@@ -2188,6 +2188,9 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
 }
 
 // median SAD cull (Frame.cc:1119-1132): sort (dist, iL); median = element size/2; drop everything with dist >= 1.5*1.4*median
+#ifndef STEREO_ROWS_LDS_MAX
+#define STEREO_ROWS_LDS_MAX (64 * 1024)   // dynamic LDS of k_stereo_rows (tests build with 0: every frame takes the global-memory path)
+#endif
 #define STEREO_CULL_BINS 1024   // SAD >> 5: an 11 x 11 patch of bytes sums to at most 121 * 255 = 30 855
 static __global__ __launch_bounds__(256) void k_stereo_cull(StereoParams P) {
     // median of the valid SADs = the value at rank size / 2 of the ascending order (Frame.cc:1120-1123: sort of (dist, index) pairs — ties do not change
@@ -2755,7 +2758,7 @@ extern "C" int orbx_stereo_matches(orbx_handle left, orbx_handle right, const or
     }
     S.rowStart = h->d_rowStart; S.rowIdx = h->d_rowIdx; S.rowCap = rowCap;
     hipStream_t st = (hipStream_t)stream;
-    const int rowsLds = std::max(0, std::min(rowCap, (64 * 1024 - (2 * h->H + 256) * 4) / 4));   // row lists staged in LDS if a frame's fit (they do: ~5 per key point)
+    const int rowsLds = std::max(0, std::min(rowCap, (STEREO_ROWS_LDS_MAX - (2 * h->H + 256) * 4) / 4));   // row lists staged in LDS if a frame's fit (they do: ~5 per key point)
     hipLaunchKernelGGL(k_stereo_rows, dim3(batch), dim3(256), (size_t)(2 * h->H + 256 + rowsLds) * 4, st, S, rowsLds);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap_per_frame + 3) / 4, batch), dim3(256), 4 * 11 * 24, st, S);
     hipLaunchKernelGGL(k_stereo_cull, dim3(batch), dim3(256), (size_t)(STEREO_CULL_BINS + 32 + 256 + 4) * 4, st, S);

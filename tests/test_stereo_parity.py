@@ -54,6 +54,15 @@ def test_emu_stereo_matches(emu_lib):
     _check(emu_lib, "emu", 3)
 
 
+def test_emu_stereo_row_lists_in_global_memory():
+    """k_stereo_rows fills and orders a frame's vRowIndices lists in LDS when they fit (always, at these sizes) and in global memory otherwise;
+    STEREO_ROWS_LDS_MAX=0 sends every frame down the global-memory path.  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    _check(_lib.bind(ctypes.CDLL(build_emu.build(defines=("STEREO_ROWS_LDS_MAX=0",), tag="rowslds0"))), "emu", 5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [3, 4])
 def test_hip_stereo_matches(hip_lib, seed):
