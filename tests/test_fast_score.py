@@ -1,0 +1,16 @@
+"""k_fast's score functions as plain C++ (tests/cpp/fast_score_test.cpp includes the product source against the HIP emulator header): the one-polarity,
+running-minima form fast_S_pk against the straightforward fast_S on two million random and adversarial 7 x 7 patches."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fast_score_forms_agree():
+    out = os.path.join(ROOT, "tests", "emu", "build", "fast_score_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                           os.path.join(ROOT, "tests", "cpp", "fast_score_test.cpp"), "-o", out, "-lpthread"])
+    r = subprocess.run([out, "2000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout, r.stdout
