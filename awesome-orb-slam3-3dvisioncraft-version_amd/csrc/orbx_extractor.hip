@@ -482,6 +482,37 @@ static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 #endif
 #define FAST_Q1W (FAST_QCAP / 4 + 64)               // a wave's q1 slice (576 entries): all of its pre-test survivors, or one row group of them (<= 256)
 
+// Stage-1 thresholds of k_fast on D = (x + 255 - v) >> 1 (one v_lerp_u8 per ring position: four pixels per instruction).  x - v > t implies
+// D >= (t + 256) >> 1 and v - x > t implies D <= (254 - t) >> 1 (>> is monotone), so both compares are necessary conditions — at most one grey
+// level weaker than the exact ones, which only the exact stage 2 decides.  A byte compare D >= th is bit 7 of (D + 256 - th) >> 1.
+static __device__ __forceinline__ void fast_pretest_consts(const int t0, uint32_t* KB, uint32_t* KG) {
+    const int tp = min(t0, 254);
+    *KB = 0x01010101u * (uint32_t)(256 - ((tp + 256) >> 1));   // bit 7 <=> D >= (t + 256) >> 1   (may be brighter than v + t)
+    *KG = 0x01010101u * (uint32_t)(255 - ((254 - tp) >> 1));    // bit 7 <=> D >  (254 - t) >> 1   (can NOT be darker than v - t)
+}
+// The pre-test of four adjacent pixels (one dword of an LDS row of pitch FAST_PITCH): bit 7 of byte t of the result is set if pixel t MAY be a FAST-9
+// corner at the threshold the constants were made for — never clear for a pixel that is one (tests/cpp/fast_score_test.cpp checks exactly that).
+// cw = the dword LEFT of the centre dword, three rows up.
+static __device__ __forceinline__ uint32_t fast_pretest4(const uint32_t* cw, const uint32_t KB, const uint32_t KG) {
+    constexpr int p4 = FAST_PITCH >> 2;
+    const uint32_t U3 = cw[1], A0 = cw[p4], A1 = cw[p4 + 1], A2 = cw[p4 + 2];                // rows -3, -2
+    const uint32_t Cp = cw[3 * p4], C = cw[3 * p4 + 1], Cn = cw[3 * p4 + 2];                 // row 0
+    const uint32_t B0 = cw[5 * p4], B1 = cw[5 * p4 + 1], B2 = cw[5 * p4 + 2], D3 = cw[6 * p4 + 1];   // rows +2, +3
+    const uint32_t nV = ~C;
+    uint32_t accB, accG;   // bit 7 of a byte: every pair so far has a member that may be brighter / a pair so far has no member that may be darker
+#define PAIR(first, xa, xb) {                                                                                                               \
+        const uint32_t Da = __builtin_amdgcn_lerp(xa, nV, 0u), Db = __builtin_amdgcn_lerp(xb, nV, 0u);                              \
+        const uint32_t b = __builtin_amdgcn_lerp(Da, KB, 0u) | __builtin_amdgcn_lerp(Db, KB, 0u);                                   \
+        const uint32_t g = __builtin_amdgcn_lerp(Da, KG, 0u) & __builtin_amdgcn_lerp(Db, KG, 0u);                                   \
+        if (first) { accB = b; accG = g; } else { accB &= b; accG |= g; } }
+    PAIR(true, D3, U3)                                                                                      // ring 0 (0, 3) and 8 (0, -3)
+    PAIR(false, __builtin_amdgcn_alignbyte(Cn, C, 3), __builtin_amdgcn_alignbyte(C, Cp, 1))                 // 4 (3, 0) and 12 (-3, 0)
+    PAIR(false, __builtin_amdgcn_alignbyte(B2, B1, 2), __builtin_amdgcn_alignbyte(A1, A0, 2))               // 2 (2, 2) and 10 (-2, -2)
+    PAIR(false, __builtin_amdgcn_alignbyte(A2, A1, 2), __builtin_amdgcn_alignbyte(B1, B0, 2))               // 6 (2, -2) and 14 (-2, 2)
+#undef PAIR
+    return (accB | ~accG) & 0x80808080u;
+}
+
 // a * b for operands below 2^24: ONE full-rate v_mul_u32_u24 (the compiler cannot prove the ranges of row indices, strides and table
 // multipliers and emits the quarter-rate v_mul_lo_u32)
 static __device__ __forceinline__ uint32_t mul24(const uint32_t a, const uint32_t b) {
@@ -725,12 +756,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
             n2w += nc;
         } else if (mc) ovf = true;
     };
-    // stage-1 thresholds on D = (x + 255 - v) >> 1 (one v_lerp_u8 per ring position: four pixels per instruction).  x - v > t implies
-    // D >= (t + 256) >> 1 and v - x > t implies D <= (254 - t) >> 1 (>> is monotone), so both compares are necessary conditions — at most
-    // one grey level weaker than the exact ones, which only the exact stage 2 decides.  A byte compare D >= th is bit 7 of (D + 256 - th) >> 1.
-    const int tp = min(t0, 254);
-    const uint32_t KB = 0x01010101u * (uint32_t)(256 - ((tp + 256) >> 1));   // bit 7 <=> D >= (t + 256) >> 1   (may be brighter than v + t)
-    const uint32_t KG = 0x01010101u * (uint32_t)(255 - ((254 - tp) >> 1));    // bit 7 <=> D >  (254 - t) >> 1   (can NOT be darker than v - t)
+    uint32_t KB, KG;   // (fast_pretest_consts: thresholds on the halved differences)
+    fast_pretest_consts(t0, &KB, &KG);
     // ---- stage 1: pre-test on four antipodal pairs of the ring, {0,8} {2,10} {4,12} {6,14}, over ALL rows of the tile.  A 9-arc of the
     //      16-ring contains at least one member of EVERY antipodal pair {i, i+8}, so a corner has a brighter (> v+t) member in each of them,
     //      or a darker one in each (cv::FAST's own "high-speed test", fast.cpp, uses all eight pairs; the two compass pairs alone let 20 % of
@@ -753,24 +780,8 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         const int ry = 8 * k + 2 * wave + rsub;
         if (ry < detH && 4 * dcol < detW) {
             // base = the dword left of the centre dword, three rows up: every operand is a non-negative instruction offset (ds_read2_b32)
-            constexpr int p4 = pitch >> 2;
             const uint32_t* cw = (const uint32_t*)(img + ((dy0 - 3 + ry) & 0xFF) * pitch) + dcol;   // (& 0xFF: a 24-bit multiply)
-            const uint32_t U3 = cw[1], A0 = cw[p4], A1 = cw[p4 + 1], A2 = cw[p4 + 2];                // rows -3, -2
-            const uint32_t Cp = cw[3 * p4], C = cw[3 * p4 + 1], Cn = cw[3 * p4 + 2];                 // row 0
-            const uint32_t B0 = cw[5 * p4], B1 = cw[5 * p4 + 1], B2 = cw[5 * p4 + 2], D3 = cw[6 * p4 + 1];   // rows +2, +3
-            const uint32_t nV = ~C;
-            uint32_t accB, accG;   // bit 7 of a byte: every pair so far has a member that may be brighter / a pair so far has no member that may be darker
-#define PAIR(first, xa, xb) {                                                                                                               \
-                const uint32_t Da = __builtin_amdgcn_lerp(xa, nV, 0u), Db = __builtin_amdgcn_lerp(xb, nV, 0u);                              \
-                const uint32_t b = __builtin_amdgcn_lerp(Da, KB, 0u) | __builtin_amdgcn_lerp(Db, KB, 0u);                                   \
-                const uint32_t g = __builtin_amdgcn_lerp(Da, KG, 0u) & __builtin_amdgcn_lerp(Db, KG, 0u);                                   \
-                if (first) { accB = b; accG = g; } else { accB &= b; accG |= g; } }
-            PAIR(true, D3, U3)                                                                                      // ring 0 (0, 3) and 8 (0, -3)
-            PAIR(false, __builtin_amdgcn_alignbyte(Cn, C, 3), __builtin_amdgcn_alignbyte(C, Cp, 1))                 // 4 (3, 0) and 12 (-3, 0)
-            PAIR(false, __builtin_amdgcn_alignbyte(B2, B1, 2), __builtin_amdgcn_alignbyte(A1, A0, 2))               // 2 (2, 2) and 10 (-2, -2)
-            PAIR(false, __builtin_amdgcn_alignbyte(A2, A1, 2), __builtin_amdgcn_alignbyte(B1, B0, 2))               // 6 (2, -2) and 14 (-2, 2)
-#undef PAIR
-            uint32_t bits = (accB | ~accG) & 0x80808080u;
+            uint32_t bits = fast_pretest4(cw, KB, KG);
             if (PASS == 1) bits &= colMask[cellRowOf(ry)];
             const int nvalid = detW - 4 * dcol;                             // columns of this dword inside the detection region
             if (nvalid < 4) bits &= (1u << (8 * nvalid)) - 1u;

@@ -1,5 +1,6 @@
 """k_fast's score functions as plain C++ (tests/cpp/fast_score_test.cpp includes the product source against the HIP emulator header): the one-polarity,
-running-minima form fast_S_pk against the straightforward fast_S on two million random and adversarial 7 x 7 patches."""
+running-minima form fast_S_pk against the straightforward fast_S on two million random and adversarial 7 x 7 patches, and the byte-parallel pre-test
+as a necessary condition for a corner at every threshold 0 .. 255."""
 import os
 import subprocess
 
@@ -13,4 +14,4 @@ def test_fast_score_forms_agree():
                            os.path.join(ROOT, "tests", "cpp", "fast_score_test.cpp"), "-o", out, "-lpthread"])
     r = subprocess.run([out, "2000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert " 0 mismatches" in r.stdout, r.stdout
+    assert " 0 mismatches" in r.stdout and " 0 corners dropped" in r.stdout, r.stdout
