@@ -15,3 +15,14 @@ def test_fast_score_forms_agree():
     r = subprocess.run([out, "2000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 mismatches" in r.stdout and " 0 corners dropped" in r.stdout, r.stdout
+
+
+def test_stereo_cull_median_on_adversarial_sads():
+    """k_stereo_cull under the emulator on ties, single / no valid entries, bin boundaries, the largest SAD: the cull threshold is 1.5 * 1.4 * the value
+    at rank size / 2 of the valid SADs (tests/cpp/stereo_cull_test.cpp)."""
+    out = os.path.join(ROOT, "tests", "emu", "build", "stereo_cull_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                           os.path.join(ROOT, "tests", "cpp", "stereo_cull_test.cpp"), "-o", out, "-lpthread"])
+    r = subprocess.run([out], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
