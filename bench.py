@@ -92,12 +92,22 @@ def match_algorithmic_bytes(N, Nq):
     return whole, per_kernel
 
 
+KNAMES = {"pyramid": "k_resize2", "fast": "k_fast", "octree": "k_octree", "describe": "k_describe2", "undistort": "k_undistort",
+          "grid_build": "k_grid_build", "sbp_candidates": "k_sbp_candidates2", "sbp_resolve": "k_sbp_resolve"}
 SHIFT = (6, -4)   # frame 2j+1 = frame 2j moved by (dx, dy) px + sensor noise: consecutive views of one scene
+CAM_EUROC = (458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05))   # EuRoC.yaml:9-20 (cam0, radtan)
 
 
-def make_batch(B, seed0=0, unique=16):
+def camera_for(w, h):
+    """EuRoC's calibration with the intrinsics scaled to the frame size (it is quoted at 752x480; identical floats there)."""
+    fx, fy, cx, cy, dist = CAM_EUROC
+    return (fx * w / 752.0, fy * h / 480.0, cx * w / 752.0, cy * h / 480.0, dist)
+
+
+def make_batch(B, seed0=0, unique=16, w=None, h=None):
     from orbhip.synth import synth_image
-    base = [synth_image(seed0 + i, W, H) for i in range(min(unique, max(1, B // 2)))]
+    w, h = w or W, h or H
+    base = [synth_image(seed0 + i, w, h) for i in range(min(unique, max(1, B // 2)))]
     rng = np.random.default_rng(seed0 + 12345)
     frames = []
     for j in range((B + 1) // 2):
@@ -106,6 +116,17 @@ def make_batch(B, seed0=0, unique=16):
         b = np.clip(np.roll(a, (SHIFT[1], SHIFT[0]), (0, 1)).astype(np.int16) + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
         frames += [a, b]
     return np.stack(frames[:B])
+
+
+def grow_batch_on_device(d_frames, B):
+    """A batch of B frames from a smaller resident one: copy i = frame i mod B0 rolled by (5, 9) px x (i div B0) — different images
+    (key points move with the content, cells and borders do not), built on the device so that a 4096-frame batch costs no host time."""
+    import torch
+    B0 = d_frames.shape[0]
+    if B <= B0:
+        return d_frames[:B].contiguous()
+    parts = [d_frames] + [torch.roll(d_frames, shifts=(5 * k, 9 * k), dims=(1, 2)) for k in range(1, -(-B // B0))]
+    return torch.cat(parts)[:B].contiguous()
 
 
 def build_match_queries(kps, counts, scale, cap):
@@ -128,6 +149,134 @@ def build_match_queries(kps, counts, scale, cap):
         q["flags"][b, :n] = Q_VALID | Q_HAS_OBS
     nq = counts[src, 0].astype(np.int32).copy()
     return q, nq, src
+
+
+class StepPipeline:
+    """The benchmark step on one GPU: ORBextractor -> Frame::UndistortKeyPoints (EuRoC calibration) -> AssignFeaturesToGrid ->
+    ORBmatcher::SearchByProjection (motion model, th = 15, TH_HIGH, rotation histogram) of every frame against its partner frame's points.
+    With `streams` >= 2 the match kernels of step i run on a second HIP stream next to the extraction of step i+1 (double-buffered extractor
+    outputs, an event pair per buffer set orders producer and consumer); with >= 3, `streams - 1` extractor handles alternate on their own
+    streams.  The same object is what tests/test_bench_config_parity.py checks against the oracle frame by frame."""
+    LAP = (0, 1000)
+
+    def __init__(self, d_frames, w, h, nfeat, device_index, streams=3):
+        import torch
+        import orbhip
+        from orbhip.frame import Camera, FrameOps
+        self.torch, self.orbhip = torch, orbhip
+        self.d_frames, self.w, self.h, self.nfeat, self.di, self.streams = d_frames, w, h, nfeat, device_index, streams
+        self.dev = d_frames.device
+        self.B = d_frames.shape[0]
+        self.cam = camera_for(w, h)
+        self.ex = orbhip.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device_index, max_batch=self.B)
+        self.m = orbhip.ORBmatcher(0.9, True)
+        self.fo = FrameOps(Camera.make(*self.cam), w, h)
+        self.grid = self.fo.grid
+        # first pass: the projection records of every frame's partner (the "last frame" of the motion model) — prepared once, resident in HBM, like a map
+        self.out = self.ex.extract_batch(d_frames, self.LAP)
+        self.cap = self.out[0].shape[1]
+        self.un = self.fo.UndistortKeyPoints(self.out[0], self.out[2].view(-1), count_stride=2)
+        torch.cuda.synchronize()
+        counts0 = self.out[2].cpu().numpy()
+        self.q, self.nq, self.src = build_match_queries(self.un.cpu().numpy(), counts0, self.ex.GetScaleFactors(), self.cap)
+        self.d_q = torch.from_numpy(self.q.view(np.uint8).reshape(self.B, self.cap, 28)).to(self.dev)
+        self.d_nq = torch.from_numpy(self.nq).to(self.dev)
+        self.d_qdesc = self.out[1][torch.from_numpy(self.src).to(self.dev)].contiguous()
+        self.work = torch.empty(self.m._L.orbm_search_workspace_bytes(self.B, self.cap), dtype=torch.uint8, device=self.dev)
+        self.res = self.gbuf = None
+        self._stream_state = None
+
+    def _match(self, out):
+        cnt = out[2].view(-1)
+        self.un = self.fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=self.un)
+        self.gbuf = self.m.grid_build(self.un, cnt, self.grid, count_stride=2, out=self.gbuf)
+        self.res = self.m.SearchByProjection(self.un, out[1], cnt, self.gbuf[0], self.gbuf[1], self.d_q, self.d_qdesc, self.d_nq, self.grid, 1, 100,
+                                             count_stride=2, work=self.work, out=self.res)
+
+    def sequential_step(self):
+        self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
+        self._match(self.out)
+
+    def kernel_times(self, warm=4):
+        """Per-kernel device times (HIP events recorded on the launch stream inside the C ABI) from one untimed, sequential step — call before
+        the extra streams exist."""
+        torch = self.torch
+        for _ in range(warm):
+            self.sequential_step()
+        torch.cuda.synchronize()
+        kern = {}
+        self.m.enable_timing(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the launches (torch's current stream)
+        self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
+        cnt = self.out[2].view(-1)
+        e0.record()
+        self.un = self.fo.UndistortKeyPoints(self.out[0], cnt, count_stride=2, out=self.un)
+        e1.record()
+        self.gbuf = self.m.grid_build(self.un, cnt, self.grid, count_stride=2, out=self.gbuf)
+        self.res = self.m.SearchByProjection(self.un, self.out[1], cnt, self.gbuf[0], self.gbuf[1], self.d_q, self.d_qdesc, self.d_nq, self.grid, 1, 100,
+                                             count_stride=2, work=self.work, out=self.res)
+        torch.cuda.synchronize()
+        for k, v in self.ex.last_timing().items():
+            kern[k if k != "total" else "extract_total"] = v
+        kern["undistort"] = e0.elapsed_time(e1)
+        kern.update(self.m.last_timing())
+        self.m.enable_timing(False)
+        return kern
+
+    def start_streams(self):
+        torch, orbhip = self.torch, self.orbhip
+        st = self.streams
+        sA = torch.cuda.current_stream(self.dev)
+        sB = torch.cuda.Stream(self.dev) if st >= 2 else sA
+        nbuf = 1 if st == 1 else max(2, st - 1)             # buffer sets in rotation (>= 3 streams: one extractor handle + stream each)
+        sX = [sA] + [torch.cuda.Stream(self.dev) if st >= 3 else sA for _ in range(nbuf - 1)]          # extraction stream of buffer set k
+        exs = [self.ex] + [orbhip.ORBextractor(self.nfeat, 1.2, 8, 20, 7, device=self.di, max_batch=self.B) if st >= 3 else self.ex for _ in range(nbuf - 1)]
+        self._stream_state = dict(sB=sB, nbuf=nbuf, sX=sX, exs=exs, outs=[self.out] + [None] * (nbuf - 1), evA=[torch.cuda.Event() for _ in range(nbuf)],
+                                  evB=[torch.cuda.Event() for _ in range(nbuf)], evB_set=[False] * nbuf, step_no=0)
+
+    def step(self):
+        torch = self.torch
+        S = self._stream_state
+        k = S["step_no"] % S["nbuf"]
+        S["step_no"] += 1
+        with torch.cuda.stream(S["sX"][k]):
+            if self.streams >= 2 and S["evB_set"][k]:
+                S["sX"][k].wait_event(S["evB"][k])                   # the match that read this buffer set two steps ago has finished
+            S["outs"][k] = S["exs"][k].extract_batch(self.d_frames, self.LAP, out=S["outs"][k])
+            self.out = S["outs"][k]
+            if self.streams >= 2:
+                S["evA"][k].record(S["sX"][k])
+        with torch.cuda.stream(S["sB"]):
+            if self.streams >= 2:
+                S["sB"].wait_event(S["evA"][k])
+            self._match(self.out)
+            if self.streams >= 2:
+                S["evB"][k].record(S["sB"])
+                S["evB_set"][k] = True
+
+    def extract_only_step(self):
+        self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
+
+    def snapshot(self, sel=None):
+        """Host copies of the last completed step's outputs (after a device synchronize) for the frames `sel` (default: all)."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        idx = slice(None) if sel is None else torch.as_tensor(np.asarray(sel), device=self.dev, dtype=torch.long)
+        g = lambda t: t[idx].cpu().numpy()
+        return dict(kps=g(self.out[0]), desc=g(self.out[1]), counts=g(self.out[2]), un=g(self.un), q_match=g(self.res[0]), kp_match=g(self.res[1]),
+                    nm=g(self.res[2]))
+
+    def check_against_oracle(self, sel=None, frames_host=None, nthreads=None):
+        """The last completed step against the oracle on the frames `sel` (default all): -> (frames compared, mismatch descriptions, totals).
+        Test / measurement-hygiene infrastructure: called after timed regions only."""
+        import bench_check
+        sel = np.arange(self.B) if sel is None else np.asarray(sel)
+        snap = self.snapshot(sel)
+        fr = frames_host[sel] if frames_host is not None else self.d_frames[self.torch.as_tensor(sel, device=self.dev, dtype=self.torch.long)].cpu().numpy()
+        cam9 = np.array(list(self.cam[:4]) + list(self.cam[4]) + [0.0], np.float32)
+        qd = self.d_qdesc[self.torch.as_tensor(sel, device=self.dev, dtype=self.torch.long)].cpu().numpy()
+        return bench_check.compare_step(fr, snap, self.q[sel].copy(), qd, self.nq[sel].copy(), cam9, np.array(self.grid, np.float32), self.nfeat,
+                                        lap=self.LAP, nthreads=nthreads)
 
 
 def usable_cores():
@@ -195,6 +344,8 @@ def main():
                     help="2: the match kernels of step i run on a second HIP stream next to the extraction of step i+1 (double-buffered extractor outputs); "
                          "3: additionally two extractor handles alternate on two streams (the extractions of consecutive steps overlap); 4 / 5: three / four "
                          "handles in rotation (measured on MI355X: 2.33-2.36 ms per step against 2.35 with 3 — nothing left to overlap); 1: everything in one stream")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = the median region")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the last timed step (profiling runs)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
@@ -231,7 +382,6 @@ def main():
     B = args.batch
     frames = make_batch(B, seed0=1000 * rank)
     d_frames = torch.from_numpy(frames).to(dev)
-    ex = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
 
     def barrier():
         torch.cuda.synchronize()
@@ -253,112 +403,62 @@ def main():
             sys.stderr.write(traceback.format_exc())
             return None
 
+    def timed(fn, steps, repeats):
+        """`repeats` timed regions of exactly `steps` steps each, every one bracketed by barrier + synchronize on both sides -> list of seconds
+        (max over ranks is taken by the caller)."""
+        dts = []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            barrier()
+            dts.append(time.perf_counter() - t0)
+        return dts
+
+    def rank_max(vals):
+        if world == 1:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
     # ---- the step: ORBextractor -> UndistortKeyPoints (EuRoC calibration) -> AssignFeaturesToGrid -> SearchByProjection (motion model)
-    from orbhip.frame import Camera, FrameOps
-    CAM = (458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05))
-    m = orbhip.ORBmatcher(0.9, True)
-    fo = FrameOps(Camera.make(*CAM), W, H)
-    grid = fo.grid
-    out = ex.extract_batch(d_frames, (0, 1000))
-    cap = out[0].shape[1]
-    un = fo.UndistortKeyPoints(out[0], out[2].view(-1), count_stride=2)
-    torch.cuda.synchronize()
-    counts0 = out[2].cpu().numpy()
-    # projection records of every frame's partner (the "last frame" of the motion model): prepared once, resident in HBM, like a map
-    q, nq, src = build_match_queries(un.cpu().numpy(), counts0, ex.GetScaleFactors(), cap)
-    d_q = torch.from_numpy(q.view(np.uint8).reshape(B, cap, 28)).to(dev)
-    d_nq = torch.from_numpy(nq).to(dev)
-    d_qdesc = out[1][torch.from_numpy(src).to(dev)].contiguous()
-    work = torch.empty(m._L.orbm_search_workspace_bytes(B, cap), dtype=torch.uint8, device=dev)
-    res = gbuf = None
-    # a few sequential passes (warm kernels and clocks), then the per-kernel timing pass — before the extra streams exist
-    for _ in range(4):
-        out = ex.extract_batch(d_frames, (0, 1000), out=out)
-        cnt = out[2].view(-1)
-        un = fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=un)
-        gbuf = m.grid_build(un, cnt, grid, count_stride=2, out=gbuf)
-        res = m.SearchByProjection(un, out[1], cnt, gbuf[0], gbuf[1], d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work, out=res)
-    torch.cuda.synchronize()
-    # per-kernel device times (HIP events recorded on the launch stream inside the C ABI) — from one untimed, sequential step
-    kern = {}
-    m.enable_timing(True)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the launches (torch's current stream)
-    out = ex.extract_batch(d_frames, (0, 1000), out=out)
-    cnt = out[2].view(-1)
-    e0.record()
-    un = fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=un)
-    e1.record()
-    gbuf = m.grid_build(un, cnt, grid, count_stride=2, out=gbuf)
-    res = m.SearchByProjection(un, out[1], cnt, gbuf[0], gbuf[1], d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work, out=res)
-    torch.cuda.synchronize()
-    for k, v in ex.last_timing().items():
-        kern[k if k != "total" else "extract_total"] = v
-    kern["undistort"] = e0.elapsed_time(e1)
-    kern.update(m.last_timing())
-    m.enable_timing(False)
-    # Two HIP streams: the extraction of step i+1 (stream A, fills the machine) runs next to the match kernels of step i (stream B: the
-    # serial-order resolver is one wave per frame and leaves the machine almost empty).  The extractor's outputs are double-buffered; an
-    # event pair per buffer set orders producer and consumer.  All K steps complete inside the timed region (device-wide synchronize).
-    sA = torch.cuda.current_stream(dev)
-    sB = torch.cuda.Stream(dev) if args.streams >= 2 else sA
-    nbuf = 1 if args.streams == 1 else max(2, args.streams - 1)             # buffer sets in rotation (>= 3 streams: one extractor handle + stream each)
-    sX = [sA] + [torch.cuda.Stream(dev) if args.streams >= 3 else sA for _ in range(nbuf - 1)]          # extraction stream of buffer set k
-    exs = [ex] + [orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=B) if args.streams >= 3 else ex for _ in range(nbuf - 1)]
-    outs = [out] + [None] * (nbuf - 1)
-    evA = [torch.cuda.Event() for _ in range(nbuf)]
-    evB = [torch.cuda.Event() for _ in range(nbuf)]
-    evB_set = [False] * nbuf
-    step_no = [0]
-
-    def step():
-        nonlocal out, res, un, gbuf
-        k = step_no[0] % nbuf
-        step_no[0] += 1
-        with torch.cuda.stream(sX[k]):
-            if args.streams >= 2 and evB_set[k]:
-                sX[k].wait_event(evB[k])                   # the match that read this buffer set two steps ago has finished
-            outs[k] = exs[k].extract_batch(d_frames, (0, 1000), out=outs[k])
-            out = outs[k]
-            if args.streams >= 2:
-                evA[k].record(sX[k])
-        with torch.cuda.stream(sB):
-            if args.streams >= 2:
-                sB.wait_event(evA[k])
-            cnt = out[2].view(-1)
-            un = fo.UndistortKeyPoints(out[0], cnt, count_stride=2, out=un)
-            gbuf = m.grid_build(un, cnt, grid, count_stride=2, out=gbuf)
-            res = m.SearchByProjection(un, out[1], cnt, gbuf[0], gbuf[1], d_q, d_qdesc, d_nq, grid, 1, 100, count_stride=2, work=work, out=res)
-            if args.streams >= 2:
-                evB[k].record(sB)
-                evB_set[k] = True
-
+    P = StepPipeline(d_frames, W, H, NFEAT, local_rank, streams=args.streams)
+    ex, m, grid, cap, q, nq, d_qdesc = P.ex, P.m, P.grid, P.cap, P.q, P.nq, P.d_qdesc
+    CAM = P.cam
+    kern = P.kernel_times()          # a few sequential passes (warm kernels and clocks), then the per-kernel timing pass — before the extra streams exist
+    P.start_streams()
     for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+        P.step()
+    # the headline: `--repeats` timed regions of exactly --steps steps; `value` is the MEDIAN region (min / max reported next to it)
+    dts = rank_max(timed(P.step, args.steps, args.repeats))
+    dt = float(np.median(dts))
     torch.cuda.synchronize()
-    step_no[0] = 0; evB_set[:] = [False] * nbuf
+    out, res = P.out, P.res
     counts = out[2].cpu().numpy()
     nm = res[2].cpu().numpy()
     extra["step"] = {"mean_matches_per_frame": float(nm.mean()), "queries_per_frame": float(nq.mean()), "mean_keypoints": float(counts[:, 0].mean()),
                      "match_only_ms": round(kern["undistort"] + kern["grid_build"] + kern["sbp_candidates"] + kern["sbp_resolve"], 4)}
+    # ---- parity of THIS run: the last timed step's outputs (all three streams, the handle whose turn it was) against the oracle, after the
+    # timed region: every frame at N=1, 64 per rank at N>1.  A mismatch makes the line invalid: reported and the exit code is 3.
+    parity = {"checked_frames": 0, "mismatches": None}
+    if not args.no_parity_check:
+        sel = np.arange(B) if world == 1 else np.unique(np.linspace(0, B - 1, min(B, 64)).astype(np.int64))
+        tpc = time.perf_counter()
+        n_chk, bad, tot = P.check_against_oracle(sel, frames_host=frames)
+        nbad = rank_max([float(len(bad))])[0]
+        parity = {"checked_frames": int(n_chk) * world, "mismatches": int(nbad), "first_mismatches": bad[:4], "seconds": round(time.perf_counter() - tpc, 2),
+                  "keypoints_compared": int(tot["keypoints"]), "matches_compared": int(tot["matches"]),
+                  "what": "last timed step (streams=%d) vs oracle per frame: {N, monoIndex}, key point records, descriptors, undistorted records, "
+                          "per-query match, mvpMapPoints, nmatches — bitwise" % args.streams}
 
     # ---- metric component: ORBextractor alone (BASELINE configs[1]), same batch, exactly --steps steps
-    def step_extract():
-        nonlocal out
-        out = ex.extract_batch(d_frames, (0, 1000), out=out)
     for _ in range(min(args.warmup, 2)):
-        step_extract()
-    barrier()
-    tx0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_extract()
-    barrier()
-    dt_extract = time.perf_counter() - tx0
+        P.extract_only_step()
+    dts_extract = rank_max(timed(P.extract_only_step, args.steps, max(1, min(args.repeats, 3))))
+    dt_extract = float(np.median(dts_extract))
+    out = P.out
 
     def leg_host_api():
         # the single-image host-buffer entry point (ORBextractor::operator() drop-in): PCIe + sync inclusive
@@ -645,6 +745,71 @@ def main():
                                    "mean_lapping_keypoints_left": float((cn[:, 0] - cn[:, 1]).mean()), "mean_matches": float(fm[4].float().mean().item()),
                                    "what": "2 x ORBextractor (lapping area 300..980) + Frame::ComputeStereoFishEyeMatches per fisheye stereo frame"}
 
+    def leg_size_1280x720():
+        # ---- north_star's second frame size: 1280x720, nFeatures = 1500 (TUM_512.yaml:62's feature count on BASELINE configs[3]'s frame shape),
+        #      the SAME step (extract + undistort + grid + SearchByProjection on 3 streams) and the extraction alone, with their roofline fractions
+        FW, FH, FN, FB = 1280, 720, 1500, 256
+        fr = make_batch(FB, seed0=5000 + 1000 * rank, unique=8, w=FW, h=FH)
+        dfr = torch.from_numpy(fr).to(dev)
+        P2 = StepPipeline(dfr, FW, FH, FN, local_rank, streams=args.streams)
+        k2 = P2.kernel_times(warm=2)
+        P2.start_streams()
+        for _ in range(3):
+            P2.step()
+        st = max(5, args.steps // 2)
+        d2 = float(np.median(rank_max(timed(P2.step, st, 3))))
+        chk = None
+        if not args.no_parity_check:
+            sel2 = np.unique(np.linspace(0, FB - 1, 32).astype(np.int64))
+            n2, bad2, _ = P2.check_against_oracle(sel2, frames_host=fr)
+            chk = {"checked_frames": int(n2), "mismatches": len(bad2), "first_mismatches": bad2[:2]}
+        d2x = float(np.median(rank_max(timed(P2.extract_only_step, st, 3))))
+        cnt2 = P2.out[2].cpu().numpy()
+        we, pk2 = algorithmic_bytes(FW, FH, FN)
+        wm, pkm2 = match_algorithmic_bytes(FN, FN)
+        pk2.update(pkm2)
+        dom2 = max(KNAMES, key=lambda k: k2.get(k, 0.0))
+        fps2, fps2x = world * FB * st / d2, world * FB * st / d2x
+        extra["size_1280x720"] = {"extract_match_frames_per_s": round(fps2, 1), "extract_frames_per_s": round(fps2x, 1), "ms_per_step": round(d2 / st * 1e3, 4),
+                                  "frames_per_gpu_per_step": FB, "nfeatures": FN, "steps": st, "mean_keypoints": float(cnt2[:, 0].mean()),
+                                  "mean_matches": float(P2.res[2].float().mean().item()), "fast_passes": P2.ex.last_fast_passes(),
+                                  "whole_step_algorithmic_bytes_per_frame": we + wm,
+                                  "whole_step_frac": round((we + wm) * fps2 / world / 1e9 / HBM_PEAK_GBS, 5),
+                                  "whole_extract_frac": round(we * fps2x / world / 1e9 / HBM_PEAK_GBS, 5),
+                                  "dominant_kernel": KNAMES[dom2], "dominant_kernel_ms": round(k2[dom2], 4),
+                                  "dominant_kernel_frac": round(pk2[dom2] * FB / (k2[dom2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                  "kernel_ms": {k: round(v, 4) for k, v in k2.items()},
+                                  "per_kernel_frac": {KNAMES[k]: round(pk2[k] * FB / (k2[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) for k in KNAMES if k2.get(k, 0) > 0},
+                                  "parity": chk}
+        del P2
+
+    def leg_batch_sweep():
+        # ---- B in {64, 512, 4096} per GPU.  The 512 input frames (185 MB) fit the 256 MiB Infinity Cache and are re-read every step;
+        #      4096 frames (1.48 GB of input, 4.6 GB of pyramid per handle) cannot — the rate must not depend on that residency.
+        sweep = {}
+        for SB in (64, 4096):
+            dfs = grow_batch_on_device(d_frames, SB)
+            Ps = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=args.streams)
+            Ps.kernel_times(warm=1)
+            Ps.start_streams()
+            st = max(3, args.steps // 4) if SB > B else args.steps
+            for _ in range(2):
+                Ps.step()
+            ds = rank_max(timed(Ps.step, st, 3))
+            ent = {"frames_per_s": round(world * SB * st / float(np.median(ds)), 1), "ms_per_step": round(float(np.median(ds)) / st * 1e3, 4), "steps": st,
+                   "frames_per_s_min": round(world * SB * st / max(ds), 1), "frames_per_s_max": round(world * SB * st / min(ds), 1),
+                   "input_bytes": int(SB) * W * H, "fast_passes": Ps.ex.last_fast_passes()}
+            if not args.no_parity_check:
+                sels = np.unique(np.linspace(0, SB - 1, 32).astype(np.int64))
+                ns, bads, _ = Ps.check_against_oracle(sels)
+                ent["parity"] = {"checked_frames": int(ns), "mismatches": len(bads), "first_mismatches": bads[:2]}
+            sweep[str(SB)] = ent
+            del Ps, dfs
+            torch.cuda.empty_cache()
+        sweep[str(B)] = {"frames_per_s": round(world * B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps,
+                         "input_bytes": int(B) * W * H, "note": "the headline"}
+        extra["batch_sweep"] = sweep
+
     def leg_exchange():
         # N > 1 only: the two exchange steps of the path on RCCL — descriptor blocks for cross-rank matching, and the
         # landmark-sharded LBA linearisation (all-reduce of the pose-side system, all-gather of the pose blocks).  Not guarded: a failing
@@ -693,7 +858,8 @@ def main():
 
     if not args.headline_only:
         for name, fn in (("host_api", leg_host_api), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
-                         ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo)):
+                         ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
+                         ("batch_sweep", leg_batch_sweep)):
             guard(name, fn)
         if world > 1:
             leg_exchange()
@@ -715,8 +881,7 @@ def main():
         whole_ext, pk = algorithmic_bytes(W, H, NFEAT)
         whole_match, pkm = match_algorithmic_bytes(NFEAT, NFEAT)    # SURVEY §8(d) figures are quoted at N = N_q = nFeatures
         pk.update(pkm)
-        names = {"pyramid": "k_resize2", "fast": "k_fast", "octree": "k_octree", "describe": "k_describe2", "undistort": "k_undistort",
-                 "grid_build": "k_grid_build", "sbp_candidates": "k_sbp_candidates2", "sbp_resolve": "k_sbp_resolve"}
+        names = KNAMES
         dom = max(names, key=lambda k: kern.get(k, 0.0))
         ach = pk[dom] * B / (kern[dom] * 1e-3) / 1e9 if kern.get(dom, 0) > 0 else 0.0
         fps = world * B * args.steps / dt
@@ -739,11 +904,14 @@ def main():
         except Exception:   # noqa: BLE001
             pass
         is_headline = (W, H, NFEAT) == (752, 480, 1000)
+        parity_note = ("; the last timed step's %d frames bit-exact vs the CPU oracle" % parity["checked_frames"]) if parity["checked_frames"] > 0 and parity["mismatches"] == 0 else ""
         res = {
             "metric": BASELINE_METRIC if is_headline else "frames/sec ORB extract+match (%dx%d, %d kp)" % (W, H, NFEAT),
             "value": round(fps, 1), "unit": "frames/s",
             "value_is": "ORB extract+match frames/s: ORBextractor + UndistortKeyPoints + AssignFeaturesToGrid + SearchByProjection per frame, "
-                        "exactly --steps steps",
+                        "median of %d timed regions of exactly --steps steps each" % args.repeats,
+            "value_min": round(world * B * args.steps / max(dts), 1), "value_max": round(world * B * args.steps / min(dts), 1), "repeats": args.repeats,
+            "region_ms": [round(v * 1e3, 3) for v in dts],
             "metric_components": {"orb_extract_match_frames_per_s": round(fps, 1),
                                   "orb_extract_frames_per_s": round(fps_extract, 1),
                                   "local_ba_linearizations_per_s": extra.get("lba", {}).get("linearizations_per_s"),
@@ -751,7 +919,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d grayscale batch, ORB extract (nFeatures=%d, 8 levels, 1.2, FAST 20/7) + SearchByProjection match "
-                                   "(motion model, th=15) against the partner frame's %d points; bit-exact vs CPU oracle" % (W, H, NFEAT, int(round(Nq))),
+                                   "(motion model, th=15) against the partner frame's %d points%s" % (W, H, NFEAT, int(round(Nq)), parity_note),
+                       "parity_checked_frames": parity["checked_frames"], "parity_mismatches": parity["mismatches"], "parity": parity,
                        "frames_per_gpu_per_step": B, "mean_keypoints": Nk, "mean_queries": Nq, "mean_matches": float(nm.mean()),
                        "parallelism": "frames sharded, %d rank(s), no collective" % world, "world": world, "hip_streams": args.streams,
                        "backend": (dist.get_backend() if world > 1 else None)},
@@ -780,6 +949,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity["mismatches"]:
+        sys.stderr.write("bench.py: the timed step's outputs differ from the oracle: %s\n" % parity.get("first_mismatches"))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

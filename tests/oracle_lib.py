@@ -195,6 +195,43 @@ def bench_extract_match_mt(frames, nthreads, frames_per_thread, cam9, grid4, que
     return s, kp.value, mt.value
 
 
+def extract_match_frames(frames, sel, cam9, grid4, queries, qdesc, nq, mode=1, th_dist=100, nnratio=0.9, check_ori=True, do_match=True,
+                         nfeatures=1000, lap=(0, 1000), nthreads=None, cap=None, cfg=(1.2, 8, 20, 7)):
+    """oracle/bench_oracle.cpp oro_extract_match_frames_mt: the benchmark step's per-frame unit (ORBextractor -> UndistortKeyPoints -> grid ->
+    SearchByProjection with prepared projection records) for the frames `sel` of the batch, in native threads, every output kept.
+    -> dict(kps [n,cap,7] f32, desc [n,cap,32] u8, counts [n,2] i32 = {N, monoIndex}, un [n,cap,7], q_match [n,cap_q], kp_match [n,cap], nm [n])"""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    B, H, W = frames.shape
+    sel = np.ascontiguousarray(sel, np.int32)
+    n = len(sel)
+    cap = int(cap or (4 * nfeatures + 64))
+    L = lib()
+    L.oro_extract_match_frames_mt.restype = C.c_int
+    L.oro_extract_match_frames_mt.argtypes = ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] +
+                                              [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int] +
+                                              [C.c_void_p] * 7)
+    if do_match:
+        cam9 = np.ascontiguousarray(cam9, np.float32); grid4 = np.ascontiguousarray(grid4, np.float32)
+        queries = np.ascontiguousarray(queries); qdesc = np.ascontiguousarray(qdesc, np.uint8); nq = np.ascontiguousarray(nq, np.int32)
+        cap_q = qdesc.shape[1]
+        assert queries.nbytes == B * cap_q * 28 and qdesc.shape == (B, cap_q, 32) and nq.shape == (B,)
+    else:
+        cam9 = np.zeros(9, np.float32); grid4 = np.zeros(4, np.float32)
+        queries = np.zeros(1, np.uint8); qdesc = np.zeros((1, 1, 32), np.uint8); nq = np.zeros(B, np.int32); cap_q = 1
+    if nthreads is None:
+        nthreads = max(1, min(len(os.sched_getaffinity(0)), 32, n))
+    out = dict(kps=np.zeros((n, cap, 7), np.float32), desc=np.zeros((n, cap, 32), np.uint8), counts=np.zeros((n, 2), np.int32),
+               un=np.zeros((n, cap, 7), np.float32), q_match=np.zeros((n, cap_q), np.int32), kp_match=np.zeros((n, cap), np.int32),
+               nm=np.zeros(n, np.int32))
+    rc = L.oro_extract_match_frames_mt(_p(frames), B, W, H, nfeatures, cfg[0], cfg[1], cfg[2], cfg[3], lap[0], lap[1], _p(cam9), _p(grid4), _p(queries),
+                                       _p(qdesc), _p(nq), cap_q, mode, th_dist, nnratio, int(check_ori), int(do_match), int(nthreads), _p(sel), n, cap,
+                                       _p(out["kps"]), _p(out["desc"]), _p(out["counts"]), _p(out["un"]), _p(out["q_match"]), _p(out["kp_match"]),
+                                       _p(out["nm"]))
+    if rc != 0:
+        raise RuntimeError("oro_extract_match_frames_mt: frame %d exceeds the output capacity %d" % (int(sel[-rc - 1]), cap))
+    return out
+
+
 # ---- stage 2 (oracle/match_oracle.cpp) ------------------------------------------------------------------
 QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("angle", "<f4"),
                         ("min_level", "<i2"), ("max_level", "<i2"), ("flags", "<u4")])

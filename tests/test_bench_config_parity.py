@@ -1,0 +1,133 @@
+"""Parity at the size the headline is quoted on (round-3 verdict, item 1): the benchmark's OWN pipeline — bench.StepPipeline: make_batch(512),
+extract_batch on two rotating extractor handles, three HIP streams, the two-pass k_fast with its retry list, UndistortKeyPoints -> grid ->
+SearchByProjection — with EVERY frame of a step compared with the oracle (key point records, descriptors, {N, monoIndex}, undistorted
+records, per-query match, mvpMapPoints, nmatches: bitwise); the same at 1280x720 / nFeatures 1500 with B = 256 and at B = 4096 (counts of all
+frames + 64 frames in full).  Reference: ORBextractor.cc:1074-1156, Frame.cc:874-924, ORBmatcher.cc:2244-2509.
+
+The CPU tier holds the checker's self-test (a planted single-bit error must be reported); the GPU tier is the comparison proper."""
+import numpy as np
+import pytest
+
+import bench
+import bench_check
+import oracle_lib as O
+
+
+def _oracle_snap(frames, nfeat, cap):
+    o = O.extract_match_frames(frames, np.arange(len(frames), dtype=np.int32), None, None, None, None, None, do_match=False, nfeatures=nfeat, cap=cap)
+    return dict(kps=o["kps"], desc=o["desc"], counts=o["counts"])
+
+
+def test_checker_reports_planted_errors():
+    from orbhip.synth import synth_image
+    frames = np.stack([synth_image(70 + i, 320, 240, n_rect=80, n_disc=40) for i in range(3)])
+    snap = _oracle_snap(frames, 300, 420)
+    n, bad, tot = bench_check.compare_step(frames, snap, None, None, None, None, None, 300, do_match=False)
+    assert n == 3 and bad == [] and tot["keypoints"] == int(snap["counts"][:, 0].sum()) > 600
+    s2 = {k: v.copy() for k, v in snap.items()}
+    s2["desc"][1, 17, 5] ^= 0x10                                  # one descriptor bit
+    assert any("frame 1: descriptors" in b for b in bench_check.compare_step(frames, s2, None, None, None, None, None, 300, do_match=False)[1])
+    s3 = {k: v.copy() for k, v in snap.items()}
+    s3["kps"].view(np.uint32)[2, 40, 3] ^= 1                       # one ulp of one angle
+    assert any("frame 2: key point records" in b for b in bench_check.compare_step(frames, s3, None, None, None, None, None, 300, do_match=False)[1])
+    s4 = {k: v.copy() for k, v in snap.items()}
+    s4["counts"][0, 0] -= 1
+    assert any("frame 0: {N, monoIndex}" in b for b in bench_check.compare_step(frames, s4, None, None, None, None, None, 300, do_match=False)[1])
+
+
+def test_oracle_batch_unit_equals_single_calls():
+    """oro_extract_match_frames_mt (threads, kept outputs) == the single-frame oracle entry points the other parity tests use."""
+    from orbhip.synth import synth_image
+    frames = np.stack([synth_image(80 + i, 320, 240, n_rect=80, n_disc=40) for i in range(4)])
+    cam = bench.camera_for(320, 240)
+    cam9 = np.array(list(cam[:4]) + list(cam[4]) + [0.0], np.float32)
+    grid4 = np.array([0.0, 0.0, 64 / 320.0, 48 / 240.0], np.float32)
+    o1 = O.extract_match_frames(frames, np.arange(4, dtype=np.int32), None, None, None, None, None, do_match=False, nfeatures=300, cap=420)
+    kun = np.zeros_like(o1["kps"])
+    for b in range(4):
+        n = o1["counts"][b, 0]
+        kun[b, :n] = O.undistort_keypoints(o1["kps"][b, :n].copy().view(O.KP_DTYPE).reshape(-1), cam9).view(np.float32).reshape(-1, 7)
+    scale = O.OrbOracle(300).tables()["scale"]
+    q, nq, src = bench.build_match_queries(kun, o1["counts"], scale, 420)
+    qd = o1["desc"][src]
+    o = O.extract_match_frames(frames, np.array([3, 1], np.int32), cam9, grid4, q, qd, nq, nfeatures=300, cap=420, nthreads=2)
+    for j, b in enumerate((3, 1)):
+        n = o["counts"][j, 0]
+        u = lambda a: np.ascontiguousarray(a).view(np.uint32)               # class_id = -1 reads as NaN in the float view
+        assert np.array_equal(u(o["kps"][j, :n]), u(o1["kps"][b, :n])) and np.array_equal(u(o["un"][j, :n]), u(kun[b, :n]))
+        oq, ok, on = O.search_by_projection(kun[b, :n].copy().view(O.KP_DTYPE).reshape(-1), o1["desc"][b, :n], q[b, :nq[b]], qd[b, :nq[b]], grid4, 1, 100, 0.9, True)
+        assert on == o["nm"][j] > 20 and np.array_equal(ok, o["kp_match"][j, :n]) and np.array_equal(oq, o["q_match"][j, :nq[b]])
+
+
+def _pipeline(B, w, h, nfeat, streams=3, seed0=0, unique=16):
+    import torch
+    frames = bench.make_batch(B, seed0=seed0, unique=unique, w=w, h=h)
+    d_frames = torch.from_numpy(frames).to("cuda:0")
+    return frames, bench.StepPipeline(d_frames, w, h, nfeat, 0, streams=streams)
+
+
+@pytest.mark.gpu
+def test_hip_bench_step_752x480_B512_every_frame(hip_lib):
+    """The headline configuration itself.  18 steps take both handles through the pass-policy probe (every 16th call); then the outputs of two
+    consecutive steps — one per extractor handle — are compared, all 512 frames each."""
+    frames, P = _pipeline(512, 752, 480, 1000)
+    P.kernel_times(warm=1)
+    P.start_streams()
+    for _ in range(18):
+        P.step()
+    seen_two_pass = 0
+    for turn in range(2):
+        P.step()
+        n, bad, tot = P.check_against_oracle(None, frames_host=frames)
+        assert n == 512 and bad == [], bad
+        assert tot["keypoints"] > 512 * 990 and tot["matches"] > 512 * 300      # the stated size, really matched
+        seen_two_pass += P._stream_state["exs"][turn % 2].last_fast_passes()["two_pass"]
+    assert seen_two_pass >= 1, "the benchmark batch is expected to run the two-pass k_fast form"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [1, 2])
+def test_hip_bench_step_752x480_B64_streams(hip_lib, streams):
+    frames, P = _pipeline(64, 752, 480, 1000, streams=streams, seed0=300)
+    P.kernel_times(warm=1)
+    P.start_streams()
+    for _ in range(3):
+        P.step()
+    n, bad, _ = P.check_against_oracle(None, frames_host=frames)
+    assert n == 64 and bad == [], bad
+
+
+@pytest.mark.gpu
+def test_hip_bench_step_1280x720_1500kp_B256_every_frame(hip_lib):
+    """north_star's second frame size at its feature count (TUM_512.yaml:62), one-pass policy territory (sparser frames)."""
+    frames, P = _pipeline(256, 1280, 720, 1500, seed0=5000, unique=8)
+    P.kernel_times(warm=1)
+    P.start_streams()
+    for _ in range(5):
+        P.step()
+    for _ in range(2):
+        P.step()
+        n, bad, tot = P.check_against_oracle(None, frames_host=frames)
+        assert n == 256 and bad == [], bad
+        assert tot["keypoints"] > 256 * 1400
+
+
+@pytest.mark.gpu
+def test_hip_bench_step_752x480_B4096(hip_lib):
+    """SURVEY 8(d)'s largest batch: 4096 frames per GPU (1.48 GB of input — nothing stays cache resident).  {N, monoIndex} of ALL frames against
+    the oracle's extraction, and 64 frames spread over the batch in full (records, descriptors, match)."""
+    import torch
+    frames512 = bench.make_batch(512, seed0=0)
+    d = bench.grow_batch_on_device(torch.from_numpy(frames512).to("cuda:0"), 4096)
+    P = bench.StepPipeline(d, 752, 480, 1000, 0, streams=3)
+    P.start_streams()
+    for _ in range(3):
+        P.step()
+    torch.cuda.synchronize()
+    host = d.cpu().numpy()
+    o = O.extract_match_frames(host, np.arange(4096, dtype=np.int32), None, None, None, None, None, do_match=False, nfeatures=1000, cap=P.cap)
+    assert np.array_equal(P.out[2].cpu().numpy(), o["counts"]), "{N, monoIndex} of the 4096 frames"
+    assert np.array_equal(P.out[1].cpu().numpy()[:, :900], o["desc"][:, :900])            # and, while the oracle's outputs are here, descriptors
+    sel = np.unique(np.linspace(0, 4095, 64).astype(np.int64))
+    n, bad, _ = P.check_against_oracle(sel, frames_host=host)
+    assert n == 64 and bad == [], bad

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --streams 1"   # one stream: kernels run back to back, clean per-kernel durations
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --streams 1 --no-parity-check --repeats 1"   # one stream: kernels run back to back, clean per-kernel durations
 date +%T; rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $CMD > $OUT/stats.log 2>&1
 date +%T; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- $CMD > $OUT/fetch.log 2>&1
 date +%T; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o pmc -- $CMD > $OUT/write.log 2>&1
