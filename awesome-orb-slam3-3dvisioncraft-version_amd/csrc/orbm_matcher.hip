@@ -192,6 +192,7 @@ struct SbpArgs {
     int chi2_gate;              // Fuse: reprojection gate of ORBmatcher.cc:1791-1815
     float inv_sigma2[16];
     int32_t* q_dist;
+    int32_t* serial_flag;       // [batch] written by k_sbp_frame: 1 = this frame is left to k_sbp_candidates_flagged -> k_sbp_resolve; nullptr: they take every frame
 };
 
 // One entry of the window's enumeration (position p of the frame's grid-index list, or -1): the tests of GetFeaturesInArea and the candidate filters
@@ -322,14 +323,14 @@ static __device__ __forceinline__ void sort_and_store_list(uint32_t* lst, uint32
     if (lane == 0) { w[0] = (uint32_t)count | (anyArea ? 0x80000000u : 0u); w[1] = 0xFFFFFFFFu; }
 }
 
-static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
+static __device__ __forceinline__ void sbp_candidates2_block(const SbpArgs& A, const int b, const int qblock) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int half = lane >> 5, hl = lane & 31;
     uint32_t* lst2 = (uint32_t*)orb_smem + wv * 2 * SBP_CAPC;       // two lists of SBP_CAPC entries per wave
     // the query record and its descriptor do not depend on the counts: they are fetched in the same memory round trip (clamping the index
     // with nq instead of cap_q makes the compiler wait for nq first — one more dependent round trip on a kernel that is a chain of them)
-    const int q0 = (blockIdx.x * 4 + wv) * 2;
+    const int q0 = (qblock * 4 + wv) * 2;
     const int q = q0 + half;
     const size_t qslot = (size_t)b * A.cap_q + min(q, A.cap_q - 1);
     const orbm_query Q = A.queries[qslot];
@@ -470,6 +471,8 @@ static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) {
     }
 }
 
+static __global__ __launch_bounds__(256) void k_sbp_candidates2(SbpArgs A) { sbp_candidates2_block(A, blockIdx.y, blockIdx.x); }
+
 static __global__ __launch_bounds__(256) void k_sbp_candidates(SbpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     uint32_t* lst = (uint32_t*)orb_smem + (threadIdx.x >> 6) * SBP_CAPC;   // this wave's compacted list: sorted in LDS, written to the workspace once
@@ -564,11 +567,15 @@ static __global__ __launch_bounds__(256) void k_fuse(SbpArgs A) {
 // reference's accept rules against the live occupancy; distances come from k_sbp_candidates.
 // The serial chain touches LDS only: queries are staged 64 at a time (count, HAS_OBS flag and the first SBP_STAGE candidates
 // of each, loaded lane-parallel), and the rotation-histogram bins are computed after the loop (they do not feed back).
+#ifndef SBP_FUSED_FRAME
+#define SBP_FUSED_FRAME 1          // 0: every frame takes k_sbp_candidates2 -> k_sbp_resolve (the round-1..3 form: the A/B build and the CPU tier's second pass)
+#endif
 #define SBP_STAGE 16
 struct __attribute__((packed, aligned(4))) SbpRow4 { uint32_t a, b, c, d; };   // 4 list entries; rows of the work buffer are 8-byte aligned
 static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (A.serial_flag && A.serial_flag[b] == 0) return;   // resolved by k_sbp_frame
     const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
     const int nq = min(A.nq[b], A.cap_q);
     int* hist = (int*)orb_smem;                       // [32]
@@ -928,6 +935,333 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
     for (int q = lane; q < nq; q += 64)
         if (q_match[q] >= 0 && kp_match[q_match[q]] != q) q_match[q] = -1;
     if (lane == 0) A.nmatches[b] = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the whole projection search of a frame in ONE workgroup — k_sbp_frame.
+//
+// (1) The frame is staged once: key point positions and octaves, descriptors (rows of 9 dwords: an odd pitch spreads the random row reads over the
+//     banks), the 64 x 48 CSR heads and the grid index list — ~59 bytes per key point + 6 KB of LDS.  k_sbp_candidates2 walked
+//     query -> CSR heads -> index -> record -> descriptor as a chain of dependent L2 gathers (0.21 ms per 512 frames at 3 % of the VALU, traffic
+//     2.6-4.9 x algorithmic); from LDS the same chain costs ~100 cycles a link, so it is given to ONE LANE per query: every query of the frame
+//     walks its window at once, serially, in the reference's order (grid columns outer, CSR order inside a column = iy inner, insertion order
+//     inside a cell: Frame.cc:779-850), and keeps its SBPF_SD best candidates sorted by (distance, enumeration position) in registers — the order
+//     in which the serial strict-'<' scans of ORBmatcher.cc:137-158 / :2355-2368 rank them (stable insertion: a later candidate goes behind
+//     equal distances).
+// (2) The serial accept loop as parallel fixed-point rounds.  The loop's state is the occupancy: candidate c is blocked for query q iff an
+//     EARLIER query q' < q accepted c while holding an observed point (ORBmatcher.cc:125-127 / :2347-2349; the call's initial occupancy is
+//     filtered in (1)).  So a query's decision d[q] = F_q(d[0..q-1]) depends on the earlier decisions only, through blk[c] = the smallest
+//     accepting-and-observed query of c: best / second-best = the first two entries of q's sorted list with blk[c] >= q.  Jacobi iteration
+//     d_{r+1}[q] = F_q(d_r) on this strictly lower-triangular system reaches its unique fixed point — the serial result, by induction over q:
+//     after round r every query whose dependency chain is shorter than r is final — and stops after the first round that changes nothing
+//     (at most nq + 1 rounds; 8-9 on the benchmark's frames, where the one-wave walk of k_sbp_resolve takes ~1000 dependent steps).  blk is
+//     double-buffered and its entries carry the round that wrote them ((0xFFFF - r) << 16 | q under atomicMin: a newer round overrides, an
+//     entry of an older round reads as "nobody"), so a round is ONE workgroup barrier.
+// (3) What the walk leaves behind is reconstructed from the fixed point: kp_match[c] = the LAST accepter of c (only accepters without an observed
+//     point can share a key point), nmatches = the number of accepters, then the rotation-histogram cull and the "a query's match is reported
+//     only while its key point still holds it" filter exactly as k_sbp_resolve applies them.
+// A frame this form does not cover raises serial_flag[b] and is redone by the gated launches behind it (k_sbp_candidates_flagged ->
+// k_sbp_resolve): rig twins / right-camera queries, or a query whose decision would need more than its SBPF_SD best candidates (at least
+// SBPF_SD - 1 of them claimed by earlier queries) in ANY round — conservative, never wrong.  INIT mode, rigs with stereo links and frames beyond the
+// LDS / K limits never come here (sbp_launch).
+// One lane's walk over the window of its query in the reference's order (Frame.cc:779-850) on the staged frame; sink(idx, oct, dist) sees every
+// candidate that GetFeaturesInArea returns and that passes the call-constant filters (initial occupancy, stereo gate), with its Hamming distance.
+struct SbpfFrame { const uint16_t* gs; const uint32_t* ge; const float* gx; const float* gy; const uint32_t* dsc; const uint8_t* occ0; const float* ur; int n; };
+#define SBPF_DP 9          // descriptor row pitch in LDS, dwords (odd: random rows spread over the banks)
+template <class Sink>
+static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_grid_params& g, const orbm_query& Q, const Desc& qd, Sink&& sink) {
+    const float r = Q.radius;
+    // Frame.cc:779-806
+    const int nMinCellX = max(0, (int)floorf((Q.u - g.min_x - r) * g.grid_w_inv));
+    const int nMaxCellX = min(ORBM_GRID_COLS - 1, (int)ceilf((Q.u - g.min_x + r) * g.grid_w_inv));
+    const int nMinCellY = max(0, (int)floorf((Q.v - g.min_y - r) * g.grid_h_inv));
+    const int nMaxCellY = min(ORBM_GRID_ROWS - 1, (int)ceilf((Q.v - g.min_y + r) * g.grid_h_inv));
+    if (nMinCellX >= ORBM_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBM_GRID_ROWS || nMaxCellY < 0 || nMaxCellY < nMinCellY) return;
+    const int minLevel = Q.min_level, maxLevel = Q.max_level;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);   // Frame.cc:810
+    const bool stereoGate = (Q.flags & ORBM_Q_STEREO) && F.ur;
+    // ONE loop over the window's entries: a grid column's cells [nMinCellY, nMaxCellY] are one contiguous CSR range (iy inner, insertion order
+    // inside a cell), the columns follow each other (ix outer).  A lane's turn either takes an entry or moves to its next column, so a wave
+    // runs max over its lanes of (entries + columns) turns instead of a sum over columns of per-column maxima.
+    int ix = nMinCellX;
+    int p = F.gs[ix * ORBM_GRID_ROWS + nMinCellY], pe = F.gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
+    for (;;) {
+        if (p >= pe) {
+            if (++ix > nMaxCellX) break;
+            p = F.gs[ix * ORBM_GRID_ROWS + nMinCellY]; pe = F.gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
+            continue;
+        }
+        const uint32_t e = F.ge[p];
+        const float x = F.gx[p], y = F.gy[p];
+        p++;
+        const int idx = (int)(e & 0xFFFFu), oct = (int)(int16_t)(e >> 16);
+        if (idx >= F.n) continue;
+        if (bCheckLevels) {
+            if (oct < minLevel) continue;
+            if (maxLevel >= 0 && oct > maxLevel) continue;
+        }
+        const float distx = x - Q.u, disty = y - Q.v;
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+        // returned by GetFeaturesInArea; now the candidate filters that do not depend on matches made during the call:
+        if (F.occ0 && F.occ0[idx]) continue;
+        if (stereoGate) {
+            const float uR = F.ur[idx];
+            if (uR > 0 && fabsf(Q.u_right - uR) > r) continue;
+        }
+        const uint32_t* dr = F.dsc + (size_t)idx * SBPF_DP;
+        int dist = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) dist += __popc(qd.w[w] ^ dr[w]);
+        sink(idx, oct, dist);
+    }
+}
+#ifndef SBPF_EXP
+#define SBPF_EXP 0      // timing experiments only (tools/build_variants.sh): 1 no deep re-walk, 2 one round, 4 no sorted insertion, 8 no window walk
+#endif
+#define SBPF_T 1024
+#define SBPF_SD 8          // best candidates kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
+template <int K>           // queries per thread: cap_q <= K * SBPF_T
+static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
+    const int nq = min(A.nq[b], A.cap_q);
+    const int capk4 = (A.cap_k + 3) & ~3;
+    int* hist = (int*)orb_smem;                          // [32]
+    int* ctl = hist + 32;                                // [8]  0-2 maxima, 3 culled, 4 "serial", 5 accepters
+    int* chg = ctl + 8;                                  // [4]  "something changed" of round r in slot r % 3
+    uint32_t* blk0 = (uint32_t*)(chg + 4);               // [capk4] x 2
+    uint32_t* blk1 = blk0 + capk4;
+    int* km = (int*)(blk1 + capk4);                      // [capk4] last accepter / -1 / -2
+    float* gx = (float*)(km + capk4);                    // [capk4] x of the key point at CSR position p
+    float* gy = gx + capk4;                              // [capk4] y
+    uint32_t* ge = (uint32_t*)(gy + capk4);              // [capk4] index | octave << 16 of the key point at CSR position p
+    uint32_t* dsc = ge + capk4;                          // [capk4][SBPF_DP] descriptors by key point index
+    uint16_t* gs = (uint16_t*)(dsc + (size_t)capk4 * SBPF_DP);   // [GRID_CELLS + 2] CSR heads
+    const int mode = A.prm.mode, th = A.prm.th_dist;
+    const float ratio = A.prm.nn_ratio;
+    const bool ori = mode == ORBM_MODE_BEST_ONLY && A.prm.check_orientation;
+    const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
+    const orbm_query* queries = A.queries + (size_t)b * A.cap_q;
+    // ---- (1a) stage the frame
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 8) ctl[tid] = 0;
+    if (tid < 4) chg[tid] = 0;
+    for (int i = tid; i < A.cap_k; i += SBPF_T) { blk0[i] = 0xFFFFFFFFu; blk1[i] = 0xFFFFFFFFu; km[i] = -1; }
+    {
+        // the grid in CSR order: position p -> (index, octave, x, y) side by side, so that a window entry is ONE round of independent LDS reads
+        // (grid index -> record was a dependent pair); key points outside the grid appear in no cell and are not staged
+        const int32_t* gsrc = A.grid_start + (size_t)b * (A.cells + 1);
+        const int32_t* isrc = A.grid_idx + (size_t)b * A.cap_k;
+        const int tot = min(gsrc[GRID_CELLS], n);
+        for (int p = tid; p < tot; p += SBPF_T) {
+            const int idx = isrc[p];
+            if (idx >= 0 && idx < n) { const orb_keypoint kp = kps[idx]; gx[p] = kp.x; gy[p] = kp.y; ge[p] = (uint32_t)idx | ((uint32_t)(kp.octave & 0xFFFF) << 16); }
+            else { gx[p] = 0.f; gy[p] = 0.f; ge[p] = 0xFFFFu; }     // never produced by k_grid_build; 0xFFFF >= n: skipped
+        }
+        for (int i = tid; i <= GRID_CELLS; i += SBPF_T) gs[i] = (uint16_t)min(gsrc[i], tot);
+        const uint4* dsrc = (const uint4*)(A.desc + (size_t)b * A.cap_k * 32);
+        for (int i = tid; i < 2 * n; i += SBPF_T) {
+            const uint4 v = dsrc[i];
+            uint32_t* d = dsc + (size_t)(i >> 1) * SBPF_DP + (i & 1) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    // ---- (1b) the query records (global, independent of the staging) and their windows
+    const orbm_grid_params& g = A.prm.grid;
+    const SbpfFrame F{gs, ge, gx, gy, dsc, A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr, A.u_right ? A.u_right + (size_t)b * A.cap_k : nullptr, n};
+    uint32_t ent[K][SBPF_SD];
+    int cntw[K];                                         // candidate count | obs << 30
+    int dq[K];
+    bool bad = false;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+#pragma unroll
+        for (int j = 0; j < SBPF_SD; j++) ent[s][j] = 0u;
+        cntw[s] = 0; dq[s] = -1;
+    }
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        if (s * SBPF_T >= nq) break;                     // workgroup-uniform: K is sized for cap_q, a frame rarely fills it
+        const int q = tid + s * SBPF_T;
+        if (q >= nq) continue;
+        const orbm_query Q = queries[q];
+        if (Q.flags & (ORBM_Q_TWIN | ORBM_Q_RIGHT)) bad = true;
+        if (!(Q.flags & ORBM_Q_VALID) || (SBPF_EXP & 8)) continue;
+        const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+        int count = 0;
+        sbpf_walk(F, g, Q, qd, [&](const int idx, const int oct, const int dist) {
+            // stable insertion into the sorted best-SBPF_SD list: behind every entry whose distance is not larger.  The distance sits in the
+            // top bits, so "entry distance <= dist" is one unsigned compare of the whole word
+            const uint32_t ne = ((uint32_t)dist << 23) | ((uint32_t)(oct & 0x3F) << 16) | (uint32_t)idx;
+            const uint32_t lim = (uint32_t)(dist + 1) << 23;
+            if (SBPF_EXP & 4) { ent[s][0] = ne; count++; return; }
+            int pos = 0;
+#pragma unroll
+            for (int j = 0; j < SBPF_SD; j++) pos += (j < count && ent[s][j] < lim) ? 1 : 0;
+#pragma unroll
+            for (int j = SBPF_SD - 1; j > 0; j--) ent[s][j] = j > pos ? ent[s][j - 1] : ent[s][j];
+#pragma unroll
+            for (int j = 0; j < SBPF_SD; j++) ent[s][j] = j == pos ? ne : ent[s][j];
+            count++;
+        });
+        cntw[s] = count | ((Q.flags & ORBM_Q_HAS_OBS) ? 1 << 30 : 0);
+    }
+#ifdef SBPF_DEBUG
+    if (bad) printf("bad: tid %d\n", tid);
+#endif
+    if (bad) ctl[4] = 1;
+    __syncthreads();
+    // ---- (2) fixed-point rounds
+    const int maxRounds = nq + 2;
+    for (int r = 0; r < maxRounds && !ctl[4]; r++) {
+        const uint32_t* cur = (r & 1) ? blk1 : blk0;     // written in round r - 1 with tag 0x10000 - r
+        uint32_t* nxt = (r & 1) ? blk0 : blk1;
+        const uint32_t tagCur = 0x10000u - (uint32_t)r, tagNxt = (0xFFFFu - (uint32_t)r) << 16;
+        bool changed = false;
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int q = tid + s * SBPF_T;
+            const int cnt = cntw[s] & 0x07FFFFFF;
+            if (cnt == 0) continue;
+            uint32_t ub = 0;
+#pragma unroll
+            for (int j = 0; j < SBPF_SD; j++) {
+                if (j < cnt) {
+                    const uint32_t v = cur[ent[s][j] & 0xFFFFu];
+                    const bool blocked = (v >> 16) == tagCur && (int)(v & 0xFFFFu) < q;   // tagCur = 0x10000 in round 0: nobody
+                    if (!blocked) ub |= 1u << j;
+                }
+            }
+            uint32_t eb1 = 0, eb2 = 0;
+            const bool have1 = ub != 0u;
+            const uint32_t ub2 = ub & (ub - 1u);
+            const bool have2 = ub2 != 0u;
+            const int j1 = have1 ? __ffs((int)ub) - 1 : -1, j2 = have2 ? __ffs((int)ub2) - 1 : -1;
+#pragma unroll
+            for (int j = 0; j < SBPF_SD; j++) { eb1 = j == j1 ? ent[s][j] : eb1; eb2 = j == j2 ? ent[s][j] : eb2; }
+            int nd = -1;
+            if (cnt > SBPF_SD && (mode == ORBM_MODE_LOCAL_MAP ? !have2 : !have1) && !(SBPF_EXP & 1)) {
+                // the list goes on behind the kept entries and this decision reads it: the lane walks its window again against the blocked set of
+                // this round with the reference's own best / second-best update (ORBmatcher.cc:137-158, :2355-2368) — exact, and rare: at
+                // least SBPF_SD - 1 of the query's SBPF_SD best candidates are claimed by earlier queries
+                const orbm_query Q = queries[q];
+                const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                sbpf_walk(F, g, Q, qd, [&](const int idx, const int oct, const int dist) {
+                    const uint32_t v = cur[idx];
+                    if ((v >> 16) == tagCur && (int)(v & 0xFFFFu) < q) return;      // holds an observed point of an earlier query
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct; bestIdx = idx; }
+                    else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; }
+                });
+                if (bestIdx >= 0 && bestDist <= th) {
+                    if (mode == ORBM_MODE_LOCAL_MAP) { if (!(bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2)) nd = bestIdx; }
+                    else nd = bestIdx;
+                }
+            } else if (have1) {
+                const int bestDist = (int)(eb1 >> 23);
+                if (bestDist <= th) {
+                    if (mode == ORBM_MODE_LOCAL_MAP) {    // ORBmatcher.cc:160-178
+                        const int bestLevel = (int)((eb1 >> 16) & 0x3F);
+                        const int bestDist2 = have2 ? (int)(eb2 >> 23) : 256;
+                        const int bestLevel2 = have2 ? (int)((eb2 >> 16) & 0x3F) : -1;
+                        if (!(bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2)) nd = (int)(eb1 & 0xFFFFu);
+                    } else nd = (int)(eb1 & 0xFFFFu);    // ORBmatcher.cc:2372
+                }
+            }
+            if (nd != dq[s]) { changed = true; dq[s] = nd; }
+            if (nd >= 0 && ((cntw[s] >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)q);
+        }
+        if (changed) chg[r % 3] = 1;
+        if (tid == 0) chg[(r + 1) % 3] = 0;
+        __syncthreads();
+        if (!chg[r % 3] || (SBPF_EXP & 2)) break;        // workgroup-uniform
+    }
+    if (ctl[4]) {                                        // workgroup-uniform (read after a barrier in every path)
+        if (tid == 0) A.serial_flag[b] = 1;
+        return;
+    }
+    if (tid == 0) A.serial_flag[b] = 0;
+    // ---- (3) what the serial walk leaves behind, from the fixed point
+    int acc = 0;
+#pragma unroll
+    for (int s = 0; s < K; s++)
+        if (dq[s] >= 0) { atomicMax(&km[dq[s]], tid + s * SBPF_T); acc++; }
+    {   // accepters of the frame: a wave sum by ballots of the bits (acc <= K <= 4), one LDS atomic per wave
+        int wsum = 0;
+#pragma unroll
+        for (int bit = 0; bit < 3; bit++) wsum += __popcll(__ballot((acc >> bit) & 1)) << bit;
+        if ((tid & 63) == 0 && wsum) atomicAdd(&ctl[5], wsum);
+    }
+    __syncthreads();
+    if (ori) {
+        // rotation histogram (ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()) of every accepted match
+        int bins[K];
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            bins[s] = -1;
+            if (dq[s] >= 0) {
+                float rot = queries[tid + s * SBPF_T].angle - kps[dq[s]].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                bin = max(0, min(bin, 31));
+                atomicAdd(&hist[bin], 1);
+                bins[s] = bin;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:2654-2695
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < ORBM_HISTO_LENGTH; i++) {
+                const int c = hist[i];
+                if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+                else if (c > max3) { max3 = c; ind3 = i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+            ctl[0] = ind1; ctl[1] = ind2; ctl[2] = ind3;
+        }
+        __syncthreads();
+        const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            if (dq[s] >= 0 && bins[s] != ind1 && bins[s] != ind2 && bins[s] != ind3) {
+                km[dq[s]] = -2;                          // CurrentFrame.mvpMapPoints[...] = NULL, :2499 (-2: claimed during the call, then culled)
+                atomicAdd(&ctl[3], 1);
+            }
+        }
+        __syncthreads();
+    }
+    int32_t* q_match = A.q_match + (size_t)b * A.cap_q;
+    int32_t* kp_match = A.kp_match + (size_t)b * A.cap_k;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        const int q = tid + s * SBPF_T;
+        if (q < A.cap_q) {
+            int d = dq[s];
+            if (d >= 0 && km[d] != q) d = -1;            // a query's match is reported only while its key point still holds it
+            q_match[q] = d;
+        }
+    }
+    for (int i = tid; i < A.cap_k; i += SBPF_T) kp_match[i] = km[i];
+    if (tid == 0) A.nmatches[b] = ctl[5] - ctl[3];
+}
+
+// The candidate lists of the frames k_sbp_frame flagged, for k_sbp_resolve: one workgroup per frame walks the frame's query blocks through the
+// body of k_sbp_candidates2 (rare frames: the launch is a count check per frame otherwise).
+static __global__ __launch_bounds__(256) void k_sbp_candidates_flagged(SbpArgs A) {
+    const int b = blockIdx.x;
+    if (A.serial_flag[b] == 0) return;
+    const int nblk = (min(A.nq[b], A.cap_q) + 7) / 8;
+    for (int qb = 0; qb < nblk; qb++) {
+        sbp_candidates2_block(A, b, qb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // the wave's LDS lists are rewritten by its next block
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // ============================================================================================================
@@ -1314,7 +1648,8 @@ extern "C" int orbm_grid_build_rig(const orb_keypoint* d_kps, const int32_t* d_n
     return launch_status();
 }
 
-extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4; }
+// per query a row of SBP_WORK_PER_Q words, then one flag word per frame (k_sbp_frame -> k_sbp_resolve)
+extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4 + (((size_t)batch * 4 + 15) & ~(size_t)15); }
 
 static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0, const int32_t* d_kp_link,
                       int cells, const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start, const int32_t* d_grid_idx,
@@ -1332,16 +1667,43 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm = *params; A.q_match = d_q_match; A.kp_match = d_kp_match; A.nmatches = d_nmatches; A.work = (uint32_t*)d_work;
     A.cells = cells; A.kp_link = d_kp_link;
-    A.chi2_gate = 0; A.q_dist = nullptr;
+    A.chi2_gate = 0; A.q_dist = nullptr; A.serial_flag = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = 0.f;
+    // k_sbp_frame takes the occupancy modes of single-camera frames whose state fits its LDS layout and its K queries per thread; the frames it
+    // flags, and every other call, take k_sbp_candidates2 -> k_sbp_resolve
+    const int capk4 = (cap_k + 3) & ~3;
+    const size_t smem_f = (32 + 8 + 4) * 4 + (size_t)capk4 * (12 + 8 + 4 * SBPF_DP + 2 + 2) + (GRID_CELLS + 2) * 2;
+    const int K = (cap_q + SBPF_T - 1) / SBPF_T;
+    const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 && K <= 4 &&
+                       cap_q <= 65535;
+    if (fused) A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_PER_Q);
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
+    if (fused) {
+        static bool attr_done = false;
+        if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (idempotent; a failure surfaces at the launch)
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_done = true;
+        }
+        switch (K) {
+            case 1: hipLaunchKernelGGL(k_sbp_frame<1>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
+            case 2: hipLaunchKernelGGL(k_sbp_frame<2>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
+            case 3: hipLaunchKernelGGL(k_sbp_frame<3>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
+            default: hipLaunchKernelGGL(k_sbp_frame<4>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
+        }
+        if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
+        hipLaunchKernelGGL(k_sbp_candidates_flagged, dim3(batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
+    } else {
 #if SBP_HALF
-    hipLaunchKernelGGL(k_sbp_candidates2, dim3((cap_q + 7) / 8, batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
+        hipLaunchKernelGGL(k_sbp_candidates2, dim3((cap_q + 7) / 8, batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #else
-    hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
+        hipLaunchKernelGGL(k_sbp_candidates, dim3((cap_q + 3) / 4, batch), dim3(256), 4 * SBP_CAPC * 4, (hipStream_t)stream, A);
 #endif
-    if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
+        if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
+    }
     hipLaunchKernelGGL(k_sbp_resolve, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     if (timed) { (void)hipEventRecord(g_mt.ev[4], (hipStream_t)stream); g_mt.have_sbp = true; }
     return launch_status();

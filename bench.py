@@ -93,7 +93,7 @@ def match_algorithmic_bytes(N, Nq):
 
 
 KNAMES = {"pyramid": "k_resize2", "fast": "k_fast", "octree": "k_octree", "describe": "k_describe2", "undistort": "k_undistort",
-          "grid_build": "k_grid_build", "sbp_candidates": "k_sbp_candidates2", "sbp_resolve": "k_sbp_resolve"}
+          "grid_build": "k_grid_build", "sbp_candidates": "k_sbp_frame", "sbp_resolve": "k_sbp_resolve"}
 SHIFT = (6, -4)   # frame 2j+1 = frame 2j moved by (dx, dy) px + sensor noise: consecutive views of one scene
 CAM_EUROC = (458.654, 457.296, 367.215, 248.375, (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05))   # EuRoC.yaml:9-20 (cam0, radtan)
 

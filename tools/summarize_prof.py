@@ -96,7 +96,7 @@ if sq:
             f.write("%s,%.1f,%s,%s\n" % (k, dur.get(k, float("nan")), ",".join("%.6g" % g(n) for n in cols), ",".join("%.4f" % x for x in derived)))
             # the same figures next to the HBM bytes, for bench.py's roofline object: resident waves per SIMD and the SIMD cycles one wave-level
             # VALU instruction costs (duration x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU; 4 = a SIMD issuing one wave64 VALU instruction back to back)
-            if k in out["kernels"] and k in dur and g("SQ_INSTS_VALU") == g("SQ_INSTS_VALU"):
+            if k in out["kernels"] and k in dur and g("SQ_INSTS_VALU") == g("SQ_INSTS_VALU") and g("SQ_INSTS_VALU") > 0:
                 out["kernels"][k].update({"valu_insts_per_wave": round(derived[0], 1), "waves_per_simd": round(derived[5], 2),
                                           "simd_cycles_per_valu_inst": round(dur[k] * 1e-6 * 1024 * 2.4e9 / g("SQ_INSTS_VALU"), 2),
                                           "lds_conflict_frac": round(derived[4], 3)})
