@@ -940,34 +940,35 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
 // ------------------------------------------------------------------------------------------------------------
 // Round 4: the whole projection search of a frame in ONE workgroup — k_sbp_frame.
 //
-// (1) The frame is staged once: key point positions and octaves, descriptors (rows of 9 dwords: an odd pitch spreads the random row reads over the
-//     banks), the 64 x 48 CSR heads and the grid index list — ~59 bytes per key point + 6 KB of LDS.  k_sbp_candidates2 walked
-//     query -> CSR heads -> index -> record -> descriptor as a chain of dependent L2 gathers (0.21 ms per 512 frames at 3 % of the VALU, traffic
-//     2.6-4.9 x algorithmic); from LDS the same chain costs ~100 cycles a link, so it is given to ONE LANE per query: every query of the frame
-//     walks its window at once, serially, in the reference's order (grid columns outer, CSR order inside a column = iy inner, insertion order
-//     inside a cell: Frame.cc:779-850), and keeps its SBPF_SD best candidates sorted by (distance, enumeration position) in registers — the order
-//     in which the serial strict-'<' scans of ORBmatcher.cc:137-158 / :2355-2368 rank them (stable insertion: a later candidate goes behind
-//     equal distances).
-// (2) The serial accept loop as parallel fixed-point rounds.  The loop's state is the occupancy: candidate c is blocked for query q iff an
-//     EARLIER query q' < q accepted c while holding an observed point (ORBmatcher.cc:125-127 / :2347-2349; the call's initial occupancy is
-//     filtered in (1)).  So a query's decision d[q] = F_q(d[0..q-1]) depends on the earlier decisions only, through blk[c] = the smallest
-//     accepting-and-observed query of c: best / second-best = the first two entries of q's sorted list with blk[c] >= q.  Jacobi iteration
-//     d_{r+1}[q] = F_q(d_r) on this strictly lower-triangular system reaches its unique fixed point — the serial result, by induction over q:
-//     after round r every query whose dependency chain is shorter than r is final — and stops after the first round that changes nothing
-//     (at most nq + 1 rounds; 8-9 on the benchmark's frames, where the one-wave walk of k_sbp_resolve takes ~1000 dependent steps).  blk is
-//     double-buffered and its entries carry the round that wrote them ((0xFFFF - r) << 16 | q under atomicMin: a newer round overrides, an
-//     entry of an older round reads as "nobody"), so a round is ONE workgroup barrier.
+// (1) The frame is staged once in LDS: the grid in CSR order (position p -> key point index, octave, x, y side by side), the 64 x 48 CSR heads and
+//     the descriptors (rows of 9 dwords: an odd pitch spreads random row reads over the banks) — ~60 bytes per key point + 6 KB.
+//     k_sbp_candidates2 walked query -> CSR heads -> index -> record -> descriptor as a chain of dependent L2 gathers (0.21 ms per 512 frames at
+//     3 % of the VALU, traffic 2.6-4.9 x algorithmic); from LDS a link costs ~100 cycles, so the chain is given to ONE LANE per query: every query of
+//     the frame walks its window at once, in the reference's order (grid columns outer, CSR order inside a column = iy inner, insertion order inside
+//     a cell: Frame.cc:779-850).  That order IS ascending CSR position, so a candidate's rank in the serial strict-'<' scans of ORBmatcher.cc:137-158 /
+//     :2355-2368 is the rank of its key  dist << 22 | p << 6 | octave  — a plain unsigned compare.  A lane keeps its SBPF_SD smallest keys sorted in
+//     registers; what falls out of that list goes, unordered, to the query's row of the workspace (64 keys).
+// (2) The serial accept loop as parallel fixed-point rounds.  The loop's state is the occupancy: candidate p is blocked for query q iff an EARLIER
+//     query q' < q accepted it while holding an observed point (ORBmatcher.cc:125-127 / :2347-2349; the call's initial occupancy is filtered in (1)).
+//     So a query's decision d[q] = F_q(d[0..q-1]) depends on the earlier decisions only, through blk[p] = the smallest accepting-and-observed query
+//     of p: best / second-best = the two smallest keys of q with blk[p] >= q.  Jacobi iteration d_{r+1}[q] = F_q(d_r) on this strictly
+//     lower-triangular system reaches its unique fixed point — the serial result, by induction over q: after round r every query whose dependency
+//     chain is shorter than r is final — and stops after the first round that changes nothing (at most nq + 1 rounds; 8-9 on the benchmark's
+//     frames, where the one-wave walk of k_sbp_resolve takes ~1000 dependent steps).  blk is double-buffered and its entries carry the round that
+//     wrote them ((0xFFFF - r) << 16 | q under atomicMin: a newer round overrides, an entry of an older round reads as "nobody"), so a round is ONE
+//     workgroup barrier.  A query whose kept keys are all claimed reads on in its workspace row (two smallest unblocked keys of an unordered set);
+//     one with more than SBPF_SD + 64 candidates walks its window again with the reference's own best / second-best update.  All exact.
 // (3) What the walk leaves behind is reconstructed from the fixed point: kp_match[c] = the LAST accepter of c (only accepters without an observed
 //     point can share a key point), nmatches = the number of accepters, then the rotation-histogram cull and the "a query's match is reported
 //     only while its key point still holds it" filter exactly as k_sbp_resolve applies them.
-// A frame this form does not cover raises serial_flag[b] and is redone by the gated launches behind it (k_sbp_candidates_flagged ->
-// k_sbp_resolve): rig twins / right-camera queries, or a query whose decision would need more than its SBPF_SD best candidates (at least
-// SBPF_SD - 1 of them claimed by earlier queries) in ANY round — conservative, never wrong.  INIT mode, rigs with stereo links and frames beyond the
-// LDS / K limits never come here (sbp_launch).
-// One lane's walk over the window of its query in the reference's order (Frame.cc:779-850) on the staged frame; sink(idx, oct, dist) sees every
-// candidate that GetFeaturesInArea returns and that passes the call-constant filters (initial occupancy, stereo gate), with its Hamming distance.
+// Queries beyond the workgroup's 1024 threads (cap_q = nFeatures + 64 is a little more than 1024 at nFeatures = 1000) keep their lists in LDS
+// instead of registers (TAIL): the register budget of the common case stays that of one query per thread.
+// A frame this form does not cover — rig twins / right-camera queries — raises serial_flag[b] and is redone by the gated launches behind it
+// (k_sbp_candidates_flagged -> k_sbp_resolve).  INIT mode, rigs with stereo links and frames beyond the LDS limits never come here (sbp_launch).
 struct SbpfFrame { const uint16_t* gs; const uint32_t* ge; const float* gx; const float* gy; const uint32_t* dsc; const uint8_t* occ0; const float* ur; int n; };
 #define SBPF_DP 9          // descriptor row pitch in LDS, dwords (odd: random rows spread over the banks)
+// One lane's walk over the window of its query in the reference's order (Frame.cc:779-850) on the staged frame; sink(p, idx, oct, dist) sees every
+// candidate that GetFeaturesInArea returns and that passes the call-constant filters (initial occupancy, stereo gate), with its Hamming distance.
 template <class Sink>
 static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_grid_params& g, const orbm_query& Q, const Desc& qd, Sink&& sink) {
     const float r = Q.radius;
@@ -993,7 +994,7 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
         }
         const uint32_t e = F.ge[p];
         const float x = F.gx[p], y = F.gy[p];
-        p++;
+        const int pp = p++;
         const int idx = (int)(e & 0xFFFFu), oct = (int)(int16_t)(e >> 16);
         if (idx >= F.n) continue;
         if (bCheckLevels) {
@@ -1012,16 +1013,118 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
         int dist = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) dist += __popc(qd.w[w] ^ dr[w]);
-        sink(idx, oct, dist);
+        sink(pp, idx, oct, dist);
     }
 }
 #ifndef SBPF_EXP
-#define SBPF_EXP 0      // timing experiments only (tools/build_variants.sh): 1 no deep re-walk, 2 one round, 4 no sorted insertion, 8 no window walk
+#define SBPF_EXP 0      // timing experiments only (tools/build_variants.sh): 1 no reading on behind the kept keys, 2 one round, 4 no sorted insertion, 8 no window walk
 #endif
 #define SBPF_T 1024
-#define SBPF_SD 8          // best candidates kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
-template <int K>           // queries per thread: cap_q <= K * SBPF_T
-static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
+#ifndef SBPF_WPE
+#define SBPF_WPE 8         // waves per SIMD the register allocation aims at: 8 = two workgroups per CU (64 VGPRs)
+#endif
+#define SBPF_SD 8          // smallest keys kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
+#define SBPF_ROW 64        // keys a workspace row holds behind them
+#define SBPF_KEY(dist, p, oct) (((uint32_t)(dist) << 22) | ((uint32_t)(p) << 6) | ((uint32_t)(oct) & 0x3Fu))
+#define SBPF_KEY_P(k) (((k) >> 6) & 0xFFFFu)
+// a query's kept keys: in registers (one query per thread) or, for the queries beyond the workgroup's threads, in LDS (key-major: lanes = consecutive queries)
+struct SbpfRegList {
+    uint32_t e[SBPF_SD];
+    __device__ __forceinline__ uint32_t get(const int j) const { return e[j]; }
+    __device__ __forceinline__ void set(const int j, const uint32_t v) { e[j] = v; }
+};
+struct SbpfLdsList {
+    uint32_t* base; int stride;
+    __device__ __forceinline__ uint32_t get(const int j) const { return base[j * stride]; }
+    __device__ __forceinline__ void set(const int j, const uint32_t v) { base[j * stride] = v; }
+};
+// phase (1) for one query: walk, keep the SBPF_SD smallest keys sorted, spill the rest to the query's workspace row.  -> count | obs << 30
+template <class L>
+static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const orbm_query& Q, L& lst) {
+    const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+    uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2;
+    int count = 0;
+    sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
+        const uint32_t ne = SBPF_KEY(dist, p, oct);
+        if (SBPF_EXP & 4) { lst.set(0, ne); count++; return; }
+        int pos = 0;
+#pragma unroll
+        for (int j = 0; j < SBPF_SD; j++) pos += (j < count && lst.get(j) < ne) ? 1 : 0;
+        if (count >= SBPF_SD) {                          // the list is full: its largest key, or the new one, leaves for the row (unordered)
+            const uint32_t out = pos >= SBPF_SD ? ne : lst.get(SBPF_SD - 1);
+            if (count - SBPF_SD < SBPF_ROW) row[count - SBPF_SD] = out;
+        }
+#pragma unroll
+        for (int j = SBPF_SD - 1; j > 0; j--) { if (j > pos) lst.set(j, lst.get(j - 1)); }
+#pragma unroll
+        for (int j = 0; j < SBPF_SD; j++) { if (j == pos) lst.set(j, ne); }
+        count++;
+    });
+    return count | ((Q.flags & ORBM_Q_HAS_OBS) ? 1 << 30 : 0);
+}
+// phase (2) for one query and one round: the decision against the blocked set `cur` of this round.  -> accepted CSR position or -1
+template <class L>
+static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const int cnt, const L& lst,
+                                                 const uint32_t* cur, const uint32_t tagCur) {
+    const int mode = A.prm.mode, th = A.prm.th_dist;
+    auto blocked = [&](const uint32_t p) { const uint32_t v = cur[p]; return (v >> 16) == tagCur && (int)(v & 0xFFFFu) < q; };   // tagCur = 0x10000 in round 0: nobody
+    uint32_t e[SBPF_SD];
+    uint32_t ub = 0;
+#pragma unroll
+    for (int j = 0; j < SBPF_SD; j++) e[j] = j < cnt ? lst.get(j) : 0u;
+#pragma unroll
+    for (int j = 0; j < SBPF_SD; j++)
+        if (j < cnt && !blocked(SBPF_KEY_P(e[j]))) ub |= 1u << j;
+    uint32_t eb1 = 0, eb2 = 0;
+    bool have1 = ub != 0u;
+    const uint32_t ub2 = ub & (ub - 1u);
+    bool have2 = ub2 != 0u;
+    const int j1 = have1 ? __ffs((int)ub) - 1 : -1, j2 = have2 ? __ffs((int)ub2) - 1 : -1;
+#pragma unroll
+    for (int j = 0; j < SBPF_SD; j++) { eb1 = j == j1 ? e[j] : eb1; eb2 = j == j2 ? e[j] : eb2; }
+    const bool wantSecond = mode == ORBM_MODE_LOCAL_MAP;
+    if (cnt > SBPF_SD && (wantSecond ? !have2 : !have1) && !(SBPF_EXP & 1)) {
+        if (cnt <= SBPF_SD + SBPF_ROW) {
+            // the kept keys are (nearly) all claimed: read on in the row — every key there is larger than the kept ones, so the two smallest unblocked
+            // keys of the row continue the list
+            const uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2;
+            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+            for (int k = 0; k < cnt - SBPF_SD; k++) {
+                const uint32_t key = row[k];
+                if (blocked(SBPF_KEY_P(key))) continue;
+                if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key;
+            }
+            if (!have1) { have1 = m1 != 0xFFFFFFFFu; eb1 = m1; have2 = m2 != 0xFFFFFFFFu; eb2 = m2; }
+            else { have2 = m1 != 0xFFFFFFFFu; eb2 = m1; }
+        } else {
+            // more candidates than list + row hold: the lane walks its window again with the reference's own update (ORBmatcher.cc:137-158, :2355-2368)
+            const orbm_query Q = (A.queries + (size_t)b * A.cap_q)[q];
+            const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestP = -1;
+            sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
+                if (blocked((uint32_t)p)) return;            // holds an observed point of an earlier query
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct & 0x3F; bestP = p; }
+                else if (dist < bestDist2) { bestLevel2 = oct & 0x3F; bestDist2 = dist; }
+            });
+            have1 = bestP >= 0; eb1 = SBPF_KEY(bestDist, max(bestP, 0), bestLevel);
+            have2 = bestLevel2 >= 0 || bestDist2 < 256; eb2 = SBPF_KEY(min(bestDist2, 256), 0, bestLevel2);   // only distance and level of the second are read
+            if (!have2) eb2 = 0;
+        }
+    }
+    if (!have1) return -1;
+    const int bestDist = (int)(eb1 >> 22);
+    if (bestDist > th) return -1;
+    if (wantSecond) {                                    // ORBmatcher.cc:160-178
+        const int bestLevel = (int)(eb1 & 0x3Fu);
+        const int bestDist2 = have2 ? (int)(eb2 >> 22) : 256;
+        const int bestLevel2 = have2 ? (int)(eb2 & 0x3Fu) : -1;
+        if (bestLevel == bestLevel2 && (float)bestDist > A.prm.nn_ratio * (float)bestDist2) return -1;
+    }
+    return (int)SBPF_KEY_P(eb1);                         // ORBmatcher.cc:2372
+}
+
+template <bool TAIL>       // queries beyond SBPF_T (cap_q <= 2 * SBPF_T): lists in LDS
+static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min(A.nkp[(size_t)b * A.cstride], A.cap_k);
@@ -1030,17 +1133,17 @@ static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
     int* hist = (int*)orb_smem;                          // [32]
     int* ctl = hist + 32;                                // [8]  0-2 maxima, 3 culled, 4 "serial", 5 accepters
     int* chg = ctl + 8;                                  // [4]  "something changed" of round r in slot r % 3
-    uint32_t* blk0 = (uint32_t*)(chg + 4);               // [capk4] x 2
+    uint32_t* blk0 = (uint32_t*)(chg + 4);               // [capk4] x 2, by CSR position
     uint32_t* blk1 = blk0 + capk4;
-    int* km = (int*)(blk1 + capk4);                      // [capk4] last accepter / -1 / -2
+    int* km = (int*)(blk1 + capk4);                      // [capk4] by key point index: last accepter / -1 / -2
     float* gx = (float*)(km + capk4);                    // [capk4] x of the key point at CSR position p
     float* gy = gx + capk4;                              // [capk4] y
     uint32_t* ge = (uint32_t*)(gy + capk4);              // [capk4] index | octave << 16 of the key point at CSR position p
     uint32_t* dsc = ge + capk4;                          // [capk4][SBPF_DP] descriptors by key point index
     uint16_t* gs = (uint16_t*)(dsc + (size_t)capk4 * SBPF_DP);   // [GRID_CELLS + 2] CSR heads
-    const int mode = A.prm.mode, th = A.prm.th_dist;
-    const float ratio = A.prm.nn_ratio;
-    const bool ori = mode == ORBM_MODE_BEST_ONLY && A.prm.check_orientation;
+    const int tq = TAIL ? A.cap_q - SBPF_T : 0;          // queries with an LDS list
+    uint32_t* tl = (uint32_t*)(gs + GRID_CELLS + 2);     // [SBPF_SD][tq]
+    const bool ori = A.prm.mode == ORBM_MODE_BEST_ONLY && A.prm.check_orientation;
     const orb_keypoint* kps = A.kps + (size_t)b * A.cap_k;
     const orbm_query* queries = A.queries + (size_t)b * A.cap_q;
     // ---- (1a) stage the frame
@@ -1067,51 +1170,29 @@ static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     }
-    // ---- (1b) the query records (global, independent of the staging) and their windows
-    const orbm_grid_params& g = A.prm.grid;
     const SbpfFrame F{gs, ge, gx, gy, dsc, A.occupied0 ? A.occupied0 + (size_t)b * A.cap_k : nullptr, A.u_right ? A.u_right + (size_t)b * A.cap_k : nullptr, n};
-    uint32_t ent[K][SBPF_SD];
-    int cntw[K];                                         // candidate count | obs << 30
-    int dq[K];
+    // ---- (1b) every query walks its window
+    SbpfRegList r0;
+    SbpfLdsList r1{tl + tid, tq};
+#pragma unroll
+    for (int j = 0; j < SBPF_SD; j++) r0.e[j] = 0u;
+    int cntw0 = 0, cntw1 = 0, d0 = -1, d1 = -1;          // candidate count | obs << 30, decision (CSR position or -1), per slot
     bool bad = false;
+    const int q1 = tid + SBPF_T;
+    const bool has1 = TAIL && q1 < nq;                   // (tid < tq follows: nq <= cap_q)
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-#pragma unroll
-        for (int j = 0; j < SBPF_SD; j++) ent[s][j] = 0u;
-        cntw[s] = 0; dq[s] = -1;
-    }
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        if (s * SBPF_T >= nq) break;                     // workgroup-uniform: K is sized for cap_q, a frame rarely fills it
-        const int q = tid + s * SBPF_T;
-        if (q >= nq) continue;
-        const orbm_query Q = queries[q];
+    if (tid < nq) {
+        const orbm_query Q = queries[tid];
         if (Q.flags & (ORBM_Q_TWIN | ORBM_Q_RIGHT)) bad = true;
-        if (!(Q.flags & ORBM_Q_VALID) || (SBPF_EXP & 8)) continue;
-        const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-        int count = 0;
-        sbpf_walk(F, g, Q, qd, [&](const int idx, const int oct, const int dist) {
-            // stable insertion into the sorted best-SBPF_SD list: behind every entry whose distance is not larger.  The distance sits in the
-            // top bits, so "entry distance <= dist" is one unsigned compare of the whole word
-            const uint32_t ne = ((uint32_t)dist << 23) | ((uint32_t)(oct & 0x3F) << 16) | (uint32_t)idx;
-            const uint32_t lim = (uint32_t)(dist + 1) << 23;
-            if (SBPF_EXP & 4) { ent[s][0] = ne; count++; return; }
-            int pos = 0;
-#pragma unroll
-            for (int j = 0; j < SBPF_SD; j++) pos += (j < count && ent[s][j] < lim) ? 1 : 0;
-#pragma unroll
-            for (int j = SBPF_SD - 1; j > 0; j--) ent[s][j] = j > pos ? ent[s][j - 1] : ent[s][j];
-#pragma unroll
-            for (int j = 0; j < SBPF_SD; j++) ent[s][j] = j == pos ? ne : ent[s][j];
-            count++;
-        });
-        cntw[s] = count | ((Q.flags & ORBM_Q_HAS_OBS) ? 1 << 30 : 0);
+        if ((Q.flags & ORBM_Q_VALID) && !(SBPF_EXP & 8)) cntw0 = sbpf_collect(F, A, b, tid, Q, r0);
     }
-#ifdef SBPF_DEBUG
-    if (bad) printf("bad: tid %d\n", tid);
-#endif
+    if (has1) {
+        const orbm_query Q = queries[q1];
+        if (Q.flags & (ORBM_Q_TWIN | ORBM_Q_RIGHT)) bad = true;
+        if ((Q.flags & ORBM_Q_VALID) && !(SBPF_EXP & 8)) cntw1 = sbpf_collect(F, A, b, q1, Q, r1);
+    }
     if (bad) ctl[4] = 1;
+    __threadfence_block();                               // the rows' keys are read back by their own lanes only (same thread: program order)
     __syncthreads();
     // ---- (2) fixed-point rounds
     const int maxRounds = nq + 2;
@@ -1120,58 +1201,15 @@ static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
         uint32_t* nxt = (r & 1) ? blk0 : blk1;
         const uint32_t tagCur = 0x10000u - (uint32_t)r, tagNxt = (0xFFFFu - (uint32_t)r) << 16;
         bool changed = false;
-#pragma unroll
-        for (int s = 0; s < K; s++) {
-            const int q = tid + s * SBPF_T;
-            const int cnt = cntw[s] & 0x07FFFFFF;
-            if (cnt == 0) continue;
-            uint32_t ub = 0;
-#pragma unroll
-            for (int j = 0; j < SBPF_SD; j++) {
-                if (j < cnt) {
-                    const uint32_t v = cur[ent[s][j] & 0xFFFFu];
-                    const bool blocked = (v >> 16) == tagCur && (int)(v & 0xFFFFu) < q;   // tagCur = 0x10000 in round 0: nobody
-                    if (!blocked) ub |= 1u << j;
-                }
-            }
-            uint32_t eb1 = 0, eb2 = 0;
-            const bool have1 = ub != 0u;
-            const uint32_t ub2 = ub & (ub - 1u);
-            const bool have2 = ub2 != 0u;
-            const int j1 = have1 ? __ffs((int)ub) - 1 : -1, j2 = have2 ? __ffs((int)ub2) - 1 : -1;
-#pragma unroll
-            for (int j = 0; j < SBPF_SD; j++) { eb1 = j == j1 ? ent[s][j] : eb1; eb2 = j == j2 ? ent[s][j] : eb2; }
-            int nd = -1;
-            if (cnt > SBPF_SD && (mode == ORBM_MODE_LOCAL_MAP ? !have2 : !have1) && !(SBPF_EXP & 1)) {
-                // the list goes on behind the kept entries and this decision reads it: the lane walks its window again against the blocked set of
-                // this round with the reference's own best / second-best update (ORBmatcher.cc:137-158, :2355-2368) — exact, and rare: at
-                // least SBPF_SD - 1 of the query's SBPF_SD best candidates are claimed by earlier queries
-                const orbm_query Q = queries[q];
-                const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-                sbpf_walk(F, g, Q, qd, [&](const int idx, const int oct, const int dist) {
-                    const uint32_t v = cur[idx];
-                    if ((v >> 16) == tagCur && (int)(v & 0xFFFFu) < q) return;      // holds an observed point of an earlier query
-                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct; bestIdx = idx; }
-                    else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; }
-                });
-                if (bestIdx >= 0 && bestDist <= th) {
-                    if (mode == ORBM_MODE_LOCAL_MAP) { if (!(bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2)) nd = bestIdx; }
-                    else nd = bestIdx;
-                }
-            } else if (have1) {
-                const int bestDist = (int)(eb1 >> 23);
-                if (bestDist <= th) {
-                    if (mode == ORBM_MODE_LOCAL_MAP) {    // ORBmatcher.cc:160-178
-                        const int bestLevel = (int)((eb1 >> 16) & 0x3F);
-                        const int bestDist2 = have2 ? (int)(eb2 >> 23) : 256;
-                        const int bestLevel2 = have2 ? (int)((eb2 >> 16) & 0x3F) : -1;
-                        if (!(bestLevel == bestLevel2 && (float)bestDist > ratio * (float)bestDist2)) nd = (int)(eb1 & 0xFFFFu);
-                    } else nd = (int)(eb1 & 0xFFFFu);    // ORBmatcher.cc:2372
-                }
-            }
-            if (nd != dq[s]) { changed = true; dq[s] = nd; }
-            if (nd >= 0 && ((cntw[s] >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)q);
+        if (cntw0 & 0x07FFFFFF) {
+            const int nd = sbpf_decide(F, A, b, tid, cntw0 & 0x07FFFFFF, r0, cur, tagCur);
+            if (nd != d0) { changed = true; d0 = nd; }
+            if (nd >= 0 && ((cntw0 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)tid);
+        }
+        if (TAIL && (cntw1 & 0x07FFFFFF)) {
+            const int nd = sbpf_decide(F, A, b, q1, cntw1 & 0x07FFFFFF, r1, cur, tagCur);
+            if (nd != d1) { changed = true; d1 = nd; }
+            if (nd >= 0 && ((cntw1 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)q1);
         }
         if (changed) chg[r % 3] = 1;
         if (tid == 0) chg[(r + 1) % 3] = 0;
@@ -1183,34 +1221,29 @@ static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
         return;
     }
     if (tid == 0) A.serial_flag[b] = 0;
-    // ---- (3) what the serial walk leaves behind, from the fixed point
+    // ---- (3) what the serial walk leaves behind, from the fixed point (decisions: CSR position -> key point index)
+    d0 = d0 >= 0 ? (int)(ge[d0] & 0xFFFFu) : -1;
+    d1 = (TAIL && d1 >= 0) ? (int)(ge[d1] & 0xFFFFu) : -1;
     int acc = 0;
-#pragma unroll
-    for (int s = 0; s < K; s++)
-        if (dq[s] >= 0) { atomicMax(&km[dq[s]], tid + s * SBPF_T); acc++; }
-    {   // accepters of the frame: a wave sum by ballots of the bits (acc <= K <= 4), one LDS atomic per wave
-        int wsum = 0;
-#pragma unroll
-        for (int bit = 0; bit < 3; bit++) wsum += __popcll(__ballot((acc >> bit) & 1)) << bit;
+    if (d0 >= 0) { atomicMax(&km[d0], tid); acc++; }
+    if (d1 >= 0) { atomicMax(&km[d1], q1); acc++; }
+    {   // accepters of the frame: a wave sum by ballots of the bits (acc <= 2), one LDS atomic per wave
+        const int wsum = __popcll(__ballot(acc & 1)) + 2 * __popcll(__ballot(acc >> 1));
         if ((tid & 63) == 0 && wsum) atomicAdd(&ctl[5], wsum);
     }
     __syncthreads();
     if (ori) {
         // rotation histogram (ORBmatcher.cc:2387-2395: factor = 1/HISTO_LENGTH quirk, C round()) of every accepted match
-        int bins[K];
-#pragma unroll
-        for (int s = 0; s < K; s++) {
-            bins[s] = -1;
-            if (dq[s] >= 0) {
-                float rot = queries[tid + s * SBPF_T].angle - kps[dq[s]].angle;
-                if (rot < 0.0f) rot += 360.0f;
-                int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
-                if (bin == ORBM_HISTO_LENGTH) bin = 0;
-                bin = max(0, min(bin, 31));
-                atomicAdd(&hist[bin], 1);
-                bins[s] = bin;
-            }
-        }
+        auto bin_of = [&](const int q, const int idx) {
+            float rot = queries[q].angle - kps[idx].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / ORBM_HISTO_LENGTH));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            bin = max(0, min(bin, 31));
+            atomicAdd(&hist[bin], 1);
+            return bin;
+        };
+        const int bin0 = d0 >= 0 ? bin_of(tid, d0) : -1, bin1 = d1 >= 0 ? bin_of(q1, d1) : -1;
         __syncthreads();
         if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:2654-2695
             int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -1226,26 +1259,16 @@ static __global__ __launch_bounds__(SBPF_T) void k_sbp_frame(SbpArgs A) {
         }
         __syncthreads();
         const int ind1 = ctl[0], ind2 = ctl[1], ind3 = ctl[2];
-#pragma unroll
-        for (int s = 0; s < K; s++) {
-            if (dq[s] >= 0 && bins[s] != ind1 && bins[s] != ind2 && bins[s] != ind3) {
-                km[dq[s]] = -2;                          // CurrentFrame.mvpMapPoints[...] = NULL, :2499 (-2: claimed during the call, then culled)
-                atomicAdd(&ctl[3], 1);
-            }
-        }
+        // CurrentFrame.mvpMapPoints[...] = NULL, :2499 (-2: claimed during the call, then culled)
+        if (d0 >= 0 && bin0 != ind1 && bin0 != ind2 && bin0 != ind3) { km[d0] = -2; atomicAdd(&ctl[3], 1); }
+        if (d1 >= 0 && bin1 != ind1 && bin1 != ind2 && bin1 != ind3) { km[d1] = -2; atomicAdd(&ctl[3], 1); }
         __syncthreads();
     }
     int32_t* q_match = A.q_match + (size_t)b * A.cap_q;
     int32_t* kp_match = A.kp_match + (size_t)b * A.cap_k;
-#pragma unroll
-    for (int s = 0; s < K; s++) {
-        const int q = tid + s * SBPF_T;
-        if (q < A.cap_q) {
-            int d = dq[s];
-            if (d >= 0 && km[d] != q) d = -1;            // a query's match is reported only while its key point still holds it
-            q_match[q] = d;
-        }
-    }
+    // a query's match is reported only while its key point still holds it
+    if (tid < A.cap_q) q_match[tid] = (d0 >= 0 && km[d0] == tid) ? d0 : -1;
+    if (TAIL && q1 < A.cap_q) q_match[q1] = (d1 >= 0 && km[d1] == q1) ? d1 : -1;
     for (int i = tid; i < A.cap_k; i += SBPF_T) kp_match[i] = km[i];
     if (tid == 0) A.nmatches[b] = ctl[5] - ctl[3];
 }
@@ -1672,28 +1695,22 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     // k_sbp_frame takes the occupancy modes of single-camera frames whose state fits its LDS layout and its K queries per thread; the frames it
     // flags, and every other call, take k_sbp_candidates2 -> k_sbp_resolve
     const int capk4 = (cap_k + 3) & ~3;
-    const size_t smem_f = (32 + 8 + 4) * 4 + (size_t)capk4 * (12 + 8 + 4 * SBPF_DP + 2 + 2) + (GRID_CELLS + 2) * 2;
-    const int K = (cap_q + SBPF_T - 1) / SBPF_T;
-    const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 && K <= 4 &&
-                       cap_q <= 65535;
+    const int tailq = cap_q > SBPF_T ? cap_q - SBPF_T : 0;
+    const size_t smem_f = (32 + 8 + 4) * 4 + (size_t)capk4 * (12 + 12 + 4 * SBPF_DP) + (GRID_CELLS + 2) * 2 + (size_t)tailq * SBPF_SD * 4;
+    const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 &&
+                       cap_q <= 2 * SBPF_T;
     if (fused) A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_PER_Q);
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
     if (fused) {
         static bool attr_done = false;
         if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (idempotent; a failure surfaces at the launch)
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_sbp_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_done = true;
         }
-        switch (K) {
-            case 1: hipLaunchKernelGGL(k_sbp_frame<1>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
-            case 2: hipLaunchKernelGGL(k_sbp_frame<2>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
-            case 3: hipLaunchKernelGGL(k_sbp_frame<3>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
-            default: hipLaunchKernelGGL(k_sbp_frame<4>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A); break;
-        }
+        if (tailq) hipLaunchKernelGGL(k_sbp_frame<true>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);
+        else hipLaunchKernelGGL(k_sbp_frame<false>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);
         if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);
         hipLaunchKernelGGL(k_sbp_candidates_flagged, dim3(batch), dim3(256), 8 * SBP_CAPC * 4, (hipStream_t)stream, A);
     } else {
