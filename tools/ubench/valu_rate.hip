@@ -34,11 +34,15 @@ __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getre
 #define OP32(NAME, ASM)                                                                                    \
     struct NAME { using T = uint32_t; static constexpr const char* name = #NAME;                           \
         static __device__ __forceinline__ void op(uint32_t& a, uint32_t b, uint32_t c) {                   \
+            asm volatile(ASM : "+v"(a) : "v"(b), "v"(c)); } };
+#define OP32C(NAME, ASM)   /* bodies that write vcc / s20 / s21: the clobber list makes the compiler put an s_nop behind every statement — w = 1 figures of these rows include it */ \
+    struct NAME { using T = uint32_t; static constexpr const char* name = #NAME;                           \
+        static __device__ __forceinline__ void op(uint32_t& a, uint32_t b, uint32_t c) {                   \
             asm volatile(ASM : "+v"(a) : "v"(b), "v"(c) : "vcc", "s20", "s21"); } };
 #define OP64(NAME, ASM)                                                                                    \
     struct NAME { using T = double; static constexpr const char* name = #NAME;                             \
         static __device__ __forceinline__ void op(double& a, double b, double c) {                         \
-            asm volatile(ASM : "+v"(a) : "v"(b), "v"(c) : "vcc", "s20", "s21"); } };
+            asm volatile(ASM : "+v"(a) : "v"(b), "v"(c)); } };
 
 OP32(v_add_u32, "v_add_u32 %0, %0, %1")
 OP32(v_and_b32, "v_and_b32 %0, %0, %1")
@@ -67,7 +71,7 @@ OP32(v_mul_u32_u24, "v_mul_u32_u24 %0, %0, %1")
 OP32(v_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %1")
 OP32(v_mul_lo_u32, "v_mul_lo_u32 %0, %0, %1")
 OP32(v_mul_hi_u32, "v_mul_hi_u32 %0, %0, %1")
-OP32(v_cmp_cndmask, "v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")   // TWO instructions per op (reported per pair)
+OP32C(v_cmp_cndmask, "v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")   // TWO instructions per op (reported per pair)
 OP32(v_fma_f32, "v_fma_f32 %0, %0, %1, %2")
 OP32(v_mul_f32, "v_mul_f32 %0, %0, %1")
 OP32(v_cvt_f32_u32, "v_cvt_f32_u32 %0, %0")
@@ -75,19 +79,19 @@ OP32(v_rcp_f32, "v_rcp_f32 %0, %0")
 OP32(v_add_u32_dpp_row_shr, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 OP32(v_mov_b32_dpp_quad, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 OP32(v_add_u32_dpp_row_bcast, "v_add_u32_dpp %0, %1, %0 row_bcast:15 row_mask:0xa bank_mask:0xf")
-OP32(v_readfirstlane_mov, "v_readfirstlane_b32 s20, %0\n\tv_mov_b32 %0, s20")       // TWO instructions per op; s20 clobbered
+OP32C(v_readfirstlane_mov, "v_readfirstlane_b32 s20, %0\n\tv_mov_b32 %0, s20")       // TWO instructions per op; s20 clobbered
 OP32(v_or_b32, "v_or_b32 %0, %0, %1")
 OP32(v_sub_u32, "v_sub_u32 %0, %0, %1")
 OP32(v_mov_b32, "v_mov_b32 %0, %1")
 OP32(v_not_b32, "v_not_b32 %0, %0")
 OP32(v_add_u32_e64, "v_add_u32_e64 %0, %0, %1")
-OP32(v_add_u32_sgpr, "v_add_u32 %0, s20, %0")
+OP32C(v_add_u32_sgpr, "v_add_u32 %0, s20, %0")
 OP32(v_add_u32_lit, "v_add_u32 %0, 0x12345, %0")
 OP32(v_and_b32_inl, "v_and_b32 %0, 15, %0")
-OP32(v_add_co_u32, "v_add_co_u32 %0, vcc, %0, %1")
-OP32(v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
-OP32(v_cmp_gt_u32_vcc, "v_cmp_gt_u32 vcc, %0, %1")
-OP32(v_cmp_gt_u32_sgpr, "v_cmp_gt_u32 s[20:21], %0, %1")
+OP32C(v_add_co_u32, "v_add_co_u32 %0, vcc, %0, %1")
+OP32C(v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
+OP32C(v_cmp_gt_u32_vcc, "v_cmp_gt_u32 vcc, %0, %1")
+OP32C(v_cmp_gt_u32_sgpr, "v_cmp_gt_u32 s[20:21], %0, %1")
 OP32(v_lshrrev_b32, "v_lshrrev_b32 %0, 1, %0")
 OP32(v_ashrrev_i32, "v_ashrrev_i32 %0, 1, %0")
 OP32(v_max_u32, "v_max_u32 %0, %0, %1")

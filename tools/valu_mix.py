@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Static VALU instruction mix of the product kernels against the measured issue rates (profiles/valu_rates.csv, tools/ubench/valu_rate.hip):
+which share of a kernel's vector instructions are full-rate forms (2.15 SIMD cycles per wave64 instruction: add / sub / and / or / xor / not / mov /
+right shifts / f32 add-mul-fma), half-rate (4.2: everything else 32-bit, packed 16-bit, dot, DPP/SDWA, 64-bit) or quarter-rate (8.1: rcp, sqrt,
+sin, ...), and the issue-cycle floor per instruction that mix implies.  Static counts (every instruction once, loops not weighted): an indication
+of the mix, not a profile.   usage: tools/valu_mix.py <file.s from hipcc -S --cuda-device-only> [kernel substring ...]"""
+import collections
+import re
+import sys
+
+FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_lshrrev_b32", "v_ashrrev_i32",
+        "v_add_u16", "v_sub_u16", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_add_nc_u32"}
+QUARTER = {"v_rcp_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_rcp_iflag_f32", "v_rcp_f64", "v_rsq_f64", "v_sqrt_f64"}
+RATE = {"full": 2.15, "half": 4.2, "quarter": 8.1}
+
+
+def main():
+    path = sys.argv[1]
+    want = sys.argv[2:]
+    cur, mix = None, collections.OrderedDict()
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            mix[cur] = collections.Counter()
+            continue
+        if cur is None:
+            continue
+        if ".end_amdhsa_kernel" in line or line.startswith("\t.section"):
+            continue
+        m = re.match(r"^\s+(v_\w+|ds_\w+|s_\w+|global_\w+|buffer_\w+|flat_\w+|scratch_\w+)", line)
+        if m:
+            mix[cur][m.group(1)] += 1
+    for k, c in mix.items():
+        if want and not any(w in k for w in want):
+            continue
+        valu = {o: n for o, n in c.items() if o.startswith("v_")}
+        tot = sum(valu.values())
+        if tot == 0:
+            continue
+        base = lambda o: re.sub(r"_(e32|e64|dpp|sdwa)$", "", o)
+        cls = collections.Counter()
+        for o, n in valu.items():
+            b = base(o)
+            variant = o.endswith("_dpp") or o.endswith("_sdwa")
+            cls["quarter" if b in QUARTER else ("full" if b in FULL and not variant else "half")] += n
+        floor = sum(RATE[x] * n for x, n in cls.items()) / tot
+        print("%s: %d VALU (full-rate %.1f %%, half %.1f %%, quarter %.1f %%) -> %.2f SIMD cycles per instruction at the measured rates; %d LDS, %d SALU, %d VMEM"
+              % (k, tot, 100.0 * cls["full"] / tot, 100.0 * cls["half"] / tot, 100.0 * cls["quarter"] / tot, floor,
+                 sum(n for o, n in c.items() if o.startswith("ds_")), sum(n for o, n in c.items() if o.startswith("s_")),
+                 sum(n for o, n in c.items() if o.startswith(("global_", "buffer_", "flat_", "scratch_")))))
+        print("   top:", ", ".join("%s %d" % (o, n) for o, n in sorted(valu.items(), key=lambda kv: -kv[1])[:14]))
+
+
+if __name__ == "__main__":
+    main()
