@@ -1614,12 +1614,28 @@ static int launch_status() { return hipGetLastError() == hipSuccess ? ORB_OK : O
 // around k_grid_build / k_sbp_candidates2 / k_sbp_resolve while enabled.  Process-wide and not re-entrant: a measurement facility only.
 // per calling thread: Tracking, LocalMapping and LoopClosing each drive their own matcher calls on their own streams; a thread that enables the
 // timing gets events of its own and reads back its own last call, whatever the others do
-static thread_local struct { bool on = false, made = false, have_grid = false, have_sbp = false; hipEvent_t ev[5]; } g_mt;
+// The events belong to the thread AND to the device that was current when they were made: they are destroyed with the thread (short-lived
+// worker threads do not leak them) and made again when the thread has moved to another device.
+struct MatcherTiming {
+    bool on = false, made = false, have_grid = false, have_sbp = false;
+    int device = -1;
+    hipEvent_t ev[5];
+    void drop() {
+        if (made) for (auto& e : ev) (void)hipEventDestroy(e);
+        made = have_grid = have_sbp = false;
+    }
+    ~MatcherTiming() { drop(); }
+};
+static thread_local MatcherTiming g_mt;
 static bool mt_ready() {
     if (!g_mt.on) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_mt.made && g_mt.device != dev) g_mt.drop();
     if (!g_mt.made) {
-        for (auto& e : g_mt.ev) if (hipEventCreate(&e) != hipSuccess) return false;
-        g_mt.made = true;
+        int n = 0;
+        for (auto& e : g_mt.ev) { if (hipEventCreate(&e) != hipSuccess) { for (int i = 0; i < n; i++) (void)hipEventDestroy(g_mt.ev[i]); return false; } n++; }
+        g_mt.made = true; g_mt.device = dev;
     }
     return true;
 }

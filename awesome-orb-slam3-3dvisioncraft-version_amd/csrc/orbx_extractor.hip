@@ -424,6 +424,16 @@ static __device__ __forceinline__ int wave_scan_incl(int x) {
 // wave-wide sum / minimum through the same DPP steps (the result forms in lane 63 and is broadcast with one v_readlane): seven register-only
 // instructions where a __shfl_xor butterfly is six dependent ds_bpermute round trips.  All 64 lanes must be active.
 static __device__ __forceinline__ int wave_sum(int x) { return __builtin_amdgcn_readlane(wave_scan_incl(x), 63); }
+// the same on unsigned words (two packed 16-bit sums per register: the adds must wrap, not overflow a signed int)
+static __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
 #define WMIN_STEP(ctrl, rows) x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ctrl, rows, 0xF, false))
     WMIN_STEP(0x111, 0xF); WMIN_STEP(0x112, 0xF); WMIN_STEP(0x114, 0xF); WMIN_STEP(0x118, 0xF);   // row_shr:1, 2, 4, 8
@@ -2150,8 +2160,8 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float vDists[11];
             int bestSad = 2147483647, bestincR = 0;
-            // a lane's contributions to the eleven SADs first, two per register (a SAD is at most 121 * 255 < 2^16, so the halves never carry), then six
-            // wave sums (rounds 1-2: eleven butterflies of six dependent ds_bpermute each — the kernel was that chain)
+            // a lane's contributions to the eleven SADs first, two per register (a SAD is at most 120 * 510 = 61 200 < 2^16, so the halves never carry;
+            // the sums are unsigned: the upper half alone exceeds INT_MAX), then six wave sums (rounds 1-2: eleven butterflies of six dependent ds_bpermute each — the kernel was that chain)
             uint32_t part[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int inc = 0; inc < 11; inc++) {
@@ -2169,7 +2179,7 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
                 part[inc >> 1] |= (uint32_t)sum << (16 * (inc & 1));
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) part[k] = (uint32_t)wave_sum((int)part[k]);
+            for (int k = 0; k < 6; k++) part[k] = wave_sum_u32(part[k]);
 #pragma unroll
             for (int inc = 0; inc < 11; inc++) {
                 const int incR = inc - Lw;
@@ -2202,11 +2212,13 @@ static __global__ __launch_bounds__(256) void k_stereo_match(StereoParams P) {
 #ifndef STEREO_ROWS_LDS_MAX
 #define STEREO_ROWS_LDS_MAX (64 * 1024)   // dynamic LDS of k_stereo_rows (tests build with 0: every frame takes the global-memory path)
 #endif
-#define STEREO_CULL_BINS 1024   // SAD >> 5: an 11 x 11 patch of bytes sums to at most 121 * 255 = 30 855
+#define STEREO_CULL_BINS 2048   // SAD >> 5: the patches are centre-subtracted (Frame.cc:1055-1075, IL - IL.at(w, w)), so a pixel contributes up to 510 and the
+                                // centre itself 0: a SAD is at most 120 * 510 = 61 200 (bin 1 912); nothing is clamped into a shared last bin
 static __global__ __launch_bounds__(256) void k_stereo_cull(StereoParams P) {
     // median of the valid SADs = the value at rank size / 2 of the ascending order (Frame.cc:1120-1123: sort of (dist, index) pairs — ties do not change
-    // the VALUE at a rank), by a two-level histogram: 1 024 bins of 32 values, then the 32 values of the bin that holds the rank.  (Rounds 1-2 ranked
+    // the VALUE at a rank), by a two-level histogram: 2 048 bins of 32 values, then the 32 values of the bin that holds the rank.  (Rounds 1-2 ranked
     // every value against every other from an LDS copy: 4 000 turns per thread at 1 000 key points, 0.18 ms per 512 frames — and cap + 2 words of LDS.)
+    // 2 048 bins cover 65 535 >= the largest possible SAD, so min(s >> 5, BINS - 1) never merges distinct bins and `s & 31` is the rank inside one.
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     int* hist = (int*)orb_smem;               // [STEREO_CULL_BINS]
     int* sub = hist + STEREO_CULL_BINS;       // [32]
@@ -2624,13 +2636,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
         h->fastLastTwoPass = two;
         if (two) {
+            // [0] the list's count, [1] the tiles of THIS call: both words travel back in one copy, so the pair the next call's policy (and
+            // orbx_last_fast_passes) reads always belongs to one call, whatever batch sizes alternate on the handle
             HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
+            HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_retry + 1), (int)((uint32_t)nTiles * (uint32_t)batch), 1, st));
             hipLaunchKernelGGL((k_fast<0>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
             hipLaunchKernelGGL((k_fast<1>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
-            if (!h->capturing) {
-                h->h_retry[1] = (uint32_t)nTiles * (uint32_t)batch;
-                HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 4, hipMemcpyDeviceToHost, st));
-            }
+            if (!h->capturing) HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 8, hipMemcpyDeviceToHost, st));
         } else {
             hipLaunchKernelGGL((k_fast<2>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
         }

@@ -106,7 +106,8 @@ int orbx_last_timing(orbx_handle h, float* ms5);
 /* How the last batch call ran FAST (a scheduling decision only: the key points do not depend on it).  two_pass: 1 = detection at iniThFAST followed by a
  * second launch on the cells that came back empty (ORBextractor.cc:812-828), 0 = one pass at min(ini, min).  listed / tiles: the tiles the handle's
  * most recent two-pass call sent to its second pass, of how many — the share that decides whether the next call takes two passes again (copied back
- * asynchronously: synchronise the stream first for the figure of the call just made).  Any pointer may be NULL. */
+ * asynchronously, both words in one copy: synchronise the stream first for the figure of the call just made; the pair always belongs to ONE call).
+ * A HIP graph captured from a batch call keeps the pass form it was captured with (the copy-back is not part of a capture).  Any pointer may be NULL. */
 int orbx_last_fast_passes(orbx_handle h, int* two_pass, uint32_t* listed, uint32_t* tiles);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -238,7 +239,8 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
 /* Measurement facility (bench.py's roofline legs), the stage-2 counterpart of orbx_last_timing: while enabled, HIP events are recorded on the launch
  * stream around the kernels of orbm_grid_build and orbm_search_by_projection; orbm_last_timing synchronises on them and returns the device time of the
  * last call's kernels: ms[0] = grid build, ms[1] = candidate enumeration + Hamming, ms[2] = serial-order resolution.  The switch and the events are per calling thread: a thread times its own calls only, concurrent matcher
- * calls of other threads neither record into nor disturb them. */
+ * calls of other threads neither record into nor disturb them — so orbm_enable_timing, the timed calls and orbm_last_timing must come from the SAME thread
+ * (another thread reads zeros), on one device (the events are re-made, and the last figures dropped, when the thread's current device changes). */
 int orbm_enable_timing(int on);
 int orbm_last_timing(float* ms3);
 

@@ -5,8 +5,9 @@
 // them would terminate the process.  The adapters (include/orbslam3_hip/*.h) do throw — a failing HIP call, a device allocation that does
 // not fit, ORB_E_CAPACITY — because a flattened caller wants to know.  Every glue function is therefore a function-try-block whose
 // handler ends here: the failure is reported on stderr and counted, the function returns what the reference returns when it found nothing
-// (0 matches / 0 inliers / void), and — because every glue function does all of its device work BEFORE its first write to the map or the
-// frame — the caller's state is exactly what it was before the call.  A host that wants to react (drop to its CPU bodies, stop the
+// (0 matches / 0 inliers / void).  Every glue function does all of its device work BEFORE its first write to the map, so map geometry,
+// observations and outlier flags are what they were before the call; the OUTPUT containers are in the function's nothing-found state, which
+// for SearchForInitialization / SearchByBoW means vnMatches12 / vpMapPointMatches / vpMatches12 reset (the reference resets them first, too).  A host that wants to react (drop to its CPU bodies, stop the
 // session) polls glue_failures().  What "untouched" covers: map geometry, observations, match vectors, outlier flags.  The window-selection
 // stamps the reference itself writes while it gathers (mnBALocalForKF / mnBAFixedForKF, IMU::Preintegrated::SetNewBias) are written as
 // there; the three Frame-constructor steps (integration/Frame_hip.cc) leave their outputs sized and filled with "nothing found" (-1), which
@@ -15,6 +16,7 @@
 #define ORBSLAM3_HIP_GLUEGUARD_H
 #include <atomic>
 #include <cstdio>
+#include <cstring>
 #include <exception>
 
 namespace orbslam3_hip {
@@ -23,19 +25,37 @@ inline std::atomic<unsigned long>& glue_failure_counter() noexcept {
     static std::atomic<unsigned long> n{0};
     return n;
 }
-// number of glue calls that ended in the handler since process start
+// number of glue calls that ended in the handler since process start.  A host MUST look at it: after a failure LocalBundleAdjustment /
+// LocalInertialBA return without having optimised anything and PoseOptimization returns 0 inliers (which Tracking reads as "lost") — under a
+// persistent fault (device lost, out of memory) every later call does the same, so poll it after LocalBundleAdjustment / once per frame and
+// drop to the CPU bodies or stop the session (integration/README.md), or install a callback with glue_set_failure_callback().
 inline unsigned long glue_failures() noexcept { return glue_failure_counter().load(); }
 
-inline int glue_failed(const char* fn, const std::exception& e) noexcept {
-    glue_failure_counter()++;
-    std::fprintf(stderr, "[orbhip] %s: %s -- call dropped, caller state untouched\n", fn, e.what());
+// the most recent failure: the glue function's name and the exception text (what() of the adapters' errors carries the ORB_E_* code), for a
+// host that polls.  Plain buffers written before the counter is bumped; concurrent failures may interleave the text, never the counter.
+struct GlueLastError { char function[64]; char what[192]; };
+inline GlueLastError& glue_last_error_slot() noexcept { static GlueLastError e{{0}, {0}}; return e; }
+inline GlueLastError glue_last_error() noexcept { return glue_last_error_slot(); }
+
+// optional notification, called from the failing thread after the counter is bumped: (function name, message, total failures so far)
+using GlueFailureCallback = void (*)(const char* fn, const char* what, unsigned long total);
+inline std::atomic<GlueFailureCallback>& glue_failure_callback_slot() noexcept { static std::atomic<GlueFailureCallback> cb{nullptr}; return cb; }
+inline void glue_set_failure_callback(GlueFailureCallback cb) noexcept { glue_failure_callback_slot().store(cb); }
+
+inline int glue_report(const char* fn, const char* what) noexcept {
+    GlueLastError& le = glue_last_error_slot();
+    std::strncpy(le.function, fn, sizeof(le.function) - 1); le.function[sizeof(le.function) - 1] = 0;
+    std::strncpy(le.what, what, sizeof(le.what) - 1); le.what[sizeof(le.what) - 1] = 0;
+    const unsigned long n = ++glue_failure_counter();
+    // stderr is rate-limited: the first 8 failures, then every 256th — a persistent fault fails at frame rate
+    if (n <= 8 || (n & 255u) == 0)
+        std::fprintf(stderr, "[orbhip] %s: %s -- call dropped: the reference's nothing-found value is returned (failure %lu%s)\n", fn, what, n,
+                     n == 8 ? "; further reports every 256th" : "");
+    if (GlueFailureCallback cb = glue_failure_callback_slot().load()) cb(fn, what, n);
     return 0;
 }
-inline int glue_failed(const char* fn) noexcept {
-    glue_failure_counter()++;
-    std::fprintf(stderr, "[orbhip] %s: unknown exception -- call dropped, caller state untouched\n", fn);
-    return 0;
-}
+inline int glue_failed(const char* fn, const std::exception& e) noexcept { return glue_report(fn, e.what()); }
+inline int glue_failed(const char* fn) noexcept { return glue_report(fn, "unknown exception"); }
 
 }  // namespace orbslam3_hip
 

@@ -1,6 +1,7 @@
 // CPU unit test of k_stereo_cull (test infrastructure; the product source against the HIP emulator): the two-level-histogram median must be the value at
 // rank size / 2 of the ascending order of the valid SADs (Frame.cc:1120-1123), and the cull 1.5 * 1.4 * median, on adversarial inputs: ties, a single
-// valid entry, all equal, values on bin boundaries, the largest possible SAD, mostly-invalid frames.
+// valid entry, all equal, values on bin boundaries, the largest possible SAD (120 * 510 = 61 200: centre-subtracted patches), medians above 32 767,
+// mostly-invalid frames.
 #include "../../awesome-orb-slam3-3dvisioncraft-version_amd/csrc/orbx_extractor.hip"
 
 #include <algorithm>
@@ -20,12 +21,12 @@ int main() {
         for (int i = 0; i < cap; i++) {
             int s;
             switch (kind) {
-                case 0: s = (int)(rng() % 30856); break;                                   // whole range
+                case 0: s = (int)(rng() % 61201); break;                                   // whole range: 0 .. 120 * 510
                 case 1: s = 777; break;                                                    // all equal
                 case 2: s = (rng() % 3) ? -1 : (int)(rng() % 4000); break;                 // mostly invalid
-                case 3: s = 32 * (int)(rng() % 960) + ((rng() & 1) ? 31 : 0); break;       // bin boundaries
-                case 4: s = (rng() % 5) ? 1000 + (int)(rng() % 8) : 30855; break;          // ties + the maximum
-                case 5: s = (int)(rng() % 64); break;                                      // two bins
+                case 3: s = 32 * (int)(rng() % 1912) + ((rng() & 1) ? 31 : 0); break;      // bin boundaries
+                case 4: s = (rng() % 5) ? 1000 + (int)(rng() % 8) : 61200; break;          // ties + the maximum
+                case 5: s = (f & 8) ? 61137 + (int)(rng() % 64) : (int)(rng() % 64); break;  // two bins: the lowest two, or the highest two (median >= 32 768)
                 case 6: s = i < 3 ? 5 * i : -1; break;                                     // three valid entries
                 default: s = 2000 + (int)(rng() % 33); break;                              // straddles one boundary
             }

@@ -337,6 +337,8 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp,
 }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+typedef void* hipDeviceptr_t;
+inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t = nullptr) { for (size_t i = 0; i < count; i++) ((int*)d)[i] = v; return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 // HIP graphs are not emulated: capture reports "not supported" and the product falls back to direct launches
