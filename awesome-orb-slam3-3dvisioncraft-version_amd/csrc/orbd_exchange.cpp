@@ -3,6 +3,9 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
+#include <vector>
+
 #include "orbd.h"
 
 static int rc_of(ncclResult_t r) { return r == ncclSuccess ? ORB_OK : ORB_E_HIP; }
@@ -36,6 +39,85 @@ extern "C" int orbd_allreduce_pose_system(orbd_comm comm, double* d_Hpp, double*
 extern "C" int orbd_allgather_pose_blocks(orbd_comm comm, int world, const double* d_local, double* d_all, int poses_per_rank, void* stream) {
     if (!comm || world < 1 || !d_local || !d_all || poses_per_rank < 1) return ORB_E_INVALID;
     return rc_of(ncclAllGather(d_local, d_all, (size_t)poses_per_rank * 7, ncclDouble, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+// ---- the all-gather as explicit peer copies (no RCCL): one pull per peer and slab, the peers on streams of their own -------------------------
+extern "C" int orbd_ipc_export(const void* d_ptr, uint8_t handle_out[64]) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the exchanged handle is 64 bytes");
+    if (!d_ptr || !handle_out) return ORB_E_INVALID;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, const_cast<void*>(d_ptr)) != hipSuccess) { (void)hipGetLastError(); return ORB_E_HIP; }
+    std::memcpy(handle_out, &h, 64);
+    return ORB_OK;
+}
+extern "C" int orbd_ipc_open(const uint8_t handle[64], void** d_ptr_out) {
+    if (!handle || !d_ptr_out) return ORB_E_INVALID;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, 64);
+    if (hipIpcOpenMemHandle(d_ptr_out, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return ORB_E_HIP; }
+    return ORB_OK;
+}
+extern "C" int orbd_ipc_close(void* d_ptr) {
+    if (!d_ptr) return ORB_E_INVALID;
+    return hipIpcCloseMemHandle(d_ptr) == hipSuccess ? ORB_OK : ORB_E_HIP;
+}
+
+namespace {
+// per calling thread (= per rank in a one-process-per-GPU host, per device thread otherwise): the copy streams and their events, made once
+struct PeerStreams {
+    int device = -1;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> done;
+    hipEvent_t start = nullptr;
+    void drop() {
+        for (auto s : st) (void)hipStreamDestroy(s);
+        for (auto e : done) (void)hipEventDestroy(e);
+        if (start) (void)hipEventDestroy(start);
+        st.clear(); done.clear(); start = nullptr; device = -1;
+    }
+    bool ensure(int n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (device != dev) drop();
+        device = dev;
+        if (!start && hipEventCreateWithFlags(&start, hipEventDisableTiming) != hipSuccess) return false;
+        while ((int)st.size() < n) {
+            hipStream_t s; hipEvent_t e;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s); return false; }
+            st.push_back(s); done.push_back(e);
+        }
+        return true;
+    }
+    ~PeerStreams() { drop(); }
+};
+thread_local PeerStreams g_peer;
+}  // namespace
+
+extern "C" int orbd_allgather_frames_peer(int world, int rank, int frames_per_rank, int cap, const void* const* peer_kps, const void* const* peer_desc,
+                                          const void* const* peer_counts, orb_keypoint* d_all_kps, uint8_t* d_all_desc, int32_t* d_all_counts,
+                                          void* stream) {
+    if (world < 1 || rank < 0 || rank >= world || frames_per_rank < 1 || cap < 1 || !peer_kps || !peer_desc || !peer_counts || !d_all_kps ||
+        !d_all_desc || !d_all_counts)
+        return ORB_E_INVALID;
+    for (int s = 0; s < world; s++)
+        if (!peer_kps[s] || !peer_desc[s] || !peer_counts[s]) return ORB_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_peer.ensure(world)) return ORB_E_HIP;
+    const size_t F = (size_t)frames_per_rank;
+    const size_t bk = F * cap * sizeof(orb_keypoint), bd = F * cap * 32, bc = F * 2 * sizeof(int32_t);
+    if (hipEventRecord(g_peer.start, st) != hipSuccess) return ORB_E_HIP;
+    bool ok = true;
+    for (int i = 0; i < world && ok; i++) {
+        const int s = (rank + 1 + i) % world;           // own block last; no two ranks start on the same source
+        hipStream_t cs = s == rank ? st : g_peer.st[s];
+        if (s != rank) ok = hipStreamWaitEvent(cs, g_peer.start, 0) == hipSuccess;
+        ok = ok && hipMemcpyAsync((uint8_t*)d_all_kps + (size_t)s * bk, peer_kps[s], bk, hipMemcpyDeviceToDevice, cs) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_all_desc + (size_t)s * bd, peer_desc[s], bd, hipMemcpyDeviceToDevice, cs) == hipSuccess;
+        ok = ok && hipMemcpyAsync((uint8_t*)d_all_counts + (size_t)s * bc, peer_counts[s], bc, hipMemcpyDeviceToDevice, cs) == hipSuccess;
+        if (s != rank) ok = ok && hipEventRecord(g_peer.done[s], cs) == hipSuccess && hipStreamWaitEvent(st, g_peer.done[s], 0) == hipSuccess;
+    }
+    return ok ? ORB_OK : ORB_E_HIP;
 }
 
 extern "C" int orbd_comm_init_all_local(int n_devices, const int* devices, orbd_comm* comms) {

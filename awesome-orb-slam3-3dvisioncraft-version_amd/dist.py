@@ -63,3 +63,99 @@ def allreduce_pose_system(Hpp, bp, group=None):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     n = Hpp.numel()
     return buf[:n].reshape(Hpp.shape), buf[n:].reshape(bp.shape)
+
+
+class _DevSlab:
+    """A hipMalloc'ed buffer of its own (an IPC handle names a whole allocation: a tensor carved out of torch's caching allocator would export
+    its neighbours too), visible to torch through __cuda_array_interface__."""
+
+    def __init__(self, hip, device, shape, typestr, itemsize):
+        import ctypes as C
+        self._hip, self.shape = hip, tuple(shape)
+        n = itemsize
+        for s in shape:
+            n *= s
+        p = C.c_void_p()
+        if hip.orb_dev_alloc(device, n, C.byref(p)) != 0:
+            raise MemoryError("orb_dev_alloc(%d bytes)" % n)
+        self.ptr, self.nbytes = p.value, n
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": typestr, "data": (self.ptr, False), "version": 2}
+
+    def free(self):
+        if self.ptr:
+            import ctypes as C
+            self._hip.orb_dev_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+class PeerExchange:
+    """allgather_frame_blocks without RCCL (include/orbd.h orbd_allgather_frames_peer): every rank pulls each peer's three slabs straight out of
+    the peer's memory, one device-to-device copy per peer and slab on a stream per peer — on xGMI one slab per point-to-point link, all seven at
+    once.  One process per GPU: the slabs are allocated here (`kps`, `desc`, `counts`: hand them to ORBextractor.extract_batch(out=...)), their
+    IPC handles are exchanged once through the process group, and `allgather()` fills `all_kps / all_desc / all_counts` (rank-major).
+    The caller orders the ranks around `allgather()` (peers' slabs complete before, not rewritten until every rank is done): a
+    torch.cuda.synchronize() + dist.barrier() on both sides, as for any one-sided read."""
+
+    def __init__(self, frames_per_rank, cap, device, group=None):
+        import ctypes as C
+        import os
+        from . import _lib
+        self.C = C
+        self.group, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.F, self.cap, self.device = int(frames_per_rank), int(cap), device
+        hip = _lib.load()
+        hip.orb_dev_alloc.restype = C.c_int; hip.orb_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        hip.orb_dev_free.restype = C.c_int; hip.orb_dev_free.argtypes = [C.c_void_p]
+        self.L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liborbd.so"))
+        self.L.orbd_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.orbd_ipc_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        self.L.orbd_ipc_close.argtypes = [C.c_void_p]
+        self.L.orbd_allgather_frames_peer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+        di = device.index if hasattr(device, "index") else int(device)
+        F, W = self.F, self.world
+        self._slabs = [_DevSlab(hip, di, (F, cap, 7), "<f4", 4), _DevSlab(hip, di, (F, cap, 32), "|u1", 1), _DevSlab(hip, di, (F, 2), "<i4", 4)]
+        dev = torch.device("cuda", di)
+        self.kps, self.desc, self.counts = (torch.as_tensor(s, device=dev) for s in self._slabs)
+        self.all_kps = torch.empty((W * F, cap, 7), dtype=torch.float32, device=dev)
+        self.all_desc = torch.empty((W * F, cap, 32), dtype=torch.uint8, device=dev)
+        self.all_counts = torch.empty((W * F, 2), dtype=torch.int32, device=dev)
+        mine = []
+        for s in self._slabs:
+            h = (C.c_uint8 * 64)()
+            if self.L.orbd_ipc_export(C.c_void_p(s.ptr), h) != 0:
+                raise RuntimeError("orbd_ipc_export failed (hipIpcGetMemHandle): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?")
+            mine.append(bytes(h))
+        allh = [None] * W
+        dist.all_gather_object(allh, mine, group=group)
+        self._opened = []
+        self._peer = [(C.c_void_p * W)() for _ in range(3)]
+        for r in range(W):
+            for k in range(3):
+                if r == self.rank:
+                    self._peer[k][r] = self._slabs[k].ptr
+                else:
+                    p = C.c_void_p()
+                    hb = (C.c_uint8 * 64).from_buffer_copy(allh[r][k])
+                    if self.L.orbd_ipc_open(hb, C.byref(p)) != 0:
+                        raise RuntimeError("orbd_ipc_open failed for rank %d" % r)
+                    self._opened.append(p.value)
+                    self._peer[k][r] = p.value
+
+    def allgather(self, stream=None):
+        C = self.C
+        st = stream if stream is not None else torch.cuda.current_stream(self.kps.device).cuda_stream
+        rc = self.L.orbd_allgather_frames_peer(self.world, self.rank, self.F, self.cap, self._peer[0], self._peer[1], self._peer[2],
+                                               C.c_void_p(self.all_kps.data_ptr()), C.c_void_p(self.all_desc.data_ptr()),
+                                               C.c_void_p(self.all_counts.data_ptr()), C.c_void_p(st))
+        if rc != 0:
+            raise RuntimeError("orbd_allgather_frames_peer: %d" % rc)
+        return self.all_kps, self.all_desc, self.all_counts
+
+    def close(self):
+        """collective in spirit: call after a barrier that follows the last allgather of every rank"""
+        for p in self._opened:
+            self.L.orbd_ipc_close(self.C.c_void_p(p))
+        self._opened = []
+        self.kps = self.desc = self.counts = None
+        for s in self._slabs:
+            s.free()

@@ -346,6 +346,10 @@ def main():
                          "handles in rotation (measured on MI355X: 2.33-2.36 ms per step against 2.35 with 3 — nothing left to overlap); 1: everything in one stream")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = the median region")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the last timed step (profiling runs)")
+    ap.add_argument("--exchange", default="rccl", choices=("rccl", "peer", "both"),
+                    help="N > 1: how the exchange leg all-gathers the frame blocks — RCCL (one all_gather_into_tensor), explicit peer copies over IPC "
+                         "handles (orbd_allgather_frames_peer: one pull per peer and slab, a stream per peer), or both; the peer form has never run "
+                         "on more than one GPU (DESIGN section 5), so the driver's default stays RCCL and a failing peer leg is reported, not fatal")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
@@ -827,7 +831,30 @@ def main():
         blk = out[0].shape[1] * 60 + 8
         extra["exchange"] = {"allgather_frame_blocks_ms": round(dtx * 1e3, 3), "bytes_per_rank": int(B * blk),
                              "GBps_into_each_rank": round((world - 1) * B * blk / dtx / 1e9, 2),
-                             "frames_visible_to_each_rank": int(ak.shape[0]), "what": "one all_gather_into_tensor of per-frame blocks [desc|kps|count]"}
+                             "frames_visible_to_each_rank": int(ak.shape[0]), "what": "one all_gather_into_tensor of per-frame blocks [desc|kps|count]",
+                             "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "world": world, "backend": dist.get_backend()}
+        if args.exchange in ("peer", "both"):
+            # the RCCL-free form: IPC handles once, then one pull per peer and slab.  Never run on more than one GPU before: a failure
+            # here is reported in the line and does not fail the run (every rank takes the same branch: the handle exchange is a collective)
+            try:
+                px = D.PeerExchange(B, out[0].shape[1], dev)
+                px.kps.copy_(out[0]); px.desc.copy_(out[1]); px.counts.copy_(out[2])
+                barrier()
+                px.allgather()
+                barrier()
+                tp = time.perf_counter()
+                for _ in range(3):
+                    pk, pd, pc = px.allgather()
+                    barrier()
+                dtp = (time.perf_counter() - tp) / 3
+                same = bool(torch.equal(pk, ak) and torch.equal(pd, ad) and torch.equal(pc, ac))
+                extra["exchange"]["peer"] = {"allgather_frame_blocks_ms": round(dtp * 1e3, 3), "GBps_into_each_rank": round((world - 1) * B * blk / dtp / 1e9, 2),
+                                             "equal_to_rccl_result": same, "what": "orbd_allgather_frames_peer: hipMemcpyAsync pull per peer and slab over IPC handles, "
+                                                                                   "one stream per peer (timed with a barrier per call)"}
+                barrier()
+                px.close()
+            except Exception as err:   # noqa: BLE001
+                extra["exchange"]["peer_error"] = "%s: %s" % (type(err).__name__, err)
         w, cams = synth_window(77, 100, 20, 20000, 8, "mono")   # the same window on every rank, landmarks sharded
         llo, lhi = D.shard(len(w["points"]), rank, world)
         e = w["edges"]

@@ -36,6 +36,23 @@ int orbd_allreduce_pose_system(orbd_comm comm, double* d_Hpp, double* d_bp, int 
 /* d_local [poses_per_rank][7] doubles (the pose blocks this rank updated) -> d_all [world * poses_per_rank][7], rank-major. */
 int orbd_allgather_pose_blocks(orbd_comm comm, int world, const double* d_local, double* d_all, int poses_per_rank, void* stream);
 
+/* The same all-gather WITHOUT RCCL (xGMI is point-to-point, 7 links per GPU — an all-gather of equal shards is one
+ * slab per link): every rank PULLS each peer's three slabs straight out of the peer's memory with one device-to-device copy per peer, each on
+ * its own stream, so the 7 incoming slabs travel on the 7 links at once; no ring, no staging buffer, no reduction kernel.
+ *   orbd_ipc_export / orbd_ipc_open / orbd_ipc_close: one process per GPU — a rank exports an IPC handle (64 bytes) of each slab once, the handles
+ *     are exchanged out of band (the launcher's rendezvous; orbhip.dist.PeerExchange uses torch.distributed.all_gather_object), every rank opens
+ *     its peers' handles once and keeps the pointers.  (A single process driving several GPUs passes the peers' device pointers directly.)
+ *   orbd_allgather_frames_peer: peer_* [world] = the slabs' device pointers as seen from THIS rank (entry [rank] = its own slabs).  Copies peer
+ *     s's slabs into block s of the d_all_* slabs, peers taken in the order rank+1, rank+2, ... so that no two ranks start on the same source.
+ *     The copies of different peers run on internal per-peer streams that start after `stream`'s work and are joined back into `stream`.
+ *     The CALLER orders the ranks: the peers' slabs must be complete (their producer streams synchronised) before any rank calls this, and must
+ *     not be rewritten until every rank's copies are done — a barrier of the launcher on both sides, as for any one-sided read. */
+int orbd_ipc_export(const void* d_ptr, uint8_t handle_out[64]);
+int orbd_ipc_open(const uint8_t handle[64], void** d_ptr_out);
+int orbd_ipc_close(void* d_ptr);
+int orbd_allgather_frames_peer(int world, int rank, int frames_per_rank, int cap, const void* const* peer_kps, const void* const* peer_desc,
+                               const void* const* peer_counts, orb_keypoint* d_all_kps, uint8_t* d_all_desc, int32_t* d_all_counts, void* stream);
+
 /* Convenience for a single process that drives n_devices GPUs (and for the 1-GPU test): ncclCommInitAll.  comms[i] belongs to devices[i]. */
 int orbd_comm_init_all_local(int n_devices, const int* devices, orbd_comm* comms);
 int orbd_comm_destroy(orbd_comm comm);

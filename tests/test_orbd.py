@@ -14,7 +14,8 @@ SO = os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "liborbd.
 def test_library_exports_every_declared_symbol():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "orbd.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(orbd_[a-z0-9_]+)\s*\(", txt)))
-    assert {"orbd_allgather_frames", "orbd_allreduce_pose_system", "orbd_allgather_pose_blocks"} <= set(names)
+    assert {"orbd_allgather_frames", "orbd_allreduce_pose_system", "orbd_allgather_pose_blocks", "orbd_allgather_frames_peer", "orbd_ipc_export",
+            "orbd_ipc_open", "orbd_ipc_close"} <= set(names)
     if not os.path.exists(SO):
         import __graft_entry__ as ge
         ge.build()
@@ -26,3 +27,10 @@ def test_library_exports_every_declared_symbol():
 def test_single_rank_exchange_on_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "orbd_single_rank.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "exchange OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_two_rank_peer_allgather_on_one_gpu():
+    """the RCCL-free all-gather (IPC handles + one pull per peer): two processes sharing GPU 0"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "orbd_peer_two_rank.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "peer exchange OK" in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
