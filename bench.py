@@ -847,7 +847,7 @@ def main():
                     pk, pd, pc = px.allgather()
                     barrier()
                 dtp = (time.perf_counter() - tp) / 3
-                same = bool(torch.equal(pk, ak) and torch.equal(pd, ad) and torch.equal(pc, ac))
+                same = bool(torch.equal(pk.view(torch.int32), ak.view(torch.int32)) and torch.equal(pd, ad) and torch.equal(pc, ac))   # (bit patterns: class_id = -1 reads as NaN)
                 extra["exchange"]["peer"] = {"allgather_frame_blocks_ms": round(dtp * 1e3, 3), "GBps_into_each_rank": round((world - 1) * B * blk / dtp / 1e9, 2),
                                              "equal_to_rccl_result": same, "what": "orbd_allgather_frames_peer: hipMemcpyAsync pull per peer and slab over IPC handles, "
                                                                                    "one stream per peer (timed with a barrier per call)"}
@@ -888,8 +888,8 @@ def main():
                          ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
                          ("batch_sweep", leg_batch_sweep)):
             guard(name, fn)
-        if world > 1:
-            leg_exchange()
+    if world > 1 and (not args.headline_only or args.exchange != "rccl"):
+        leg_exchange()
     lba_ms = extra.get("lba", {}).get("ms_per_step", 0.0)
     if world > 1:   # max over ranks of every timed region (all ranks ran the same number of steps between the same barriers)
         t = torch.tensor([dt, dt_extract, lba_ms], dtype=torch.float64, device=dev)
