@@ -12,27 +12,7 @@
 
 #include "../../include/orbhip.h"
 
-static __device__ __host__ inline void undistort_point(const orbf_camera& c, const float xin, const float yin, float* xo, float* yo) {
-    const double fx = (double)c.fx, fy = (double)c.fy, cx = (double)c.cx, cy = (double)c.cy;
-    const double ifx = 1. / fx, ify = 1. / fy;
-    const double k0 = (double)c.dist[0], k1 = (double)c.dist[1], p0 = (double)c.dist[2], p1 = (double)c.dist[3], k4 = (double)c.dist[4];
-    double x = (double)xin, y = (double)yin;
-    const double x0 = x = (x - cx) * ifx;
-    const double y0 = y = (y - cy) * ify;
-    for (int j = 0; j < 5; j++) {
-        const double r2 = x * x + y * y;
-        // k[5..7] (rational model) and k[8..11] (thin prism) are zero for the reference's 4/5-coefficient mDistCoef: the numerator of
-        // icdist is exactly 1 and the prism terms add exact zeros
-        const double icdist = 1. / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
-        const double deltaX = 2 * p0 * x * y + p1 * (r2 + 2 * x * x);
-        const double deltaY = p0 * (r2 + 2 * y * y) + 2 * p1 * x * y;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    // RR = P * I with P = K: xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1/(0*x + 0*y + 1) = 1
-    *xo = (float)(fx * x + cx);
-    *yo = (float)(fy * y + cy);
-}
+#include "frame_undistort.inc"
 
 static __global__ __launch_bounds__(256) void k_undistort(const orb_keypoint* kps, const int32_t* nkp, const int countStride, const int capK,
                                                           const orbf_camera cam, orb_keypoint* out) {

@@ -176,6 +176,81 @@ static __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* k
     }
 }
 
+// Frame::UndistortKeyPoints + AssignFeaturesToGrid of a frame in ONE workgroup (round 4): the two steps are a few microseconds of work per frame
+// each, and as two launches (k_undistort: a thread per key point; k_grid_build: a 256-thread workgroup per frame walking the undistorted records
+// again) they cost 0.036 + 0.036 ms per 512 frames — launch, fill and drain of two kernels that never hold more than one wave per SIMD.  Here a
+// thread undistorts its key point, writes the record and keeps its cell; counts, the exclusive scan over the 64 x 48 cells (three cells per thread,
+// DPP wave scans) and the fill follow in LDS.  Same outputs as the two calls, bit for bit.
+#include "frame_undistort.inc"
+#define UG_T 1024
+static __global__ __launch_bounds__(UG_T) void k_undistort_grid(const orb_keypoint* kps, const int32_t* nkp, const int cstride, const int cap_k, const orbf_camera cam,
+                                                               const orbm_grid_params g, orb_keypoint* kps_un, int32_t* grid_start, int32_t* grid_idx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    int* cnt = (int*)orb_smem;            // [GRID_CELLS] counts -> starts
+    int* fill = cnt + GRID_CELLS;         // [GRID_CELLS]
+    int* wtot = fill + GRID_CELLS;        // [16] per-wave totals of the scan
+    uint16_t* lst = (uint16_t*)(wtot + 16);   // [cap_k] the CSR index list, sorted per cell before it is written out
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(nkp[(size_t)b * cstride], cap_k);
+    kps += (size_t)b * cap_k; kps_un += (size_t)b * cap_k; grid_start += (size_t)b * (GRID_CELLS + 1); grid_idx += (size_t)b * cap_k;
+    for (int c = tid; c < GRID_CELLS; c += UG_T) { cnt[c] = 0; fill[c] = 0; }
+    __syncthreads();
+    constexpr int KP = 4;                 // key points per thread: cap_k <= KP * UG_T (checked on the host)
+    int cell[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const int i = tid + k * UG_T;
+        cell[k] = -1;
+        if (i < n) {
+            orb_keypoint kp = kps[i];
+            if (cam.dist[0] != 0.0f) undistort_point(cam, kp.x, kp.y, &kp.x, &kp.y);   // Frame.cc:879-883: k1 == 0 -> mvKeysUn = mvKeys
+            kps_un[i] = kp;
+            int c;
+            if (pos_in_grid(kp, g, c)) { cell[k] = c; atomicAdd(&cnt[c], 1); }
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the counts: three consecutive cells per thread, a DPP scan per wave, the sixteen wave totals through LDS
+        constexpr int per = GRID_CELLS / UG_T;
+        static_assert(per * UG_T == GRID_CELLS, "cells per thread");
+        int c3[per], sum = 0;
+#pragma unroll
+        for (int k = 0; k < per; k++) { c3[k] = cnt[tid * per + k]; sum += c3[k]; }
+        int incl = sum;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w = 0; w < wv; w++) run += wtot[w];
+#pragma unroll
+        for (int k = 0; k < per; k++) { cnt[tid * per + k] = run; grid_start[tid * per + k] = run; run += c3[k]; }
+        if (tid == UG_T - 1) grid_start[GRID_CELLS] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KP; k++)
+        if (cell[k] >= 0) lst[cnt[cell[k]] + atomicAdd(&fill[cell[k]], 1)] = (uint16_t)(tid + k * UG_T);
+    __syncthreads();
+    // insertion order inside each cell = ascending index (cells hold a handful of entries), then the list goes out coalesced
+    for (int c = tid; c < GRID_CELLS; c += UG_T) {
+        const int s = cnt[c], m = fill[c];
+        for (int a = 1; a < m; a++) {
+            const uint16_t v = lst[s + a];
+            int p = a - 1;
+            while (p >= 0 && lst[s + p] > v) { lst[s + p + 1] = lst[s + p]; p--; }
+            lst[s + p + 1] = v;
+        }
+    }
+    __syncthreads();
+    const int tot = cnt[GRID_CELLS - 1] + fill[GRID_CELLS - 1];
+    for (int i = tid; i < tot; i += UG_T) grid_idx[i] = lst[i];
+}
+
 // ============================================================================================================
 // M3-M5  windowed projection search
 // ============================================================================================================
@@ -1684,6 +1759,22 @@ extern "C" int orbm_grid_build_rig(const orb_keypoint* d_kps, const int32_t* d_n
     if (!d_kps || !d_nkp || !d_nleft || !gp || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 1 || count_stride < 1) return ORB_E_INVALID;
     hipLaunchKernelGGL(k_grid_build, dim3(batch), dim3(256), (4 * GRID_CELLS + 256) * 4, (hipStream_t)stream, d_kps, d_nkp, count_stride, cap_k,
                        *gp, d_grid_start, d_grid_idx, d_nleft, 2 * GRID_CELLS);
+    return launch_status();
+}
+
+extern "C" int orbm_undistort_and_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch, const orbf_camera* cam,
+                                             const orbm_grid_params* gp, orb_keypoint* d_kps_un, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream) {
+    if (!d_kps || !d_nkp || !cam || !gp || !d_kps_un || !d_grid_start || !d_grid_idx || cap_k < 1 || batch < 0 || count_stride < 1) return ORB_E_INVALID;
+    if (batch == 0) return ORB_OK;
+    if (cap_k > 4 * UG_T) {   // beyond the fused kernel's four key points per thread: the two separate steps
+        const int rc = orbf_undistort_keypoints(d_kps, d_nkp, count_stride, cap_k, batch, cam, d_kps_un, stream);
+        return rc != ORB_OK ? rc : orbm_grid_build(d_kps_un, d_nkp, count_stride, cap_k, batch, gp, d_grid_start, d_grid_idx, stream);
+    }
+    const bool timed = mt_ready();
+    if (timed) (void)hipEventRecord(g_mt.ev[0], (hipStream_t)stream);
+    hipLaunchKernelGGL(k_undistort_grid, dim3(batch), dim3(UG_T), (2 * GRID_CELLS + 16) * 4 + (((size_t)cap_k + 1) & ~(size_t)1) * 2, (hipStream_t)stream, d_kps, d_nkp,
+                       count_stride, cap_k, *cam, *gp, d_kps_un, d_grid_start, d_grid_idx);
+    if (timed) { (void)hipEventRecord(g_mt.ev[1], (hipStream_t)stream); g_mt.have_grid = true; }
     return launch_status();
 }
 

@@ -28,6 +28,7 @@ def bind(lib):
     protos = {
         "orbf_undistort_keypoints": (i32, [vp, vp, i32, i32, i32, C.POINTER(Camera), vp, vp]),
         "orbf_image_bounds": (i32, [C.POINTER(Camera), i32, i32, C.POINTER(f32 * 4), C.POINTER(GridParams)]),
+        "orbm_undistort_and_grid_build": (i32, [vp, vp, i32, i32, i32, C.POINTER(Camera), C.POINTER(GridParams), vp, vp, vp, vp]),
         "orbf_stereo_from_rgbd": (i32, [vp, vp, vp, i32, i32, i32, vp, sz, i32, i32, i32, f32, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
@@ -56,6 +57,18 @@ class FrameOps:
         out = _like(kps, tuple(kps.shape), np.float32) if out is None else out
         self._check(self._L.orbf_undistort_keypoints(_ptr(kps), _ptr(counts), count_stride, cap, B, C.byref(self.camera), _ptr(out), _stream(kps)))
         return out
+
+    def UndistortAndGrid(self, kps, counts, count_stride=1, out=None):
+        """UndistortKeyPoints + AssignFeaturesToGrid in one launch (orbm_undistort_and_grid_build).
+        -> (mvKeysUn [B, cap, 7] f32, grid_start [B, 64*48+1] i32, grid_idx [B, cap] i32), the same arrays as the two separate calls"""
+        from .matcher import GRID_COLS, GRID_ROWS
+        B, cap = kps.shape[0], kps.shape[1]
+        un, gs, gi = out if out is not None else (_like(kps, tuple(kps.shape), np.float32), _like(kps, (B, GRID_COLS * GRID_ROWS + 1), np.int32),
+                                                  _like(kps, (B, cap), np.int32))
+        gp = GridParams(*self.grid)
+        self._check(self._L.orbm_undistort_and_grid_build(_ptr(kps), _ptr(counts), count_stride, cap, B, C.byref(self.camera), C.byref(gp), _ptr(un),
+                                                          _ptr(gs), _ptr(gi), _stream(kps)))
+        return un, gs, gi
 
     def ComputeStereoFromRGBD(self, kps, kps_un, counts, depth, mbf, count_stride=1):
         """depth [B, H, W] float32 -> (mvuRight, mvDepth) [B, cap] float32"""

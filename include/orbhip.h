@@ -159,6 +159,11 @@ typedef struct orbf_camera {
  * dist[0] == 0 copies (:879-883).  In place (d_kps_un == d_kps) is allowed. */
 int orbf_undistort_keypoints(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch,
                              const orbf_camera* cam, orb_keypoint* d_kps_un, void* stream);
+/* UndistortKeyPoints followed by AssignFeaturesToGrid (the Frame constructor's order, Frame.cc:137-167) as ONE launch, one workgroup per frame:
+ * d_kps_un and the CSR grid exactly as orbf_undistort_keypoints + orbm_grid_build write them (single camera; gp from orbf_image_bounds).
+ * d_kps_un == d_kps is allowed.  With orbm_enable_timing on, orbm_last_timing's ms[0] is this launch. */
+int orbm_undistort_and_grid_build(const orb_keypoint* d_kps, const int32_t* d_nkp, int count_stride, int cap_k, int batch, const orbf_camera* cam,
+                                  const orbm_grid_params* gp, orb_keypoint* d_kps_un, int32_t* d_grid_start, int32_t* d_grid_idx, void* stream);
 /* Frame::ComputeImageBounds (Frame.cc:926-953) -> bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY} (host), and, if gp != NULL, the grid scalars
  * mfGridElementWidthInv / HeightInv of Frame.cc:394-397 ready for orbm_grid_build.  Synchronous (runs once per calibration). */
 int orbf_image_bounds(const orbf_camera* cam, int width, int height, float bounds[4], orbm_grid_params* gp);

@@ -92,10 +92,21 @@ def check_frame_ops(lib, backend, cam, W, H):
     depth[rng.random((B, H, W)) < 0.2] = 0.0
     ur, dz = F.ComputeStereoFromRGBD(dev(kf), dev(un), dev(counts), dev(depth), 40.0)
     ur, dz = to_host(ur), to_host(dz)
+    # the fused launch (orbm_undistort_and_grid_build) writes the same records and the same CSR grid as the two separate steps
+    un2, gs2, gi2 = [to_host(x) for x in F.UndistortAndGrid(dev(kf), dev(counts))]
+    m = orbhip.ORBmatcher(lib=lib)
+    gs1, gi1 = [to_host(x) for x in m.grid_build(dev(un), dev(counts), F.grid)]
     for b in range(B):
         n = counts[b]
         ou = O.undistort_keypoints(kps[b, :n], camera.as_array())
         assert np.array_equal(un[b, :n].view(np.uint8), ou.view(np.float32).reshape(n, 7).view(np.uint8)), b
+        assert np.array_equal(un2[b, :n].view(np.uint8), un[b, :n].view(np.uint8)), b
+        ogs, ogi = O.grid_build(ou, F.grid)
+        tot = int(ogs[-1])
+        assert np.array_equal(gs2[b], ogs) and np.array_equal(gi2[b, :tot], ogi[:tot]), ("fused grid vs oracle", b)
+        assert np.array_equal(gs1[b], ogs) and np.array_equal(gi1[b, :tot], ogi[:tot]), ("separate grid vs oracle", b)
+        if n:
+            assert 0 < tot <= n
         our, odz = O.stereo_from_rgbd(kps[b, :n], ou, depth[b], 40.0)
         assert np.array_equal(ur[b, :n], our) and np.array_equal(dz[b, :n], odz)
         assert (ur[b, n:] == -1).all() and (dz[b, n:] == -1).all()
