@@ -1055,27 +1055,28 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
     if (nMinCellX >= ORBM_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBM_GRID_ROWS || nMaxCellY < 0 || nMaxCellY < nMinCellY) return;
     const int minLevel = Q.min_level, maxLevel = Q.max_level;
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);   // Frame.cc:810
+    // the level filter of Frame.cc:826-832 (`octave < minLevel` -> skip; `maxLevel >= 0 && octave > maxLevel` -> skip, both only if bCheckLevels) as one
+    // unsigned range test on the 16-bit octave: lo <= oct <= hi with lo / hi open where the reference does not test
+    const int lo = bCheckLevels ? minLevel : -32768, hi = (bCheckLevels && maxLevel >= 0) ? maxLevel : 32767;
+    const uint32_t span = (uint32_t)(hi - lo);               // hi < lo (an empty level window) wraps to a huge span only if lo > hi: handled below
+    const bool noLevel = hi < lo;
     const bool stereoGate = (Q.flags & ORBM_Q_STEREO) && F.ur;
     // ONE loop over the window's entries: a grid column's cells [nMinCellY, nMaxCellY] are one contiguous CSR range (iy inner, insertion order
-    // inside a cell), the columns follow each other (ix outer).  A lane's turn either takes an entry or moves to its next column, so a wave
-    // runs max over its lanes of (entries + columns) turns instead of a sum over columns of per-column maxima.
-    int ix = nMinCellX;
-    int p = F.gs[ix * ORBM_GRID_ROWS + nMinCellY], pe = F.gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
+    // inside a cell), the columns follow each other (ix outer).  A lane's turn moves to its next column when the current one is used up AND takes an
+    // entry if there is one, so a wave runs max over its lanes of (entries + empty columns) turns instead of a sum over columns of per-column maxima.
+    int ix = nMinCellX - 1, p = 0, pe = 0;
     for (;;) {
         if (p >= pe) {
             if (++ix > nMaxCellX) break;
             p = F.gs[ix * ORBM_GRID_ROWS + nMinCellY]; pe = F.gs[ix * ORBM_GRID_ROWS + nMaxCellY + 1];
-            continue;
         }
+        if (p >= pe) continue;
         const uint32_t e = F.ge[p];
         const float x = F.gx[p], y = F.gy[p];
         const int pp = p++;
         const int idx = (int)(e & 0xFFFFu), oct = (int)(int16_t)(e >> 16);
         if (idx >= F.n) continue;
-        if (bCheckLevels) {
-            if (oct < minLevel) continue;
-            if (maxLevel >= 0 && oct > maxLevel) continue;
-        }
+        if (noLevel || (uint32_t)(oct - lo) > span) continue;
         const float distx = x - Q.u, disty = y - Q.v;
         if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
         // returned by GetFeaturesInArea; now the candidate filters that do not depend on matches made during the call:
@@ -1113,6 +1114,15 @@ struct SbpfLdsList {
     __device__ __forceinline__ uint32_t get(const int j) const { return base[j * stride]; }
     __device__ __forceinline__ void set(const int j, const uint32_t v) { base[j * stride] = v; }
 };
+static __device__ __forceinline__ uint32_t sbpf_umed3(const uint32_t a, const uint32_t b, const uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return max(min(a, b), min(max(a, b), c));
+#endif
+}
 // phase (1) for one query: walk, keep the SBPF_SD smallest keys sorted, spill the rest to the query's workspace row.  -> count | obs << 30
 template <class L>
 static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const orbm_query& Q, L& lst) {
@@ -1122,17 +1132,12 @@ static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const Sbp
     sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
         const uint32_t ne = SBPF_KEY(dist, p, oct);
         if (SBPF_EXP & 4) { lst.set(0, ne); count++; return; }
-        int pos = 0;
+        // the list is ascending with 0xFFFFFFFF in its empty slots (every key is smaller): inserting one key is e'[j] = median(e[j - 1], key, e[j]) —
+        // min(max(e[j - 1], key), e[j]) — for every slot at once, one v_med3_u32 each; what leaves at the end is the larger of the last slot and the key
+        if (count >= SBPF_SD && count - SBPF_SD < SBPF_ROW) row[count - SBPF_SD] = max(lst.get(SBPF_SD - 1), ne);   // (unordered: the row is a set)
 #pragma unroll
-        for (int j = 0; j < SBPF_SD; j++) pos += (j < count && lst.get(j) < ne) ? 1 : 0;
-        if (count >= SBPF_SD) {                          // the list is full: its largest key, or the new one, leaves for the row (unordered)
-            const uint32_t out = pos >= SBPF_SD ? ne : lst.get(SBPF_SD - 1);
-            if (count - SBPF_SD < SBPF_ROW) row[count - SBPF_SD] = out;
-        }
-#pragma unroll
-        for (int j = SBPF_SD - 1; j > 0; j--) { if (j > pos) lst.set(j, lst.get(j - 1)); }
-#pragma unroll
-        for (int j = 0; j < SBPF_SD; j++) { if (j == pos) lst.set(j, ne); }
+        for (int j = SBPF_SD - 1; j > 0; j--) lst.set(j, sbpf_umed3(lst.get(j - 1), ne, lst.get(j)));
+        lst.set(0, min(lst.get(0), ne));
         count++;
     });
     return count | ((Q.flags & ORBM_Q_HAS_OBS) ? 1 << 30 : 0);
@@ -1250,7 +1255,11 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
     SbpfRegList r0;
     SbpfLdsList r1{tl + tid, tq};
 #pragma unroll
-    for (int j = 0; j < SBPF_SD; j++) r0.e[j] = 0u;
+    for (int j = 0; j < SBPF_SD; j++) r0.e[j] = 0xFFFFFFFFu;
+    if (TAIL && tid < tq) {
+#pragma unroll
+        for (int j = 0; j < SBPF_SD; j++) r1.set(j, 0xFFFFFFFFu);
+    }
     int cntw0 = 0, cntw1 = 0, d0 = -1, d1 = -1;          // candidate count | obs << 30, decision (CSR position or -1), per slot
     bool bad = false;
     const int q1 = tid + SBPF_T;
