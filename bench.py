@@ -922,6 +922,16 @@ def main():
                 sq_info = {k: pm["kernels"][names[dom]][k] for k in ("valu_insts_per_wave", "waves_per_simd", "simd_cycles_per_valu_inst", "lds_conflict_frac")
                            if k in pm["kernels"][names[dom]]}
                 traffic_note = "profiles/%s_pmc.csv: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes" % pm.get("tag")
+                # the kernel's issue rate against the MEASURED VALU roof (tools/ubench/valu_rate.hip -> profiles/valu_rates.csv: 2.15 SIMD cycles per wave64
+                # instruction for add / sub / logic / mov / right shifts / f32 add-mul-fma, 4.2 for every other 32-bit, packed, dot, DPP and 64-bit form,
+                # 8.1 for rcp / sqrt / sin), priced on the kernel's static instruction mix (tools/valu_mix.py -> profiles/valu_mix.json)
+                vm = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+                if vm.get("source_sha") == source_sha() and "simd_cycles_per_valu_inst" in sq_info:
+                    inst = {"k_fast": "k_fast<0>", "k_sbp_frame": "k_sbp_frame<1>" if cap > 1024 else "k_sbp_frame<0>"}.get(names[dom], names[dom])
+                    floor = vm["kernels"][inst]["floor_cycles_per_inst"]
+                    sq_info["valu_floor_cycles_per_inst_static_mix"] = floor
+                    sq_info["valu_issue_frac_of_measured_peak"] = round(floor / sq_info["simd_cycles_per_valu_inst"], 4)
+                    sq_info["valu_mix"] = {k: vm["kernels"][inst][k] for k in ("valu", "full_rate", "half_rate", "quarter_rate")}
         except Exception:   # noqa: BLE001
             pass
         is_headline = (W, H, NFEAT) == (752, 480, 1000)
@@ -947,8 +957,9 @@ def main():
                        "backend": (dist.get_backend() if world > 1 else None)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
-                         # SQ counters of the same profile: the kernel's occupancy and issue rate (4 SIMD cycles per wave-level VALU instruction = the
-                         # SIMDs issue VALU back to back: the kernel is instruction-issue bound and its HBM fraction follows from its instruction count)
+                         # SQ counters of the same profile: the kernel's occupancy and the SIMD cycles one wave-level VALU instruction costs it, next to the
+                         # floor its instruction mix allows at the MEASURED issue rates (valu_issue_frac_of_measured_peak = floor / measured: 1 = the SIMDs
+                         # issue back to back, the kernel's HBM fraction then follows from its instruction count alone)
                          "occupancy_and_issue": sq_info or None,
                          "algorithmic_bytes_per_launch": pk[dom] * B, "kernel_ms": round(kern[dom], 4),
                          # a batch runs k_fast as two launches — instance <0> detects at iniThFAST, instance <1> again the cells that came back empty

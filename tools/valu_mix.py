@@ -3,7 +3,7 @@
 which share of a kernel's vector instructions are full-rate forms (2.15 SIMD cycles per wave64 instruction: add / sub / and / or / xor / not / mov /
 right shifts / f32 add-mul-fma), half-rate (4.2: everything else 32-bit, packed 16-bit, dot, DPP/SDWA, 64-bit) or quarter-rate (8.1: rcp, sqrt,
 sin, ...), and the issue-cycle floor per instruction that mix implies.  Static counts (every instruction once, loops not weighted): an indication
-of the mix, not a profile.   usage: tools/valu_mix.py <file.s from hipcc -S --cuda-device-only> [kernel substring ...]"""
+of the mix, not a profile.   usage: tools/valu_mix.py <file.s from hipcc -S --cuda-device-only> ... [kernel substring ...] [--json profiles/valu_mix.json]"""
 import collections
 import re
 import sys
@@ -15,8 +15,38 @@ RATE = {"full": 2.15, "half": 4.2, "quarter": 8.1}
 
 
 def main():
-    path = sys.argv[1]
-    want = sys.argv[2:]
+    args = sys.argv[1:]
+    jout = None
+    if "--json" in args:
+        i = args.index("--json")
+        jout = args[i + 1]
+        del args[i:i + 2]
+    paths = [a for a in args if a.endswith(".s")]
+    want = [a for a in args if not a.endswith(".s")]
+    result = {}
+    for path in paths:
+        one(path, want, result)
+    if jout:
+        import json
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        json.dump({"source_sha": bench.source_sha(), "rates_simd_cycles_per_wave64_instruction": RATE,
+                   "note": "static instruction mix of the compiled kernels (tools/valu_mix.py on hipcc -S output) priced with the measured issue rates of "
+                           "profiles/valu_rates.csv: floor = the SIMD cycles per VALU instruction the mix allows when nothing but issue limits the kernel",
+                   "kernels": result}, open(jout, "w"), indent=1)
+
+
+def demangle(k):
+    m = re.match(r"^_ZL?(\d+)(k_\w+)", k)
+    if not m:
+        return k
+    name = m.group(2)[:int(m.group(1))]
+    t = re.search(r"ILi(\d+)E", k) or re.search(r"ILb(\d)E", k)
+    return name + ("<%s>" % t.group(1) if t else "")
+
+
+def one(path, want, result):
     cur, mix = None, collections.OrderedDict()
     for line in open(path):
         m = re.match(r"^(_Z\w+):", line)
@@ -45,6 +75,7 @@ def main():
             variant = o.endswith("_dpp") or o.endswith("_sdwa")
             cls["quarter" if b in QUARTER else ("full" if b in FULL and not variant else "half")] += n
         floor = sum(RATE[x] * n for x, n in cls.items()) / tot
+        result[demangle(k)] = {"valu": tot, "full_rate": cls["full"], "half_rate": cls["half"], "quarter_rate": cls["quarter"], "floor_cycles_per_inst": round(floor, 3)}
         print("%s: %d VALU (full-rate %.1f %%, half %.1f %%, quarter %.1f %%) -> %.2f SIMD cycles per instruction at the measured rates; %d LDS, %d SALU, %d VMEM"
               % (k, tot, 100.0 * cls["full"] / tot, 100.0 * cls["half"] / tot, 100.0 * cls["quarter"] / tot, floor,
                  sum(n for o, n in c.items() if o.startswith("ds_")), sum(n for o, n in c.items() if o.startswith("s_")),
