@@ -1819,11 +1819,15 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
     if (fused) {
-        static bool attr_done = false;
-        if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (idempotent; a failure surfaces at the launch)
+        // > 64 KB of dynamic LDS needs the opt-in, once per device of the process (idempotent: a race between two host threads sets it twice; a
+        // failure surfaces at the launch)
+        static bool attr_done[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
             (void)hipFuncSetAttribute((const void*)k_sbp_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             (void)hipFuncSetAttribute((const void*)k_sbp_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_done = true;
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
         if (tailq) hipLaunchKernelGGL(k_sbp_frame<true>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);
         else hipLaunchKernelGGL(k_sbp_frame<false>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);

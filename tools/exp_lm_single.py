@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Runs ON THE GPU BOX: one C5-size window through LbaWindows.optimize(5), timed; with ORBHIP_LM_TRACE=1 only two calls (for a rocprofv3 kernel trace)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orbhip.lba import LbaWindows, synth_window  # noqa: E402
+
+dev = torch.device("cuda", 0)
+w, cams = synth_window(100, 100, 20, 20000, 8, "mono")
+L1 = LbaWindows([w], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+q0, y0 = L1.d["poses"].clone(), L1.d["points"].clone()
+L1.optimize(5)
+torch.cuda.synchronize()
+n = 2 if os.environ.get("ORBHIP_LM_TRACE") else 10
+t = time.perf_counter()
+for _ in range(n):
+    L1.d["poses"].copy_(q0); L1.d["points"].copy_(y0)
+    st = L1.optimize(5)
+torch.cuda.synchronize()
+print("ms per optimize(5):", round((time.perf_counter() - t) / n * 1e3, 3), "iterations", st[0, 0], "trials", st[0, 3])
