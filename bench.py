@@ -390,7 +390,7 @@ def main():
                          "handles (orbd_allgather_frames_peer: one pull per peer and slab, a stream per peer), or both; the peer form has never run "
                          "on more than one GPU (DESIGN section 5), so the driver's default stays RCCL and a failing peer leg is reported, not fatal")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
-    ap.add_argument("--lba-windows", type=int, default=16, help="LBA windows per GPU per step")
+    ap.add_argument("--lba-windows", type=int, default=256, help="LBA windows per GPU per step (linearisations/s against windows per launch on MI355X: 4 -> 67 k, 16 -> 78 k, 64 -> 83 k, 256 -> 91 k; tools/exp_lba_windows.py)")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
     ap.add_argument("--size", default="752x480", help="frame size WxH (the headline is 752x480; 1280x720 is BASELINE configs[3]'s frame shape)")
     ap.add_argument("--nfeatures", type=int, default=1000, help="ORBextractor nFeatures (1500 with --size 1280x720)")
