@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for so in exp_so/*.so; do
-  ORBHIP_LIB=$R/$so python bench.py --no-cpu-baseline --headline-only --no-parity-check --repeats 2 --steps 10 --warmup 2 2>/dev/null | python -c "
+  ORBHIP_LIB=$R/$so python bench.py --no-cpu-baseline --headline-only --no-parity-check --repeats 3 --steps 20 --warmup 3 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms']
 print('$so', 'e+m', d['value'], 'extract', d['metric_components']['orb_extract_frames_per_s'], {a: round(b,3) for a,b in k.items()}, 'matches', d['config']['mean_matches'], 'kp', d['config']['mean_keypoints'])"
