@@ -127,6 +127,45 @@ def test_hip_frame_ops_match_oracle(hip_lib, cam, size):
     check_frame_ops(hip_lib, "hip", cam, *size)
 
 
+def check_undistort_and_grid_edges(lib, backend):
+    """orbm_undistort_and_grid_build on the shapes its kernel treats specially: in place, an empty frame, key points outside the grid (dropped by PosInGrid),
+    a capacity beyond four key points per thread (the call falls back to the two separate launches), cap not a multiple of anything."""
+    rng = np.random.default_rng(11)
+    dev = to_dev(backend)
+    camera = Camera.make(**EUROC)
+    F = FrameOps(camera, 752, 480, lib=lib)
+    for cap, counts in ((1063, [1063, 0, 1, 500]), (4100, [4100, 37]), (64, [64, 64])):
+        B = len(counts)
+        counts = np.array(counts, np.int32)
+        kps = np.zeros((B, cap), KP_DTYPE)
+        for b in range(B):
+            k = keypoints(rng, counts[b], 752, 480)
+            if counts[b] > 10:                            # a few far outside the image: no grid cell
+                k["x"][:3] = [-500.0, 5000.0, 100.0]; k["y"][:3] = [100.0, 100.0, -900.0]
+            kps[b, :counts[b]] = k
+        kf = kps.view(np.float32).reshape(B, cap, 7).copy()
+        buf = dev(kf.copy())
+        un, gs, gi = F.UndistortAndGrid(buf, dev(counts), out=(buf, dev(np.zeros((B, 64 * 48 + 1), np.int32)), dev(np.zeros((B, cap), np.int32))))   # in place
+        un, gs, gi = to_host(un), to_host(gs), to_host(gi)
+        for b in range(B):
+            n = counts[b]
+            ou = O.undistort_keypoints(kps[b, :n], camera.as_array())
+            assert np.array_equal(un[b, :n].view(np.uint8), ou.view(np.float32).reshape(n, 7).view(np.uint8)), (cap, b)
+            ogs, ogi = O.grid_build(ou, F.grid)
+            tot = int(ogs[-1])
+            assert np.array_equal(gs[b], ogs) and np.array_equal(gi[b, :tot], ogi[:tot]), (cap, b)
+            assert tot <= n and (n <= 10 or tot <= n - 3)
+
+
+def test_emu_undistort_and_grid_edges(emu_lib):
+    check_undistort_and_grid_edges(emu_lib, "emu")
+
+
+@pytest.mark.gpu
+def test_hip_undistort_and_grid_edges(hip_lib):
+    check_undistort_and_grid_edges(hip_lib, "hip")
+
+
 # ---- Frame::ComputeStereoFishEyeMatches (two KannalaBrandt8 cameras) ------------------------------------------------------------------
 from orbhip.frame import ComputeStereoFishEyeMatches, FisheyeRig  # noqa: E402
 from orbhip.lba import _kb8_project, _rodrigues  # noqa: E402

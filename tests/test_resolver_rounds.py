@@ -96,7 +96,11 @@ CASES = [
     ("par_chain_8", MODE_BEST_ONLY, 255, 0.9, True, 40, 8, 640, 1.0, False),              # 16 queries fight over 8 key points per cluster
     ("par_shared_8", MODE_BEST_ONLY, 255, 0.9, True, 40, 8, 640, 0.4, True),              # ... most of them without an observed point, with ties
     ("par_local_map_7", MODE_LOCAL_MAP, 255, 0.8, True, 60, 7, 900, 0.7, True),
-    ("par_over_1024_queries", MODE_LOCAL_MAP, 255, 0.95, True, 150, 8, 2300, 0.8, False),
+    ("par_over_1024_queries", MODE_LOCAL_MAP, 255, 0.95, True, 150, 8, 2300, 0.8, False),   # cap_q > 2 048: beyond k_sbp_frame, the rounds-1-3 pair (flags stay 0: unused)
+    # 1 024 < cap_q <= 2 048: the queries beyond the workgroup's threads keep their lists in LDS (k_sbp_frame<TAIL>)
+    ("par_tail_1500", MODE_BEST_ONLY, 255, 0.9, True, 120, 8, 1500, 0.8, True),
+    ("tail_deep_1300", MODE_LOCAL_MAP, 255, 0.9, True, 30, 40, 1300, 0.9, False),        # ... and read on in their workspace rows
+    ("tail_2040", MODE_BEST_ONLY, 118, 0.9, True, 60, 20, 2040, 0.7, False),
 ]
 
 
