@@ -202,6 +202,9 @@ static inline void resize2_footprint(int t0, int tlen, int dlen, int slen, doubl
     if (alignX) { lo = a & ~3; ext = ((e - lo) >> 2) + 1; }   // dwords
     else { lo = a; ext = e - a + 1; }                          // rows
 }
+#ifndef R2_PAIR
+#define R2_PAIR 2         // vertically adjacent destination tiles per workgroup (2: the second tile's staging loads are in flight during the first tile's H pass)
+#endif
 static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     typedef unsigned short u16x2 __attribute__((vector_size(4)));
@@ -211,34 +214,43 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     uint32_t* hbuf = (uint32_t*)(rowt + R2_TH);   // [R2_ROWS][R2_HP]  16 * ((p0*a0 + p1*a1) >> 4)
     uint8_t* tile = (uint8_t*)(hbuf + R2_ROWS * R2_HP);   // [R2_ROWS][RS_PITCH]
     const int tid = threadIdx.x;
+    constexpr int NP = R2_PAIR;
+    const int unitsY = (P.tilesY + NP - 1) / NP;
 #if R2_XCD
     int frameZ, tileI;
-    if (!xcd_frame_unit(P.tilesX * P.tilesY, P.batch, &frameZ, &tileI)) return;
-    const int tyI = tileI / P.tilesX, txI = tileI - tyI * P.tilesX;
-    const int bx0 = txI * RS_TW, by0 = tyI * R2_TH;
+    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI)) return;
+    const int uyI = tileI / P.tilesX, txI = tileI - uyI * P.tilesX;
 #else
     const int frameZ = blockIdx.z;
-    const int txI = blockIdx.x, tyI = blockIdx.y;
-    const int bx0 = blockIdx.x * RS_TW, by0 = blockIdx.y * R2_TH;
+    const int txI = blockIdx.x, uyI = blockIdx.y;
 #endif
+    const int bx0 = txI * RS_TW;
     const uint8_t* S = P.src + (size_t)frameZ * P.sFrame;
     const int* xs = P.coef; const int* xw = xs + P.dw; const int* ys = xw + P.dw; const int* yw = ys + P.dh;
     // Source footprint of the tile (resize2_footprint, tabulated per level): two scalar loads from a table the scalar cache holds, instead of
     // float arithmetic on workgroup-uniform values in every lane; the staging loads still do not wait for the coefficient-table (vector) loads.
-    const int2 fx = ((const int2*)P.tileTab)[txI], fy = ((const int2*)P.tileTab)[P.tilesX + tyI];
-    const int xal = fx.x, ndw = fx.y, ylo = fy.x, nrows = fy.y;           // <= RS_PITCH/4, <= R2_ROWS for scale <= 1.3
-    {   // stage the source footprint: lane = dword column, 8 rows per pass (coalesced aligned row segments)
-        const int c = tid & 31, r0 = tid >> 5;
-        uint32_t v[(R2_ROWS + 7) / 8];
-        const bool on = c < ndw;
-        const uint8_t* g = S + (size_t)(ylo + r0) * P.sStride + xal + 4 * c;
+    const int2 fx = ((const int2*)P.tileTab)[txI];
+    const int xal = fx.x, ndw = fx.y;                      // <= RS_PITCH/4 for scale <= 1.3
+    constexpr int NV = (R2_ROWS + 7) / 8;
+    const int sc = tid & 31, sr0 = tid >> 5;              // staging: lane = dword column, 8 rows per pass (coalesced aligned row segments)
+    const bool son = sc < ndw;
+    // the footprint rows of destination tile row tyI, and its staging loads into registers
+    auto issue = [&](const int tyI, int& ylo, int& nrows, uint32_t* v) {
+        const int2 fy = ((const int2*)P.tileTab)[P.tilesX + tyI];
+        ylo = fy.x; nrows = fy.y;                          // <= R2_ROWS for scale <= 1.3
+        const uint8_t* g = S + (size_t)(ylo + sr0) * P.sStride + xal + 4 * sc;
 #pragma unroll
-        for (int k = 0; k < (R2_ROWS + 7) / 8; k++)
-            if (on && r0 + 8 * k < nrows) v[k] = *(const uint32_t*)(g + (size_t)(8 * k) * P.sStride);
-        if (tid < RS_TW) {
-            const int x = min(bx0 + tid, P.dw - 1);
-            cxs[tid] = xs[x]; cxw[tid] = xw[x];
-        } else if (tid < RS_TW + R2_TH) {
+        for (int k = 0; k < NV; k++)
+            if (son && sr0 + 8 * k < nrows) v[k] = *(const uint32_t*)(g + (size_t)(8 * k) * P.sStride);
+    };
+    auto commit = [&](const int nrows, const uint32_t* v) {
+        uint8_t* t = tile + sr0 * RS_PITCH + 4 * sc;
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (son && sr0 + 8 * k < nrows) *(uint32_t*)(t + 8 * k * RS_PITCH) = v[k];
+    };
+    auto row_table = [&](const int by0, const int ylo) {
+        if (tid >= RS_TW && tid < RS_TW + R2_TH) {
             const int t = tid - RS_TW, y = min(by0 + t, P.dh - 1);
             int sy0 = ys[y];
             const uint32_t bw = (uint32_t)yw[y];
@@ -247,24 +259,38 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
             sy1 = sy1 < 0 ? 0 : (sy1 < P.sh ? sy1 : P.sh - 1);
             rowt[t] = make_uint4((uint32_t)((sy0 - ylo) * R2_HP * 4), (uint32_t)((sy1 - ylo) * R2_HP * 4), (bw & 0xFFFFu) << 12, (bw >> 16) << 12);
         }
-        uint8_t* t = tile + r0 * RS_PITCH + 4 * c;
-#pragma unroll
-        for (int k = 0; k < (R2_ROWS + 7) / 8; k++)
-            if (on && r0 + 8 * k < nrows) *(uint32_t*)(t + 8 * k * RS_PITCH) = v[k];
+    };
+    int ylo, nrows;
+    uint32_t v[NV];
+    issue(uyI * NP, ylo, nrows, v);
+    if (tid < RS_TW) {
+        const int x = min(bx0 + tid, P.dw - 1);
+        cxs[tid] = xs[x]; cxw[tid] = xw[x];
     }
+    row_table(uyI * NP * R2_TH, ylo);
+    commit(nrows, v);
     __syncthreads();
-    {   // H pass: thread = 4 adjacent destination columns of one source row, 16 rows per pass
-        const int x0 = (tid & 15) * 4;
-        const int c0 = cxs[x0], o0 = c0 - xal;
-        const uint32_t sh = (uint32_t)(o0 & 3);
-        uint32_t sel[4]; u16x2 aw[4];
+    // H pass set-up (the same for every tile of the column): thread = 4 adjacent destination columns of one source row, 16 rows per pass
+    const int x0 = (tid & 15) * 4;
+    const int c0 = cxs[x0], o0 = c0 - xal;
+    const uint32_t sh = (uint32_t)(o0 & 3);
+    uint32_t sel[4]; u16x2 aw[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t off = (uint32_t)(cxs[x0 + j] - c0);   // 0..4 for scale <= 1.3: both bytes of every pair lie inside the 8-byte window
-            sel[j] = off | ((off + 1u) << 16) | 0x0c000c00u;
-            aw[j] = __builtin_bit_cast(u16x2, (uint32_t)cxw[x0 + j]);   // weights are in [0, 2048]
-        }
-        const uint32_t* rowp = (const uint32_t*)(tile + (o0 & ~3)) ;
+    for (int j = 0; j < 4; j++) {
+        const uint32_t off = (uint32_t)(cxs[x0 + j] - c0);   // 0..4 for scale <= 1.3: both bytes of every pair lie inside the 8-byte window
+        sel[j] = off | ((off + 1u) << 16) | 0x0c000c00u;
+        aw[j] = __builtin_bit_cast(u16x2, (uint32_t)cxw[x0 + j]);   // weights are in [0, 2048]
+    }
+    const uint32_t* rowp = (const uint32_t*)(tile + (o0 & ~3));
+    const int xg = tid & 15;
+    const int dx0 = bx0 + xg * 4;
+#pragma unroll
+    for (int half = 0; half < NP; half++) {
+        const int tyI = uyI * NP + half, by0 = tyI * R2_TH;
+        const bool more = half + 1 < NP && tyI + 1 < P.tilesY;
+        int ylo2 = 0, nrows2 = 0;
+        uint32_t v2[NV];
+        if (more) issue(tyI + 1, ylo2, nrows2, v2);       // in flight during this tile's H pass
         for (int r = tid >> 4; r < nrows; r += 16) {
             const uint32_t* d = (const uint32_t*)((const uint8_t*)rowp + r * RS_PITCH);
             const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
@@ -279,32 +305,36 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
             }
             *(uint4*)(hbuf + r * R2_HP + x0) = T;
         }
-    }
-    __syncthreads();
-    const int xg = tid & 15;
-    const int dx0 = bx0 + xg * 4;
-    if (dx0 >= P.dw) return;
-    uint8_t* D = P.dst + (size_t)frameZ * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
+        __syncthreads();
+        if (more) commit(nrows2, v2);                     // the staged tile is free: every thread is through its H pass
+        if (dx0 < P.dw) {
+            uint8_t* D = P.dst + (size_t)frameZ * P.dFrame + (size_t)(by0 + (tid >> 4)) * P.dStride + dx0;
 #pragma unroll
-    for (int k = 0; k < R2_TH / 16; k++) {
-        const int ty = (tid >> 4) + 16 * k;
-        if (by0 + ty >= P.dh) break;
-        const uint4 rt = rowt[ty];
-        // both factors are below 2^24 (weights << 12 <= 2^23, H-pass sums < 2^19); saying so on BOTH lets the compiler pick the full-rate
-        // v_mul_hi_u32_u24 — with only one side masked it emitted v_mul_hi_u32 plus the sixteen v_and of the masks
-        const uint32_t b0 = rt.z & 0xFFFFFFu, b1 = rt.w & 0xFFFFFFu;
-        const uint4 T0 = *(const uint4*)((const uint8_t*)hbuf + rt.x + xg * 16);
-        const uint4 T1 = *(const uint4*)((const uint8_t*)hbuf + rt.y + xg * 16);
+            for (int k = 0; k < R2_TH / 16; k++) {
+                const int ty = (tid >> 4) + 16 * k;
+                if (by0 + ty >= P.dh) break;
+                const uint4 rt = rowt[ty];
+                // both factors are below 2^24 (weights << 12 <= 2^23, H-pass sums < 2^19); saying so on BOTH lets the compiler pick the full-rate
+                // v_mul_hi_u32_u24 — with only one side masked it emitted v_mul_hi_u32 plus the sixteen v_and of the masks
+                const uint32_t b0 = rt.z & 0xFFFFFFu, b1 = rt.w & 0xFFFFFFu;
+                const uint4 T0 = *(const uint4*)((const uint8_t*)hbuf + rt.x + xg * 16);
+                const uint4 T1 = *(const uint4*)((const uint8_t*)hbuf + rt.y + xg * 16);
 #define R2_PIX(t0, t1) (((uint32_t)(((uint64_t)b0 * ((t0) & 0xFFFFFFu)) >> 32) + (uint32_t)(((uint64_t)b1 * ((t1) & 0xFFFFFFu)) >> 32) + 2u) >> 2)
-        // a pixel is <= 255 without a clamp: the two weights add up to 2048 (+-1), the H sums are <= 255 * 2048, so the two products sum to <= 1020
-        const uint32_t out = R2_PIX(T0.x, T1.x) | (R2_PIX(T0.y, T1.y) << 8) | (R2_PIX(T0.z, T1.z) << 16) | (R2_PIX(T0.w, T1.w) << 24);
+                // a pixel is <= 255 without a clamp: the two weights add up to 2048 (+-1), the H sums are <= 255 * 2048, so the two products sum to <= 1020
+                const uint32_t out = R2_PIX(T0.x, T1.x) | (R2_PIX(T0.y, T1.y) << 8) | (R2_PIX(T0.z, T1.z) << 16) | (R2_PIX(T0.w, T1.w) << 24);
 #undef R2_PIX
-        uint8_t* Dk = D + (size_t)(16 * k) * P.dStride;
-        if (dx0 + 3 < P.dw) {
-            *(uint32_t*)Dk = out;  // dStride and dx0 are multiples of 4
-        } else {
-            for (int j = 0; j < 4 && dx0 + j < P.dw; j++) Dk[j] = (uint8_t)(out >> (8 * j));
+                uint8_t* Dk = D + (size_t)(16 * k) * P.dStride;
+                if (dx0 + 3 < P.dw) {
+                    *(uint32_t*)Dk = out;  // dStride and dx0 are multiples of 4
+                } else {
+                    for (int j = 0; j < 4 && dx0 + j < P.dw; j++) Dk[j] = (uint8_t)(out >> (8 * j));
+                }
+            }
         }
+        if (!more) break;
+        __syncthreads();                                  // the H buffer and the row table are free; the next tile is staged
+        ylo = ylo2; nrows = nrows2;
+        row_table((tyI + 1) * R2_TH, ylo);                // (read behind the next H pass's barrier)
     }
 }
 
@@ -2590,9 +2620,9 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
 #if R2_XCD
-            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * R.tilesY * 8 * ((batch + 7) / 8)), dim3(256), R2_SMEM, st, R);
+            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8)), dim3(256), R2_SMEM, st, R);
 #else
-            dim3 grid(R.tilesX, R.tilesY, batch);
+            dim3 grid(R.tilesX, (R.tilesY + R2_PAIR - 1) / R2_PAIR, batch);
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
 #endif
         } else {
