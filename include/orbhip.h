@@ -243,7 +243,8 @@ int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, 
 
 /* Measurement facility (bench.py's roofline legs), the stage-2 counterpart of orbx_last_timing: while enabled, HIP events are recorded on the launch
  * stream around the kernels of orbm_grid_build and orbm_search_by_projection; orbm_last_timing synchronises on them and returns the device time of the
- * last call's kernels: ms[0] = grid build, ms[1] = candidate enumeration + Hamming, ms[2] = serial-order resolution.  The switch and the events are per calling thread: a thread times its own calls only, concurrent matcher
+ * last call's kernels: ms[0] = grid build (or the fused undistort + grid launch), ms[1] = the projection search of the frames in one workgroup each (k_sbp_frame; calls it does not
+ * cover — INIT mode, rigs, cap_q > 2048 —: candidate enumeration + Hamming), ms[2] = the gated launches behind it for flagged frames (those calls: the serial-order resolution).  The switch and the events are per calling thread: a thread times its own calls only, concurrent matcher
  * calls of other threads neither record into nor disturb them — so orbm_enable_timing, the timed calls and orbm_last_timing must come from the SAME thread
  * (another thread reads zeros), on one device (the events are re-made, and the last figures dropped, when the thread's current device changes). */
 int orbm_enable_timing(int on);
