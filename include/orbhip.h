@@ -232,7 +232,10 @@ typedef struct orbm_search_params {
  * Outputs: q_match[b][q] = matched keypoint index or -1; kp_match[b][idx] = index of the query whose map point
  * mvpMapPoints[idx] holds after the call, -1 = untouched by the call (mvpMapPoints[idx] keeps its value), -2 = claimed during the
  * call and then set to NULL by the orientation cull (ORBmatcher.cc:2499, :2637); nmatches[b] = the reference's return value.
- * d_work: scratch of orbm_search_workspace_bytes(batch, cap_q) bytes. */
+ * d_work: scratch of orbm_search_workspace_bytes(batch, cap_q) bytes.
+ * Form: the occupancy modes (LOCAL_MAP, BEST_ONLY) on single-camera frames with cap_q <= 2048 run as ONE workgroup per frame — window walk from an LDS copy of the
+ * frame, the serial accept loop as parallel fixed-point rounds: the same result by construction (DESIGN.md stage-2 notes); every other call as per-query candidate
+ * lists followed by a one-wave walk in query order. */
 size_t orbm_search_workspace_bytes(int batch, int cap_q);
 int orbm_search_by_projection(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0,
                               const int32_t* d_nkp, int count_stride, int cap_k,
