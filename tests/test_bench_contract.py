@@ -57,6 +57,40 @@ def test_headline_is_the_metric_it_names():
     assert "SearchByProjection" in c["sample"] and c["per_core"] > 0 and c["cores"] <= (c.get("cpu_quota") or 1e9) * 2 + 1
 
 
+def test_round4_fields_of_the_line():
+    """median-of-regions headline with its spread, the oracle check of the timed step, the 1280x720 leg and the batch sweep, the measured VALU roof"""
+    d, path = _latest()
+    assert d["value_min"] <= d["value"] <= d["value_max"] and d["repeats"] >= 5 and len(d["region_ms"]) == d["repeats"], path
+    assert abs(d["value"] - d["config"]["frames_per_gpu_per_step"] * d["n_gpus"] * d["steps"] / (sorted(d["region_ms"])[len(d["region_ms"]) // 2] * 1e-3)) / d["value"] < 1e-3
+    c = d["config"]
+    assert c["parity_checked_frames"] == c["frames_per_gpu_per_step"] * d["n_gpus"] and c["parity_mismatches"] == 0
+    assert "bit-exact" in c["workload"]                      # only claimed next to a non-zero parity_checked_frames
+    s = d["extra"]["size_1280x720"]
+    assert s["nfeatures"] == 1500 and s["extract_match_frames_per_s"] > 0 and s["extract_frames_per_s"] >= s["extract_match_frames_per_s"] * 0.98
+    assert s["whole_step_algorithmic_bytes_per_frame"] == 7084076 + 276000 and 0 < s["whole_step_frac"] < 1 and s["dominant_kernel"].startswith("k_")
+    assert s["parity"]["mismatches"] == 0 and s["parity"]["checked_frames"] >= 32
+    bs = d["extra"]["batch_sweep"]
+    assert {"64", "512", "4096"} <= set(bs) and all(v["frames_per_s"] > 0 for v in bs.values())
+    assert bs["4096"]["input_bytes"] > 256 * 1024 * 1024 and bs["4096"]["parity"]["mismatches"] == 0     # beyond the Infinity Cache
+    r = d["roofline"]
+    assert r["traffic"] is not None and r["traffic"] >= r["traffic_raw"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    oi = r["occupancy_and_issue"]
+    assert 0.3 < oi["valu_issue_frac_of_measured_peak"] <= 1.0 and 2.0 < oi["valu_floor_cycles_per_inst_static_mix"] < 4.3
+
+
+def test_valu_rates_table_is_committed():
+    import csv
+    rows = [r for r in csv.reader(open(os.path.join(ROOT, "profiles", "valu_rates.csv"))) if r and not r[0].startswith("#")]
+    head, rows = rows[0], rows[1:]
+    assert head[:4] == ["instruction", "mode", "waves_per_simd", "simd_cycles_per_inst"]
+    rate = {(r[0], r[1], int(r[2])): float(r[3]) for r in rows}
+    for op in ("v_add_u32", "v_and_b32", "v_fma_f32"):       # full rate with four or more waves per SIMD
+        assert 1.9 < rate[(op, "indep8", 8)] < 2.6, op
+    for op in ("v_lerp_u8", "v_pk_min_u16", "v_dot4_u32_u8", "v_alignbyte_b32", "v_perm_b32", "v_mad_u32_u24", "v_fma_f64", "v_lshlrev_b32"):
+        assert 3.9 < rate[(op, "indep8", 8)] < 4.5, op      # half rate
+    assert rate[("ds_bpermute_b32", "indep8", 8)] > 2.5 * rate[("ds_read_b32", "indep8", 8)]
+
+
 def test_roofline_uses_algorithmic_bytes():
     sys.path.insert(0, ROOT)
     import bench
