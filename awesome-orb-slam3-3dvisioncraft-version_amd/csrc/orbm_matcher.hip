@@ -267,6 +267,7 @@ struct SbpArgs {
     int chi2_gate;              // Fuse: reprojection gate of ORBmatcher.cc:1791-1815
     float inv_sigma2[16];
     int32_t* q_dist;
+    uint32_t* spill_ext;        // [batch][cap_q][SBPF_ROW - 64] k_sbp_frame: the keys a query's 64-entry workspace row does not hold (behind the flag words)
     int32_t* serial_flag;       // [batch] written by k_sbp_frame: 1 = this frame is left to k_sbp_candidates_flagged -> k_sbp_resolve; nullptr: they take every frame
 };
 
@@ -1100,7 +1101,8 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
 #define SBPF_WPE 8         // waves per SIMD the register allocation aims at: 8 = two workgroups per CU (64 VGPRs)
 #endif
 #define SBPF_SD 8          // smallest keys kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
-#define SBPF_ROW 64        // keys a workspace row holds behind them
+#define SBPF_ROW 128       // keys kept behind them: 64 in the query's workspace row, the next 64 in the extension area behind the flag words
+                           // (the th = 15 local-map search after a relocalisation holds up to ~90 candidates per query; beyond list + rows a lane walks its window again)
 #define SBPF_KEY(dist, p, oct) (((uint32_t)(dist) << 22) | ((uint32_t)(p) << 6) | ((uint32_t)(oct) & 0x3Fu))
 #define SBPF_KEY_P(k) (((k) >> 6) & 0xFFFFu)
 // a query's kept keys: in registers (one query per thread) or, for the queries beyond the workgroup's threads, in LDS (key-major: lanes = consecutive queries)
@@ -1128,13 +1130,17 @@ template <class L>
 static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const orbm_query& Q, L& lst) {
     const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
     uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2;
+    uint32_t* ext = A.spill_ext + ((size_t)b * A.cap_q + q) * (SBPF_ROW - 64);
     int count = 0;
     sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
         const uint32_t ne = SBPF_KEY(dist, p, oct);
         if (SBPF_EXP & 4) { lst.set(0, ne); count++; return; }
         // the list is ascending with 0xFFFFFFFF in its empty slots (every key is smaller): inserting one key is e'[j] = median(e[j - 1], key, e[j]) —
         // min(max(e[j - 1], key), e[j]) — for every slot at once, one v_med3_u32 each; what leaves at the end is the larger of the last slot and the key
-        if (count >= SBPF_SD && count - SBPF_SD < SBPF_ROW) row[count - SBPF_SD] = max(lst.get(SBPF_SD - 1), ne);   // (unordered: the row is a set)
+        if (count >= SBPF_SD && count - SBPF_SD < SBPF_ROW) {   // (unordered: the rows are a set)
+            const int k = count - SBPF_SD;
+            (k < 64 ? row + k : ext + (k - 64))[0] = max(lst.get(SBPF_SD - 1), ne);
+        }
 #pragma unroll
         for (int j = SBPF_SD - 1; j > 0; j--) lst.set(j, sbpf_umed3(lst.get(j - 1), ne, lst.get(j)));
         lst.set(0, min(lst.get(0), ne));
@@ -1142,19 +1148,32 @@ static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const Sbp
     });
     return count | ((Q.flags & ORBM_Q_HAS_OBS) ? 1 << 30 : 0);
 }
-// phase (2) for one query and one round: the decision against the blocked set `cur` of this round.  -> accepted CSR position or -1
+// wave-wide minimum by DPP steps (register only; the result forms in lane 63): the cooperative row scans below take two per query
+static __device__ __forceinline__ uint32_t sbpf_wave_min(uint32_t x) {
+#define SBPF_WMIN(ctrl, rows) x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, ctrl, rows, 0xF, false))
+    SBPF_WMIN(0x111, 0xF); SBPF_WMIN(0x112, 0xF); SBPF_WMIN(0x114, 0xF); SBPF_WMIN(0x118, 0xF);   // row_shr:1, 2, 4, 8
+    SBPF_WMIN(0x142, 0xA); SBPF_WMIN(0x143, 0xC);                                                 // row_bcast:15 -> rows 1, 3; row_bcast:31 -> rows 2, 3
+#undef SBPF_WMIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// phase (2) for one round: every lane's decision against the blocked set `cur` of this round.  -> accepted CSR position or -1.
+// Called by ALL 64 lanes of a wave (cnt = 0 for a lane without a query or without candidates): the lanes whose kept keys are (nearly) all claimed have
+// their workspace rows read by the whole wave, one query after the other — 64 keys per coalesced load and 64 blocked tests at once, two wave minima —
+// instead of each walking its row alone through a chain of dependent global loads (wide windows: 0.46 instead of 3.1 ms per 512 frames of the
+// th = 15 local-map search, where a tenth of the queries reads on every round).
 template <class L>
 static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const int cnt, const L& lst,
                                                  const uint32_t* cur, const uint32_t tagCur) {
     const int mode = A.prm.mode, th = A.prm.th_dist;
-    auto blocked = [&](const uint32_t p) { const uint32_t v = cur[p]; return (v >> 16) == tagCur && (int)(v & 0xFFFFu) < q; };   // tagCur = 0x10000 in round 0: nobody
+    const int lane = threadIdx.x & 63;
+    auto blocked_for = [&](const uint32_t p, const int qq) { const uint32_t v = cur[p]; return (v >> 16) == tagCur && (int)(v & 0xFFFFu) < qq; };   // tagCur = 0x10000 in round 0: nobody
     uint32_t e[SBPF_SD];
     uint32_t ub = 0;
 #pragma unroll
     for (int j = 0; j < SBPF_SD; j++) e[j] = j < cnt ? lst.get(j) : 0u;
 #pragma unroll
     for (int j = 0; j < SBPF_SD; j++)
-        if (j < cnt && !blocked(SBPF_KEY_P(e[j]))) ub |= 1u << j;
+        if (j < cnt && !blocked_for(SBPF_KEY_P(e[j]), q)) ub |= 1u << j;
     uint32_t eb1 = 0, eb2 = 0;
     bool have1 = ub != 0u;
     const uint32_t ub2 = ub & (ub - 1u);
@@ -1163,33 +1182,41 @@ static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpA
 #pragma unroll
     for (int j = 0; j < SBPF_SD; j++) { eb1 = j == j1 ? e[j] : eb1; eb2 = j == j2 ? e[j] : eb2; }
     const bool wantSecond = mode == ORBM_MODE_LOCAL_MAP;
-    if (cnt > SBPF_SD && (wantSecond ? !have2 : !have1) && !(SBPF_EXP & 1)) {
-        if (cnt <= SBPF_SD + SBPF_ROW) {
-            // the kept keys are (nearly) all claimed: read on in the row — every key there is larger than the kept ones, so the two smallest unblocked
-            // keys of the row continue the list
-            const uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2;
-            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-            for (int k = 0; k < cnt - SBPF_SD; k++) {
-                const uint32_t key = row[k];
-                if (blocked(SBPF_KEY_P(key))) continue;
-                if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key;
-            }
-            if (!have1) { have1 = m1 != 0xFFFFFFFFu; eb1 = m1; have2 = m2 != 0xFFFFFFFFu; eb2 = m2; }
-            else { have2 = m1 != 0xFFFFFFFFu; eb2 = m1; }
-        } else {
-            // more candidates than list + row hold: the lane walks its window again with the reference's own update (ORBmatcher.cc:137-158, :2355-2368)
-            const orbm_query Q = (A.queries + (size_t)b * A.cap_q)[q];
-            const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-            int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestP = -1;
-            sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
-                if (blocked((uint32_t)p)) return;            // holds an observed point of an earlier query
-                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct & 0x3F; bestP = p; }
-                else if (dist < bestDist2) { bestLevel2 = oct & 0x3F; bestDist2 = dist; }
-            });
-            have1 = bestP >= 0; eb1 = SBPF_KEY(bestDist, max(bestP, 0), bestLevel);
-            have2 = bestLevel2 >= 0 || bestDist2 < 256; eb2 = SBPF_KEY(min(bestDist2, 256), 0, bestLevel2);   // only distance and level of the second are read
-            if (!have2) eb2 = 0;
+    const bool need = cnt > SBPF_SD && (wantSecond ? !have2 : !have1) && !(SBPF_EXP & 1);
+    // (a) the kept keys are (nearly) all claimed and the row holds the rest of the list: every key there is larger than the kept ones, so the two
+    //     smallest unblocked keys of the row (an unordered set) continue the list
+    unsigned long long todo = __ballot(need && cnt <= SBPF_SD + SBPF_ROW);
+    while (todo) {                                       // wave-uniform
+        const int ls = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int qL = __builtin_amdgcn_readlane(q, ls), nrow = __builtin_amdgcn_readlane(cnt, ls) - SBPF_SD;
+        const uint32_t* row = A.work + ((size_t)b * A.cap_q + qL) * SBP_WORK_PER_Q + 2;
+        const uint32_t* ext = A.spill_ext + ((size_t)b * A.cap_q + qL) * (SBPF_ROW - 64);
+        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+        for (int k = lane; k < nrow; k += 64) {          // (at most two turns)
+            const uint32_t key = k < 64 ? row[k] : ext[k - 64];
+            if (blocked_for(SBPF_KEY_P(key), qL)) continue;
+            if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key;
         }
+        const uint32_t M1 = sbpf_wave_min(m1);
+        const uint32_t M2 = sbpf_wave_min((m1 == M1) ? m2 : m1);   // keys are unique: one lane held M1
+        if (lane == ls) {
+            if (!have1) { have1 = M1 != 0xFFFFFFFFu; eb1 = M1; have2 = M2 != 0xFFFFFFFFu; eb2 = M2; }
+            else { have2 = M1 != 0xFFFFFFFFu; eb2 = M1; }
+        }
+    }
+    // (b) more candidates than list + row hold: the lane walks its window again with the reference's own update (ORBmatcher.cc:137-158, :2355-2368)
+    if (need && cnt > SBPF_SD + SBPF_ROW) {
+        const orbm_query Q = (A.queries + (size_t)b * A.cap_q)[q];
+        const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestP = -1;
+        sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
+            if (blocked_for((uint32_t)p, q)) return;         // holds an observed point of an earlier query
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct & 0x3F; bestP = p; }
+            else if (dist < bestDist2) { bestLevel2 = oct & 0x3F; bestDist2 = dist; }
+        });
+        have1 = bestP >= 0; eb1 = SBPF_KEY(bestDist, max(bestP, 0), bestLevel);
+        have2 = bestLevel2 >= 0; eb2 = have2 ? SBPF_KEY(min(bestDist2, 256), 0, bestLevel2) : 0u;   // only distance and level of the second are read
     }
     if (!have1) return -1;
     const int bestDist = (int)(eb1 >> 22);
@@ -1285,12 +1312,12 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
         uint32_t* nxt = (r & 1) ? blk0 : blk1;
         const uint32_t tagCur = 0x10000u - (uint32_t)r, tagNxt = (0xFFFFu - (uint32_t)r) << 16;
         bool changed = false;
-        if (cntw0 & 0x07FFFFFF) {
+        {   // (all lanes: the decision function reads workspace rows with the whole wave)
             const int nd = sbpf_decide(F, A, b, tid, cntw0 & 0x07FFFFFF, r0, cur, tagCur);
             if (nd != d0) { changed = true; d0 = nd; }
             if (nd >= 0 && ((cntw0 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)tid);
         }
-        if (TAIL && (cntw1 & 0x07FFFFFF)) {
+        if (TAIL) {
             const int nd = sbpf_decide(F, A, b, q1, cntw1 & 0x07FFFFFF, r1, cur, tagCur);
             if (nd != d1) { changed = true; d1 = nd; }
             if (nd >= 0 && ((cntw1 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)q1);
@@ -1788,7 +1815,10 @@ extern "C" int orbm_undistort_and_grid_build(const orb_keypoint* d_kps, const in
 }
 
 // per query a row of SBP_WORK_PER_Q words, then one flag word per frame (k_sbp_frame -> k_sbp_resolve)
-extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4 + (((size_t)batch * 4 + 15) & ~(size_t)15); }
+// ... and k_sbp_frame's extension rows (SBPF_ROW - 64 keys per query)
+extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) {
+    return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4 + (((size_t)batch * 4 + 15) & ~(size_t)15) + (size_t)batch * cap_q * (SBPF_ROW - 64) * 4;
+}
 
 static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0, const int32_t* d_kp_link,
                       int cells, const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start, const int32_t* d_grid_idx,
@@ -1815,7 +1845,11 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     const size_t smem_f = (32 + 8 + 4) * 4 + (size_t)capk4 * (12 + 12 + 4 * SBPF_DP) + (GRID_CELLS + 2) * 2 + (size_t)tailq * SBPF_SD * 4;
     const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 &&
                        cap_q <= 2 * SBPF_T;
-    if (fused) A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_PER_Q);
+    A.spill_ext = nullptr;
+    if (fused) {
+        A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_PER_Q);
+        A.spill_ext = (uint32_t*)((char*)A.serial_flag + (((size_t)batch * 4 + 15) & ~(size_t)15));
+    }
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
     if (fused) {
@@ -1905,7 +1939,7 @@ extern "C" int orbm_fuse(const orb_keypoint* d_kps, const uint8_t* d_desc, const
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm.mode = ORBM_MODE_BEST_ONLY; A.prm.th_dist = params->th_dist; A.prm.nn_ratio = 1.f; A.prm.check_orientation = 0; A.prm.grid = params->grid;
     A.q_match = d_q_match; A.kp_match = nullptr; A.nmatches = d_nfused; A.work = nullptr; A.q_dist = d_q_dist;
-    A.chi2_gate = params->chi2_gate ? 1 : 0; A.cells = GRID_CELLS; A.kp_link = nullptr;
+    A.chi2_gate = params->chi2_gate ? 1 : 0; A.cells = GRID_CELLS; A.kp_link = nullptr; A.serial_flag = nullptr; A.spill_ext = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = params->inv_level_sigma2[i];
     if (hipMemsetAsync(d_nfused, 0, (size_t)batch * 4, (hipStream_t)stream) != hipSuccess) return ORB_E_HIP;
     hipLaunchKernelGGL(k_fuse, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);
