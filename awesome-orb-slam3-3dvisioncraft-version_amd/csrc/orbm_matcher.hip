@@ -267,7 +267,6 @@ struct SbpArgs {
     int chi2_gate;              // Fuse: reprojection gate of ORBmatcher.cc:1791-1815
     float inv_sigma2[16];
     int32_t* q_dist;
-    uint32_t* spill_ext;        // [batch][cap_q][SBPF_ROW - 64] k_sbp_frame: the keys a query's 64-entry workspace row does not hold (behind the flag words)
     int32_t* serial_flag;       // [batch] written by k_sbp_frame: 1 = this frame is left to k_sbp_candidates_flagged -> k_sbp_resolve; nullptr: they take every frame
 };
 
@@ -1101,7 +1100,7 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
 #define SBPF_WPE 8         // waves per SIMD the register allocation aims at: 8 = two workgroups per CU (64 VGPRs)
 #endif
 #define SBPF_SD 8          // smallest keys kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
-#define SBPF_ROW 128       // keys kept behind them: 64 in the query's workspace row, the next 64 in the extension area behind the flag words
+#define SBPF_ROW 128       // keys kept behind them in the query's workspace row (k_sbp_frame's rows are SBPF_ROW words; the fallback kernels lay their own 66-word rows over them)
                            // (the th = 15 local-map search after a relocalisation holds up to ~90 candidates per query; beyond list + rows a lane walks its window again)
 #define SBPF_KEY(dist, p, oct) (((uint32_t)(dist) << 22) | ((uint32_t)(p) << 6) | ((uint32_t)(oct) & 0x3Fu))
 #define SBPF_KEY_P(k) (((k) >> 6) & 0xFFFFu)
@@ -1129,18 +1128,14 @@ static __device__ __forceinline__ uint32_t sbpf_umed3(const uint32_t a, const ui
 template <class L>
 static __device__ __forceinline__ int sbpf_collect(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const orbm_query& Q, L& lst) {
     const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-    uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBP_WORK_PER_Q + 2;
-    uint32_t* ext = A.spill_ext + ((size_t)b * A.cap_q + q) * (SBPF_ROW - 64);
+    uint32_t* row = A.work + ((size_t)b * A.cap_q + q) * SBPF_ROW;
     int count = 0;
     sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
         const uint32_t ne = SBPF_KEY(dist, p, oct);
         if (SBPF_EXP & 4) { lst.set(0, ne); count++; return; }
         // the list is ascending with 0xFFFFFFFF in its empty slots (every key is smaller): inserting one key is e'[j] = median(e[j - 1], key, e[j]) —
         // min(max(e[j - 1], key), e[j]) — for every slot at once, one v_med3_u32 each; what leaves at the end is the larger of the last slot and the key
-        if (count >= SBPF_SD && count - SBPF_SD < SBPF_ROW) {   // (unordered: the rows are a set)
-            const int k = count - SBPF_SD;
-            (k < 64 ? row + k : ext + (k - 64))[0] = max(lst.get(SBPF_SD - 1), ne);
-        }
+        if (count >= SBPF_SD && count - SBPF_SD < SBPF_ROW) row[count - SBPF_SD] = max(lst.get(SBPF_SD - 1), ne);   // (unordered: the row is a set)
 #pragma unroll
         for (int j = SBPF_SD - 1; j > 0; j--) lst.set(j, sbpf_umed3(lst.get(j - 1), ne, lst.get(j)));
         lst.set(0, min(lst.get(0), ne));
@@ -1162,8 +1157,8 @@ static __device__ __forceinline__ uint32_t sbpf_wave_min(uint32_t x) {
 // instead of each walking its row alone through a chain of dependent global loads (wide windows: 0.46 instead of 3.1 ms per 512 frames of the
 // th = 15 local-map search, where a tenth of the queries reads on every round).
 template <class L>
-static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpArgs& A, const int b, const int q, const int cnt, const L& lst,
-                                                 const uint32_t* cur, const uint32_t tagCur) {
+static __device__ __forceinline__ int sbpf_decide(const SbpArgs& A, const int b, const int q, const int cnt, const L& lst,
+                                                 const uint32_t* cur, const uint32_t tagCur, int* overflow) {
     const int mode = A.prm.mode, th = A.prm.th_dist;
     const int lane = threadIdx.x & 63;
     auto blocked_for = [&](const uint32_t p, const int qq) { const uint32_t v = cur[p]; return (v >> 16) == tagCur && (int)(v & 0xFFFFu) < qq; };   // tagCur = 0x10000 in round 0: nobody
@@ -1186,15 +1181,14 @@ static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpA
     // (a) the kept keys are (nearly) all claimed and the row holds the rest of the list: every key there is larger than the kept ones, so the two
     //     smallest unblocked keys of the row (an unordered set) continue the list
     unsigned long long todo = __ballot(need && cnt <= SBPF_SD + SBPF_ROW);
-    while (todo) {                                       // wave-uniform
+    while (todo) {                                       // wave-uniform; rare in the tracking searches
         const int ls = __ffsll((long long)todo) - 1;
         todo &= todo - 1ull;
         const int qL = __builtin_amdgcn_readlane(q, ls), nrow = __builtin_amdgcn_readlane(cnt, ls) - SBPF_SD;
-        const uint32_t* row = A.work + ((size_t)b * A.cap_q + qL) * SBP_WORK_PER_Q + 2;
-        const uint32_t* ext = A.spill_ext + ((size_t)b * A.cap_q + qL) * (SBPF_ROW - 64);
+        const uint32_t* row = A.work + ((size_t)b * A.cap_q + qL) * SBPF_ROW;
         uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
         for (int k = lane; k < nrow; k += 64) {          // (at most two turns)
-            const uint32_t key = k < 64 ? row[k] : ext[k - 64];
+            const uint32_t key = row[k];
             if (blocked_for(SBPF_KEY_P(key), qL)) continue;
             if (key < m1) { m2 = m1; m1 = key; } else if (key < m2) m2 = key;
         }
@@ -1205,19 +1199,10 @@ static __device__ __forceinline__ int sbpf_decide(const SbpfFrame& F, const SbpA
             else { have2 = M1 != 0xFFFFFFFFu; eb2 = M1; }
         }
     }
-    // (b) more candidates than list + row hold: the lane walks its window again with the reference's own update (ORBmatcher.cc:137-158, :2355-2368)
-    if (need && cnt > SBPF_SD + SBPF_ROW) {
-        const orbm_query Q = (A.queries + (size_t)b * A.cap_q)[q];
-        const Desc qd = load_desc(A.qdesc + ((size_t)b * A.cap_q + q) * 32);
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestP = -1;
-        sbpf_walk(F, A.prm.grid, Q, qd, [&](const int p, const int, const int oct, const int dist) {
-            if (blocked_for((uint32_t)p, q)) return;         // holds an observed point of an earlier query
-            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct & 0x3F; bestP = p; }
-            else if (dist < bestDist2) { bestLevel2 = oct & 0x3F; bestDist2 = dist; }
-        });
-        have1 = bestP >= 0; eb1 = SBPF_KEY(bestDist, max(bestP, 0), bestLevel);
-        have2 = bestLevel2 >= 0; eb2 = have2 ? SBPF_KEY(min(bestDist2, 256), 0, bestLevel2) : 0u;   // only distance and level of the second are read
-    }
+    // (b) more candidates than list + row hold (> 136 in one window: no search of the path comes near) and this round reads past them: the frame is
+    //     handed to the one-wave walk, which works from the window itself.  (Walking the window again right here is exact too, but inlined into
+    //     the round loop it pushed the kept keys into scratch — eight reloads per query and round, 0.091 -> 0.105 ms per 512 benchmark frames.)
+    if (need && cnt > SBPF_SD + SBPF_ROW) *overflow = 1;
     if (!have1) return -1;
     const int bestDist = (int)(eb1 >> 22);
     if (bestDist > th) return -1;
@@ -1239,8 +1224,8 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
     const int capk4 = (A.cap_k + 3) & ~3;
     int* hist = (int*)orb_smem;                          // [32]
     int* ctl = hist + 32;                                // [8]  0-2 maxima, 3 culled, 4 "serial", 5 accepters
-    int* chg = ctl + 8;                                  // [4]  "something changed" of round r in slot r % 3
-    uint32_t* blk0 = (uint32_t*)(chg + 4);               // [capk4] x 2, by CSR position
+    int* chg = ctl + 8;                                  // [8]  "something changed" of round r in slot r % 3; "a list ran out" in slot 4 + r % 3
+    uint32_t* blk0 = (uint32_t*)(chg + 8);               // [capk4] x 2, by CSR position
     uint32_t* blk1 = blk0 + capk4;
     int* km = (int*)(blk1 + capk4);                      // [capk4] by key point index: last accepter / -1 / -2
     float* gx = (float*)(km + capk4);                    // [capk4] x of the key point at CSR position p
@@ -1256,7 +1241,7 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
     // ---- (1a) stage the frame
     if (tid < 32) hist[tid] = 0;
     if (tid < 8) ctl[tid] = 0;
-    if (tid < 4) chg[tid] = 0;
+    if (tid < 8) chg[tid] = 0;
     for (int i = tid; i < A.cap_k; i += SBPF_T) { blk0[i] = 0xFFFFFFFFu; blk1[i] = 0xFFFFFFFFu; km[i] = -1; }
     {
         // the grid in CSR order: position p -> (index, octave, x, y) side by side, so that a window entry is ONE round of independent LDS reads
@@ -1307,27 +1292,29 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
     __syncthreads();
     // ---- (2) fixed-point rounds
     const int maxRounds = nq + 2;
+    bool ran_out = false;
     for (int r = 0; r < maxRounds && !ctl[4]; r++) {
         const uint32_t* cur = (r & 1) ? blk1 : blk0;     // written in round r - 1 with tag 0x10000 - r
         uint32_t* nxt = (r & 1) ? blk0 : blk1;
         const uint32_t tagCur = 0x10000u - (uint32_t)r, tagNxt = (0xFFFFu - (uint32_t)r) << 16;
         bool changed = false;
-        {   // (all lanes: the decision function reads workspace rows with the whole wave)
-            const int nd = sbpf_decide(F, A, b, tid, cntw0 & 0x07FFFFFF, r0, cur, tagCur);
+        if (__ballot(cntw0 & 0x07FFFFFF)) {   // (wave-uniform: the decision function reads workspace rows with the whole wave)
+            const int nd = sbpf_decide(A, b, tid, cntw0 & 0x07FFFFFF, r0, cur, tagCur, &chg[4 + r % 3]);
             if (nd != d0) { changed = true; d0 = nd; }
             if (nd >= 0 && ((cntw0 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)tid);
         }
-        if (TAIL) {
-            const int nd = sbpf_decide(F, A, b, q1, cntw1 & 0x07FFFFFF, r1, cur, tagCur);
+        if (TAIL && __ballot(cntw1 & 0x07FFFFFF)) {
+            const int nd = sbpf_decide(A, b, q1, cntw1 & 0x07FFFFFF, r1, cur, tagCur, &chg[4 + r % 3]);
             if (nd != d1) { changed = true; d1 = nd; }
             if (nd >= 0 && ((cntw1 >> 30) & 1)) atomicMin(&nxt[nd], tagNxt | (uint32_t)q1);
         }
         if (changed) chg[r % 3] = 1;
         if (tid == 0) chg[(r + 1) % 3] = 0;
         __syncthreads();
-        if (!chg[r % 3] || (SBPF_EXP & 2)) break;        // workgroup-uniform
+        if (chg[4 + r % 3]) { ran_out = true; break; }   // workgroup-uniform, like the next line (the slots of round r are not written again before r + 3)
+        if (!chg[r % 3] || (SBPF_EXP & 2)) break;
     }
-    if (ctl[4]) {                                        // workgroup-uniform (read after a barrier in every path)
+    if (ctl[4] || ran_out) {                             // workgroup-uniform (read after a barrier in every path)
         if (tid == 0) A.serial_flag[b] = 1;
         return;
     }
@@ -1815,10 +1802,9 @@ extern "C" int orbm_undistort_and_grid_build(const orb_keypoint* d_kps, const in
 }
 
 // per query a row of SBP_WORK_PER_Q words, then one flag word per frame (k_sbp_frame -> k_sbp_resolve)
-// ... and k_sbp_frame's extension rows (SBPF_ROW - 64 keys per query)
-extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) {
-    return (size_t)batch * cap_q * SBP_WORK_PER_Q * 4 + (((size_t)batch * 4 + 15) & ~(size_t)15) + (size_t)batch * cap_q * (SBPF_ROW - 64) * 4;
-}
+// (k_sbp_frame's rows are SBPF_ROW words; a frame it hands on is rewritten in the fallback kernels' own 66-word rows, which fit inside)
+#define SBP_WORK_ROW (SBPF_ROW > SBP_WORK_PER_Q ? SBPF_ROW : SBP_WORK_PER_Q)
+extern "C" size_t orbm_search_workspace_bytes(int batch, int cap_q) { return (size_t)batch * cap_q * SBP_WORK_ROW * 4 + (((size_t)batch * 4 + 15) & ~(size_t)15); }
 
 static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const float* d_u_right, const uint8_t* d_occupied0, const int32_t* d_kp_link,
                       int cells, const int32_t* d_nkp, int count_stride, int cap_k, const int32_t* d_grid_start, const int32_t* d_grid_idx,
@@ -1842,14 +1828,10 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     // flags, and every other call, take k_sbp_candidates2 -> k_sbp_resolve
     const int capk4 = (cap_k + 3) & ~3;
     const int tailq = cap_q > SBPF_T ? cap_q - SBPF_T : 0;
-    const size_t smem_f = (32 + 8 + 4) * 4 + (size_t)capk4 * (12 + 12 + 4 * SBPF_DP) + (GRID_CELLS + 2) * 2 + (size_t)tailq * SBPF_SD * 4;
+    const size_t smem_f = (32 + 8 + 8) * 4 + (size_t)capk4 * (12 + 12 + 4 * SBPF_DP) + (GRID_CELLS + 2) * 2 + (size_t)tailq * SBPF_SD * 4;
     const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 &&
                        cap_q <= 2 * SBPF_T;
-    A.spill_ext = nullptr;
-    if (fused) {
-        A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_PER_Q);
-        A.spill_ext = (uint32_t*)((char*)A.serial_flag + (((size_t)batch * 4 + 15) & ~(size_t)15));
-    }
+    if (fused) A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_ROW);
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
     if (fused) {
@@ -1939,7 +1921,7 @@ extern "C" int orbm_fuse(const orb_keypoint* d_kps, const uint8_t* d_desc, const
     A.grid_start = d_grid_start; A.grid_idx = d_grid_idx; A.queries = d_queries; A.qdesc = d_qdesc; A.nq = d_nq; A.cap_q = cap_q;
     A.prm.mode = ORBM_MODE_BEST_ONLY; A.prm.th_dist = params->th_dist; A.prm.nn_ratio = 1.f; A.prm.check_orientation = 0; A.prm.grid = params->grid;
     A.q_match = d_q_match; A.kp_match = nullptr; A.nmatches = d_nfused; A.work = nullptr; A.q_dist = d_q_dist;
-    A.chi2_gate = params->chi2_gate ? 1 : 0; A.cells = GRID_CELLS; A.kp_link = nullptr; A.serial_flag = nullptr; A.spill_ext = nullptr;
+    A.chi2_gate = params->chi2_gate ? 1 : 0; A.cells = GRID_CELLS; A.kp_link = nullptr; A.serial_flag = nullptr;
     for (int i = 0; i < 16; i++) A.inv_sigma2[i] = params->inv_level_sigma2[i];
     if (hipMemsetAsync(d_nfused, 0, (size_t)batch * 4, (hipStream_t)stream) != hipSuccess) return ORB_E_HIP;
     hipLaunchKernelGGL(k_fuse, dim3((cap_q + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, A);

@@ -71,7 +71,7 @@ def run_frames(lib, frames, mode, th_dist, nnratio, ori, rig_oracle=()):
     qm, km, nm = [to_host(x) for x in m.SearchByProjection(dk, dv(desc), dn, gs, gi, dv(Q.view(np.uint8).reshape(B, cap_q, 28)), dv(qd), dv(nq), GRID,
                                                           mode, th_dist, work=work)]
     # the per-frame flag words behind the query rows (orbm_search_workspace_bytes): 1 = k_sbp_frame left the frame to the one-wave walk
-    flags = to_host(work)[B * cap_q * 66 * 4:].view(np.int32)[:B].copy()
+    flags = to_host(work)[B * cap_q * 128 * 4:].view(np.int32)[:B].copy()
     for b, (k, d, q, qdd) in enumerate(frames):
         if b in rig_oracle:   # the rig restatement with every key point in the left camera and no stereo links: TWIN semantics (ORBmatcher.cc:166-167, :2332)
             oq, ok, on = O.search_by_projection_rig(k, d, len(k), None, q, qdd, GRID, mode, th_dist, nnratio, ori)
@@ -128,8 +128,9 @@ def test_emu_deep_lists_and_flagged_frames(emu_backend):
 
 @pytest.mark.gpu
 def test_hip_deep_lists_and_flagged_frames(hip_lib):
-    """Frame 1 holds clusters of 90 key points: its queries run out of kept candidates and walk their windows again against the round's blocked
-    set (exact; the frame stays with k_sbp_frame).  An empty frame and a frame without queries ride along.  A frame whose queries carry the
+    """Frame 1 holds clusters of 90 key points: its queries run out of kept candidates and read on in their workspace rows (exact; the frame stays
+    with k_sbp_frame).  Clusters of 150 are more than list + row hold: the frame goes to the one-wave walk (flag 1) next to frames that stay.
+    An empty frame and a frame without queries ride along.  A frame whose queries carry the
     rig's TWIN flag is not k_sbp_frame's: it raises its flag and is redone by k_sbp_candidates_flagged -> k_sbp_resolve (checked against the
     rig oracle with every key point in the left camera), next to frames that stay parallel."""
     from orbhip.matcher import Q_TWIN
@@ -144,6 +145,10 @@ def test_hip_deep_lists_and_flagged_frames(hip_lib):
     assert fl.sum() == 0, fl
     _, fl = run_frames(hip_lib, [f1, f0, f4, f3, f2], MODE_LOCAL_MAP, 255, 0.8, True)
     assert fl.sum() == 0, fl
+    f5 = crowded_frame(rng, 3, 150, 300, spread=5.0, near_desc=True)   # ties: every query of a cluster wants the same key points in the same order
+    for mode, ratio in ((MODE_BEST_ONLY, 0.9), (MODE_LOCAL_MAP, 1.0)):   # (ratio 1: equal first and second distances on one level still pass)
+        _, fl = run_frames(hip_lib, [f0, f5, f1, f2], mode, 255, ratio, True)
+        assert fl.tolist() == [0, 1, 0, 0], fl
     ft = crowded_frame(rng, 12, 8, 300, lattice=True)
     ft[2]["flags"][1::2] |= Q_TWIN                        # every second query: "right-camera twin of the previous one" (left grid: no Q_RIGHT)
     for mode, ratio in ((MODE_BEST_ONLY, 0.9), (MODE_LOCAL_MAP, 0.8)):
