@@ -385,6 +385,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps steps each; value = the median region")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc passes of a short sub-run (N = 1 only; ~20 s)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the last timed step (profiling runs)")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: run every auxiliary leg on every rank (default: the LBA and 1280x720 legs + the exchange leg)")
     ap.add_argument("--exchange", default="rccl", choices=("rccl", "peer", "both"),
                     help="N > 1: how the exchange leg all-gathers the frame blocks — RCCL (one all_gather_into_tensor), explicit peer copies over IPC "
                          "handles (orbd_allgather_frames_peer: one pull per peer and slab, a stream per peer), or both; the peer form has never run "
@@ -435,10 +436,9 @@ def main():
     extra = {}
 
     def guard(name, fn):
-        """Auxiliary legs: at N=1 a failure is reported and never costs the headline line; at N>1 every failure is fatal (the ranks must stay
-        in lock-step through the barriers, and a broken collective must fail the run)."""
-        if world > 1:
-            return fn()
+        """Auxiliary legs: a failure is reported in the line (`extra.<leg>_error`) and never costs the headline.  At N>1 a leg that fails at the same
+        point on every rank (a bug, a size limit) leaves the ranks in lock-step: they have passed the same barriers; a failure on ONE rank leaves the
+        others in a barrier or collective, and RCCL's watchdog ends the run — with or without this guard."""
         try:
             return fn()
         except Exception as err:   # noqa: BLE001
@@ -855,8 +855,8 @@ def main():
 
     def leg_exchange():
         # N > 1 only: the two exchange steps of the path on RCCL — descriptor blocks for cross-rank matching, and the
-        # landmark-sharded LBA linearisation (all-reduce of the pose-side system, all-gather of the pose blocks).  Not guarded: a failing
-        # collective fails the run.
+        # landmark-sharded LBA linearisation (all-reduce of the pose-side system, all-gather of the pose blocks).  The headline has no collective in
+        # its data path: a failure here is reported as `extra.exchange_error` next to it.
         from orbhip import dist as D
         from orbhip.lba import LbaWindows, synth_window
         barrier()
@@ -923,12 +923,17 @@ def main():
                                         "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
 
     if not args.headline_only:
-        for name, fn in (("host_api", leg_host_api), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
-                         ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
-                         ("batch_sweep", leg_batch_sweep)):
-            guard(name, fn)
+        legs = (("host_api", leg_host_api), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
+                ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
+                ("batch_sweep", leg_batch_sweep))
+        # N>1: the legs the multi-GPU line is read for (the metric's LBA component, north_star's second frame size); the per-GPU side figures are the
+        # N=1 line's business and would only add run time and failure surface to a scaling run (--all-legs runs them anyway)
+        keep = None if (world == 1 or args.all_legs) else ("lba", "size_1280x720")
+        for name, fn in legs:
+            if keep is None or name in keep:
+                guard(name, fn)
     if world > 1 and (not args.headline_only or args.exchange != "rccl"):
-        leg_exchange()
+        guard("exchange", leg_exchange)
     lba_ms = extra.get("lba", {}).get("ms_per_step", 0.0)
     if world > 1:   # max over ranks of every timed region (all ranks ran the same number of steps between the same barriers)
         t = torch.tensor([dt, dt_extract, lba_ms], dtype=torch.float64, device=dev)

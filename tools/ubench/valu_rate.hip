@@ -117,6 +117,16 @@ OP64(v_add_f64, "v_add_f64 %0, %0, %1")
 OP64(v_mul_f64, "v_mul_f64 %0, %0, %1")
 OP64(v_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
 OP64(v_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
+// 64-bit integer forms the compiler makes of size_t index arithmetic (the 32-bit factors are the low halves of b and c)
+#define OP64I(NAME, ASM)                                                                                   \
+    struct NAME { using T = double; static constexpr const char* name = #NAME;                             \
+        static __device__ __forceinline__ void op(double& a, double b, double c) {                         \
+            const uint32_t bl = (uint32_t)__double2loint(b), cl = (uint32_t)__double2loint(c);             \
+            asm volatile(ASM : "+v"(a) : "v"(bl), "v"(cl), "v"(b) : "s20", "s21"); } };
+OP64I(v_mad_u64_u32, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0")
+OP64I(v_mad_i64_i32, "v_mad_i64_i32 %0, s[20:21], %1, %2, %0")
+OP64I(v_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
+OP64I(v_mov_b64, "v_mov_b64 %0, %3")
 
 template <class OP, int CHAINS>
 __global__ __launch_bounds__(256) void k_valu(Rec* out, int iters, uint32_t seed) {
@@ -389,6 +399,10 @@ int main() {
     run_op<v_mul_f64>(d_out, clock_hz);
     run_op<v_pk_fma_f32>(d_out, clock_hz);
     run_op<v_lshlrev_b64>(d_out, clock_hz);
+    run_op<v_mad_u64_u32>(d_out, clock_hz);
+    run_op<v_mad_i64_i32>(d_out, clock_hz);
+    run_op<v_lshl_add_u64>(d_out, clock_hz);
+    run_op<v_mov_b64>(d_out, clock_hz);
     for (int w : {1, 2, 4, 8}) run("ds_read_b32", "indep8", k_lds<1, 8>, w, 64, 64.0, d_out, clock_hz);
     for (int w : {1, 2, 4, 8}) run("ds_read_b32", "dep1", k_lds<1, 1>, w, 16, 64.0, d_out, clock_hz);
     for (int w : {1, 2, 4, 8}) run("ds_read_b64", "indep8", k_lds<2, 8>, w, 64, 64.0, d_out, clock_hz);
