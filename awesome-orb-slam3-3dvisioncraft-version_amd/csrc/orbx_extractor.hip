@@ -563,6 +563,20 @@ static __device__ __forceinline__ uint32_t mul24(const uint32_t a, const uint32_
 #endif
 }
 
+// signed form (v_mul_i32_i24 / v_mad_i32_i24)
+static __device__ __forceinline__ int imul24(const int a, const int b) {   // the low 24 bits of both, sign-extended
+#ifdef HIP_EMULATED
+    return (int)((uint32_t)(((int)((uint32_t)a << 8)) >> 8) * (uint32_t)(((int)((uint32_t)b << 8)) >> 8));
+#else
+    return __mul24(a, b);
+#endif
+}
+// cvRound / lrintf for |x| < 2^22 by the float adder: x + 1.5 * 2^23 is rounded to an integer (ties to even, like v_rndne_f32) that sits in the low
+// mantissa bits — rint_bits(x) = RINT_BIAS + rint(x) as an integer, one full-rate v_add_f32 where v_rndne_f32 + v_cvt_i32_f32 are two half-rate
+// instructions; users fold RINT_BIAS into a constant they add anyway
+#define RINT_BIAS 0x4B400000u
+static __device__ __forceinline__ uint32_t rint_bits(const float x) { return __float_as_uint(x + 12582912.0f); }
+
 static __device__ __forceinline__ int wave_append(bool pass, int* counter, int lane) {
     // ordered-within-wave append: returns the slot for passing lanes (one LDS atomic per wave)
     const unsigned long long m = __ballot(pass);
@@ -1859,6 +1873,16 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
     if (grp == 0 && kpair == 0 && lane == 0) { P.counts[2 * frame] = nTotal; P.counts[2 * frame + 1] = monoTotal; }
     const bool valid[2] = {pos0 < L.selCap && pos0 < nLevel, pos0 + 1 < L.selCap && pos0 + 1 < nLevel};
     if (!valid[0]) return;                                   // (positions fill from the front: no second key point without a first)
+    // IC_Angle's circular patch as byte masks of the lane's patch row (lane = row, |row - 21| <= 15), read BEFORE the patches are asked for: a
+    // table read behind the staging barrier was a memory round trip of its own in the middle of every key point
+    const int icv = lane - 21;
+    uint32_t icm[9];
+    {
+        const int av = icv < 0 ? -icv : icv;
+        const uint32_t* mk = c_icmask[min(av, 15)];
+#pragma unroll
+        for (int k = 0; k < 9; k++) icm[k] = av <= 15 ? mk[k + 1] : 0u;
+    }
     int cx[2], cy[2], ox[2] = {0, 0};
     const uint8_t* img = L.base + (size_t)frame * L.frameStride;
     // ---- both patches -> LDS (all loads of a key point in flight before its first store; the second key point's follow the first's stores)
@@ -1872,13 +1896,15 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             const int x0 = xs & ~3;
             ox[s] = xs - x0;
             const int c = lane % 12, r5 = lane / 12;       // lanes 0..59 = 5 rows x 12 dwords per pass, 9 passes
-            const uint8_t* src = img + (size_t)(ys + r5) * L.rowStride + x0 + 4 * c;
+            // 32-bit byte offsets inside the level (img is wave-uniform: scalar base + vector offset, no 64-bit multiply-adds per load)
+            const uint32_t off0 = mul24((uint32_t)(ys + r5), (uint32_t)L.rowStride) + (uint32_t)(x0 + 4 * c);
+            const uint32_t rs5 = 5u * (uint32_t)L.rowStride;
             uint8_t* dstp = pt + r5 * DPP + 4 * c;
             uint32_t v[9];
             if (lane < 60) {
 #pragma unroll
                 for (int k = 0; k < 9; k++)
-                    if (k < 8 || r5 < 3) v[k] = *(const uint32_t*)(src + (size_t)(5 * k) * L.rowStride);
+                    if (k < 8 || r5 < 3) v[k] = *(const uint32_t*)(img + (off0 + (uint32_t)k * rs5));
 #pragma unroll
                 for (int k = 0; k < 9; k++)
                     if (k < 8 || r5 < 3) *(uint32_t*)(dstp + 5 * k * DPP) = v[k];
@@ -1905,22 +1931,19 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             for (int k = 0; k < 12; k++) d[k] = rw[k];
 #pragma unroll
             for (int k = 0; k < 11; k++) e[s][k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ox[s]);
-            const int v = lane - 21;
-            const int av = v < 0 ? -v : v;
-            if (av <= 15) {
-                const uint32_t* mk = c_icmask[av];
+            {   // (rows outside the circle have an all-zero mask: both sums are 0)
                 uint32_t s1 = 0, sw = 0;
 #pragma unroll
                 for (int k = 1; k <= 9; k++) {
                     uint32_t W = 0;
 #pragma unroll
                     for (int t = 0; t < 4; t++) { const int j = 4 * k + t; if (j >= 6 && j <= 36) W |= (uint32_t)(j - 6) << (8 * t); }
-                    const uint32_t m = e[s][k] & mk[k];
+                    const uint32_t m = e[s][k] & icm[k - 1];
                     s1 = __builtin_amdgcn_udot4(m, 0x01010101u, s1, false);
                     sw = __builtin_amdgcn_udot4(m, W, sw, false);
                 }
-                m10[s] = (int)sw - 15 * (int)s1;
-                m01[s] = v * (int)s1;
+                m10[s] = (int)(sw - mul24(s1, 15u));         // (s1 <= 31 * 255)
+                m01[s] = imul24(icv, (int)s1);
             }
         }
     }
@@ -1966,10 +1989,19 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
         const float angle = trig[3 * s], b = trig[3 * s + 1], a = trig[3 * s + 2];
         uint32_t nib = 0;
         const u16x2 Wa = {18, 34}, Wb = {49, 55}, Wc = {49, 34}, Wd = {18, 0};
-        auto blurred = [&](const int r, const int c) {
-            const int rr = 18 + r;
-            const uint32_t* cq = (const uint32_t*)(rowp + (18 + c) * DRP + (rr & ~1));
-            const uint32_t sh = (uint32_t)(rr & 1) * 2u;
+        // byte address of the run's aligned start inside the row-pass buffer: column 18 + c is (18 + c) * 2 * DRP bytes in, row 18 + r another
+        // 2 * (18 + r), rounded down to a dword.  r and c arrive as rint_bits (RINT_BIAS + value): c * 2 * DRP + K is ONE v_mad_i32_i24 on the raw
+        // bits (their low 24 are 0x400000 + c), 2 * r one add, and K takes every constant — the biases (2 * RINT_BIAS and 36 = 2 * 18 are multiples
+        // of 4: they pass the "& ~3" untouched and leave the two low bits alone) — which the compiler must not see through: folded into the reads'
+        // immediate offsets (1 692 bytes: beyond ds_read2's reach) the constant cost a second address register per point
+        uint32_t K = (uint32_t)(18 * 2 * DRP + 36) - 0x400000u * (uint32_t)(2 * DRP) - 2u * RINT_BIAS;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+        asm volatile("" : "+s"(K));
+#endif
+        auto blurred = [&](const uint32_t rb, const uint32_t cb) {
+            const uint32_t r2 = rb + rb;
+            const uint32_t* cq = (const uint32_t*)((const uint8_t*)rowp + ((uint32_t)imul24((int)cb, 2 * DRP) + K + (r2 & ~3u)));
+            const uint32_t sh = r2 & 2u;
             const uint32_t d0 = cq[0], d1 = cq[1], d2 = cq[2], d3 = cq[3];   // (the run's seventh value is the low or the high half of d3)
             uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d1, d0, sh)), Wa, 32768u, false);
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_alignbyte(d2, d1, sh)), Wb, acc, false);
@@ -1983,9 +2015,8 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
             const float4 pt = c_patternf[lane * 4 + j];
             const f32x2 X = {pt.x, pt.z}, Y = {pt.y, pt.w}, Bv = {b, b}, Av = {a, a};
             const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
-            const int r0 = __float2int_rn(R[0]), q0 = __float2int_rn(Q[0]);
-            const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
-            nib |= (uint32_t)(blurred(r0, q0) < blurred(r1, q1)) << j;
+            // cvRound of the rotated coordinates (ORBextractor.cc:120-123; |coordinates| <= 19)
+            nib |= (uint32_t)(blurred(rint_bits(R[0]), rint_bits(Q[0])) < blurred(rint_bits(R[1]), rint_bits(Q[1]))) << j;
         }
         // eight lanes' nibbles -> one descriptor dword in the first of them, by DPP moves inside the row (quad_perm [1,0,3,2], row_shl:2 / 4 / 6)
         const uint32_t v = nib | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, false) << 4);           // valid on even lanes
