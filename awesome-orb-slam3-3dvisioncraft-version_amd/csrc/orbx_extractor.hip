@@ -46,7 +46,7 @@ __device__ unsigned long long g_prof[2][8][256];   // [kernel][phase][shard]: sh
 static const int8_t h_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-static __constant__ float4 c_patternf[256];   // the same pairs as floats (x0, y0, x1, y1): no per-keypoint int8 -> float conversions
+static __constant__ float4 c_patternf[256];   // the same pairs as floats, stored (x0, x1, y0, y1): the packed rotation takes (x0, x1) and (y0, y1) as register pairs straight from the load
 static __constant__ int c_umax[16];
 // n / g == (n * c_div16[g]) >> 16 for n * g < 65536: k_fast's index maps divide thread ids (< 256) by workgroup-uniform divisors (< 16) — a
 // 24-bit multiply and a shift instead of the ~20-instruction integer division sequence
@@ -1405,16 +1405,13 @@ static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
     const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // the reference's two branches (ax >= ay: c = ay / (ax + eps); else c = ax / (ay + eps) and a = 90 - a) as selects around ONE division and
+    // polynomial: the same operations on the same values, and lanes that disagree do not run the ~22 instructions twice
+    const bool steep = ax < ay;
+    const float c = (steep ? ax : ay) / ((steep ? ay : ax) + (float)DBL_EPSILON);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (steep) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
@@ -1749,7 +1746,7 @@ static __global__ __launch_bounds__(64 * DESC_WPB, DESC_WAVES) void k_describe(D
         // component as the scalar form, no contraction)
         typedef float f32x2 __attribute__((vector_size(8)));
         const float4 pt = c_patternf[lane * 4 + j];
-        const f32x2 X = {pt.x, pt.z}, Y = {pt.y, pt.w}, Bv = {b, b}, Av = {a, a};
+        const f32x2 X = {pt.x, pt.y}, Y = {pt.z, pt.w}, Bv = {b, b}, Av = {a, a};
         const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
         const int r0 = __float2int_rn(R[0]), q0 = __float2int_rn(Q[0]);
         const int r1 = __float2int_rn(R[1]), q1 = __float2int_rn(Q[1]);
@@ -1920,12 +1917,15 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
     // ---- lane r owns patch row r of both key points: packed rows into registers, IC_Angle moments (ORBextractor.cc:75-102) on the way
     uint32_t e[2][11];
     int m10[2] = {0, 0}, m01[2] = {0, 0};
+    const int prow = min(lane, DP - 1);   // the lanes beyond the patch repeat its last row: their masks are 0 and the row pass leaves them out — no divergent
+                                          // branch around the reads, no zeroed copy of the row for the lanes that would have skipped it
 #pragma unroll
     for (int s = 0; s < 2; s++) {
+        if (!valid[s]) {                  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 11; k++) e[s][k] = 0;
-        if (valid[s] && lane < DP) {
-            const uint32_t* rw = (const uint32_t*)(patch + s * DESC2_PATCH + lane * DPP);
+            for (int k = 0; k < 11; k++) e[s][k] = 0;
+        } else {
+            const uint32_t* rw = (const uint32_t*)(patch + s * DESC2_PATCH + prow * DPP);
             uint32_t d[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) d[k] = rw[k];
@@ -1942,7 +1942,7 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
                     s1 = __builtin_amdgcn_udot4(m, 0x01010101u, s1, false);
                     sw = __builtin_amdgcn_udot4(m, W, sw, false);
                 }
-                m10[s] = (int)(sw - mul24(s1, 15u));         // (s1 <= 31 * 255)
+                m10[s] = imul24((int)s1, -15) + (int)sw;     // (s1 <= 31 * 255: one v_mad_i32_i24)
                 m01[s] = imul24(icv, (int)s1);
             }
         }
@@ -2013,7 +2013,7 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
         for (int j = 0; j < 4; j++) {
             typedef float f32x2 __attribute__((vector_size(8)));
             const float4 pt = c_patternf[lane * 4 + j];
-            const f32x2 X = {pt.x, pt.z}, Y = {pt.y, pt.w}, Bv = {b, b}, Av = {a, a};
+            const f32x2 X = {pt.x, pt.y}, Y = {pt.z, pt.w}, Bv = {b, b}, Av = {a, a};
             const f32x2 R = X * Bv + Y * Av, Q = X * Av - Y * Bv;
             // cvRound of the rotated coordinates (ORBextractor.cc:120-123; |coordinates| <= 19)
             nib |= (uint32_t)(blurred(rint_bits(R[0]), rint_bits(Q[0])) < blurred(rint_bits(R[1]), rint_bits(Q[1]))) << j;
@@ -2585,7 +2585,10 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
     {
         float pf[1024];
-        for (int i = 0; i < 1024; i++) pf[i] = (float)h_pattern[i];
+        for (int i = 0; i < 256; i++) {   // h_pattern: x0, y0, x1, y1 per pair (ORBextractor.cc:149-406)
+            pf[4 * i] = (float)h_pattern[4 * i]; pf[4 * i + 1] = (float)h_pattern[4 * i + 2];
+            pf[4 * i + 2] = (float)h_pattern[4 * i + 1]; pf[4 * i + 3] = (float)h_pattern[4 * i + 3];
+        }
         CK(hipMemcpyToSymbol(HIP_SYMBOL(c_patternf), pf, sizeof(pf)));
     }
     {
