@@ -2642,6 +2642,10 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     // E1 pyramid
+#ifndef ORBX_EXP_DUP
+#define ORBX_EXP_DUP 0   // experiment only (tools/build_variants.sh): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
+#endif                   // three-stream step (every one of them is idempotent) next to its standalone time
+    for (int rep = 0; rep < ((ORBX_EXP_DUP & 1) ? 2 : 1); rep++)
     for (int l = 1; l < nl; l++) {
         ResizeParams R;
         level_view(h, l - 1, R.src, R.sFrame, R.sStride);
@@ -2727,7 +2731,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
         const bool cache = batch <= OCT_CACHE_MAX_BATCH && h->octSmem > (size_t)h->octKeyOff;
         O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
-        hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
+        for (int rep = 0; rep < ((ORBX_EXP_DUP & 2) ? 2 : 1); rep++)
+            hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly
@@ -2746,7 +2751,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         for (int l = nl + 1; l <= ORBX_MAX_LEVELS; l++) D.unitStart[l] = INT_MAX;
         D.groups = D.unitStart[nl]; D.batch = batch;
 #if DESC_KPW == 2
-        hipLaunchKernelGGL(k_describe2, dim3(D.groups * 2 * 8 * ((batch + 7) / 8)), dim3(64), DESC2_WAVE_BYTES + 48, st, D);
+        for (int rep = 0; rep < ((ORBX_EXP_DUP & 4) ? 2 : 1); rep++)
+            hipLaunchKernelGGL(k_describe2, dim3(D.groups * 2 * 8 * ((batch + 7) / 8)), dim3(64), DESC2_WAVE_BYTES + 48, st, D);
 #else
         hipLaunchKernelGGL(k_describe, dim3(D.groups * (4 / DESC_WPB) * 8 * ((batch + 7) / 8)), dim3(64 * DESC_WPB), DESC_WPB * DESC_WAVE_STRIDE + 96, st, D);
 #endif
