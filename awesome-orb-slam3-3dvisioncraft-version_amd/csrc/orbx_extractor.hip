@@ -589,8 +589,10 @@ static __device__ __forceinline__ int wave_append(bool pass, int* counter, int l
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// One tile.  listId (PASS 1): the tile's entry in the retry list.  Every `return` in here is taken by the whole workgroup (the conditions are
+// workgroup-uniform), so k_fast<1> may call it in a loop with a barrier between the tiles.
 template <int PASS>   // 0: first pass at iniThFAST, 1: the listed tiles at min(ini, min), 2: one pass at min(ini, min) (see below)
-static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
+static __device__ __forceinline__ void fast_tile(const FastParams& P, const int listId) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     PROF_DECL;
@@ -627,8 +629,7 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
 #else
         const uint32_t* rl = P.retry;
 #endif
-        const int id = blockIdx.x + gridDim.x * blockIdx.y;
-        if (id >= (int)rl[0]) return;
+        const int id = listId;                           // (< rl[0]: k_fast<1>'s loop)
         const uint32_t e = rl[2 + 2 * id];
         emitMask = rl[3 + 2 * id];
         tileIdx = (int)(e & 0xFFFFu); frame = (int)(e >> 16);
@@ -997,6 +998,25 @@ static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
         if (gbase + i < L.candCap) out[gbase + i] = elist[i];
     PROF_MARK(0, 6);   // emit
     PROF_FLUSH(0);
+}
+// Passes 0 and 2: one tile per workgroup, grid = (tiles, frames).  Pass 1: a 1-D grid sized by the host from the PREVIOUS call's list (a scheduling
+// guess only: any size is correct) walks the retry list with a workgroup stride — launched on the full (tiles, frames) grid, seven of eight of its
+// workgroups did nothing but read the list's length, each holding a slot with the kernel's 20 KB of LDS while it did.
+template <int PASS>
+static __global__ __launch_bounds__(256) void k_fast(FastParams P) {
+    if (PASS == 1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+        const uint32_t n = *(const uint32_t __attribute__((address_space(4)))*)(unsigned long long)P.retry;
+#else
+        const uint32_t n = P.retry[0];
+#endif
+        for (uint32_t id = blockIdx.x; id < n; id += gridDim.x) {
+            fast_tile<1>(P, (int)id);
+            __syncthreads();                             // the next tile rewrites the LDS this one's last phase reads
+        }
+    } else {
+        fast_tile<PASS>(P, 0);
+    }
 }
 
 // ============================================================================================================
@@ -2709,7 +2729,14 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
             HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_retry + 1), (int)((uint32_t)nTiles * (uint32_t)batch), 1, st));
             hipLaunchKernelGGL((k_fast<0>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
-            hipLaunchKernelGGL((k_fast<1>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
+            {
+                // the second pass's grid: the previous two-pass call's list length (+ 25 % + 1 024) if that call had the same tile count, else every tile
+                const volatile uint32_t* hr2 = h->h_retry;
+                const uint32_t all = (uint32_t)nTiles * (uint32_t)batch;
+                uint32_t g1 = all;
+                if (hr2[1] == all) g1 = std::min(all, std::max(2048u, hr2[0] + hr2[0] / 4u + 1024u));
+                hipLaunchKernelGGL((k_fast<1>), dim3(g1), dim3(256), h->fastSmem, st, F);
+            }
             if (!h->capturing) HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 8, hipMemcpyDeviceToHost, st));
         } else {
             hipLaunchKernelGGL((k_fast<2>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
