@@ -26,3 +26,14 @@ def test_stereo_cull_median_on_adversarial_sads():
                            os.path.join(ROOT, "tests", "cpp", "stereo_cull_test.cpp"), "-o", out, "-lpthread"])
     r = subprocess.run([out], capture_output=True, text=True)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+def test_describe_arithmetic_forms():
+    """k_describe2's round-4 arithmetic (tests/cpp/describe_arith_test.cpp): cvRound by the float adder == lrintf, the sampled point's address from raw
+    rint bits with the biases folded into one constant == the plain form, fastAtan2 as selects == its two-branch form."""
+    out = os.path.join(ROOT, "tests", "emu", "build", "describe_arith_test")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "include"), "-x", "c++",
+                           os.path.join(ROOT, "tests", "cpp", "describe_arith_test.cpp"), "-o", out, "-lpthread"])
+    r = subprocess.run([out], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
