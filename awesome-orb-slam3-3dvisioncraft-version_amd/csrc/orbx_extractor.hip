@@ -1028,6 +1028,7 @@ struct OctLevel {
     int N;               // mnFeaturesPerLevel[level]
     int nIni; float hX;  // ORBextractor.cc:541-543
     int nCols, wCell, hCell;
+    int wCellM19, hCellM19;   // ceil(2^19 / cell side): v / side == (v * M) >> 19 for v < 4096 and sides <= 127 (v * (side * M - 2^19) < 2^19)
     size_t candOff; int candCap;
     int selOff; int selCap;   // per-frame offsets into sel/selAux (u32 units)
     float scale;         // mvScaleFactor[level]
@@ -1327,7 +1328,9 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             if (ndv[u] < 0) continue;
             const uint32_t key = kyv[u];
             const int x = (int)(key & 0xFFF) - 3, y = (int)((key >> 12) & 0xFFF) - 3;
-            const int cj = x / L.wCell, ci = y / L.hCell;
+            // (two integer divisions by run-time values per candidate were a fifth of the kernel's instructions: multiply-shift by tabulated reciprocals,
+            // exact for the 12-bit coordinates and cell sides below 128)
+            const int cj = (int)(mul24((uint32_t)x, (uint32_t)L.wCellM19) >> 19), ci = (int)(mul24((uint32_t)y, (uint32_t)L.hCellM19) >> 19);
             const uint32_t ord = (uint32_t)((((ci * L.nCols + cj) * 128 + (y - ci * L.hCell)) * 128) + (x - cj * L.wCell));  // cell sides < 70
             atomicMax(&best[ndv[u]], ((unsigned long long)((key >> 24) + 1u) << 32) | (0x7FFFFFFFu - ord));
         }
@@ -2514,6 +2517,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
             }
         maxRows = std::max(maxRows, crows * L.hCell + 6 + crows);
         if (L.hCell > 64) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell higher than 64 rows"); }
+        if (L.wCell > 127) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST cell wider than 127 columns"); }   // (k_octree's reciprocal tables)
     }
     h->pyrFrame = pyrOff; h->candFrame = candOff; h->selFrame = selOff; h->nodeCap = nodeCap; h->maxKp = maxKp;
     h->nTiles = (int)tiles.size(); h->nTiles1 = (int)tiles1.size();
@@ -2752,6 +2756,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             OctLevel& ol = O.lv[l]; const LevelHost& L = h->lv[l];
             ol.W = L.maxBX - ORBX_MINB; ol.H = L.maxBY - ORBX_MINB; ol.N = h->nfeat[l]; ol.nIni = L.nIni; ol.hX = L.hX;
             ol.nCols = L.nCols; ol.wCell = L.wCell; ol.hCell = L.hCell; ol.candOff = L.candOff; ol.candCap = L.candCap;
+            ol.wCellM19 = ((1 << 19) + L.wCell - 1) / L.wCell; ol.hCellM19 = ((1 << 19) + L.hCell - 1) / L.hCell;
             ol.selOff = L.selOff; ol.selCap = L.selCap; ol.scale = h->scale[l];
         }
         O.cand = h->d_cand; O.candFrame = h->candFrame; O.candCount = h->d_candCount; O.nlevels = nl; O.keyNode = h->d_keyNode;
