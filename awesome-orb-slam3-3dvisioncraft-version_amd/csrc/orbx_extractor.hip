@@ -1069,6 +1069,53 @@ static __device__ int block_scan_excl(int* a, int n, int* scratch) {
     return total;
 }
 
+// The same scan over values that are COMPUTED by the scanning thread: f(i) for the entries of its own chunk (no barrier between producing the
+// values and scanning them).  a[i] receives the exclusive prefix; two workgroup barriers.
+template <class F>
+static __device__ __forceinline__ int block_scan_excl_fn(int* a, const int n, int* scratch, F f) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + OCT_T - 1) / OCT_T;
+    const int s0 = tid * chunk, s1 = min(s0 + chunk, n);
+    int sum = 0;
+    for (int i = s0; i < s1; i++) { const int t = f(i); a[i] = t; sum += t; }
+    const int incl = wave_scan_incl(sum);
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_T / 64; w++) { const int v = scratch[w]; base += w < wave ? v : 0; total += v; }
+    int run = base + incl - sum;
+    for (int i = s0; i < s1; i++) { const int t = a[i]; a[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+// Two such scans behind the same two barriers: a[0..na) over fa, b[0..nb) over fb.
+template <class FA, class FB>
+static __device__ __forceinline__ void block_scan_excl_fn2(int* a, const int na, FA fa, int* b, const int nb, FB fb, int* scratch, int* totalA, int* totalB) {
+    constexpr int NW = OCT_T / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ca = (na + OCT_T - 1) / OCT_T, cb = (nb + OCT_T - 1) / OCT_T;
+    const int a0 = tid * ca, a1 = min(a0 + ca, na), b0 = tid * cb, b1 = min(b0 + cb, nb);
+    int sa = 0, sb2 = 0;
+    for (int i = a0; i < a1; i++) { const int t = fa(i); a[i] = t; sa += t; }
+    for (int i = b0; i < b1; i++) { const int t = fb(i); b[i] = t; sb2 += t; }
+    const int ia = wave_scan_incl(sa), ib = wave_scan_incl(sb2);
+    if (lane == 63) { scratch[wave] = ia; scratch[NW + wave] = ib; }
+    __syncthreads();
+    int baseA = 0, totA = 0, baseB = 0, totB = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int va = scratch[w], vb = scratch[NW + w];
+        baseA += w < wave ? va : 0; totA += va;
+        baseB += w < wave ? vb : 0; totB += vb;
+    }
+    int ra = baseA + ia - sa, rb = baseB + ib - sb2;
+    for (int i = a0; i < a1; i++) { const int t = a[i]; a[i] = ra; ra += t; }
+    for (int i = b0; i < b1; i++) { const int t = b[i]; b[i] = rb; rb += t; }
+    __syncthreads();
+    *totalA = totA; *totalB = totB;
+}
+
 struct ONode { short x0, y0, x1, y1; };
 #ifndef OCT_KEYCAP
 #define OCT_KEYCAP 4096   // candidates per (frame, level) that the LDS key cache holds (6 B each); levels with more take the global-memory path
@@ -1152,46 +1199,57 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         int* ccn = ccb[ccCur ^ 1];
         const ONode* R = rect[cur];
         const int* CN = cnt[cur];
+        // Barriers, not instructions, are this kernel's time (a round had 17, a sorted one 26): flags are evaluated inside the scans by the thread
+        // that owns the entry, the two scans of step 4 share their barriers, a list-order round needs no copy of the list and no scatter of
+        // its "divided" marks, and the children of a node are counted where the node is listed — 7 barriers per list-order round, 21 per sorted one.
         // 1. expandable nodes E (count > 1), list order
-        for (int i = tid; i < size; i += OCT_T) { sb[i] = CN[i] > 1 ? 1 : 0; nchild[i] = 0; }
-        __syncthreads();
-        const int nE = block_scan_excl(sb, size, scratch);
+        if (tid == 0) ctl[1] = 0;                           // (step 5's counter: last read before the previous round's closing barrier)
+        const int nE = block_scan_excl_fn(sb, size, scratch, [&](const int i) { return CN[i] > 1 ? 1 : 0; });
         if (nE == 0) break;  // nothing can be divided: size stays == prevSize (:667)
-        for (int i = tid; i < size; i += OCT_T)
-            if (CN[i] > 1) { elist[sb[i]] = i; if (!haveCounts) { cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; } }
+        // nchild[i]: #non-empty children of an expandable node; | 0x100 = "divided" — in a list-order round every expandable node is
+        const int dflag = sortedMode ? 0 : 0x100;
+        for (int i = tid; i < size; i += OCT_T) {
+            int nc = 0;
+            if (CN[i] > 1) {
+                elist[sb[i]] = i;
+                if (!haveCounts) { cc[4 * i] = 0; cc[4 * i + 1] = 0; cc[4 * i + 2] = 0; cc[4 * i + 3] = 0; }
+                else nc = ((cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0)) | dflag;
+            }
+            nchild[i] = nc;
+        }
         __syncthreads();
-        // 2. child key counts (DivideNode :479-535)
+        // 2. child key counts (DivideNode :479-535): the first round (later ones get them from the previous round's key move)
         // (key walks are unrolled by 4 with the loads hoisted: the walk is a chain of global-memory round trips otherwise, and a
         // workgroup's lifetime — not its instruction count — is what bounds this kernel)
-        if (!haveCounts)
-        for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
-            int ndv[OCT_U]; uint32_t kyv[OCT_U];
+        if (!haveCounts) {
+            for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
+                int ndv[OCT_U]; uint32_t kyv[OCT_U];
 #pragma unroll
-            for (int u = 0; u < OCT_U; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
+                for (int u = 0; u < OCT_U; u++) { const int k = k0 + u * OCT_T; ndv[u] = k < nk ? (int)keyNode[k] : -1; kyv[u] = k < nk ? keys[k] : 0u; }
 #pragma unroll
-            for (int u = 0; u < OCT_U; u++) {
-                const int nd = ndv[u];
-                if (nd >= 0 && CN[nd] > 1) {
-                    const ONode n = R[nd];
-                    const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-                    const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
-                    const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                    atomicAdd(&cc[4 * nd + q], 1);
+                for (int u = 0; u < OCT_U; u++) {
+                    const int nd = ndv[u];
+                    if (nd >= 0 && CN[nd] > 1) {
+                        const ONode n = R[nd];
+                        const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                        const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
+                        const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                        atomicAdd(&cc[4 * nd + q], 1);
+                    }
                 }
             }
+            __syncthreads();
+            for (int e = tid; e < nE; e += OCT_T) {
+                const int i = elist[e];
+                nchild[i] = ((cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0)) | dflag;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int e = tid; e < nE; e += OCT_T) {
-            const int i = elist[e];
-            nchild[i] = (cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0);
-        }
-        __syncthreads();
         // 3. processing order and cut
         int nProc = nE;
-        if (!sortedMode) {
-            for (int e = tid; e < nE; e += OCT_T) porder[e] = elist[e];
-            __syncthreads();
-        } else {
+        const int* po = elist;                              // list order: the list itself
+        if (sortedMode) {
+            po = porder;
             // descending (size, creation seq): rule R1 replaces the reference's pointer tie-break (:679-683)
             // (sb / pb are free here: the (count, seq) sort keys are staged list-order so the rank loop reads two broadcast words per
             // step instead of chasing elist -> CN / seq)
@@ -1225,24 +1283,24 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             nProc = ctl[0];
             __syncthreads();
         }
-        // 4. push bases (children are push_front'ed in processing order, n1..n4)
-        for (int i = tid; i < size; i += OCT_T) sb[i] = 1;  // 1 = survives
-        for (int e = tid; e < nProc; e += OCT_T) pb[e] = nchild[porder[e]];
-        __syncthreads();
-        for (int e = tid; e < nProc; e += OCT_T) sb[porder[e]] = 0;
-        __syncthreads();
-        const int totalPushed = block_scan_excl(pb, nProc, scratch);
-        // dflag lives in nchild's sign: remember divided nodes before sb is scanned
-        for (int i = tid; i < size; i += OCT_T) if (sb[i] == 0) nchild[i] |= 0x100;
-        __syncthreads();
-        const int nSurv = block_scan_excl(sb, size, scratch);
+        // 4. push bases (children are push_front'ed in processing order, n1..n4) and the survivors' positions: one pair of scans
+        if (sortedMode) {                                   // the cut leaves expandable nodes undivided: mark the processed ones
+            for (int i = tid; i < size; i += OCT_T) sb[i] = 1;  // 1 = survives
+            __syncthreads();
+            for (int e = tid; e < nProc; e += OCT_T) { sb[po[e]] = 0; nchild[po[e]] |= 0x100; }
+            __syncthreads();
+        }
+        int totalPushed, nSurv;
+        if (sortedMode)
+            block_scan_excl_fn2(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return sb[i]; }, scratch, &totalPushed, &nSurv);
+        else
+            block_scan_excl_fn2(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return CN[i] > 1 ? 0 : 1; }, scratch, &totalPushed,
+                                &nSurv);
         const int newSize = totalPushed + nSurv;
         // 5. build the next list: [children, most recently pushed first] ++ [survivors in order]
         const int nxt = cur ^ 1;
-        if (tid == 0) ctl[1] = 0;
-        __syncthreads();
         for (int e = tid; e < nProc; e += OCT_T) {
-            const int i = porder[e];
+            const int i = po[e];
             const ONode n = R[i];
             const int hx = (n.x1 - n.x0 + 1) >> 1, hy = (n.y1 - n.y0 + 1) >> 1;
             int p = pb[e];
