@@ -1162,36 +1162,52 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     int* lapCountOut = P.lapCount + (size_t)frame * P.nlevels + level;
     const int N = L.N;
     int cur = 0;
+    PROF_DECL;   // (-DORBX_PROF builds: slot 1 of the phase timers is k_octree's — k_describe, whose slot it was, is not launched)
     // ---- roots (ORBextractor.cc:550-561) and key assignment by kp.pt.x/hX (:564-568)
     for (int i = tid; i < L.nIni; i += OCT_T) {
         ONode n;
         n.x0 = (short)(int)(L.hX * (float)i); n.y0 = 0;
         n.x1 = (short)(int)(L.hX * (float)(i + 1)); n.y1 = (short)L.H;
         rect[0][i] = n; cnt[0][i] = 0; seq[0][i] = i;
+        if (P.merge) { int* c1 = ccb[1]; c1[4 * i] = 0; c1[4 * i + 1] = 0; c1[4 * i + 2] = 0; c1[4 * i + 3] = 0; }
     }
     __syncthreads();
+    // (with the second child-count buffer the assignment walk also counts the keys into the roots' children — the first round's own key walk — and
+    // the walk that renumbers the keys runs only if a root came back empty: two of a level's nine key walks)
     for (int k = tid; k < nk; k += OCT_T) {
-        const float x = (float)(keys[k] & 0xFFF);
+        const uint32_t key = keys[k];
+        const float x = (float)(key & 0xFFF);
         int r = (int)(x / L.hX);
         r = min(r, L.nIni - 1);
         keyNode[k] = (uint16_t)r;
         atomicAdd(&cnt[0][r], 1);
+        if (P.merge) {
+            const ONode n = rect[0][r];
+            const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+            const int kx = key & 0xFFF, ky = (key >> 12) & 0xFFF;
+            atomicAdd(&ccb[1][4 * r + ((kx < mx) ? (ky < my ? 0 : 2) : (ky < my ? 1 : 3))], 1);
+        }
     }
     __syncthreads();
     // drop empty roots (:572-583), keep order
-    for (int i = tid; i < L.nIni; i += OCT_T) sb[i] = cnt[0][i] > 0 ? 1 : 0;
-    __syncthreads();
-    int size = block_scan_excl(sb, L.nIni, scratch);
+    int size = block_scan_excl_fn(sb, L.nIni, scratch, [&](const int i) { return cnt[0][i] > 0 ? 1 : 0; });
     for (int i = tid; i < L.nIni; i += OCT_T)
-        if (cnt[0][i] > 0) { const int np = sb[i]; rect[1][np] = rect[0][i]; cnt[1][np] = cnt[0][i]; seq[1][np] = seq[0][i]; }
+        if (cnt[0][i] > 0) {
+            const int np = sb[i];
+            rect[1][np] = rect[0][i]; cnt[1][np] = cnt[0][i]; seq[1][np] = seq[0][i];
+            if (P.merge) *(int4*)&ccb[0][4 * np] = *(const int4*)&ccb[1][4 * i];
+        }
     __syncthreads();
-    for (int k = tid; k < nk; k += OCT_T) keyNode[k] = (uint16_t)sb[keyNode[k]];
-    __syncthreads();
+    if (size != L.nIni) {                                // (workgroup-uniform)
+        for (int k = tid; k < nk; k += OCT_T) keyNode[k] = (uint16_t)sb[keyNode[k]];
+        __syncthreads();
+    }
     cur = 1;
+    PROF_MARK(1, 0);   // roots, key assignment, empty roots dropped
     int seqCounter = L.nIni;
     bool sortedMode = false;
     int ccCur = 0;
-    bool haveCounts = false;
+    bool haveCounts = P.merge != 0;                      // (counted by the assignment walk)
 
     for (;;) {
         const int prevSize = size;
@@ -1218,6 +1234,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             nchild[i] = nc;
         }
         __syncthreads();
+        PROF_MARK(1, 1);   // expandable-node scan + list
         // 2. child key counts (DivideNode :479-535): the first round (later ones get them from the previous round's key move)
         // (key walks are unrolled by 4 with the loads hoisted: the walk is a chain of global-memory round trips otherwise, and a
         // workgroup's lifetime — not its instruction count — is what bounds this kernel)
@@ -1245,6 +1262,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             }
             __syncthreads();
         }
+        PROF_MARK(1, 2);   // first round: child counts by a key walk
         // 3. processing order and cut
         int nProc = nE;
         const int* po = elist;                              // list order: the list itself
@@ -1283,6 +1301,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             nProc = ctl[0];
             __syncthreads();
         }
+        PROF_MARK(1, 3);   // sorted rounds: rank, cut
         // 4. push bases (children are push_front'ed in processing order, n1..n4) and the survivors' positions: one pair of scans
         if (sortedMode) {                                   // the cut leaves expandable nodes undivided: mark the processed ones
             for (int i = tid; i < size; i += OCT_T) sb[i] = 1;  // 1 = survives
@@ -1296,6 +1315,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         else
             block_scan_excl_fn2(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return CN[i] > 1 ? 0 : 1; }, scratch, &totalPushed,
                                 &nSurv);
+        PROF_MARK(1, 4);   // the two scans of step 4
         const int newSize = totalPushed + nSurv;
         // 5. build the next list: [children, most recently pushed first] ++ [survivors in order]
         const int nxt = cur ^ 1;
@@ -1327,6 +1347,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
                 if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
             }
         __syncthreads();
+        PROF_MARK(1, 5);   // next list built
         // 6. move keys, and count them into the children of their NEW node (next round's step 2)
         {
             const ONode* Rn = rect[nxt];
@@ -1361,6 +1382,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         }
         const int nToExpand = ctl[1];
         __syncthreads();
+        PROF_MARK(1, 6);   // key move
         cur = nxt;
         if (P.merge) { ccCur ^= 1; haveCounts = true; }
         size = min(newSize, C);
@@ -1421,6 +1443,8 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         selAux[i] = (uint32_t)rank | ((uint32_t)lap << 31);
     }
     if (tid == 0) { *selCountOut = nsel; *lapCountOut = nLap; }
+    PROF_MARK(1, 7);   // best key per node, outputs
+    PROF_FLUSH(1);
 }
 
 static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
