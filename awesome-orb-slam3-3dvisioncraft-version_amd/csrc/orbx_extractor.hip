@@ -2821,6 +2821,9 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
                 const uint32_t all = (uint32_t)nTiles * (uint32_t)batch;
                 uint32_t g1 = all;
                 if (hr2[1] == all) g1 = std::min(all, std::max(2048u, hr2[0] + hr2[0] / 4u + 1024u));
+#ifdef FAST_P1_GRID   // tests: a fixed, tiny second-pass grid — every workgroup then walks several list entries
+                g1 = std::min(all, (uint32_t)(FAST_P1_GRID));
+#endif
                 hipLaunchKernelGGL((k_fast<1>), dim3(g1), dim3(256), h->fastSmem, st, F);
             }
             if (!h->capturing) HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 8, hipMemcpyDeviceToHost, st));

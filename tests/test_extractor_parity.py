@@ -128,6 +128,27 @@ def test_emulated_fast_two_threshold_passes():
                 assert np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2), (tag, ini, mn)
 
 
+def test_emulated_fast_second_pass_walks_the_list_with_a_stride():
+    """k_fast<1> runs on a 1-D grid sized from the previous call's list and walks the retry list with a workgroup stride (a barrier between the tiles
+    of one workgroup: the next tile rewrites the LDS the last phase of this one reads).  The product's grid is never smaller than the list it was
+    sized for, so FAST_P1_GRID=3 forces it: three workgroups take every listed tile of the call, several each.  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("FAST_TALL_MIN_BATCH=1", "FAST_TWO_PASS_MIN_BATCH=1", "FAST_P1_GRID=3", "FAST_TWO_PASS_MAX_LISTED=1.0"), tag="tall1_p1grid3_alwaystwo")))
+    imgs = [synth_image(31, 400, 300, n_rect=25, n_disc=10, noise=1.0), synth_image(33, 480, 360, n_rect=60, n_disc=20, noise=2.0, contrast=0.7)]
+    for ini, mn in ((20, 7), (40, 5)):
+        for img in imgs:
+            o = O.OrbOracle(500, 1.2, 6, ini, mn)
+            mono, k, d = o.extract(img)
+            e = orbhip.ORBextractor(500, 1.2, 6, ini, mn, lib=lib)
+            for _ in range(2):   # (the second call sees the first one's list length)
+                m2, k2, d2 = e(img)
+                assert e.last_fast_passes()["two_pass"] == 1 and e.last_fast_passes()["listed"] > 6, e.last_fast_passes()
+                assert m2 == mono and len(k) == len(k2), (ini, mn, len(k), len(k2))
+                assert np.array_equal(k.view(np.uint8), k2.view(np.uint8)) and np.array_equal(d, d2), (ini, mn)
+
+
 def test_emulated_fast_pass_policy_never_changes_results():
     """Which form a batch call takes is decided from the listed share of the handle's previous two-pass call: a sparsely textured frame (most tiles
     have an empty cell) sends the second call down the one-pass form, a textured one keeps the two passes — and the key points are the same either
