@@ -1156,7 +1156,10 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     int* elist = lp; lp += C;                      // [C] expandable node indices (list order)
     int* porder = lp; lp += C;                     // [C] processing order
     int* pb = lp; lp += C;                         // [C] push base per processed node
-    uint16_t* childPos = (uint16_t*)lp;            // [C][4]
+    // [C] what the key move needs of a node of the CURRENT list in one 16-byte read: {x0 | undivided << 15 | y0 << 16, x1 | y1 << 16, and the list positions
+    // of its children n1..n4 as four u16 (0xFFFF: empty) — of an undivided node its own new position four times}.  A key then costs ONE LDS read where
+    // divided flag, rectangle, child position and the child's rectangle were a chain of four (the kernel's LDS pipe is its busiest unit: 59 % conflicts).
+    uint4* mv = (uint4*)(((uintptr_t)lp + 15) & ~(uintptr_t)15);
 
     int* selCountOut = P.selCount + (size_t)frame * P.nlevels + level;
     int* lapCountOut = P.lapCount + (size_t)frame * P.nlevels + level;
@@ -1325,9 +1328,10 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             const int hx = (n.x1 - n.x0 + 1) >> 1, hy = (n.y1 - n.y0 + 1) >> 1;
             int p = pb[e];
             int nexp = 0;
+            uint32_t cp[4];
             for (int q = 0; q < 4; q++) {
                 const int c = cc[4 * i + q];
-                if (c == 0) { childPos[4 * i + q] = 0xFFFF; continue; }
+                if (c == 0) { cp[q] = 0xFFFFu; continue; }
                 ONode ch;
                 ch.x0 = (q & 1) ? (short)(n.x0 + hx) : n.x0;
                 ch.x1 = (q & 1) ? n.x1 : (short)(n.x0 + hx);
@@ -1335,23 +1339,26 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
                 ch.y1 = (q & 2) ? n.y1 : (short)(n.y0 + hy);
                 const int np = totalPushed - 1 - p;
                 if (np < C) { rect[nxt][np] = ch; cnt[nxt][np] = c; seq[nxt][np] = seqCounter + p; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
-                childPos[4 * i + q] = (uint16_t)np;
+                cp[q] = (uint32_t)np & 0xFFFFu;
                 nexp += c > 1;
                 p++;
             }
+            mv[i] = make_uint4((uint32_t)(uint16_t)n.x0 | ((uint32_t)(uint16_t)n.y0 << 16), (uint32_t)(uint16_t)n.x1 | ((uint32_t)(uint16_t)n.y1 << 16),
+                               cp[0] | (cp[1] << 16), cp[2] | (cp[3] << 16));
             if (nexp) atomicAdd(&ctl[1], nexp);
         }
         for (int i = tid; i < size; i += OCT_T)
             if (!(nchild[i] & 0x100)) {
                 const int np = totalPushed + sb[i];
-                if (np < C) { rect[nxt][np] = R[i]; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
+                const ONode n = R[i];
+                if (np < C) { rect[nxt][np] = n; cnt[nxt][np] = CN[i]; seq[nxt][np] = seq[cur][i]; if (P.merge) *(int4*)&ccn[4 * np] = make_int4(0, 0, 0, 0); }
+                const uint32_t pp = ((uint32_t)np & 0xFFFFu) * 0x00010001u;
+                mv[i] = make_uint4((uint32_t)(uint16_t)n.x0 | 0x8000u | ((uint32_t)(uint16_t)n.y0 << 16), (uint32_t)(uint16_t)n.x1 | ((uint32_t)(uint16_t)n.y1 << 16), pp, pp);
             }
         __syncthreads();
         PROF_MARK(1, 5);   // next list built
         // 6. move keys, and count them into the children of their NEW node (next round's step 2)
         {
-            const ONode* Rn = rect[nxt];
-            const int* CNn = cnt[nxt];
             for (int k0 = tid; k0 < nk; k0 += OCT_U * OCT_T) {
                 int ndv[OCT_U]; uint32_t kyv[OCT_U];
 #pragma unroll
@@ -1361,21 +1368,24 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
                     const int nd = ndv[u], k = k0 + u * OCT_T;
                     if (nd < 0) continue;
                     const int x = kyv[u] & 0xFFF, y = (kyv[u] >> 12) & 0xFFF;
-                    int nn;
-                    if (nchild[nd] & 0x100) {
-                        const ONode n = R[nd];
-                        const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-                        const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                        nn = childPos[4 * nd + q];
-                    } else {
-                        nn = totalPushed + sb[nd];
-                    }
+                    const uint4 rec = mv[nd];
+                    const bool und = (rec.x & 0x8000u) != 0;
+                    const int x0 = (int)(rec.x & 0x7FFFu), y0 = (int)(rec.x >> 16), x1 = (int)(rec.y & 0xFFFFu), y1 = (int)(rec.y >> 16);
+                    const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+                    const int q = (x < x0 + hx ? 0 : 1) | (y < y0 + hy ? 0 : 2);   // == (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3)
+                    const uint32_t cpw = (q & 2) ? rec.w : rec.z;
+                    const int nn = (int)((q & 1) ? cpw >> 16 : cpw & 0xFFFFu);      // (an undivided node: its own new position in all four)
                     keyNode[k] = (uint16_t)nn;
-                    if (P.merge && nn < C && CNn[nn] > 1) {
-                        const ONode n = Rn[nn];
-                        const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-                        const int q = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                        atomicAdd(&ccn[4 * nn + q], 1);
+                    if (P.merge && nn < C) {
+                        // the rectangle of the key's NEW node, as step 5 made it (the quadrant's child, or the node itself), and the key's quadrant in it;
+                        // counted for every node (the counts of a node with one key are never read)
+                        int cx0 = x0, cx1 = x1, cy0 = y0, cy1 = y1;
+                        if (!und) {
+                            if (q & 1) cx0 = x0 + hx; else cx1 = x0 + hx;
+                            if (q & 2) cy0 = y0 + hy; else cy1 = y0 + hy;
+                        }
+                        const int cmx = cx0 + ((cx1 - cx0 + 1) >> 1), cmy = cy0 + ((cy1 - cy0 + 1) >> 1);
+                        atomicAdd(&ccn[4 * nn + ((x < cmx ? 0 : 1) | (y < cmy ? 0 : 2))], 1);
                     }
                 }
             }
@@ -2606,9 +2616,9 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     if (maxPitch > FAST_PITCH) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "FAST tile wider than FAST_PITCH"); }
     h->fastImgBytes = (maxRows * FAST_PITCH + 15) & ~15;
     h->fastSmem = (size_t)h->fastImgBytes + 4 * FAST_Q1W * 2 + FAST_Q2CAP * 2 + FAST_TW + (8 + FAST_MAXCELLS) * 4;
-    // 92 B per node with the second child-count buffer, 76 without: very large nFeatures fall back to two key walks per round
-    h->octMerge = (size_t)(256 + 16) * 4 + (size_t)nodeCap * 92 + 15 <= 150 * 1024 ? 1 : 0;
-    h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (h->octMerge ? 92 : 76) + 15) & ~(size_t)15);
+    // 100 B per node with the second child-count buffer, 84 without (+ 16 for the alignment of the 16-byte move records)
+    h->octMerge = (size_t)(256 + 16) * 4 + (size_t)nodeCap * 100 + 16 + 15 <= 150 * 1024 ? 1 : 0;
+    h->octKeyOff = (int)(((size_t)(256 + 16) * 4 + (size_t)nodeCap * (h->octMerge ? 100 : 84) + 16 + 15) & ~(size_t)15);
     h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;   // with the key cache; launches without it pass octKeyOff bytes
     if (h->octSmem > 150 * 1024) h->octSmem = (size_t)h->octKeyOff;   // node arrays of a very large nFeatures leave no room: no cache
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
