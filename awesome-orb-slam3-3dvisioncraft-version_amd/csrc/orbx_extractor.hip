@@ -1116,6 +1116,26 @@ static __device__ __forceinline__ void block_scan_excl_fn2(int* a, const int na,
     *totalA = totA; *totalB = totB;
 }
 
+// cnt[t] += 1 for every lane with t >= 0, aggregated by the wave — for the assignment walk, where ALL keys of a level fall on one or two roots and
+// their eight quadrants: a plain ds_add_u32 then works through 64 lanes on the same word.  Up to OCT_AGG distinct targets are taken one by one
+// (leader's target -> ballot of its lanes -> one add of their number); what is left adds directly.  Every lane of the wave must call it.
+// (The later rounds' key moves spread over many nodes: aggregating those made the kernel slower.)
+#ifndef OCT_AGG
+#define OCT_AGG 8
+#endif
+static __device__ __forceinline__ void wave_agg_add(int* cnt, const int t) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(t >= 0);
+    for (int it = 0; it < OCT_AGG && todo; it++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tt = __builtin_amdgcn_readlane(t, leader);
+        const unsigned long long m = __ballot(t == tt);
+        if (lane == leader) atomicAdd(&cnt[tt], __popcll(m));
+        todo &= ~m;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&cnt[t], 1);
+}
+
 struct ONode { short x0, y0, x1, y1; };
 #ifndef OCT_KEYCAP
 #define OCT_KEYCAP 4096   // candidates per (frame, level) that the LDS key cache holds (6 B each); levels with more take the global-memory path
@@ -1177,19 +1197,24 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     __syncthreads();
     // (with the second child-count buffer the assignment walk also counts the keys into the roots' children — the first round's own key walk — and
     // the walk that renumbers the keys runs only if a root came back empty: two of a level's nine key walks)
-    for (int k = tid; k < nk; k += OCT_T) {
-        const uint32_t key = keys[k];
-        const float x = (float)(key & 0xFFF);
-        int r = (int)(x / L.hX);
-        r = min(r, L.nIni - 1);
-        keyNode[k] = (uint16_t)r;
-        atomicAdd(&cnt[0][r], 1);
-        if (P.merge) {
-            const ONode n = rect[0][r];
-            const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
-            const int kx = key & 0xFFF, ky = (key >> 12) & 0xFFF;
-            atomicAdd(&ccb[1][4 * r + ((kx < mx) ? (ky < my ? 0 : 2) : (ky < my ? 1 : 3))], 1);
+    for (int kb = 0; kb < nk; kb += OCT_T) {             // (wave-uniform trip count: wave_agg_add)
+        const int k = kb + tid;
+        int r = -1, cq = -1;
+        if (k < nk) {
+            const uint32_t key = keys[k];
+            const float x = (float)(key & 0xFFF);
+            r = (int)(x / L.hX);
+            r = min(r, L.nIni - 1);
+            keyNode[k] = (uint16_t)r;
+            if (P.merge) {
+                const ONode n = rect[0][r];
+                const int mx = n.x0 + ((n.x1 - n.x0 + 1) >> 1), my = n.y0 + ((n.y1 - n.y0 + 1) >> 1);
+                const int kx = key & 0xFFF, ky = (key >> 12) & 0xFFF;
+                cq = 4 * r + ((kx < mx) ? (ky < my ? 0 : 2) : (ky < my ? 1 : 3));
+            }
         }
+        wave_agg_add(cnt[0], r);
+        if (P.merge) wave_agg_add(ccb[1], cq);
     }
     __syncthreads();
     // drop empty roots (:572-583), keep order
