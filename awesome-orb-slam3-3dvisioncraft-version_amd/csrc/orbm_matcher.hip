@@ -1022,7 +1022,7 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
 //     the frame walks its window at once, in the reference's order (grid columns outer, CSR order inside a column = iy inner, insertion order inside
 //     a cell: Frame.cc:779-850).  That order IS ascending CSR position, so a candidate's rank in the serial strict-'<' scans of ORBmatcher.cc:137-158 /
 //     :2355-2368 is the rank of its key  dist << 22 | p << 6 | octave  — a plain unsigned compare.  A lane keeps its SBPF_SD smallest keys sorted in
-//     registers; what falls out of that list goes, unordered, to the query's row of the workspace (64 keys).
+//     registers; what falls out of that list goes, unordered, to the query's row of the workspace (SBPF_ROW = 128 keys).
 // (2) The serial accept loop as parallel fixed-point rounds.  The loop's state is the occupancy: candidate p is blocked for query q iff an EARLIER
 //     query q' < q accepted it while holding an observed point (ORBmatcher.cc:125-127 / :2347-2349; the call's initial occupancy is filtered in (1)).
 //     So a query's decision d[q] = F_q(d[0..q-1]) depends on the earlier decisions only, through blk[p] = the smallest accepting-and-observed query
@@ -1031,14 +1031,14 @@ static __global__ __launch_bounds__(64) void k_sbp_resolve(SbpArgs A) {
 //     chain is shorter than r is final — and stops after the first round that changes nothing (at most nq + 1 rounds; 8-9 on the benchmark's
 //     frames, where the one-wave walk of k_sbp_resolve takes ~1000 dependent steps).  blk is double-buffered and its entries carry the round that
 //     wrote them ((0xFFFF - r) << 16 | q under atomicMin: a newer round overrides, an entry of an older round reads as "nobody"), so a round is ONE
-//     workgroup barrier.  A query whose kept keys are all claimed reads on in its workspace row (two smallest unblocked keys of an unordered set);
-//     one with more than SBPF_SD + 64 candidates walks its window again with the reference's own best / second-best update.  All exact.
+//     workgroup barrier.  A query whose kept keys are all claimed reads on in its workspace row (two smallest unblocked keys of an unordered set, read
+//     by the whole wave); one that reads past SBPF_SD + SBPF_ROW candidates raises the frame's flag (the one-wave walk below redoes it).  All exact.
 // (3) What the walk leaves behind is reconstructed from the fixed point: kp_match[c] = the LAST accepter of c (only accepters without an observed
 //     point can share a key point), nmatches = the number of accepters, then the rotation-histogram cull and the "a query's match is reported
 //     only while its key point still holds it" filter exactly as k_sbp_resolve applies them.
 // Queries beyond the workgroup's 1024 threads (cap_q = nFeatures + 64 is a little more than 1024 at nFeatures = 1000) keep their lists in LDS
 // instead of registers (TAIL): the register budget of the common case stays that of one query per thread.
-// A frame this form does not cover — rig twins / right-camera queries — raises serial_flag[b] and is redone by the gated launches behind it
+// A frame this form does not cover — rig twins / right-camera queries, a list read past its kept keys — raises serial_flag[b] and is redone by the gated launches behind it
 // (k_sbp_candidates_flagged -> k_sbp_resolve).  INIT mode, rigs with stereo links and frames beyond the LDS limits never come here (sbp_launch).
 struct SbpfFrame { const uint16_t* gs; const uint32_t* ge; const float* gx; const float* gy; const uint32_t* dsc; const uint8_t* occ0; const float* ur; int n; };
 #define SBPF_DP 9          // descriptor row pitch in LDS, dwords (odd: random rows spread over the banks)
@@ -1101,7 +1101,7 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
 #endif
 #define SBPF_SD 8          // smallest keys kept per query (the benchmark's lists hold 3.4 entries on average, 16 at most)
 #define SBPF_ROW 128       // keys kept behind them in the query's workspace row (k_sbp_frame's rows are SBPF_ROW words; the fallback kernels lay their own 66-word rows over them)
-                           // (the th = 15 local-map search after a relocalisation holds up to ~90 candidates per query; beyond list + rows a lane walks its window again)
+                           // (the th = 15 local-map search after a relocalisation holds up to ~90 candidates per query; a list read past list + row hands the frame to the one-wave walk)
 #define SBPF_KEY(dist, p, oct) (((uint32_t)(dist) << 22) | ((uint32_t)(p) << 6) | ((uint32_t)(oct) & 0x3Fu))
 #define SBPF_KEY_P(k) (((k) >> 6) & 0xFFFFu)
 // a query's kept keys: in registers (one query per thread) or, for the queries beyond the workgroup's threads, in LDS (key-major: lanes = consecutive queries)
