@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/orbhip.h"
+#include "lds_optin.inc"
 
 struct Quat { double x, y, z, w; };
 struct SE3 { Quat r; double t[3]; };
@@ -1282,14 +1283,10 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     const size_t cholSmem = A.panExt ? wg_chol_smem_bytes_ext_t<LM_CHOL_NT, CH_NB>((int)np6)
                                      : nb32 ? wg_chol_smem_bytes_t<LM_CHOL_NT, 32>((int)np6) : wg_chol_smem_bytes_t<LM_CHOL_NT, CH_NB>((int)np6);
     if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)
-    if (cholSmem > 64 * 1024 &&
-        hipFuncSetAttribute(nb32 ? (const void*)k_lm_chol<32> : (const void*)k_lm_chol<CH_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
-        return ORB_E_HIP;
+    if (orb_lds_optin(nb32 ? (const void*)k_lm_chol<32> : (const void*)k_lm_chol<CH_NB>, cholSmem) != ORB_OK) return ORB_E_HIP;
     // few windows: the factorisation as one launch per phase, its trailing updates spread over the machine (k_lm_chol_panel / _update / _back)
     const bool cholSplit = nb32 && batch <= LM_CHOL_SPLIT_MAX_BATCH;
-    if (cholSplit && cholSmem > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k_lm_chol_back<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cholSmem) != hipSuccess)
-        return ORB_E_HIP;
+    if (cholSplit && orb_lds_optin((const void*)k_lm_chol_back<32>, cholSmem) != ORB_OK) return ORB_E_HIP;
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
@@ -1304,9 +1301,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     const int schurNW = fills ? 1 : lm_schur_smem_bytes(rowCap, 4) <= 48 * 1024 ? 4 : lm_schur_smem_bytes(rowCap, 2) <= 48 * 1024 ? 2 : 1;
     const size_t schurSmem = lm_schur_smem_bytes(rowCap, schurNW);
     hipLaunchKernelGGL(k_lm_rowmeta, dim3((P.cap_e + 8 + 255) / 256, batch), dim3(256), 0, st, A);
-    if (schurSmem > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)k_lm_schur_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schurSmem) != hipSuccess)
-        return ORB_E_HIP;
+    if (orb_lds_optin((const void*)k_lm_schur_rows<1>, schurSmem) != ORB_OK) return ORB_E_HIP;
     int aborted = 0;
     for (int it = 0; it < iterations && !aborted; it++) {
         // computeActiveErrors + activeRobustChi2, buildSystem.  After the first iteration the state is the one the last lambda trial left —

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "../../include/orbhip.h"
+#include "lds_optin.inc"
 #include "dense_chol.inc"
 
 #define LIBA_T 256
@@ -937,7 +938,7 @@ extern "C" int liba_optimize(const liba_problem* prob, int batch, double lambda_
     A.cholOff = head;
     const size_t smem = head + std::max(wg_chol_smem_bytes(A.DRmax), (size_t)LIBA_T * LIBA_MAX_FREE * 4);
     if (smem > 160 * 1024) return ORB_E_INVALID;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_liba_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    if (orb_lds_optin((const void*)k_liba_optimize, smem) != ORB_OK) return ORB_E_HIP;
     hipLaunchKernelGGL(k_liba_optimize, dim3(batch), dim3(LIBA_T), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
@@ -1315,7 +1316,7 @@ extern "C" int liba_pose_inertial_kf(liba_keyframe* d_frames, const liba_keyfram
     PoseInertialArgs A{d_frames, const_cast<liba_keyframe*>(d_keyframes), d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, nullptr, rec_init, d_outlier, d_H, d_n_good};
     const size_t smem = pose_inertial_smem(cap_e, 15);
     if (smem > 160 * 1024) return ORB_E_INVALID;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    if (orb_lds_optin((const void*)k_pose_inertial<false>, smem) != ORB_OK) return ORB_E_HIP;
     hipLaunchKernelGGL(k_pose_inertial<false>, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }
@@ -1329,7 +1330,7 @@ extern "C" int liba_pose_inertial_lastframe(liba_keyframe* d_frames, liba_keyfra
     PoseInertialArgs A{d_frames, d_prev_frames, d_rigs, rig_stride, d_edges, d_n_edges, cap_e, d_imu, d_priors, rec_init, d_outlier, d_H, d_n_good};
     const size_t smem = pose_inertial_smem(cap_e, 30);
     if (smem > 160 * 1024) return ORB_E_INVALID;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k_pose_inertial<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return ORB_E_HIP;
+    if (orb_lds_optin((const void*)k_pose_inertial<true>, smem) != ORB_OK) return ORB_E_HIP;
     hipLaunchKernelGGL(k_pose_inertial<true>, dim3(batch), dim3(64), smem, (hipStream_t)stream, A);
     return hipGetLastError() == hipSuccess ? ORB_OK : ORB_E_HIP;
 }

@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include "../../include/orbhip.h"
+#include "lds_optin.inc"
 
 #define GRID_CELLS (ORBM_GRID_COLS * ORBM_GRID_ROWS)
 #define SBP_CAPC 64                 // cached candidates per query (more -> the resolver re-enumerates that query inline)
@@ -1829,22 +1830,15 @@ static int sbp_launch(const orb_keypoint* d_kps, const uint8_t* d_desc, const fl
     const int capk4 = (cap_k + 3) & ~3;
     const int tailq = cap_q > SBPF_T ? cap_q - SBPF_T : 0;
     const size_t smem_f = (32 + 8 + 8) * 4 + (size_t)capk4 * (12 + 12 + 4 * SBPF_DP) + (GRID_CELLS + 2) * 2 + (size_t)tailq * SBPF_SD * 4;
+    // (> 64 KB of dynamic LDS: only where the device grants it to both instantiations — lds_optin.inc, once per device and kernel, thread safe;
+    //  a device with a smaller LDS takes the rounds pair below like every call k_sbp_frame does not cover)
     const bool fused = SBP_FUSED_FRAME && params->mode != ORBM_MODE_INIT && !d_kp_link && cells == GRID_CELLS && smem_f <= 150 * 1024 &&
-                       cap_q <= 2 * SBPF_T;
+                       cap_q <= 2 * SBPF_T &&
+                       orb_lds_optin(tailq ? (const void*)k_sbp_frame<true> : (const void*)k_sbp_frame<false>, smem_f) == ORB_OK;
     if (fused) A.serial_flag = (int32_t*)((uint32_t*)d_work + (size_t)batch * cap_q * SBP_WORK_ROW);
     const bool timed = mt_ready();
     if (timed) (void)hipEventRecord(g_mt.ev[2], (hipStream_t)stream);
     if (fused) {
-        // > 64 KB of dynamic LDS needs the opt-in, once per device of the process (idempotent: a race between two host threads sets it twice; a
-        // failure surfaces at the launch)
-        static bool attr_done[64] = {false};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_sbp_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (dev >= 0 && dev < 64) attr_done[dev] = true;
-        }
         if (tailq) hipLaunchKernelGGL(k_sbp_frame<true>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);
         else hipLaunchKernelGGL(k_sbp_frame<false>, dim3(batch), dim3(SBPF_T), smem_f, (hipStream_t)stream, A);
         if (timed) (void)hipEventRecord(g_mt.ev[3], (hipStream_t)stream);

@@ -24,6 +24,8 @@
 #include <vector>
 
 #include "../../include/orbhip.h"
+#include "lds_optin.inc"
+#include <mutex>
 
 #define ORBX_MAX_LEVELS 16
 // Phase timers for kernel experiments (-DORBX_PROF builds under exp_so/ only; never in the product build): lane 0 of every wave adds the
@@ -2513,7 +2515,9 @@ struct orbx_extractor {
     std::string err;
 };
 
-static std::string g_create_err;
+// error text of the calling thread's last failed orbx_create (no handle exists to hold it): per thread, so that two threads creating extractors
+// concurrently — the reference builds its left / right extractors from Tracking's constructor, hosts may do it anywhere — never share a std::string
+static thread_local std::string g_create_err;
 
 static inline int cvRoundF(float v) { return (int)lrintf(v); }
 static inline int cvRoundD(double v) { return (int)lrint(v); }
@@ -2647,11 +2651,11 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     h->octSmem = (size_t)h->octKeyOff + (size_t)OCT_KEYCAP * 6;   // with the key cache; launches without it pass octKeyOff bytes
     if (h->octSmem > 150 * 1024) h->octSmem = (size_t)h->octKeyOff;   // node arrays of a very large nFeatures leave no room: no cache
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
-    if (h->octSmem > 64 * 1024 && hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octSmem) != hipSuccess) {
-        orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipFuncSetAttribute(k_octree) failed");
-    }
 
     if (hipSetDevice(device) != hipSuccess) { orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipSetDevice failed"); }
+    if (orb_lds_optin((const void*)k_octree, h->octSmem) != ORB_OK) {      // (on `device`: the opt-in is per device and kernel)
+        orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipFuncSetAttribute(k_octree) failed");
+    }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::string m = std::string(#call) + ": " + hipGetErrorString(e_); orbx_free(h); return orbx_fail(nullptr, e_ == hipErrorOutOfMemory ? ORB_E_NOMEM : ORB_E_HIP, m); } } while (0)
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& e : h->ev) CK(hipEventCreate(&e));
@@ -2723,24 +2727,31 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipHostMalloc((void**)&h->h_retry, 8, hipHostMallocDefault));
     h->h_retry[0] = 0; h->h_retry[1] = 1;
     CK(hipHostMalloc((void**)&h->h_out, h->out1Bytes, hipHostMallocDefault));
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
     {
-        float pf[1024];
-        for (int i = 0; i < 256; i++) {   // h_pattern: x0, y0, x1, y1 per pair (ORBextractor.cc:149-406)
-            pf[4 * i] = (float)h_pattern[4 * i]; pf[4 * i + 1] = (float)h_pattern[4 * i + 2];
-            pf[4 * i + 2] = (float)h_pattern[4 * i + 1]; pf[4 * i + 3] = (float)h_pattern[4 * i + 3];
-        }
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(c_patternf), pf, sizeof(pf)));
-    }
-    {
-        uint32_t icmask[16][12];
-        for (int v = 0; v < 16; v++)
-            for (int k = 0; k < 12; k++) {
-                uint32_t m = 0;
-                for (int t = 0; t < 4; t++) { const int u = 4 * k + t - 21; if (u >= -h->umax[v] && u <= h->umax[v]) m |= 0xFFu << (8 * t); }
-                icmask[v][k] = m;
+        // c_umax / c_patternf / c_icmask do not depend on the configuration (HALF_PATCH_SIZE = 15, the 256 test pairs): uploaded by the FIRST handle of a
+        // device, under a mutex — a later orbx_create (another camera's extractor, an adapter re-creating its handle for a new image size, any host
+        // thread) must not rewrite constant memory that the kernels of a live handle are reading
+        static std::mutex constMu;
+        static bool constDone[64] = {false};
+        std::lock_guard<std::mutex> lock(constMu);
+        if (device < 0 || device >= 64 || !constDone[device]) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->umax, sizeof(h->umax)));
+            float pf[1024];
+            for (int i = 0; i < 256; i++) {   // h_pattern: x0, y0, x1, y1 per pair (ORBextractor.cc:149-406)
+                pf[4 * i] = (float)h_pattern[4 * i]; pf[4 * i + 1] = (float)h_pattern[4 * i + 2];
+                pf[4 * i + 2] = (float)h_pattern[4 * i + 1]; pf[4 * i + 3] = (float)h_pattern[4 * i + 3];
             }
-        CK(hipMemcpyToSymbol(HIP_SYMBOL(c_icmask), icmask, sizeof(icmask)));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(c_patternf), pf, sizeof(pf)));
+            uint32_t icmask[16][12];
+            for (int v = 0; v < 16; v++)
+                for (int k = 0; k < 12; k++) {
+                    uint32_t m = 0;
+                    for (int t = 0; t < 4; t++) { const int u = 4 * k + t - 21; if (u >= -h->umax[v] && u <= h->umax[v]) m |= 0xFFu << (8 * t); }
+                    icmask[v][k] = m;
+                }
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(c_icmask), icmask, sizeof(icmask)));
+            if (device >= 0 && device < 64) constDone[device] = true;
+        }
     }
 #undef CK
     *out = h;

@@ -57,9 +57,15 @@ def algorithmic_bytes(W, H, N):
         "pyramid": P[0] + sum(P[1:-1]) + p_ge1,      # read levels 0..6 once, write levels 1..7 once
         "fast": sum(P) + 4 * 10 * N,                   # read every level once + ~10N packed candidates out
         "octree": 4 * 10 * N * 2 + 8 * N,              # candidates in (twice: assign + select), selection out
-        "describe": N * (43 * 43 + 60),                # 43x43 neighbourhood in, 28 B keypoint + 32 B descriptor out
+        "describe": N * (961 + 512 + 60),              # 31x31 orientation patch + 512 rBRIEF samples in, 28 B key point + 32 B descriptor out
     }
     return whole, per_kernel
+
+
+def describe_patch_bytes(N):
+    """What k_describe2 really stages per key point: the 43x43 neighbourhood the 7x7 blur of the 31x31 patch reads (+ the 60 bytes out).  Reported
+    next to the SURVEY figure (`algorithmic_bytes()["describe"]`), never used for a roofline fraction."""
+    return N * (43 * 43 + 60)
 
 
 _C_TOKEN = re.compile(r'"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'|//[^\n]*|/\*.*?\*/', re.S)
@@ -105,11 +111,38 @@ def camera_for(w, h):
     return (fx * w / 752.0, fy * h / 480.0, cx * w / 752.0, cy * h / 480.0, dist)
 
 
-def make_batch(B, seed0=0, unique=16, w=None, h=None):
-    from orbhip.synth import synth_image
-    w, h = w or W, h or H
-    base = [synth_image(seed0 + i, w, h) for i in range(min(unique, max(1, B // 2)))]
-    rng = np.random.default_rng(seed0 + 12345)
+def _synth_one(spec):
+    """One base scene by kind (SURVEY 8(d) "Synthetic inputs"): textured = the corner-rich generator, sparse = 10 rectangles and 5 discs on the smooth
+    background, low_contrast = the textured scene at 12 % contrast (forces the minThFAST retries), flat = constant grey (zero key points), noise =
+    uniform random bytes (every cell full of corners)."""
+    from orbhip.synth import flat_image, low_contrast_image, synth_image
+    kind, seed, w, h = spec
+    if kind == "textured":
+        return synth_image(seed, w, h)
+    if kind == "sparse":
+        return synth_image(seed, w, h, n_rect=10, n_disc=5)
+    if kind == "low_contrast":
+        return low_contrast_image(seed, w, h)
+    if kind == "flat":
+        return flat_image(w, h, 40 + seed % 160)
+    if kind == "noise":
+        return np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+    raise ValueError(kind)
+
+
+def synth_many(specs, workers=1):
+    """[(kind, seed, w, h)] -> list of images.  `workers` > 1 forks a process pool (0.15 s per textured 752x480 scene on one core): only to be used
+    BEFORE this process initialises HIP."""
+    if workers <= 1 or len(specs) < 8:
+        return [_synth_one(sp) for sp in specs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, len(specs))) as pool:
+        return pool.map(_synth_one, specs, chunksize=max(1, len(specs) // (4 * workers)))
+
+
+def _pair_up(base, B, rng):
+    """Frames 2j, 2j+1 = base scene j mod len(base) (rolled when the bases are used more than once), and the same moved by SHIFT px + sensor noise:
+    consecutive views of one scene."""
     frames = []
     for j in range((B + 1) // 2):
         k = j // len(base)
@@ -117,6 +150,34 @@ def make_batch(B, seed0=0, unique=16, w=None, h=None):
         b = np.clip(np.roll(a, (SHIFT[1], SHIFT[0]), (0, 1)).astype(np.int16) + rng.integers(-3, 4, a.shape), 0, 255).astype(np.uint8)
         frames += [a, b]
     return np.stack(frames[:B])
+
+
+def make_batch(B, seed0=0, unique=16, w=None, h=None, workers=1):
+    """B frames = B/2 pairs (a scene, the scene moved by SHIFT + noise) over `unique` distinct base scenes (seeds seed0 ..).  The headline uses
+    unique = B/2: every pair its own seeded scene."""
+    w, h = w or W, h or H
+    base = synth_many([("textured", seed0 + i, w, h) for i in range(min(unique, max(1, B // 2)))], workers)
+    return _pair_up(base, B, np.random.default_rng(seed0 + 12345))
+
+
+MIXED_SHARES = (("textured", 0.60), ("sparse", 0.20), ("low_contrast", 0.10), ("flat", 0.05), ("noise", 0.05))
+
+
+def make_mixed_batch(B, seed0=0, w=None, h=None, workers=1):
+    """The mixed batch of the round-4 verdict: B/2 pairs whose base scenes are 60 % textured, 20 % sparse, 10 % low-contrast, 5 % flat, 5 % uniform
+    noise — every scene its own seed, the pairs shuffled — so that neighbouring workgroups see different amounts of work.  -> (frames, kinds per frame)"""
+    w, h = w or W, h or H
+    npairs = (B + 1) // 2
+    kinds = []
+    for kind, share in MIXED_SHARES:
+        kinds += [kind] * int(round(share * npairs))
+    kinds = (kinds + ["textured"] * npairs)[:npairs]
+    rng = np.random.default_rng(seed0 + 777)
+    order = rng.permutation(npairs)
+    kinds = [kinds[i] for i in order]
+    base = synth_many([(k, seed0 + i, w, h) for i, k in enumerate(kinds)], workers)
+    frames = _pair_up(base, B, np.random.default_rng(seed0 + 12345))
+    return frames, [kinds[i // 2] for i in range(B)]
 
 
 def grow_batch_on_device(d_frames, B):
@@ -160,32 +221,50 @@ class StepPipeline:
     streams.  The same object is what tests/test_bench_config_parity.py checks against the oracle frame by frame."""
     LAP = (0, 1000)
 
-    def __init__(self, d_frames, w, h, nfeat, device_index, streams=3):
+    def __init__(self, d_frames, w, h, nfeat, device_index, streams=3, frames_host=None):
+        """d_frames: one resident batch [B,H,W] u8, or a LIST of them = input sets the steps rotate over (step i reads set i mod len: consecutive
+        steps never see the same images; every set has its own prepared projection records).  frames_host: the same on the host (for the checker)."""
         import torch
         import orbhip
         from orbhip.frame import Camera, FrameOps
         self.torch, self.orbhip = torch, orbhip
-        self.d_frames, self.w, self.h, self.nfeat, self.di, self.streams = d_frames, w, h, nfeat, device_index, streams
-        self.dev = d_frames.device
-        self.B = d_frames.shape[0]
+        sets = list(d_frames) if isinstance(d_frames, (list, tuple)) else [d_frames]
+        hosts = (list(frames_host) if isinstance(frames_host, (list, tuple)) else [frames_host]) if frames_host is not None else [None] * len(sets)
+        self.w, self.h, self.nfeat, self.di, self.streams = w, h, nfeat, device_index, streams
+        self.dev = sets[0].device
+        self.B = sets[0].shape[0]
+        assert all(s_.shape == sets[0].shape for s_ in sets) and len(hosts) == len(sets)
         self.cam = camera_for(w, h)
         self.ex = orbhip.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device_index, max_batch=self.B)
         self.m = orbhip.ORBmatcher(0.9, True)
         self.fo = FrameOps(Camera.make(*self.cam), w, h)
         self.grid = self.fo.grid
-        # first pass: the projection records of every frame's partner (the "last frame" of the motion model) — prepared once, resident in HBM, like a map
-        self.out = self.ex.extract_batch(d_frames, self.LAP)
-        self.cap = self.out[0].shape[1]
-        self.un = self.fo.UndistortKeyPoints(self.out[0], self.out[2].view(-1), count_stride=2)
-        torch.cuda.synchronize()
-        counts0 = self.out[2].cpu().numpy()
-        self.q, self.nq, self.src = build_match_queries(self.un.cpu().numpy(), counts0, self.ex.GetScaleFactors(), self.cap)
-        self.d_q = torch.from_numpy(self.q.view(np.uint8).reshape(self.B, self.cap, 28)).to(self.dev)
-        self.d_nq = torch.from_numpy(self.nq).to(self.dev)
-        self.d_qdesc = self.out[1][torch.from_numpy(self.src).to(self.dev)].contiguous()
+        # first pass per input set: the projection records of every frame's partner (the "last frame" of the motion model) — prepared once, resident in
+        # HBM, like a map
+        self.sets = []
+        self.out = None
+        for d_set, host in zip(sets, hosts):
+            self.out = self.ex.extract_batch(d_set, self.LAP, out=self.out)
+            self.cap = self.out[0].shape[1]
+            un = self.fo.UndistortKeyPoints(self.out[0], self.out[2].view(-1), count_stride=2)
+            torch.cuda.synchronize()
+            counts0 = self.out[2].cpu().numpy()
+            q, nq, src = build_match_queries(un.cpu().numpy(), counts0, self.ex.GetScaleFactors(), self.cap)
+            self.sets.append(dict(d_frames=d_set, frames_host=host, q=q, nq=nq, src=src,
+                                  d_q=torch.from_numpy(q.view(np.uint8).reshape(self.B, self.cap, 28)).to(self.dev), d_nq=torch.from_numpy(nq).to(self.dev),
+                                  d_qdesc=self.out[1][torch.from_numpy(src).to(self.dev)].contiguous()))
+            self.un = un
+        self._use_set(0)
         self.work = torch.empty(self.m._L.orbm_search_workspace_bytes(self.B, self.cap), dtype=torch.uint8, device=self.dev)
         self.res = self.gbuf = None
         self._stream_state = None
+
+    def _use_set(self, i):
+        """Make input set i the current one: what the next extraction / match reads and what snapshot() / check_against_oracle() refer to."""
+        self.cur = i
+        st = self.sets[i]
+        self.d_frames, self.frames_host, self.q, self.nq, self.src = st["d_frames"], st["frames_host"], st["q"], st["nq"], st["src"]
+        self.d_q, self.d_nq, self.d_qdesc = st["d_q"], st["d_nq"], st["d_qdesc"]
 
     def _match(self, out):
         cnt = out[2].view(-1)
@@ -232,6 +311,8 @@ class StepPipeline:
         torch = self.torch
         S = self._stream_state
         k = S["step_no"] % S["nbuf"]
+        if len(self.sets) > 1:
+            self._use_set(S["step_no"] % len(self.sets))
         S["step_no"] += 1
         with torch.cuda.stream(S["sX"][k]):
             if self.streams >= 2 and S["evB_set"][k]:
@@ -249,6 +330,8 @@ class StepPipeline:
                 S["evB_set"][k] = True
 
     def extract_only_step(self):
+        if len(self.sets) > 1:
+            self._use_set((self.cur + 1) % len(self.sets))
         self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
 
     def snapshot(self, sel=None):
@@ -266,6 +349,8 @@ class StepPipeline:
         import bench_check
         sel = np.arange(self.B) if sel is None else np.asarray(sel)
         snap = self.snapshot(sel)
+        if frames_host is None:
+            frames_host = self.frames_host
         fr = frames_host[sel] if frames_host is not None else self.d_frames[self.torch.as_tensor(sel, device=self.dev, dtype=self.torch.long)].cpu().numpy()
         cam9 = np.array(list(self.cam[:4]) + list(self.cam[4]) + [0.0], np.float32)
         qd = self.d_qdesc[self.torch.as_tensor(sel, device=self.dev, dtype=self.torch.long)].cpu().numpy()
@@ -289,7 +374,7 @@ def measure_traffic_live(kernel_base, batch, size, nfeat, timeout_s=150):
     tmp = tempfile.mkdtemp(prefix="orbhip_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--headline-only", "--no-parity-check",
-           "--streams", "1", "--no-pmc", "--batch", str(batch), "--size", size, "--nfeatures", str(nfeat)]
+           "--streams", "1", "--no-pmc", "--input-sets", "1", "--batch", str(batch), "--size", size, "--nfeatures", str(nfeat)]
     got = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -371,9 +456,52 @@ def cpu_baseline(frames, q, qdesc, nq, cam9, grid4, budget_s=24.0):
                       % (cores, nt, per_thread, len(frames), W, H, fps1, n1, meankp, meanmt)}
 
 
+def resolve_world(gpus, environ, visible_devices=None):
+    """What `--gpus N` means for this process.  -> ("run", world) when this process is a rank (or the single-GPU run), ("launch", N) when it must
+    start the N ranks itself; raises SystemExit(2) with a message when --gpus contradicts the launcher's WORLD_SIZE or asks for more GPUs than the
+    node shows.  The driver starts N>1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE = N: "run"); a bare
+    `python bench.py --gpus N` (WORLD_SIZE unset) launches the same thing itself — it never silently measures one GPU and prints n_gpus = 1."""
+    env_world = environ.get("WORLD_SIZE")
+    if env_world is not None:
+        world = int(env_world)
+        if gpus is not None and gpus != world:
+            raise SystemExit("bench.py: --gpus %d contradicts WORLD_SIZE=%d set by the launcher; refusing to run" % (gpus, world))
+        return "run", world
+    n = 1 if gpus is None else gpus
+    if n < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if n == 1:
+        return "run", 1
+    if visible_devices is not None and environ.get("ORBHIP_BENCH_ONE_DEVICE") != "1" and visible_devices < n:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); refusing to run (ORBHIP_BENCH_ONE_DEVICE=1 puts every rank on device 0: "
+                         "a dry run of the N>1 code path, not a measurement)" % (n, visible_devices))
+    return "launch", n
+
+
+def self_launch(n, argv):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py <argv>`
+    (one rank per GPU over RCCL; the same command line the driver uses)."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node = ranks (default: WORLD_SIZE if a launcher set it, else 1).  Without a launcher, "
+                                                            "N > 1 starts the N ranks itself (torch.distributed.run, 127.0.0.1); a --gpus that contradicts WORLD_SIZE is refused")
+    ap.add_argument("--launch-check", action="store_true", help="resolve --gpus / WORLD_SIZE, start the ranks, form the process group, print "
+                                                                 '{"n_gpus": world, "ranks": [...]} on rank 0 and exit — no GPU touched (CPU-tier test of the launch logic)')
     ap.add_argument("--steps", type=int, default=50)   # 50 x 2.4 ms: the un-overlapped match of the last step (0.5 ms) is 0.4 % of the timed region (1 % at 20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
@@ -393,6 +521,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
     ap.add_argument("--lba-windows", type=int, default=256, help="LBA windows per GPU per step (linearisations/s against windows per launch on MI355X: 4 -> 67 k, 16 -> 78 k, 64 -> 83 k, 256 -> 91 k; tools/exp_lba_windows.py)")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
+    ap.add_argument("--input-sets", type=int, default=3, help="resident input sets the steps rotate over (step i reads set i mod N; every set = --batch frames "
+                                                               "from --batch/2 distinct seeded scenes with its own projection records): consecutive steps never see the same images")
+    ap.add_argument("--scenes", type=int, default=0, help="distinct base scenes per input set (0 = --batch/2: every frame pair its own scene; round 4 used 16)")
     ap.add_argument("--size", default="752x480", help="frame size WxH (the headline is 752x480; 1280x720 is BASELINE configs[3]'s frame shape)")
     ap.add_argument("--nfeatures", type=int, default=1000, help="ORBextractor nFeatures (1500 with --size 1280x720)")
     args = ap.parse_args()
@@ -400,13 +531,48 @@ def main():
     W, H = [int(v) for v in args.size.lower().split("x")]
     NFEAT = args.nfeatures
 
+    ndev = None
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1 and not args.launch_check:
+        import torch
+        ndev = torch.cuda.device_count()
+    action, world = resolve_world(args.gpus, os.environ, ndev)
+    if action == "launch":
+        self_launch(world, sys.argv[1:])        # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        import torch.distributed as dist
+        ranks = [rank]
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("ORBHIP_BENCH_BACKEND", "gloo"))
+            got = [None] * world
+            dist.all_gather_object(got, (rank, local_rank))
+            ranks = got
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks": ranks, "launch_check": True}))
+        return
+
+    # ---- host inputs first (a forked worker pool: before this process initialises HIP).  Headline: --input-sets resident sets of B frames, every frame
+    # pair its own seeded scene (B/2 distinct scenes per set; the ranks use disjoint seeds)
+    B = args.batch
+    t_in = time.perf_counter()
+    workers = max(1, min(16, usable_cores()[0] // max(1, world)))
+    scenes = args.scenes or max(1, B // 2)
+    host_sets = [make_batch(B, seed0=1000 * rank + 100000 * s_, unique=scenes, workers=workers) for s_ in range(max(1, args.input_sets))]
+    frames = host_sets[0]
+    aux_legs = not args.headline_only and (world == 1 or args.all_legs)
+    host_mixed = make_mixed_batch(B, seed0=7000 + 1000 * rank, workers=workers) if aux_legs else None
+    host_16 = make_batch(B, seed0=1000 * rank, unique=16, workers=workers) if aux_legs else None
+    host_1280 = make_batch(256, seed0=5000 + 1000 * rank, unique=32, w=1280, h=720, workers=workers) if not args.headline_only else None
+    input_seconds = time.perf_counter() - t_in
+
     import torch
     import torch.distributed as dist
     import orbhip
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -415,6 +581,8 @@ def main():
         backend = os.environ.get("ORBHIP_BENCH_BACKEND", "nccl")
         if os.environ.get("ORBHIP_BENCH_ONE_DEVICE") == "1":
             local_rank = 0
+        elif local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (local rank %d, %d visible); refusing to run" % (rank, local_rank, torch.cuda.device_count()))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -422,10 +590,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    B = args.batch
-    frames = make_batch(B, seed0=1000 * rank)
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_sets = [torch.from_numpy(f_).to(dev) for f_ in host_sets]
+    d_frames = d_sets[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -467,16 +633,23 @@ def main():
         return [float(v) for v in t.tolist()]
 
     # ---- the step: ORBextractor -> UndistortKeyPoints (EuRoC calibration) -> AssignFeaturesToGrid -> SearchByProjection (motion model)
-    P = StepPipeline(d_frames, W, H, NFEAT, local_rank, streams=args.streams)
-    ex, m, grid, cap, q, nq, d_qdesc = P.ex, P.m, P.grid, P.cap, P.q, P.nq, P.d_qdesc
+    P = StepPipeline(d_sets, W, H, NFEAT, local_rank, streams=args.streams, frames_host=host_sets)
+    ex, m, grid, cap = P.ex, P.m, P.grid, P.cap
+    q, nq, d_qdesc = P.sets[0]["q"], P.sets[0]["nq"], P.sets[0]["d_qdesc"]          # set 0's projection records (the CPU baseline's sample)
     CAM = P.cam
     kern = P.kernel_times()          # a few sequential passes (warm kernels and clocks), then the per-kernel timing pass — before the extra streams exist
     P.start_streams()
     for _ in range(args.warmup):
         P.step()
     # the headline: `--repeats` timed regions of exactly --steps steps; `value` is the MEDIAN region (min / max reported next to it)
-    dts = rank_max(timed(P.step, args.steps, args.repeats))
+    dts_rank = timed(P.step, args.steps, args.repeats)
+    dts = rank_max(dts_rank)
     dt = float(np.median(dts))
+    per_rank_fps = [B * args.steps / float(np.median(dts_rank))]
+    if world > 1:       # every rank's own median region (the barriers make them nearly equal; a slow GPU shows in the spread of the step's kernels instead)
+        tg = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tg, torch.tensor(per_rank_fps, dtype=torch.float64, device=dev))
+        per_rank_fps = [float(t_.item()) for t_ in tg]
     torch.cuda.synchronize()
     out, res = P.out, P.res
     counts = out[2].cpu().numpy()
@@ -489,7 +662,7 @@ def main():
     if not args.no_parity_check:
         sel = np.arange(B) if world == 1 else np.unique(np.linspace(0, B - 1, min(B, 64)).astype(np.int64))
         tpc = time.perf_counter()
-        n_chk, bad, tot = P.check_against_oracle(sel, frames_host=frames)
+        n_chk, bad, tot = P.check_against_oracle(sel)           # (the input set the last timed step read)
         nbad = rank_max([float(len(bad))])[0]
         parity = {"checked_frames": int(n_chk) * world, "mismatches": int(nbad), "first_mismatches": bad[:4], "seconds": round(time.perf_counter() - tpc, 2),
                   "keypoints_compared": int(tot["keypoints"]), "matches_compared": int(tot["matches"]),
@@ -691,7 +864,8 @@ def main():
         #      synthetic node descriptors) followed by SearchByBoW of every frame pair, all on the device CSRs
         from orbhip.bow import ORBVocabulary, synth_vocabulary_fast
         kps, desc = out[0], out[1]
-        voc = ORBVocabulary(synth_vocabulary_fast(5, 10, 6, sample_desc=desc[0, :int(counts[0, 0])].cpu().numpy()), device=dev.index or 0)
+        counts_b = out[2].cpu().numpy()      # (the batch `out` holds: the input set the last extraction read)
+        voc = ORBVocabulary(synth_vocabulary_fast(5, 10, 6, sample_desc=desc[0, :int(counts_b[0, 0])].cpu().numpy()), device=dev.index or 0)
         nfeat = out[2][:, 0].contiguous()
         bw = voc.transform(desc, nfeat, 4)
         barrier()
@@ -792,9 +966,9 @@ def main():
         # ---- north_star's second frame size: 1280x720, nFeatures = 1500 (TUM_512.yaml:62's feature count on BASELINE configs[3]'s frame shape),
         #      the SAME step (extract + undistort + grid + SearchByProjection on 3 streams) and the extraction alone, with their roofline fractions
         FW, FH, FN, FB = 1280, 720, 1500, 256
-        fr = make_batch(FB, seed0=5000 + 1000 * rank, unique=8, w=FW, h=FH)
+        fr = host_1280                       # 256 frames over 32 distinct seeded scenes (generated before HIP came up)
         dfr = torch.from_numpy(fr).to(dev)
-        P2 = StepPipeline(dfr, FW, FH, FN, local_rank, streams=args.streams)
+        P2 = StepPipeline(dfr, FW, FH, FN, local_rank, streams=args.streams, frames_host=fr)
         k2 = P2.kernel_times(warm=2)
         P2.start_streams()
         for _ in range(3):
@@ -831,7 +1005,7 @@ def main():
         #      4096 frames (1.48 GB of input, 4.6 GB of pyramid per handle) cannot — the rate must not depend on that residency.
         sweep = {}
         for SB in (64, 4096):
-            dfs = grow_batch_on_device(d_frames, SB)
+            dfs = grow_batch_on_device(torch.cat(d_sets) if SB > B else d_frames, SB)      # 4096 = the resident sets' distinct frames, then rolled copies
             Ps = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=args.streams)
             Ps.kernel_times(warm=1)
             Ps.start_streams()
@@ -852,6 +1026,54 @@ def main():
         sweep[str(B)] = {"frames_per_s": round(world * B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps,
                          "input_bytes": int(B) * W * H, "note": "the headline"}
         extra["batch_sweep"] = sweep
+
+    def leg_scene_diversity():
+        # ---- round-4 verdict, weak #2: the headline now reads --input-sets x B frames, every pair its own scene.  This leg times round 4's input (ONE
+        #      resident set, 512 frames rolled out of 16 base scenes) with the same step, so the line shows what the input change alone did to the rate
+        d16 = torch.from_numpy(host_16).to(dev)
+        P16 = StepPipeline(d16, W, H, NFEAT, local_rank, streams=args.streams, frames_host=host_16)
+        P16.kernel_times(warm=2)
+        P16.start_streams()
+        for _ in range(3):
+            P16.step()
+        d16s = rank_max(timed(P16.step, args.steps, 3))
+        fps16 = world * B * args.steps / float(np.median(d16s))
+        ent = {"headline_distinct_scenes": int(scenes * len(d_sets)), "headline_input_sets": len(d_sets), "headline_frames_per_s": round(world * B * args.steps / dt, 1),
+               "r04_input_16_scenes_one_set_frames_per_s": round(fps16, 1), "ratio_headline_over_r04_input": round((world * B * args.steps / dt) / fps16, 4),
+               "r04_input_fast_passes": P16.ex.last_fast_passes()}
+        if not args.no_parity_check:
+            sel16 = np.unique(np.linspace(0, B - 1, 32).astype(np.int64))
+            n16, bad16, _ = P16.check_against_oracle(sel16)
+            ent["r04_input_parity"] = {"checked_frames": int(n16), "mismatches": len(bad16), "first_mismatches": bad16[:2]}
+        extra["scene_diversity"] = ent
+        del P16, d16
+
+    def leg_mixed_batch():
+        # ---- round-4 verdict, item 3(b): B frames = 60 % textured, 20 % sparse, 10 % low-contrast, 5 % flat, 5 % uniform-noise scenes, shuffled — workgroups of one
+        #      launch see very different amounts of work (empty cells and minThFAST retries next to full ones, octree levels far below / far above their quota)
+        fm, kinds = host_mixed
+        dm = torch.from_numpy(fm).to(dev)
+        Pm = StepPipeline(dm, W, H, NFEAT, local_rank, streams=args.streams, frames_host=fm)
+        km = Pm.kernel_times(warm=2)
+        Pm.start_streams()
+        for _ in range(3):
+            Pm.step()
+        dms = rank_max(timed(Pm.step, args.steps, 3))
+        cm = Pm.out[2].cpu().numpy()[:, 0]
+        nmm = Pm.res[2].cpu().numpy()
+        kinds_a = np.array(kinds)
+        ent = {"frames_per_s": round(world * B * args.steps / float(np.median(dms)), 1), "ms_per_step": round(float(np.median(dms)) / args.steps * 1e3, 4),
+               "frames_per_s_min": round(world * B * args.steps / max(dms), 1), "frames_per_s_max": round(world * B * args.steps / min(dms), 1),
+               "shares": dict(MIXED_SHARES), "fast_passes": Pm.ex.last_fast_passes(), "kernel_ms": {k: round(v, 4) for k, v in km.items()},
+               "mean_keypoints_by_kind": {k: round(float(cm[kinds_a == k].mean()), 1) for k in sorted(set(kinds))},
+               "mean_matches_by_kind": {k: round(float(nmm[kinds_a == k].mean()), 1) for k in sorted(set(kinds))},
+               "frames_by_kind": {k: int((kinds_a == k).sum()) for k in sorted(set(kinds))}}
+        if not args.no_parity_check:
+            nmx, badm, totm = Pm.check_against_oracle(None)
+            ent["parity"] = {"checked_frames": int(nmx), "mismatches": len(badm), "first_mismatches": badm[:2], "keypoints_compared": int(totm["keypoints"]),
+                             "matches_compared": int(totm["matches"])}
+        extra["mixed_batch"] = ent
+        del Pm, dm
 
     def leg_exchange():
         # N > 1 only: the two exchange steps of the path on RCCL — descriptor blocks for cross-rank matching, and the
@@ -925,7 +1147,7 @@ def main():
     if not args.headline_only:
         legs = (("host_api", leg_host_api), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
                 ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
-                ("batch_sweep", leg_batch_sweep))
+                ("scene_diversity", leg_scene_diversity), ("mixed_batch", leg_mixed_batch), ("batch_sweep", leg_batch_sweep))
         # N>1: the legs the multi-GPU line is read for (the metric's LBA component, north_star's second frame size); the per-GPU side figures are the
         # N=1 line's business and would only add run time and failure surface to a scaling run (--all-legs runs them anyway)
         keep = None if (world == 1 or args.all_legs) else ("lba", "size_1280x720")
@@ -1005,16 +1227,24 @@ def main():
                                   "orb_extract_frames_per_s": round(fps_extract, 1),
                                   "local_ba_linearizations_per_s": extra.get("lba", {}).get("linearizations_per_s"),
                                   "local_ba_lm_iterations_per_s": extra.get("lba", {}).get("lm_iterations_per_s")},
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "n_gpus": world, "rccl_ranks": (world if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
+            "per_rank": {"frames_per_s": [round(v, 1) for v in per_rank_fps], "min": round(min(per_rank_fps), 1), "max": round(max(per_rank_fps), 1),
+                         "what": "every rank's own median timed region (frames it processed / its own clock between the same barriers)"},
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d grayscale batch, ORB extract (nFeatures=%d, 8 levels, 1.2, FAST 20/7) + SearchByProjection match "
                                    "(motion model, th=15) against the partner frame's %d points%s" % (W, H, NFEAT, int(round(Nq)), parity_note),
                        "parity_checked_frames": parity["checked_frames"], "parity_mismatches": parity["mismatches"], "parity": parity,
-                       "frames_per_gpu_per_step": B, "mean_keypoints": Nk, "mean_queries": Nq, "mean_matches": float(nm.mean()),
+                       "frames_per_gpu_per_step": B, "input_sets": len(d_sets), "distinct_scenes_per_set": int(scenes), "input_seconds": round(input_seconds, 2),
+                       "inputs": "%d resident input sets x %d frames per GPU, rotated step by step; every frame pair its own seeded scene (%d distinct scenes per set), "
+                                 "partner = the scene moved by (%d, %d) px + sensor noise" % (len(d_sets), B, int(scenes), SHIFT[0], SHIFT[1]),
+                       "mean_keypoints": Nk, "mean_queries": Nq, "mean_matches": float(nm.mean()),
                        "parallelism": "frames sharded, %d rank(s), no collective" % world, "world": world, "hip_streams": args.streams,
                        "backend": (dist.get_backend() if world > 1 else None)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": traffic_note,
+                         "traffic_ratio": (round(traffic / (pk[dom] * B), 3) if traffic else None),        # corrected HBM bytes / algorithmic bytes of the dominant kernel
+                         "describe_patch_bytes_per_frame": describe_patch_bytes(NFEAT),                       # what k_describe2 stages (43x43 per key point); the fraction uses SURVEY's 1 533 B
                          # SQ counters of the same profile: the kernel's occupancy and the SIMD cycles one wave-level VALU instruction costs it, next to the
                          # floor its instruction mix allows at the MEASURED issue rates (valu_issue_frac_of_measured_peak = floor / measured: 1 = the SIMDs
                          # issue back to back, the kernel's HBM fraction then follows from its instruction count alone)

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <mutex>
 
 namespace orbslam3_hip {
 
@@ -32,26 +33,40 @@ inline std::atomic<unsigned long>& glue_failure_counter() noexcept {
 inline unsigned long glue_failures() noexcept { return glue_failure_counter().load(); }
 
 // the most recent failure: the glue function's name and the exception text (what() of the adapters' errors carries the ORB_E_* code), for a
-// host that polls.  Plain buffers written before the counter is bumped; concurrent failures may interleave the text, never the counter.
+// host that polls.  Tracking, LocalMapping and LoopClosing can fail (and a host thread can poll) at the same time: the slot is written and copied
+// out under a mutex — a reader sees one failure's (function, what) pair whole, never a mix of two.
 struct GlueLastError { char function[64]; char what[192]; };
 inline GlueLastError& glue_last_error_slot() noexcept { static GlueLastError e{{0}, {0}}; return e; }
-inline GlueLastError glue_last_error() noexcept { return glue_last_error_slot(); }
+inline std::mutex& glue_last_error_mutex() noexcept { static std::mutex m; return m; }
+inline GlueLastError glue_last_error() noexcept {
+    std::lock_guard<std::mutex> lock(glue_last_error_mutex());
+    return glue_last_error_slot();
+}
 
-// optional notification, called from the failing thread after the counter is bumped: (function name, message, total failures so far)
+// optional notification, called from the failing thread after the counter is bumped: (function name, message, total failures so far).  It runs
+// inside a noexcept function on a thread the reference starts bare: it should not throw; if it does, the exception is swallowed here (a report on
+// stderr), it never reaches std::terminate
 using GlueFailureCallback = void (*)(const char* fn, const char* what, unsigned long total);
 inline std::atomic<GlueFailureCallback>& glue_failure_callback_slot() noexcept { static std::atomic<GlueFailureCallback> cb{nullptr}; return cb; }
 inline void glue_set_failure_callback(GlueFailureCallback cb) noexcept { glue_failure_callback_slot().store(cb); }
 
 inline int glue_report(const char* fn, const char* what) noexcept {
-    GlueLastError& le = glue_last_error_slot();
-    std::strncpy(le.function, fn, sizeof(le.function) - 1); le.function[sizeof(le.function) - 1] = 0;
-    std::strncpy(le.what, what, sizeof(le.what) - 1); le.what[sizeof(le.what) - 1] = 0;
-    const unsigned long n = ++glue_failure_counter();
+    unsigned long n;
+    {
+        std::lock_guard<std::mutex> lock(glue_last_error_mutex());
+        GlueLastError& le = glue_last_error_slot();
+        std::strncpy(le.function, fn, sizeof(le.function) - 1); le.function[sizeof(le.function) - 1] = 0;
+        std::strncpy(le.what, what, sizeof(le.what) - 1); le.what[sizeof(le.what) - 1] = 0;
+        n = ++glue_failure_counter();
+    }
     // stderr is rate-limited: the first 8 failures, then every 256th — a persistent fault fails at frame rate
     if (n <= 8 || (n & 255u) == 0)
         std::fprintf(stderr, "[orbhip] %s: %s -- call dropped: the reference's nothing-found value is returned (failure %lu%s)\n", fn, what, n,
                      n == 8 ? "; further reports every 256th" : "");
-    if (GlueFailureCallback cb = glue_failure_callback_slot().load()) cb(fn, what, n);
+    if (GlueFailureCallback cb = glue_failure_callback_slot().load()) {
+        try { cb(fn, what, n); }
+        catch (...) { std::fprintf(stderr, "[orbhip] %s: the failure callback threw; ignored\n", fn); }
+    }
     return 0;
 }
 inline int glue_failed(const char* fn, const std::exception& e) noexcept { return glue_report(fn, e.what()); }

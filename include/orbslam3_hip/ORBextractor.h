@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../orbhip.h"
+#include "GlueGuard.h"
 #ifdef ORBHIP_WITH_OPENCV
 #include <opencv2/core/core.hpp>
 #endif
@@ -57,8 +58,21 @@ public:
 
 #ifdef ORBHIP_WITH_OPENCV
     // ORBextractor.h:57-59 — identical signature; `_mask` is ignored exactly as in the reference.
-    int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
-                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    // The reference calls this on two bare std::threads (Frame::ExtractORB, Frame.cc:111-112,1209-1210) where an exception is std::terminate, and its
+    // own operator() never throws: a failure below (device lost, allocation) is reported through GlueGuard.h and the call returns what the reference
+    // returns for an image it finds nothing in — no key points, released descriptors, -1.  extract() (the flattened form) keeps throwing.
+    int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea) noexcept {
+        try { return call(_image, _mask, _keypoints, _descriptors, vLappingArea); }
+        catch (const std::exception& e) { (void)glue_failed("ORBextractor::operator()", e); }
+        catch (...) { (void)glue_failed("ORBextractor::operator()"); }
+        try { _keypoints.clear(); _descriptors.release(); } catch (...) {}
+        return -1;
+    }
+    // _descriptors.create(n, 32, CV_8U) yields a continuous Mat (a fresh allocation, or the caller's own n x 32 CV_8U Mat of the same size, which
+    // cv::Mat::create leaves in place only if it already is that shape): the single memcpy below relies on it, so it is checked.
+    int call(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+             cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
         if (_image.empty()) return -1;
         cv::Mat image = _image.getMat();
         CV_Assert(image.type() == CV_8UC1);  // ORBextractor.cc:1082
@@ -71,7 +85,9 @@ public:
         if (k.empty()) _descriptors.release();
         else {
             _descriptors.create((int)k.size(), 32, CV_8U);
-            std::memcpy(_descriptors.getMat().data, d.data(), d.size());
+            cv::Mat dm = _descriptors.getMat();
+            if (dm.isContinuous()) std::memcpy(dm.data, d.data(), d.size());
+            else for (int r = 0; r < dm.rows; r++) std::memcpy(dm.ptr(r), d.data() + (size_t)r * 32, 32);   // (an ROI header handed in as the output)
         }
         // mvImagePyramid is a public member read by Frame::ComputeStereoMatches (Frame.cc:1052,1071): keep it populated,
         // each level as the ROI of a bordered parent exactly like ORBextractor.cc:1164-1179

@@ -38,6 +38,9 @@ public:
     template <class T> const T& at(int r, int c) const { return ((const T*)data)[(size_t)r * cols + c]; }
     template <class T> T& at(int i) { return ((T*)data)[i]; }
     template <class T> const T& at(int i) const { return ((const T*)data)[i]; }
+    bool isContinuous() const { return step == (size_t)cols * esz(); }
+    unsigned char* ptr(int r = 0) { return data + (size_t)r * step; }
+    const unsigned char* ptr(int r = 0) const { return data + (size_t)r * step; }
     template <class T> T* ptr(int r = 0) { return (T*)data + (size_t)r * cols; }
     template <class T> const T* ptr(int r = 0) const { return (const T*)data + (size_t)r * cols; }
     Mat rowRange(int a, int b) const { return block(a, b, 0, cols); }

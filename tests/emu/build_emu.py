@@ -18,9 +18,10 @@ SRCS = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 CXX = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w", "-I", EMU, "-I", os.path.join(ROOT, "include")]
 
 
-def build(force=False, defines=(), tag=""):
+def build(force=False, defines=(), tag="", flags=()):
+    """flags: extra compiler / linker switches for every object of the variant (e.g. -fsanitize=thread for the TSAN build of the threading test)"""
     out = OUT if not tag else OUT.replace(".so", "_" + tag + ".so")
-    return _build(out, force, tuple(defines))
+    return _build(out, force, tuple(defines), tuple(flags))
 
 
 def _headers():
@@ -33,24 +34,24 @@ def _mentions(path, names):
     return any(re.search(r"\b%s\b" % re.escape(n), text) for n in names)
 
 
-def _object(src, defines, headers, force):
+def _object(src, defines, headers, force, flags=()):
     """the object of one source file under `defines` (only those that can reach it), rebuilt when the file or a header is newer"""
     names = [d.split("=")[0] for d in defines]
     everywhere = [n for n in names if any(_mentions(h, [n]) for h in headers)]
     mine = tuple(d for d in defines if d.split("=")[0] in everywhere or _mentions(src, [d.split("=")[0]]))
-    key = hashlib.sha1(" ".join(mine).encode()).hexdigest()[:10] if mine else "plain"
+    key = hashlib.sha1(" ".join(mine + tuple(flags)).encode()).hexdigest()[:10] if (mine or flags) else "plain"
     obj = os.path.join(EMU, "build", "obj", "%s__%s.o" % (os.path.basename(src), key))
     deps = [src] + headers
     if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
         return obj
     os.makedirs(os.path.dirname(obj), exist_ok=True)
     tmp = obj + ".tmp%d" % os.getpid()
-    subprocess.check_call(CXX + ["-D" + d for d in mine] + ["-x", "c++", "-c", src, "-o", tmp])
+    subprocess.check_call(CXX + list(flags) + ["-D" + d for d in mine] + ["-x", "c++", "-c", src, "-o", tmp])
     os.replace(tmp, obj)
     return obj
 
 
-def _build(out, force, defines):
+def _build(out, force, defines, flags=()):
     headers = _headers()
     deps = SRCS + headers
 
@@ -65,9 +66,9 @@ def _build(out, force, defines):
         fcntl.flock(lk, fcntl.LOCK_EX)
         if not force and fresh():
             return out
-        objs = [_object(s, defines, headers, force) for s in SRCS]
+        objs = [_object(s, defines, headers, force, flags) for s in SRCS]
         tmp = out + ".tmp%d" % os.getpid()
-        subprocess.check_call(["g++", "-shared", "-o", tmp] + objs)
+        subprocess.check_call(["g++", "-shared"] + list(flags) + ["-o", tmp] + objs)
         os.replace(tmp, out)
     return out
 

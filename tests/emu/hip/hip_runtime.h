@@ -1,11 +1,12 @@
-// TEST INFRASTRUCTURE ONLY — a single-threaded, fiber-based emulator of the small slice of the HIP
+// TEST INFRASTRUCTURE ONLY — a fiber-based emulator of the small slice of the HIP
 // programming model the product kernels use, so that the *unmodified* kernel sources under
 // awesome-orb-slam3-3dvisioncraft-version_amd/csrc/ can be compiled with g++ and their LOGIC checked
 // against the oracle in the CPU-only (`-m "not gpu"`) test tier.  This file shadows <hip/hip_runtime.h>
 // only when tests/emu is put on the include path by tests/emu/build_emu.py.  The product never loads
 // the emulated library; the shipped path is the hipcc-built liborbhip.so and nothing else.
 //
-// Model: one workgroup at a time; every work-item is a ucontext fiber; __syncthreads() and the wave
+// Model: one workgroup at a time PER HOST THREAD (all scheduler state, the built-in index variables and the LDS image are thread_local: host
+// threads may launch concurrently, as Tracking / LocalMapping / LoopClosing do — tests/cpp/threads_test.cpp); every work-item is a ucontext fiber; __syncthreads() and the wave
 // intrinsics (__ballot, __shfl*) are barriers among the fibers of the block / of one 64-lane wave.
 // Fibers are run in ascending or (EMU_REVERSE=1) descending lane order between barriers, which makes
 // most missing-barrier races show up as wrong answers in one of the two orders.
@@ -27,7 +28,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__
+#define __shared__ thread_local
 #define __constant__
 #define HIP_EMULATED 1
 
@@ -58,23 +59,52 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErr
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 
+#if defined(__SANITIZE_THREAD__)
+// ThreadSanitizer cannot follow swapcontext on its own: every fiber is announced through its fiber API (a switch with flags = 0 also
+// synchronises the two fibers, so the lanes of one launch — one host thread's sequential schedule — never race with each other; races BETWEEN
+// host threads are what the TSAN build of tests/cpp/threads_test.cpp is for)
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+}
+#define EMU_TSAN 1
+#endif
+
 namespace emu {
 enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+// one work-item slot of a host thread: created on first use, then reused by every block that thread runs (its trampoline loops over launches, so
+// its stack — and, under TSAN, its shadow call stack — is back at the same depth whenever a block starts)
+struct Fiber {
+    ucontext_t ctx;            // never moved once made (glibc's ucontext_t points into itself)
+    char* stack = nullptr;
+    void* tsan = nullptr;
+};
 struct State {
     ucontext_t sched;
-    std::vector<ucontext_t> ctx;
+    std::vector<Fiber*> fib;
     std::vector<int> st;
-    std::vector<char> stacks;
     std::function<void()> body;
     int cur = 0, nthreads = 0;
+    void* tsan_main = nullptr;
     dim3 block;
     uint64_t wavebuf[16][64];
+    ~State() {
+        for (Fiber* f : fib) {
+#ifdef EMU_TSAN
+            if (f->tsan) __tsan_destroy_fiber(f->tsan);
+#endif
+            free(f->stack);
+            delete f;
+        }
+    }
 };
-inline State& S() { static State s; return s; }
+inline State& S() { static thread_local State s; return s; }
 }  // namespace emu
 
-inline dim3 threadIdx, blockIdx, blockDim, gridDim;
-alignas(256) inline unsigned char orb_smem[160 * 1024];
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+alignas(256) inline thread_local unsigned char orb_smem[160 * 1024];
 static const int warpSize = 64;
 
 namespace emu {
@@ -84,16 +114,30 @@ inline void set_tid(int t) {
     threadIdx.y = (t / s.block.x) % s.block.y;
     threadIdx.z = t / (s.block.x * s.block.y);
 }
+inline void to_sched(State& s) {
+#ifdef EMU_TSAN
+    __tsan_switch_to_fiber(s.tsan_main, 0);
+#endif
+    swapcontext(&s.fib[s.cur]->ctx, &s.sched);
+}
+inline void to_fiber(State& s, int i) {
+#ifdef EMU_TSAN
+    __tsan_switch_to_fiber(s.fib[i]->tsan, 0);
+#endif
+    swapcontext(&s.sched, &s.fib[i]->ctx);
+}
 inline void yield(int why) {
     State& s = S();
     s.st[s.cur] = why;
-    swapcontext(&s.ctx[s.cur], &s.sched);
+    to_sched(s);
 }
 inline void trampoline() {
-    State& s = S();
-    s.body();
-    s.st[s.cur] = DONE;
-    swapcontext(&s.ctx[s.cur], &s.sched);
+    State& s = S();     // (a fiber only ever runs on the host thread that made it)
+    for (;;) {          // one turn per block this slot takes part in
+        s.body();
+        s.st[s.cur] = DONE;
+        to_sched(s);
+    }
 }
 inline void run_block(dim3 block, const std::function<void()>& body) {
     State& s = S();
@@ -102,15 +146,22 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
     s.block = block;
     s.nthreads = n;
     s.body = body;
-    s.ctx.resize(n);
     s.st.assign(n, RUNNABLE);
-    if (s.stacks.size() < STK * (size_t)n) s.stacks.resize(STK * (size_t)n);
-    for (int i = 0; i < n; i++) {
-        getcontext(&s.ctx[i]);
-        s.ctx[i].uc_stack.ss_sp = s.stacks.data() + STK * (size_t)i;
-        s.ctx[i].uc_stack.ss_size = STK;
-        s.ctx[i].uc_link = &s.sched;
-        makecontext(&s.ctx[i], (void (*)())trampoline, 0);
+#ifdef EMU_TSAN
+    s.tsan_main = __tsan_get_current_fiber();
+#endif
+    while ((int)s.fib.size() < n) {
+        Fiber* f = new Fiber;
+        f->stack = (char*)malloc(STK);
+        getcontext(&f->ctx);
+        f->ctx.uc_stack.ss_sp = f->stack;
+        f->ctx.uc_stack.ss_size = STK;
+        f->ctx.uc_link = &s.sched;
+        makecontext(&f->ctx, (void (*)())trampoline, 0);
+#ifdef EMU_TSAN
+        f->tsan = __tsan_create_fiber(0);
+#endif
+        s.fib.push_back(f);
     }
     static const bool reverse = getenv("EMU_REVERSE") && atoi(getenv("EMU_REVERSE"));
     const int nw = (n + 63) / 64;
@@ -121,7 +172,7 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
             if (s.st[i] != RUNNABLE) continue;
             s.cur = i;
             set_tid(i);
-            swapcontext(&s.sched, &s.ctx[i]);
+            to_fiber(s, i);
             ran = true;
         }
         bool released = false, alldone = true, allblock = true;

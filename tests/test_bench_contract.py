@@ -112,6 +112,61 @@ def test_bench_cli_parses_without_gpu():
         assert flag in out.stdout
 
 
+def test_gpus_flag_resolution():
+    """Round-4 verdict, item 1: `--gpus N` without a launcher starts N ranks, with a launcher it must agree with WORLD_SIZE, and it never silently
+    runs one rank."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_world(None, {}) == ("run", 1) and bench.resolve_world(1, {}) == ("run", 1)
+    assert bench.resolve_world(8, {}, visible_devices=8) == ("launch", 8)
+    assert bench.resolve_world(8, {"WORLD_SIZE": "8"}) == ("run", 8) and bench.resolve_world(None, {"WORLD_SIZE": "4"}) == ("run", 4)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {"WORLD_SIZE": "1"})
+    with pytest.raises(SystemExit):
+        bench.resolve_world(1, {"WORLD_SIZE": "2"})
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {}, visible_devices=1)             # more GPUs asked for than the node has: refuse, do not measure one
+    assert bench.resolve_world(2, {"ORBHIP_BENCH_ONE_DEVICE": "1"}, visible_devices=1) == ("launch", 2)    # the documented one-device dry run
+    with pytest.raises(SystemExit):
+        bench.resolve_world(0, {})
+
+
+def test_gpus_2_self_launch_starts_two_ranks():
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) re-executes under torch.distributed.run: two ranks form a group and rank 0 prints
+    n_gpus = 2.  --launch-check stops before anything touches a GPU (gloo), so the launch logic itself runs in the CPU tier."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and sorted(r[0] for r in d["ranks"]) == [0, 1] and sorted(r[1] for r in d["ranks"]) == [0, 1]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "contradicts WORLD_SIZE" in bad.stderr
+
+
+def test_inputs_of_the_headline():
+    """make_batch keeps round 4's frames for the same arguments (committed fixtures and the GPU-tier parity tests depend on them); the mixed batch holds
+    the five scene kinds in the stated shares, every pair from its own seed."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    a = bench.make_batch(6, seed0=3, unique=2, w=160, h=120)
+    b = bench.make_batch(6, seed0=3, unique=2, w=160, h=120, workers=1)
+    assert a.shape == (6, 120, 160) and np.array_equal(a, b)
+    assert np.array_equal(a[4], np.roll(a[0], (7, 13), (0, 1)))                     # third pair = first scene again, rolled
+    assert not np.array_equal(a[0], a[2])
+    f, kinds = bench.make_mixed_batch(64, seed0=1, w=160, h=120, workers=2)
+    assert f.shape == (64, 120, 160) and len(kinds) == 64 and kinds[0::2] == kinds[1::2]
+    cnt = {k: kinds.count(k) // 2 for k in set(kinds)}
+    assert cnt["textured"] == 19 and cnt["sparse"] == 6 and cnt["low_contrast"] == 3 and cnt["flat"] == 2 and cnt["noise"] == 2
+    flat = [i for i, k in enumerate(kinds) if k == "flat"][0]
+    assert f[flat].min() == f[flat].max()
+    whole, pk = bench.algorithmic_bytes(752, 480, 1000)
+    assert pk["describe"] == 1000 * (961 + 512 + 60) and bench.describe_patch_bytes(1000) == 1000 * (43 * 43 + 60)      # SURVEY 8(d)'s figure for the fraction
+
+
 def test_source_sha_ignores_comments_only(tmp_path, monkeypatch):
     """profiles/pmc_latest.json is tied to the kernel sources by bench.source_sha(): a comment / white-space edit keeps the tie, a code
     edit (or an edit inside a string literal) breaks it."""
