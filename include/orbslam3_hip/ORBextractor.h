@@ -85,9 +85,11 @@ public:
         if (k.empty()) _descriptors.release();
         else {
             _descriptors.create((int)k.size(), 32, CV_8U);
-            cv::Mat dm = _descriptors.getMat();
-            if (dm.isContinuous()) std::memcpy(dm.data, d.data(), d.size());
-            else for (int r = 0; r < dm.rows; r++) std::memcpy(dm.ptr(r), d.data() + (size_t)r * 32, 32);   // (an ROI header handed in as the output)
+            if (_descriptors.getMat().isContinuous()) std::memcpy(_descriptors.getMat().data, d.data(), d.size());
+            else {   // (an ROI header of a wider Mat handed in as the output: row by row through its step)
+                cv::Mat dm = _descriptors.getMat();
+                for (int r = 0; r < dm.rows; r++) std::memcpy(dm.ptr(r), d.data() + (size_t)r * 32, 32);
+            }
         }
         // mvImagePyramid is a public member read by Frame::ComputeStereoMatches (Frame.cc:1052,1071): keep it populated,
         // each level as the ROI of a bordered parent exactly like ORBextractor.cc:1164-1179
