@@ -551,7 +551,9 @@ struct LmArgs {
     double* Dinv; double* db;               // [cap_l][9], [cap_l][3]
     double* Hs; double* xp; double* xl;     // [np6][np6], [np6], [cap_l*3]
     double* panExt;                         // [np6][CH_LD] per window: Cholesky panel of systems too large for LDS, else nullptr
-    double* cholScratch;                    // [LM_CHOLS_SCRATCH] per window: the per-phase factorisation's diagonal block between two launches
+    double* cholL; double* cholY;           // [np6][np6], [np6] per window: L and y = L^-1 b of the one-launch-per-panel factorisation (k_lm_chol_step), else nullptr
+    double* schurPart; int schurG;          // [batch][np6 / 6][schurG][(np6 / 12 + 1) * 36 + 6]: partial rows of the reduced system when a row is split over schurG workgroups (few windows per call), else nullptr / 1
+    double* cholX;                          // [ceil(np6 / 32)][32][32] per window: the inverses of L's diagonal blocks (row-major), for its backward substitution
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
     int4* rowMeta;                          // [batch][cap_e] per entry of the pose-major edge lists: (edge, landmark, first / end edge of the landmark's run)
@@ -717,24 +719,30 @@ static inline size_t lm_schur_smem_bytes(int rowCap, int nw) { return ((size_t)n
 template <int NW>
 static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int rowCap, int batch, const int32_t* nfreeArr) {
     constexpr int SCH_NT = 64 * NW;
+    // A.schurG > 1 (few windows per call: fewer rows than compute units): blockIdx.y = g takes every schurG-th slice of the row's edges and leaves
+    // its sums — blocks and right-hand-side terms — in A.schurPart; k_lm_schur_combine adds the slices in g order (a fixed order: reproducible)
+    // and does the write-out.  The walk is bound by one compute unit's LDS atomics and L1: a lone window's 80 rows then use 240 units instead of 80.
+    const int G = A.schurG, g = (int)blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* Sall = (double*)orb_smem;                 // [NW][rowCap][SCH_LD]
     double* Srow = Sall + (size_t)wave * rowCap * SCH_LD;   // this wave's copy
     double* coefw = Sall + (size_t)NW * rowCap * SCH_LD;    // [NW][6]
     const lba_problem& P = A.P;
-#ifndef LM_SCHUR_NO_XCD
-    // All rows of a window run on ONE XCD, back to back (workgroup w is dispatched to XCD w % 8): the rows walk the same landmark-major edge
-    // array in the same direction, so a run of B_j blocks fetched for one row is still in that XCD's L2 when the window's other rows want it.
-    const int slot = (int)blockIdx.x >> 3;
-    const int b = (slot / P.cap_p) * 8 + ((int)blockIdx.x & 7);
+    // Eight windows or more: all rows of a window run on ONE XCD, back to back (workgroup w is dispatched to XCD w % 8) — the rows walk the same
+    // landmark-major edge array in the same direction, so a run of B_j blocks fetched for one row is still in that XCD's L2 when the window's
+    // other rows want it.  Fewer windows (the grid is then batch x cap_p wide): rows go round the XCDs — a lone window pinned to one XCD would
+    // run its 80 rows on 32 of the 256 compute units.
+    int b, i1;
+    if (batch >= 8) {
+        const int slot = (int)blockIdx.x >> 3;
+        b = (slot / P.cap_p) * 8 + ((int)blockIdx.x & 7);
+        i1 = P.cap_p - 1 - slot % P.cap_p;            // late (long) rows first
+    } else {
+        b = (int)blockIdx.x / P.cap_p;
+        i1 = P.cap_p - 1 - (int)blockIdx.x % P.cap_p;
+    }
     if (b >= batch) return;
-    const int i1 = P.cap_p - 1 - slot % P.cap_p;      // late (long) rows first
-#else
-    const int b = (int)blockIdx.x / P.cap_p;
-    const int i1 = P.cap_p - 1 - (int)blockIdx.x % P.cap_p;
-    if (b >= batch) return;
-#endif
     if (!A.st[b].needTrial) return;
     const int np = min(P.n_poses[b], P.cap_p), ne = min(P.n_edges[b], P.cap_e);
     if (i1 >= np) return;
@@ -763,14 +771,15 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
         const int nblk = min(rowCap, nslot - c0);
         for (int t = lane; t < nblk * SCH_LD; t += 64) Srow[t] = 0.0;
         __syncthreads();
-        for (int k = s0 + tid; k < s1; k += SCH_NT) {
+        for (int k = s0 + g * SCH_NT + tid; k < s1; k += G * SCH_NT) {
             const int4 mt = meta[k];
             const int e1 = mt.x, l = mt.y;
             double Bi[18];
-            {
-                const double* Bg = Hpl + (size_t)e1 * 18;
+            {   // a 6 x 3 block is 144 bytes on a 16-byte boundary: nine 16-byte loads (every lane reads its own block: a load instruction touches 64
+                // cache lines whatever its width, and the walk is bound by exactly that)
+                const double2* Bg = (const double2*)(Hpl + (size_t)e1 * 18);
 #pragma unroll
-                for (int q = 0; q < 18; q++) Bi[q] = Bg[q];
+                for (int q = 0; q < 9; q++) { const double2 t2 = Bg[q]; Bi[2 * q] = t2.x; Bi[2 * q + 1] = t2.y; }
             }
             const double* Di = Dinv + (size_t)l * 9;
             double BDi[18];     // B_i * Dinv, 6x3 column-major
@@ -800,7 +809,12 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
                 if (d > dlo && !(d == dtie && h1 < h2)) continue;   // the block belongs to workgroup h2
                 d -= c0;
                 if (d < 0 || d >= nblk) continue;     // another column chunk
-                const double* Bj = Hpl + (size_t)e2 * 18;
+                double Bj[18];
+                {
+                    const double2* Bg = (const double2*)(Hpl + (size_t)e2 * 18);
+#pragma unroll
+                    for (int q = 0; q < 9; q++) { const double2 t2 = Bg[q]; Bj[2 * q] = t2.x; Bj[2 * q + 1] = t2.y; }
+                }
                 double* blk = Srow + d * SCH_LD;
 #pragma unroll
                 for (int c = 0; c < 6; c++)
@@ -822,6 +836,18 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
             }
         }
         __syncthreads();
+        if (G > 1) {                                              // (one chunk: the host splits rows only when a row fits LDS whole)
+            double* part = A.schurPart + (((size_t)b * (np6 / 6) + h1) * G + g) * ((size_t)(np6 / 12 + 1) * 36 + 6);
+            for (int t = tid; t < nblk * 36; t += SCH_NT) {
+                const int q = t / 36, k = t - q * 36;
+                double v = Sall[q * SCH_LD + k];
+#pragma unroll
+                for (int w = 1; w < NW; w++) v += Sall[(size_t)w * rowCap * SCH_LD + q * SCH_LD + k];
+                part[t] = v;
+            }
+            __syncthreads();
+            continue;
+        }
         for (int t = tid; t < nblk * 36; t += SCH_NT) {
             const int q = t / 36, k = t - q * 36, d = c0 + q;
             if (d == dtie && 2 * h1 >= n) continue;               // the tie slot belongs to the lower pose of the antipodal pair
@@ -847,14 +873,46 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
     if (tid < 6) {
         double c = 0;
         for (int w = 0; w < SCH_NT / 64; w++) c += coefw[w * 6 + tid];
+        if (G > 1) A.schurPart[(((size_t)b * (np6 / 6) + h1) * G + g) * ((size_t)(np6 / 12 + 1) * 36 + 6) + (size_t)(np6 / 12 + 1) * 36 + tid] = c;
+        else A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - c;
+    }
+}
+
+// the write-out of k_lm_schur_rows for rows that were split over A.schurG workgroups: slices added in g order, then Hpp + lambda I on the diagonal
+// block, the lower / transposed placement and the right-hand side exactly as there.  One workgroup per (free pose, window).
+static __global__ __launch_bounds__(256) void k_lm_schur_combine(LmArgs A, const int32_t* nfreeArr) {
+    const lba_problem& P = A.P;
+    const int b = blockIdx.y, h1 = blockIdx.x, tid = threadIdx.x;
+    if (!A.st[b].needTrial) return;
+    const int n = nfreeArr[b], np6 = A.np6, G = A.schurG;
+    if (h1 >= n) return;
+    const int dtie = (n & 1) ? -1 : (n >> 1), nslot = (n >> 1) + 1;
+    const size_t rowD = (size_t)(np6 / 12 + 1) * 36 + 6;
+    const double* part = A.schurPart + ((size_t)b * (np6 / 6) + h1) * G * rowD;
+    double* Hs = A.Hs + (size_t)b * np6 * np6;
+    for (int t = tid; t < nslot * 36; t += 256) {
+        const int d = t / 36, k = t - d * 36;
+        if (d == dtie && 2 * h1 >= n) continue;
+        const int h2 = h1 - d + (h1 < d ? n : 0);
+        double v = part[t];
+        for (int gg = 1; gg < G; gg++) v += part[(size_t)gg * rowD + t];
+        if (d == 0) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
+        const int c = k / 6, r = k - c * 6;
+        if (h2 <= h1) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;
+        else Hs[(size_t)(h1 * 6 + r) * np6 + h2 * 6 + c] = v;
+    }
+    if (tid < 6) {
+        double c = 0;
+        for (int gg = 0; gg < G; gg++) c += part[(size_t)gg * rowD + (size_t)(np6 / 12 + 1) * 36 + tid];
         A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - c;
     }
 }
 
 #include "dense_chol.inc"
 #ifndef LM_CHOL_SPLIT_MAX_BATCH
-#define LM_CHOL_SPLIT_MAX_BATCH 128   // windows per call up to which the per-phase launches beat one workgroup per window (MI355X, 480 unknowns:
-                                      // 4.7 vs 6.8 ms per optimize(5) at 1 window, 11.4 vs 12.9 at 32, 32.7 vs 33.0 at 128, 60.7 vs 58.5 at 256)
+#define LM_CHOL_SPLIT_MAX_BATCH 64    // windows per call up to which one launch per panel (k_lm_chol_step) beats one workgroup per window (MI355X, ms per
+                                      // optimize(5) of 100-key-frame windows, per panel / per window: 1 window 2.2 / 6.8, 8: 4.0 / 7.5, 32: 10.6 / 12.7, 64: 18.8 / 19.1,
+                                      // 128: 35.6 / 31.7, 256: 67.7 / 55.8; 40-key-frame windows: 8: 1.68 / 2.17, 64: 5.4 / 5.7, 256: 16.8 / 16.4)
 #endif
 #ifndef LM_CHOL_NT
 #define LM_CHOL_NT 512    // 8 waves per window: the factorisation is one workgroup per window, its trailing update a global-memory latency problem
@@ -870,120 +928,266 @@ static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const i
         A.st[b].ok = 0;
 }
 
-// The factorisation as one launch per phase (dense_chol.inc): batches that leave most compute units idle.  kb = first column of the panel.
-//   k_lm_chol_panel   one wave per 64 rows of the panel: every wave factors the 32 x 32 diagonal block for itself (registers, the same steps
-//                     as wg_chol_solve: identical values everywhere), then solves its rows against it and takes their share of the forward
-//                     substitution.  The factored block and its 32 right-hand-side entries go to a scratch slab — other waves are still
-//                     reading the unfactored block from Hs — and are committed by the next launch.
-//   k_lm_chol_update  commit + the rank-32 update of the trailing triangle, a wave per 16 x 16 tile (fp64 matrix core, operands from Hs)
-//   k_lm_chol_back    L^T x = y, one workgroup per window
 #define LM_CHOLS_NB 32
-#define LM_CHOLS_SCRATCH (LM_CHOLS_NB * (LM_CHOLS_NB + 1) + LM_CHOLS_NB)   // doubles per window: [32][33] block + 32 y
-static __global__ __launch_bounds__(64) void k_lm_chol_panel(LmArgs A, const int32_t* nfreeArr, int kb) {
+// One launch per 32-column panel (round 5; replaces the panel + update pair above for few windows per call): a WAVE per 16 x 16 tile of the trailing
+// triangle does everything its tile needs by itself, so that nothing of a panel step waits on another launch:
+//   1. the 32 x 32 diagonal block A11 = L11 L11^T in registers (lane r < 32 = row r) and, in the SAME instruction stream on lanes 32..63, the
+//      inverse X = L11^-1 by forward substitution of the identity (lane 32 + j = column j): step c scales entry c by 1 / L(c, c) and takes
+//      L(c2, c) * entry c off every later entry c2 — for a row of A that is the right-looking Cholesky update, for a column of X the substitution.
+//      Column c of L reaches all lanes through LDS (one ds_write, broadcast ds_reads) instead of two v_readlane per entry;
+//   2. L21 rows of the tile's two row blocks as PRODUCTS on the fp64 matrix core, L21 = A21 X^T (v_mfma_f64_16x16x4_f64; the 496 dependent
+//      steps per row of a triangular solve are gone), re-laid out through LDS;
+//   3. the tile's rank-32 update C -= L21_i L21_j^T (8 more matrix instructions).
+// Every wave factors the same block (identical values).  L and y = L^-1 b go to cholL / cholY, not back into Hs / xp: other waves of the launch
+// still read the unfactored panel.  Waves of tile column 0 write their rows of L21 and take those rows' share of the forward substitution; wave 0
+// writes L11 and the block's y.  The explicit inverse costs accuracy cond(L11) * eps on the panel rows instead of eps (a 32 x 32 block of a
+// damped reduced camera system: measured against the one-workgroup kernel in test_hip_cholesky_per_phase_launches_agree_with_one_workgroup).
+#define LM_CHOLF_SMEM ((LM_CHOLS_NB * (LM_CHOLS_NB + 1) + 2 * 16 * (LM_CHOLS_NB + 1) + 2 * LM_CHOLS_NB + 2 * LM_CHOLS_NB) * 8)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
+#define LM_KEEP_LOADED(x) asm volatile("" : "+v"(x))     // the value exists in a (vector) register HERE: its load cannot be sunk below this point
+#define LM_KEEP_LOADED_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
+#else
+#define LM_KEEP_LOADED(x) do {} while (0)
+#define LM_KEEP_LOADED_S(x) do {} while (0)
+#endif
+#define LM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+static __global__ __launch_bounds__(64) void k_lm_chol_step(LmArgs A, const int32_t* nfreeArr, int kb) {
     constexpr int NB = LM_CHOLS_NB, LD = NB + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    double* blk = (double*)orb_smem;      // [NB][LD] factored diagonal block
-    double* ys = blk + NB * LD;           // [NB] forward-substituted right-hand side of the block, then [NB] reciprocal pivots
-    const int b = blockIdx.y, lane = threadIdx.x;
-    if (!A.st[b].needTrial || !A.st[b].ok) return;    // a window whose earlier panel was not positive definite stays failed
-    const int n = nfreeArr[b] * 6, ld = A.np6;
-    if (kb >= n) return;
-    const int nb = min(NB, n - kb), m = n - kb;
-    const int r = (int)blockIdx.x * 64 + lane;        // this lane's panel row
-    if ((int)blockIdx.x * 64 >= m) return;
+    double* Xs = (double*)orb_smem;        // [NB][LD] X = L11^-1, row-major (zero above the diagonal)
+    double* Li = Xs + NB * LD;             // [16][LD] L21 rows of the tile's row block
+    double* Lj = Li + 16 * LD;             // [16][LD] L21 rows of the tile's column block
+    double* col = Lj + 16 * LD;            // [2][NB]  column c of L11 (double buffered over the steps), later y of the block
+    double* bs = col + 2 * NB;             // [NB]     right-hand side of the block
+    const int b = blockIdx.y, lane = threadIdx.x, t = blockIdx.x;
+    const int ld = A.np6;                  // (kb < ld: the host launches no panel beyond the largest system of the batch)
     double* S = A.Hs + (size_t)b * ld * ld;
     double* x = A.xp + (size_t)b * ld;
-    double a[NB];
+    const int ml = lane & 15, kq = lane >> 4, j32 = lane & 31;
+    CHP_DECL;
+    // ---- every operand this wave will need, requested before anything is waited for.  The launch is a chain of memory round trips otherwise
+    // (kernel arguments -> window state -> operands): the addresses below depend on the launch geometry only — rows and columns clamped to the
+    // ALLOCATED matrix (ld), not to the window's own size n, which is still in flight — and the guards select afterwards.  (A guarded load
+    // compiles to a branch with its own s_waitcnt vmcnt(0): the 32 loads of the block alone were 32 serialised round trips, half of the kernel.)
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);                      // tile t of the trailing triangle (row-major over its lower half)
+    while (ti * (ti + 1) / 2 > t) ti--;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int i0 = NB + ti * 16, j0 = NB + tj * 16;   // panel-relative first row of the tile's two row blocks
+    const int rmax = ld - kb - 1;                     // last panel-relative row / column that exists in memory
+    double sv[NB], ai[NB / 4], aj[NB / 4], cv[4];
+    {
+        const double* Sb = S + (size_t)kb * ld + kb + min(j32, rmax);      // the diagonal block: row j32 (lanes 32..63 load it too and do not use it)
 #pragma unroll
-    for (int c = 0; c < NB; c++) a[c] = (lane < nb && c <= lane) ? S[(size_t)(kb + c) * ld + kb + lane] : (c == lane ? 1.0 : 0.0);
-    double y = lane < nb ? x[kb + lane] : 0.0;
-    // this lane's row below the block, loaded before the dependent chain of the block starts
-    const bool below = r >= nb && r < m;
+        for (int c = 0; c < NB; c++) sv[c] = Sb[(size_t)min(c, rmax) * ld];
+        const int ri = min(i0 + ml, rmax), rj = min(j0 + ml, rmax);
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) {
+            const double* Sk = S + (size_t)(kb + min(4 * kk + kq, rmax)) * ld + kb;
+            ai[kk] = Sk[ri]; aj[kk] = Sk[rj];
+        }
+        const double* Sc0 = S + (size_t)(kb + rj) * ld + kb;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cv[q] = Sc0[min(i0 + kq + 4 * q, rmax)];
+    }
+    const double xb = x[kb + min(j32, rmax)];
+    int needTrial = A.st[b].needTrial, okWin = A.st[b].ok, nfreeB = nfreeArr[b];         // three more loads in flight, one wait
+    LM_KEEP_LOADED_S(needTrial); LM_KEEP_LOADED_S(okWin); LM_KEEP_LOADED_S(nfreeB);
+#pragma unroll
+    for (int c = 0; c < NB; c++) LM_KEEP_LOADED(sv[c]);   // (or the compiler sinks every load below the early exits and into the branch that uses it: one wait per load again)
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; kk++) { LM_KEEP_LOADED(ai[kk]); LM_KEEP_LOADED(aj[kk]); }
+    if (!needTrial || !okWin) return;                 // a window whose earlier panel was not positive definite stays failed
+    const int n = nfreeB * 6;
+    if (kb >= n) return;
+    const int nb = min(NB, n - kb), m = n - kb, mt = m - NB;
+    const int T = mt > 0 ? (mt + 15) >> 4 : 0, ntiles = T * (T + 1) / 2;
+    if (t >= max(1, ntiles)) return;
+    double* LR = A.cholL + (size_t)b * ld * ld;       // L's rows under the diagonal blocks, ROW-major (what the backward substitution reads)
+    double* yv = A.cholY + (size_t)b * ld;
+    wg_chol_v4 ct = {0.0, 0.0, 0.0, 0.0};
+    bool okc[4] = {false, false, false, false};
+    double* Sc = S + (size_t)(kb + min(j0 + ml, rmax)) * ld + kb;
+    if (ntiles) {
+        const bool iok = i0 + ml < m, jok = j0 + ml < m;
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; kk++) { ai[kk] = iok ? ai[kk] : 0.0; aj[kk] = jok ? aj[kk] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = i0 + kq + 4 * q;
+            okc[q] = r < m && j0 + ml < m && r >= j0 + ml;
+            ct[q] = okc[q] ? cv[q] : 0.0;
+        }
+    }
+    // ---- 1. diagonal block and its inverse
+    const bool isA = lane < NB;
     double v[NB];
 #pragma unroll
-    for (int c = 0; c < NB; c++) v[c] = below ? S[(size_t)(kb + c) * ld + kb + r] : 0.0;
-    double acc = below ? x[kb + r] : 0.0;
-    // The launch is one dependent chain per wave (nothing else of the window can run): pivots as reciprocal square roots — one short
-    // operation per column instead of a square root and two divisions — and every division of the row solves a multiplication by them.
-    // (k_lm_chol<NB>, which shares a compute unit's time with other windows' workgroups, keeps sqrt / divide; the two agree to rounding.)
-    double rinv = 0.0;                                // lane c: 1 / L(c, c)
+    for (int c = 0; c < NB; c++) v[c] = isA ? ((lane < nb && c <= lane) ? sv[c] : (c == lane ? 1.0 : 0.0)) : (c == j32 ? 1.0 : 0.0);
+    CHP_MARK(0);
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < NB; c++) {
-        const double dkk = wg_chol_bcast(a[c], c);
+        const double dkk = wg_chol_bcast(v[c], c);
         ok = ok && (dkk > 0) && (dkk < 1.7e308);
 #ifdef HIP_EMULATED
         const double ri = 1.0 / sqrt(dkk);
 #else
         const double ri = rsqrt(dkk);
 #endif
-        const double lrc = (lane == c) ? dkk * ri : a[c] * ri;
-        a[c] = lrc;
-        rinv = (lane == c) ? ri : rinv;
+        v[c] *= ri;                                   // lane c: sqrt(dkk); row r > c: L(r, c); column j of X: X(c, j)
+        if (c + 1 < NB) {
+            double* cb = col + (c & 1) * NB;
+            if (isA) cb[lane] = v[c];
+            LM_WAVE_SYNC();
 #pragma unroll
-        for (int c2 = c + 1; c2 < NB; c2++) {
-            const double l2 = wg_chol_bcast(lrc, c2);
-            a[c2] -= (lane >= c2) ? lrc * l2 : 0.0;
+            for (int c2 = c + 1; c2 < NB; c2++) v[c2] = __builtin_fma(-cb[c2], v[c], v[c2]);   // (entries above the diagonal of A carry unused values)
         }
-        const double yc = wg_chol_bcast(y, c) * ri;
-        y = (lane == c) ? yc : (lane > c ? y - lrc * yc : y);
     }
-    if (!ok) { if (blockIdx.x == 0 && lane == 0) A.st[b].ok = 0; return; }   // uniform over the window's waves: the same values everywhere
-    if (lane < NB) {
+    CHP_MARK(1);
+    if (!ok) { if (t == 0 && lane == 0) A.st[b].ok = 0; return; }   // uniform over the window's waves: the same values everywhere
+    if (!isA) {
 #pragma unroll
-        for (int c = 0; c < NB; c++) blk[lane * LD + c] = (lane < nb && c <= lane) ? a[c] : (c == lane ? 1.0 : 0.0);
-        ys[lane] = y;
-        ys[NB + lane] = rinv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (blockIdx.x == 0 && lane < NB) {               // block + y -> scratch (committed by k_lm_chol_update)
-        double* sc = A.cholScratch + (size_t)b * LM_CHOLS_SCRATCH;
+        for (int i = 0; i < NB; i++) Xs[i * LD + j32] = v[i];
+        if (t == 0) {                                 // X of this block, for the backward substitution (k_lm_chol_back_x)
+            double* Xg = A.cholX + ((size_t)b * ((ld + NB - 1) / NB) + kb / NB) * (NB * NB);
 #pragma unroll
-        for (int c = 0; c < NB; c++) sc[lane * LD + c] = blk[lane * LD + c];
-        sc[NB * LD + lane] = y;
-    }
-    if (below) {                                      // nb == NB here: rows below a short last block do not exist
-        // right-looking over the row's 32 entries: entry c is final once columns < c have been taken off it; the updates of the later
-        // entries are independent of each other (a left-looking sum would be a chain of c dependent operations per entry)
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-            v[c] *= ys[NB + c];
-            acc -= v[c] * ys[c];
-#pragma unroll
-            for (int c2 = c + 1; c2 < NB; c2++) v[c2] -= v[c] * blk[c2 * LD + c];
+            for (int i = 0; i < NB; i++) Xg[i * NB + j32] = v[i];
         }
+    } else bs[lane] = lane < nb ? xb : 0.0;
+    LM_WAVE_SYNC();
+    if (tj == 0 || !ntiles) {                         // y of the block = X b (also the single wave of a panel without rows below it)
+        if (isA) {
+            double y = 0.0;
 #pragma unroll
-        for (int c = 0; c < NB; c++) S[(size_t)(kb + c) * ld + kb + r] = v[c];
-        x[kb + r] = acc;
+            for (int j = 0; j < NB; j++) y = __builtin_fma(Xs[lane * LD + j], bs[j], y);
+            col[lane] = y;
+            if (t == 0 && lane < nb) yv[kb + lane] = y;
+        }
     }
-}
-static __global__ __launch_bounds__(256) void k_lm_chol_update(LmArgs A, const int32_t* nfreeArr, int kb) {
-    constexpr int NB = LM_CHOLS_NB, LD = NB + 1;
-    const int b = blockIdx.y;
-    if (!A.st[b].needTrial || !A.st[b].ok) return;
-    const int n = nfreeArr[b] * 6, ld = A.np6;
-    if (kb >= n) return;
-    double* S = A.Hs + (size_t)b * ld * ld;
-    if (blockIdx.x == 0) {                            // commit the factored diagonal block and its right-hand side
-        const int nb = min(NB, n - kb);
-        const double* sc = A.cholScratch + (size_t)b * LM_CHOLS_SCRATCH;
-        for (int t = threadIdx.x; t < NB * NB; t += 256) { const int rr = t % NB, c = t / NB; if (rr < nb && c <= rr) S[(size_t)(kb + c) * ld + kb + rr] = sc[rr * LD + c]; }
-        if ((int)threadIdx.x < nb) A.xp[(size_t)b * ld + kb + threadIdx.x] = sc[NB * LD + threadIdx.x];
+    CHP_MARK(2);
+    if (!ntiles) return;
+    // ---- 2. L21 = A21 X^T for the two row blocks (nb == NB here: rows below a short last block do not exist)
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        if (side == 1 && ti == tj) break;             // a diagonal tile: one row block
+        double* Lo = side ? Lj : Li;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            wg_chol_v4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < (h ? NB / 4 : NB / 8); kk++) {   // X(c, k) = 0 for k > c: columns c < 16 need k < 16 only
+                const double bv = Xs[(16 * h + ml) * LD + 4 * kk + kq];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(side ? aj[kk] : ai[kk], bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) Lo[(kq + 4 * q) * LD + 16 * h + ml] = acc[q];
+        }
     }
-    if (kb + NB >= n) return;
-    wg_chol_update_tile<NB>(S, n, ld, kb, (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
-}
-template <int NB>
-static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol_back(LmArgs A, const int32_t* nfreeArr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    const int b = blockIdx.x;
-    if (!A.st[b].needTrial || !A.st[b].ok) return;
-    const int ld = A.np6;
-    wg_chol_backward<LM_CHOL_NT, NB>(A.Hs + (size_t)b * ld * ld, nfreeArr[b] * 6, ld, A.xp + (size_t)b * ld, orb_smem);
+    LM_WAVE_SYNC();
+    CHP_MARK(3);
+    const double* Lb = ti == tj ? Li : Lj;
+    // ---- 3. the tile: C -= L21_i L21_j^T
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; kk++)
+        ct = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[ml * LD + 4 * kk + kq], Lb[ml * LD + 4 * kk + kq], ct, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (okc[q]) Sc[i0 + kq + 4 * q] = ct[q];
+    if (tj == 0) {                                    // this row block's rows of L (row-major: two rows of 32 per store) and their share of the forward substitution
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rr = (lane >> 5) + 2 * q;
+            if (i0 + rr < m) LR[(size_t)(kb + i0 + rr) * ld + kb + j32] = Li[rr * LD + j32];
+        }
+        const int r = i0 + lane;
+        if (lane < 16 && r < m) {
+            double acc = x[kb + r];
+#pragma unroll
+            for (int c = 0; c < NB; c++) acc = __builtin_fma(-Li[lane * LD + c], col[c], acc);
+            x[kb + r] = acc;
+        }
+    }
+    CHP_MARK(4);
+#ifdef CHOL_PROF
+    if (t == 0) CHP_FLUSH();
+#endif
 }
 
+// L^T x = y behind k_lm_chol_step, one workgroup per window, without a dependent chain inside a block: with X = L11^-1 of every diagonal block at
+// hand, x_blk = X^T w_blk is a 32 x 32 product (one wave, coalesced rows of X), and the finished block is taken off every earlier entry at once —
+// thread c owns w_c and reads the 32 entries L(kb .. kb + 31, c) of its column from the ROW-major copy k_lm_chol_step leaves (consecutive threads,
+// consecutive addresses; loaded before the block's x exists: the loads do not depend on it).  15 blocks of a 480-unknown system: two barriers and one memory round trip each.  LDS: 2 x ceil(n / 32) x 32 doubles.
+static inline size_t lm_chol_back_x_smem(int np6) { return (size_t)(2 * ((np6 + 31) / 32 * 32) + 2 * 1024) * 8; }
+static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol_back_x(LmArgs A, const int32_t* nfreeArr) {
+    constexpr int NB = LM_CHOLS_NB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!A.st[b].needTrial || !A.st[b].ok) return;
+    const int n = nfreeArr[b] * 6, ld = A.np6, n32 = (n + NB - 1) / NB * NB;
+    double* w = (double*)orb_smem;         // [n32] y, then y minus the finished blocks' products
+    double* xs = w + n32;                  // [n32] the solution
+    double* Xl = xs + n32;                 // [2][NB * NB] X of the current block and (arriving) of the next one
+    const double* LR = A.cholL + (size_t)b * ld * ld;   // rows of L under the diagonal blocks, row-major (k_lm_chol_step)
+    const double* yv = A.cholY + (size_t)b * ld;
+    const double* Xw = A.cholX + (size_t)b * ((ld + NB - 1) / NB) * (NB * NB);
+    // Software pipeline over the blocks: while block kb is solved and taken off w, the rows of L and the X of block kb - 32 are already on their way
+    // (neither depends on x) — a block costs its two barriers and 64 multiply-adds per thread, not a memory round trip.
+    double lr[NB], ln[NB];
+    int kb = n32 - NB;
+    {
+        const int nb = min(NB, n - kb);
+        const double* Lc = LR + (size_t)kb * ld + min(tid, max(kb - 1, 0));   // L(kb + r, tid), r = 0 .. 31: a row of L is contiguous over the threads
+#pragma unroll
+        for (int r = 0; r < NB; r++) lr[r] = Lc[(size_t)min(r, nb - 1) * ld];
+        const double* Xg = Xw + (size_t)(kb / NB) * (NB * NB);
+        for (int i = tid; i < NB * NB; i += LM_CHOL_NT) Xl[i] = Xg[i];
+        if (nb < NB) {
+#pragma unroll
+            for (int r = 0; r < NB; r++) lr[r] = r < nb ? lr[r] : 0.0;        // a short last block: its missing rows do not exist
+        }
+    }
+    for (int i = tid; i < n32; i += LM_CHOL_NT) w[i] = i < n ? yv[i] : 0.0;
+    __syncthreads();
+    int buf = 0;
+    for (; kb >= 0; kb -= NB) {
+        const int kn = kb - NB;
+        double xq[(NB * NB + LM_CHOL_NT - 1) / LM_CHOL_NT];
+        if (kn >= 0) {                     // (full blocks from here on)
+            const double* Lc = LR + (size_t)kn * ld + min(tid, max(kn - 1, 0));
+#pragma unroll
+            for (int r = 0; r < NB; r++) ln[r] = Lc[(size_t)r * ld];
+            const double* Xg = Xw + (size_t)(kn / NB) * (NB * NB);
+#pragma unroll
+            for (int q = 0; q < (NB * NB + LM_CHOL_NT - 1) / LM_CHOL_NT; q++) xq[q] = Xg[min(tid + q * LM_CHOL_NT, NB * NB - 1)];
+        }
+        if (tid < NB) {                    // x_j = sum_{i >= j} X(i, j) w_i  (a short last block is padded with the identity, its w with zeros)
+            const double* Xc = Xl + buf * (NB * NB);
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NB; i++) acc = __builtin_fma(Xc[i * NB + tid], w[kb + i], acc);
+            xs[kb + tid] = acc;
+        }
+        __syncthreads();
+        if (tid < kb) {
+            double acc = w[tid];
+#pragma unroll
+            for (int r = 0; r < NB; r++) acc = __builtin_fma(-lr[r], xs[kb + r], acc);
+            w[tid] = acc;
+        }
+        if (kn >= 0) {
+#pragma unroll
+            for (int q = 0; q < (NB * NB + LM_CHOL_NT - 1) / LM_CHOL_NT; q++)
+                if (tid + q * LM_CHOL_NT < NB * NB) Xl[(buf ^ 1) * (NB * NB) + tid + q * LM_CHOL_NT] = xq[q];
+#pragma unroll
+            for (int r = 0; r < NB; r++) lr[r] = ln[r];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* x = A.xp + (size_t)b * ld;
+    for (int i = tid; i < n; i += LM_CHOL_NT) x[i] = xs[i];
+}
 #ifdef CHOL_PROF
 extern "C" int lba_debug_chol_prof(unsigned long long* out8, int clear) {
     static unsigned long long z[8];
@@ -1200,6 +1404,26 @@ static __global__ void k_lm_end(LmArgs A, int batch) {
 }
 
 static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
+// rows of the reduced camera system split over G workgroups each (k_lm_schur_rows / k_lm_schur_combine): only while the call has fewer rows than the
+// machine has compute units, at least 256 edges per slice, and the partial rows fit 64 MB of workspace
+#ifndef LM_SCHUR_SPLIT_MAX
+#define LM_SCHUR_SPLIT_MAX 8
+#endif
+#ifndef LM_SCHUR_SPLIT_MIN_EDGES
+#define LM_SCHUR_SPLIT_MIN_EDGES 256   // edges of a row per slice, at least (tests build with a tiny value to cover the split on their small windows)
+#endif
+static size_t lm_schur_part_doubles(size_t rows6) { return (rows6 / 12 + 1) * 36 + 6; }     // per (row, slice) of a system of rows6 unknowns
+static int lm_schur_groups(int batch, int rows, int cap_e, size_t np6alloc) {
+    if (rows < 1 || batch < 1) return 1;
+    int G = std::min(LM_SCHUR_SPLIT_MAX, 256 / std::max(1, batch * rows));
+    G = std::min(G, std::max(1, cap_e / rows / LM_SCHUR_SPLIT_MIN_EDGES));
+    const size_t perG = (size_t)batch * (np6alloc / 6) * lm_schur_part_doubles(np6alloc) * 8;
+    G = (int)std::min<size_t>((size_t)G, ((size_t)64 << 20) / std::max<size_t>(perG, 1));
+    return std::max(G, 1);
+}
+// the one-launch-per-panel factorisation (k_lm_chol_step) needs L and y next to Hs / xp: only calls that can take it reserve them
+// (reserved by the shape's capacity np6cap — the call's own system may be smaller — while that stays under 1 GB)
+static bool lm_chol_step_possible(int batch, size_t np6cap) { return batch <= LM_CHOL_SPLIT_MAX_BATCH && (size_t)batch * np6cap * np6cap * 8 <= ((size_t)1 << 30); }
 
 extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     if (!p || batch < 1) return 0;
@@ -1214,7 +1438,12 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
     s += lm_align(B * p->cap_e * 16) + lm_align(B * ((size_t)p->cap_e + 8) * 4);     // Schur row metadata
-    s += lm_align(B * 1088 * 8);                                                      // cholScratch (LM_CHOLS_SCRATCH doubles per window)
+    {   // partial Schur rows (few windows per call): sized for the most slices any free-pose count of this shape could take
+        int gmax = 1;
+        for (int rows = 1; rows <= p->cap_p; rows++) gmax = std::max(gmax, lm_schur_groups(batch, rows, p->cap_e, np6));
+        if (gmax > 1) s += lm_align(B * (np6 / 6) * gmax * lm_schur_part_doubles(np6) * 8);
+    }
+    if (lm_chol_step_possible(batch, np6)) s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * ((np6 + 31) / 32) * 1024 * 8);   // cholL, cholY, cholX (few windows per call only)
     if (np6 > WG_CHOL_LDS_MAX_LD) s += lm_align(B * np6 * CH_LD * 8);                 // out-of-LDS Cholesky panel (only if ALL poses could be free)
     return s;
 }
@@ -1259,7 +1488,11 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
     A.rowMeta = (int4*)take(B * P.cap_e * 16); A.edgeH = (int32_t*)take(B * ((size_t)P.cap_e + 8) * 4);
-    A.cholScratch = (double*)take(B * 1088 * 8);
+    A.schurG = lm_schur_groups(batch, maxFree, P.cap_e, np6cap);
+    if (A.schurG > 1) A.schurPart = (double*)take(B * (np6cap / 6) * A.schurG * lm_schur_part_doubles(np6cap) * 8);   // (used with the strides of np6)
+    if (lm_chol_step_possible(batch, np6cap)) {       // used with ld = np6
+        A.cholL = (double*)take(B * np6cap * np6cap * 8); A.cholY = (double*)take(B * np6cap * 8); A.cholX = (double*)take(B * ((np6cap + 31) / 32) * 1024 * 8);
+    }
     A.poses = (double*)P.poses; A.points = (double*)P.points; A.nPart = nPart; A.np6 = (int)np6;
 
     if (hipMemcpyAsync(nfree, nf.data(), B * 4, hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
@@ -1284,9 +1517,11 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
                                      : nb32 ? wg_chol_smem_bytes_t<LM_CHOL_NT, 32>((int)np6) : wg_chol_smem_bytes_t<LM_CHOL_NT, CH_NB>((int)np6);
     if (cholSmem > 160 * 1024) return ORB_E_CAPACITY;   // > ~20 000 unknowns: the right-hand side no longer fits LDS (documented in INTEGRATION.md)
     if (orb_lds_optin(nb32 ? (const void*)k_lm_chol<32> : (const void*)k_lm_chol<CH_NB>, cholSmem) != ORB_OK) return ORB_E_HIP;
-    // few windows: the factorisation as one launch per phase, its trailing updates spread over the machine (k_lm_chol_panel / _update / _back)
-    const bool cholSplit = nb32 && batch <= LM_CHOL_SPLIT_MAX_BATCH;
-    if (cholSplit && orb_lds_optin((const void*)k_lm_chol_back<32>, cholSmem) != ORB_OK) return ORB_E_HIP;
+    // few windows per call: one launch per 32-column panel, its tiles spread over the machine (k_lm_chol_step), then k_lm_chol_back_x — every system
+    // size that fits the backward kernel's one-thread-per-unknown layout (<= 90 free key frames), LocalMapping's 20-50 key frame windows included
+    // (one window, ms per optimize(5), one workgroup vs this: 20 free key frames 1.35 / 1.14, 30: 1.79 / 1.33, 50: 3.02 / 1.70, 80: 6.8 / 2.2)
+    const bool cholStep = A.cholL && batch <= LM_CHOL_SPLIT_MAX_BATCH && np6 <= LM_CHOL_NT + LM_CHOLS_NB;
+    if (!cholStep) A.cholL = A.cholY = A.cholX = nullptr;
     const int gB = (batch + 63) / 64;
     const size_t nPose = B * P.cap_p * 7, nPoint = B * P.cap_l * 3;
     const int gCopy = (int)((nPose + nPoint + 255) / 256);
@@ -1325,18 +1560,18 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
             {
-                const dim3 gS((unsigned)(((batch + 7) / 8) * 8 * P.cap_p));
+                const dim3 gS((unsigned)((batch >= 8 ? ((batch + 7) / 8) * 8 : batch) * P.cap_p), (unsigned)A.schurG);
                 if (schurNW == 4) hipLaunchKernelGGL(k_lm_schur_rows<4>, gS, dim3(256), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
                 else if (schurNW == 2) hipLaunchKernelGGL(k_lm_schur_rows<2>, gS, dim3(128), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
                 else hipLaunchKernelGGL(k_lm_schur_rows<1>, gS, dim3(64), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
+                if (A.schurG > 1) hipLaunchKernelGGL(k_lm_schur_combine, dim3(maxFree, batch), dim3(256), 0, st, A, (const int32_t*)nfree);
             }
-            if (cholSplit) {
+            if (cholStep) {
                 for (int kb = 0; kb < (int)np6; kb += LM_CHOLS_NB) {
-                    hipLaunchKernelGGL(k_lm_chol_panel, dim3(((int)np6 - kb + 63) / 64, batch), dim3(64), (LM_CHOLS_SCRATCH + LM_CHOLS_NB) * 8, st, A, (const int32_t*)nfree, kb);
                     const int T = std::max(0, ((int)np6 - kb - LM_CHOLS_NB + 15) >> 4);
-                    hipLaunchKernelGGL(k_lm_chol_update, dim3(std::max(1, (T * (T + 1) / 2 + 3) / 4), batch), dim3(256), 0, st, A, (const int32_t*)nfree, kb);
+                    hipLaunchKernelGGL(k_lm_chol_step, dim3(std::max(1, T * (T + 1) / 2), batch), dim3(64), LM_CHOLF_SMEM, st, A, (const int32_t*)nfree, kb);
                 }
-                hipLaunchKernelGGL(k_lm_chol_back<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
+                hipLaunchKernelGGL(k_lm_chol_back_x, dim3(batch), dim3(LM_CHOL_NT), lm_chol_back_x_smem((int)np6), st, A, (const int32_t*)nfree);
             } else if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);

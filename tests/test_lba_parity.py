@@ -279,7 +279,8 @@ def test_emu_lba_optimize_global_memory_panel():
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_LDS_MAX_LD=30",), tag="cholext")))
+    # (LM_CHOL_SPLIT_MAX_BATCH=0: few windows per call would otherwise take one launch per panel, which has no LDS panel at all)
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_LDS_MAX_LD=30", "LM_CHOL_SPLIT_MAX_BATCH=0"), tag="cholext")))
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
@@ -293,19 +294,30 @@ def test_emu_lba_optimize_schur_row_chunks():
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
-def test_emu_lba_optimize_wide_panel():
-    """WG_CHOL_NB32_MIN_LD=0: the 32-column Cholesky panel (which the GPU takes for 54 ... 88 free key frames) on the small test windows, which
-    default to 16 columns."""
+def test_emu_lba_optimize_split_schur_rows():
+    """LM_SCHUR_SPLIT_MIN_EDGES=4: every row of the reduced camera system is split over several workgroups (k_lm_schur_rows slices + k_lm_schur_combine
+    — what ONE LocalMapping window per call takes on the GPU, where 80 rows would otherwise use 80 of 256 compute units); results must not change."""
     import ctypes
     import build_emu
     from orbhip import _lib
-    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("WG_CHOL_NB32_MIN_LD=0",), tag="cholnb32")))
-    check_optimize(lib, "emu", ("mono", "stereo"), 5)   # few windows per call: the factorisation as one launch per phase (k_lm_chol_panel / _update / _back)
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_SCHUR_SPLIT_MIN_EDGES=4",), tag="schursplit")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
+def test_emu_lba_optimize_one_workgroup_per_window():
+    """LM_CHOL_SPLIT_MAX_BATCH=0: the factorisation as ONE workgroup per window with 16-column panels (k_lm_chol<16>, what a batch of more than 64
+    small windows takes).  The default build's few-window calls — every other LM test of this tier — take one launch per panel (k_lm_chol_step +
+    k_lm_chol_back_x: inverse of the diagonal block, panel rows and trailing tiles on the fp64 matrix core)."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_CHOL_SPLIT_MAX_BATCH=0",), tag="cholmono16")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
 def test_emu_lba_optimize_wide_panel_one_workgroup():
-    """The same with LM_CHOL_SPLIT_MAX_BATCH=0: the 32-column panel inside ONE workgroup per window (k_lm_chol<32>, what a batch of more than 128
-    windows takes)."""
+    """WG_CHOL_NB32_MIN_LD=0 + LM_CHOL_SPLIT_MAX_BATCH=0: the 32-column panel inside ONE workgroup per window (k_lm_chol<32>, what a batch of more
+    than 64 windows of 54 ... 88 free key frames takes) on the small test windows."""
     import ctypes
     import build_emu
     from orbhip import _lib
@@ -315,9 +327,10 @@ def test_emu_lba_optimize_wide_panel_one_workgroup():
 
 @pytest.mark.gpu
 def test_hip_cholesky_per_phase_launches_agree_with_one_workgroup(hip_lib):
-    """60 free key frames = 360 unknowns (32-column panel).  One window per call takes the per-phase launches (reciprocal pivots), 129 windows per
-    call one workgroup per window (sqrt / divide): the same factorisation to rounding — poses within 1e-9 of each other, both within 1e-6 of the
-    oracle — and the 129 copies of the batch bit-identical among themselves."""
+    """60 free key frames = 360 unknowns.  One window per call takes one launch per 32-column panel (k_lm_chol_step: reciprocal-square-root pivots,
+    the panel rows as products with the INVERSE of the diagonal block on the fp64 matrix core, Schur rows split over three workgroups each),
+    129 windows per call one workgroup per window (sqrt / divide, triangular solves): the same factorisation to rounding — poses within 1e-9 of
+    each other, both within 1e-6 of the oracle — and the 129 copies of the batch bit-identical among themselves."""
     w, cams = synth_window(5, 70, 10, 5000, 8, "mono")
     assert (w["pose_hidx"] >= 0).sum() == 60
     L1 = LbaWindows([w], cams, to_dev("hip"), lib=hip_lib, huber=HUBER)
