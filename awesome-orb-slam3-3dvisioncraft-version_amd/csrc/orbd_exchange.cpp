@@ -63,16 +63,25 @@ extern "C" int orbd_ipc_close(void* d_ptr) {
 }
 
 namespace {
-// per calling thread (= per rank in a one-process-per-GPU host, per device thread otherwise): the copy streams and their events, made once
+// per calling thread (= per rank in a one-process-per-GPU host, per device thread otherwise): the copy streams and their events, made once.
+// Nothing here is destroyed by a destructor: a thread_local's destructor runs at thread / process exit, possibly after the HIP runtime has been
+// torn down (hipStreamDestroy on a dead runtime is undefined).  A host that wants the streams back calls orbd_peer_shutdown() on the thread
+// that used them; a process that simply exits leaves them to the runtime's own teardown.
 struct PeerStreams {
     int device = -1;
     std::vector<hipStream_t> st;
     std::vector<hipEvent_t> done;
     hipEvent_t start = nullptr;
+    // copies may still be in flight on the peer streams (a failed call, or a device switch between calls): drain before destroying
     void drop() {
-        for (auto s : st) (void)hipStreamDestroy(s);
-        for (auto e : done) (void)hipEventDestroy(e);
-        if (start) (void)hipEventDestroy(start);
+        if (device >= 0) {
+            int cur = -1;
+            const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+            for (auto s : st) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+            for (auto e : done) (void)hipEventDestroy(e);
+            if (start) (void)hipEventDestroy(start);
+            if (sw) (void)hipSetDevice(cur);
+        }
         st.clear(); done.clear(); start = nullptr; device = -1;
     }
     bool ensure(int n) {
@@ -89,10 +98,32 @@ struct PeerStreams {
         }
         return true;
     }
-    ~PeerStreams() { drop(); }
 };
 thread_local PeerStreams g_peer;
 }  // namespace
+
+// Releases the calling thread's copy streams and events (after draining them).  Optional: see PeerStreams.
+extern "C" int orbd_peer_shutdown(void) {
+    g_peer.drop();
+    return ORB_OK;
+}
+
+// Same-process form (one host thread per GPU, raw device pointers of the other GPUs instead of IPC mappings): the copies need peer access from the
+// calling thread's device to every source device.  Enables it where it is missing; ORB_E_HIP if a pair cannot be connected.
+extern "C" int orbd_peer_enable_access(int n_devices, const int* devices) {
+    if (n_devices < 1 || !devices) return ORB_E_INVALID;
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return ORB_E_HIP;
+    for (int i = 0; i < n_devices; i++) {
+        if (devices[i] == cur) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, cur, devices[i]) != hipSuccess || !can) { (void)hipGetLastError(); return ORB_E_HIP; }
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return ORB_E_HIP; }
+        (void)hipGetLastError();
+    }
+    return ORB_OK;
+}
 
 extern "C" int orbd_allgather_frames_peer(int world, int rank, int frames_per_rank, int cap, const void* const* peer_kps, const void* const* peer_desc,
                                           const void* const* peer_counts, orb_keypoint* d_all_kps, uint8_t* d_all_desc, int32_t* d_all_counts,
@@ -115,8 +146,13 @@ extern "C" int orbd_allgather_frames_peer(int world, int rank, int frames_per_ra
         ok = ok && hipMemcpyAsync((uint8_t*)d_all_kps + (size_t)s * bk, peer_kps[s], bk, hipMemcpyDeviceToDevice, cs) == hipSuccess;
         ok = ok && hipMemcpyAsync(d_all_desc + (size_t)s * bd, peer_desc[s], bd, hipMemcpyDeviceToDevice, cs) == hipSuccess;
         ok = ok && hipMemcpyAsync((uint8_t*)d_all_counts + (size_t)s * bc, peer_counts[s], bc, hipMemcpyDeviceToDevice, cs) == hipSuccess;
-        if (s != rank) ok = ok && hipEventRecord(g_peer.done[s], cs) == hipSuccess && hipStreamWaitEvent(st, g_peer.done[s], 0) == hipSuccess;
+        // joined back into `stream` whether or not every copy of this peer was queued: what WAS queued must not outlive the call unobserved
+        if (s != rank) {
+            const bool joined = hipEventRecord(g_peer.done[s], cs) == hipSuccess && hipStreamWaitEvent(st, g_peer.done[s], 0) == hipSuccess;
+            ok = ok && joined;
+        }
     }
+    if (!ok) (void)hipGetLastError();
     return ok ? ORB_OK : ORB_E_HIP;
 }
 

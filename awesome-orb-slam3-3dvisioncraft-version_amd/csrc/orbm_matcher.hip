@@ -1289,8 +1289,13 @@ static __global__ __launch_bounds__(SBPF_T, SBPF_WPE) void k_sbp_frame(SbpArgs A
         if ((Q.flags & ORBM_Q_VALID) && !(SBPF_EXP & 8)) cntw1 = sbpf_collect(F, A, b, q1, Q, r1);
     }
     if (bad) ctl[4] = 1;
-    __threadfence_block();                               // the rows' keys are read back by their own lanes only (same thread: program order)
+    // The workspace rows (global memory) are written by ONE lane each (sbpf_collect) and read back in the rounds below by the WHOLE wave
+    // (sbpf_decide walks a row with all lanes): writes by one work-item, reads by others of the same workgroup.  What orders them is a release of
+    // the writer and an acquire of the readers at workgroup scope around the barrier — stated explicitly, so that the pairing does not rest on
+    // the barrier's implied fence or on how this compute unit's L1 happens to be shared (threadgroup-split mode would break an implicit one silently).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- (2) fixed-point rounds
     const int maxRounds = nq + 2;
     bool ran_out = false;

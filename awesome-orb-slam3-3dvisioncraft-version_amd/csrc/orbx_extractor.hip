@@ -1050,9 +1050,20 @@ struct OctParams {
 
 // In-place exclusive scan of a[0..n) (LDS) by the whole OCT_T-thread block; returns the total.  Thread-serial chunks, one
 // DPP scan per wave, wave totals through LDS: two workgroup barriers per call (the octree calls this ~5 times per round).
-#ifndef OCT_T
-#define OCT_T 256   // threads per (frame, level) octree problem
+// OCT_T = threads per (frame, level) octree problem, a template parameter of the section: batches run 256 (many problems share the machine), the
+// single-frame entry point — eight problems on 256 compute units, every split round a chain of barriers — runs 1 024 (measured in round 4:
+// faster for one frame, slower for a batch)
+#ifndef OCT_T_BATCH
+#define OCT_T_BATCH 256
 #endif
+#ifndef OCT_T_SINGLE
+#ifdef HIP_EMULATED
+#define OCT_T_SINGLE 256    // (the CPU tier's emulator pays per work-item and barrier: one variant test builds the 1 024-thread instantiation)
+#else
+#define OCT_T_SINGLE 1024
+#endif
+#endif
+template <int OCT_T>
 static __device__ int block_scan_excl(int* a, int n, int* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + OCT_T - 1) / OCT_T;
@@ -1073,7 +1084,7 @@ static __device__ int block_scan_excl(int* a, int n, int* scratch) {
 
 // The same scan over values that are COMPUTED by the scanning thread: f(i) for the entries of its own chunk (no barrier between producing the
 // values and scanning them).  a[i] receives the exclusive prefix; two workgroup barriers.
-template <class F>
+template <int OCT_T, class F>
 static __device__ __forceinline__ int block_scan_excl_fn(int* a, const int n, int* scratch, F f) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + OCT_T - 1) / OCT_T;
@@ -1092,7 +1103,7 @@ static __device__ __forceinline__ int block_scan_excl_fn(int* a, const int n, in
     return total;
 }
 // Two such scans behind the same two barriers: a[0..na) over fa, b[0..nb) over fb.
-template <class FA, class FB>
+template <int OCT_T, class FA, class FB>
 static __device__ __forceinline__ void block_scan_excl_fn2(int* a, const int na, FA fa, int* b, const int nb, FB fb, int* scratch, int* totalA, int* totalB) {
     constexpr int NW = OCT_T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1157,6 +1168,7 @@ struct ONode { short x0, y0, x1, y1; };
 
 // The list algorithm proper.  keys / keyNode live either in LDS (the usual case: every round walks all keys twice, and the
 // per-workgroup critical path — the big levels — is latency bound) or in global memory (more candidates than the LDS cache holds).
+template <int OCT_T>
 static __device__ __forceinline__ void octree_run(const OctParams& P, const OctLevel& L, const int level, const int frame, const int nk,
                                                   const uint32_t* keys, uint16_t* keyNode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
@@ -1220,7 +1232,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     }
     __syncthreads();
     // drop empty roots (:572-583), keep order
-    int size = block_scan_excl_fn(sb, L.nIni, scratch, [&](const int i) { return cnt[0][i] > 0 ? 1 : 0; });
+    int size = block_scan_excl_fn<OCT_T>(sb, L.nIni, scratch, [&](const int i) { return cnt[0][i] > 0 ? 1 : 0; });
     for (int i = tid; i < L.nIni; i += OCT_T)
         if (cnt[0][i] > 0) {
             const int np = sb[i];
@@ -1250,7 +1262,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         // its "divided" marks, and the children of a node are counted where the node is listed — 7 barriers per list-order round, 21 per sorted one.
         // 1. expandable nodes E (count > 1), list order
         if (tid == 0) ctl[1] = 0;                           // (step 5's counter: last read before the previous round's closing barrier)
-        const int nE = block_scan_excl_fn(sb, size, scratch, [&](const int i) { return CN[i] > 1 ? 1 : 0; });
+        const int nE = block_scan_excl_fn<OCT_T>(sb, size, scratch, [&](const int i) { return CN[i] > 1 ? 1 : 0; });
         if (nE == 0) break;  // nothing can be divided: size stays == prevSize (:667)
         // nchild[i]: #non-empty children of an expandable node; | 0x100 = "divided" — in a list-order round every expandable node is
         const int dflag = sortedMode ? 0 : 0x100;
@@ -1320,7 +1332,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
             // early break once lNodes.size() >= N (:728-729): running size after each division
             for (int e = tid; e < nE; e += OCT_T) pb[e] = nchild[porder[e]] - 1;
             __syncthreads();
-            block_scan_excl(pb, nE, scratch);  // pb[e] = growth before processing e
+            block_scan_excl<OCT_T>(pb, nE, scratch);  // pb[e] = growth before processing e
             if (tid == 0) ctl[0] = nE;
             __syncthreads();
             for (int e = tid; e < nE; e += OCT_T) {
@@ -1341,9 +1353,9 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         }
         int totalPushed, nSurv;
         if (sortedMode)
-            block_scan_excl_fn2(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return sb[i]; }, scratch, &totalPushed, &nSurv);
+            block_scan_excl_fn2<OCT_T>(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return sb[i]; }, scratch, &totalPushed, &nSurv);
         else
-            block_scan_excl_fn2(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return CN[i] > 1 ? 0 : 1; }, scratch, &totalPushed,
+            block_scan_excl_fn2<OCT_T>(pb, nProc, [&](const int e) { return nchild[po[e]] & 0xFF; }, sb, size, [&](const int i) { return CN[i] > 1 ? 0 : 1; }, scratch, &totalPushed,
                                 &nSurv);
         PROF_MARK(1, 4);   // the two scans of step 4
         const int newSize = totalPushed + nSurv;
@@ -1473,7 +1485,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
         nchild[i] = sb[i];
     }
     __syncthreads();
-    const int nLap = block_scan_excl(sb, nsel, scratch);
+    const int nLap = block_scan_excl<OCT_T>(sb, nsel, scratch);
     for (int i = tid; i < nsel; i += OCT_T) {
         const int lap = nchild[i];
         const int rank = lap ? sb[i] : (i - sb[i]);
@@ -1484,6 +1496,7 @@ static __device__ __forceinline__ void octree_run(const OctParams& P, const OctL
     PROF_FLUSH(1);
 }
 
+template <int OCT_T>
 static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int tid = threadIdx.x;
@@ -1511,9 +1524,9 @@ static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
         uint16_t* lnode = (uint16_t*)(lkeys + P.keyCap);
         for (int k = tid; k < nk; k += OCT_T) lkeys[k] = gkeys[k];
         __syncthreads();
-        octree_run(P, L, level, frame, nk, lkeys, lnode);
+        octree_run<OCT_T>(P, L, level, frame, nk, lkeys, lnode);
     } else {
-        octree_run(P, L, level, frame, nk, gkeys, P.keyNode + (size_t)frame * P.candFrame + L.candOff);
+        octree_run<OCT_T>(P, L, level, frame, nk, gkeys, P.keyNode + (size_t)frame * P.candFrame + L.candOff);
     }
 }
 
@@ -2653,7 +2666,7 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     if (h->fastSmem > 64 * 1024 || h->octSmem > 150 * 1024) { orbx_free(h); return orbx_fail(nullptr, ORB_E_INVALID, "configuration exceeds the LDS budget"); }
 
     if (hipSetDevice(device) != hipSuccess) { orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipSetDevice failed"); }
-    if (orb_lds_optin((const void*)k_octree, h->octSmem) != ORB_OK) {      // (on `device`: the opt-in is per device and kernel)
+    if (orb_lds_optin((const void*)k_octree<OCT_T_BATCH>, h->octSmem) != ORB_OK || orb_lds_optin((const void*)k_octree<OCT_T_SINGLE>, h->octSmem) != ORB_OK) {   // (on `device`: the opt-in is per device and kernel)
         orbx_free(h); return orbx_fail(nullptr, ORB_E_HIP, "hipFuncSetAttribute(k_octree) failed");
     }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { std::string m = std::string(#call) + ": " + hipGetErrorString(e_); orbx_free(h); return orbx_fail(nullptr, e_ == hipErrorOutOfMemory ? ORB_E_NOMEM : ORB_E_HIP, m); } } while (0)
@@ -2895,7 +2908,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         const bool cache = batch <= OCT_CACHE_MAX_BATCH && h->octSmem > (size_t)h->octKeyOff;
         O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
         for (int rep = 0; rep < ((ORBX_EXP_DUP & 2) ? 2 : 1); rep++)
-            hipLaunchKernelGGL(k_octree, dim3(nl * batch), dim3(OCT_T), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
+            if (batch == 1) hipLaunchKernelGGL(k_octree<OCT_T_SINGLE>, dim3(nl * batch), dim3(OCT_T_SINGLE), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
+            else hipLaunchKernelGGL(k_octree<OCT_T_BATCH>, dim3(nl * batch), dim3(OCT_T_BATCH), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly

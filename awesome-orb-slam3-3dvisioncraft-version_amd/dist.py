@@ -87,6 +87,14 @@ class _DevSlab:
             self._hip.orb_dev_free(C.c_void_p(self.ptr))
             self.ptr = 0
 
+    def __del__(self):
+        # torch keeps the object a __cuda_array_interface__ tensor was built from alive for as long as the tensor's storage lives (views included):
+        # the memory goes when the LAST tensor on it goes, never under one
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
 
 class PeerExchange:
     """allgather_frame_blocks without RCCL (include/orbd.h orbd_allgather_frames_peer): every rank pulls each peer's three slabs straight out of
@@ -94,7 +102,11 @@ class PeerExchange:
     once.  One process per GPU: the slabs are allocated here (`kps`, `desc`, `counts`: hand them to ORBextractor.extract_batch(out=...)), their
     IPC handles are exchanged once through the process group, and `allgather()` fills `all_kps / all_desc / all_counts` (rank-major).
     The caller orders the ranks around `allgather()` (peers' slabs complete before, not rewritten until every rank is done): a
-    torch.cuda.synchronize() + dist.barrier() on both sides, as for any one-sided read."""
+    torch.cuda.synchronize() + dist.barrier() on both sides, as for any one-sided read.
+
+    Lifetime: use it as a context manager (or call close(), a COLLECTIVE: every rank closes its mappings of the peers' slabs, then a barrier, then
+    this rank lets go of its own slabs).  A slab's memory is released when the last tensor on it — `kps` / `desc` / `counts` or any view a caller
+    still holds — is gone, never under a live tensor."""
 
     def __init__(self, frames_per_rank, cap, device, group=None):
         import ctypes as C
@@ -113,33 +125,62 @@ class PeerExchange:
         self.L.orbd_allgather_frames_peer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
         di = device.index if hasattr(device, "index") else int(device)
         F, W = self.F, self.world
-        self._slabs = [_DevSlab(hip, di, (F, cap, 7), "<f4", 4), _DevSlab(hip, di, (F, cap, 32), "|u1", 1), _DevSlab(hip, di, (F, 2), "<i4", 4)]
-        dev = torch.device("cuda", di)
-        self.kps, self.desc, self.counts = (torch.as_tensor(s, device=dev) for s in self._slabs)
-        self.all_kps = torch.empty((W * F, cap, 7), dtype=torch.float32, device=dev)
-        self.all_desc = torch.empty((W * F, cap, 32), dtype=torch.uint8, device=dev)
-        self.all_counts = torch.empty((W * F, 2), dtype=torch.int32, device=dev)
-        mine = []
-        for s in self._slabs:
-            h = (C.c_uint8 * 64)()
-            if self.L.orbd_ipc_export(C.c_void_p(s.ptr), h) != 0:
-                raise RuntimeError("orbd_ipc_export failed (hipIpcGetMemHandle): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?")
-            mine.append(bytes(h))
-        allh = [None] * W
-        dist.all_gather_object(allh, mine, group=group)
+        self._slabs, self._opened, self._closed = [], [], False
+        try:
+            for shape, ts, isz in (((F, cap, 7), "<f4", 4), ((F, cap, 32), "|u1", 1), ((F, 2), "<i4", 4)):
+                self._slabs.append(_DevSlab(hip, di, shape, ts, isz))
+            dev = torch.device("cuda", di)
+            self.kps, self.desc, self.counts = (torch.as_tensor(s_, device=dev) for s_ in self._slabs)
+            self.all_kps = torch.empty((W * F, cap, 7), dtype=torch.float32, device=dev)
+            self.all_desc = torch.empty((W * F, cap, 32), dtype=torch.uint8, device=dev)
+            self.all_counts = torch.empty((W * F, 2), dtype=torch.int32, device=dev)
+            mine, err = [], None
+            for s_ in self._slabs:
+                h = (C.c_uint8 * 64)()
+                if self.L.orbd_ipc_export(C.c_void_p(s_.ptr), h) != 0:
+                    err = "orbd_ipc_export failed (hipIpcGetMemHandle): is HSA_ENABLE_IPC_MODE_LEGACY=0 set?"
+                mine.append(bytes(h))
+            allh = [None] * W
+            dist.all_gather_object(allh, (mine, err), group=group)        # every rank reaches the collective, also the one whose export failed
+            bad = [(r, e) for r, (_, e) in enumerate(allh) if e]
+            if bad:
+                raise RuntimeError("rank %d: %s" % bad[0])
+            self._peer = [(C.c_void_p * W)() for _ in range(3)]
+            for r in range(W):
+                for k in range(3):
+                    if r == self.rank:
+                        self._peer[k][r] = self._slabs[k].ptr
+                    else:
+                        p = C.c_void_p()
+                        hb = (C.c_uint8 * 64).from_buffer_copy(allh[r][0][k])
+                        if self.L.orbd_ipc_open(hb, C.byref(p)) != 0:
+                            raise RuntimeError("orbd_ipc_open failed for rank %d" % r)
+                        self._opened.append(p.value)
+                        self._peer[k][r] = p.value
+        except Exception:
+            self._release()           # what this rank had allocated / opened so far (no barrier: the peers are not known to be in step)
+            raise
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close(barrier=exc[0] is None)
+        return False
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:   # noqa: BLE001
+            pass
+
+    def _release(self):
+        for p in self._opened:
+            self.L.orbd_ipc_close(self.C.c_void_p(p))
         self._opened = []
-        self._peer = [(C.c_void_p * W)() for _ in range(3)]
-        for r in range(W):
-            for k in range(3):
-                if r == self.rank:
-                    self._peer[k][r] = self._slabs[k].ptr
-                else:
-                    p = C.c_void_p()
-                    hb = (C.c_uint8 * 64).from_buffer_copy(allh[r][k])
-                    if self.L.orbd_ipc_open(hb, C.byref(p)) != 0:
-                        raise RuntimeError("orbd_ipc_open failed for rank %d" % r)
-                    self._opened.append(p.value)
-                    self._peer[k][r] = p.value
+        self.kps = self.desc = self.counts = None
+        self._slabs = []              # each slab frees itself when the last tensor on it is gone (_DevSlab.__del__)
+        self._closed = True
 
     def allgather(self, stream=None):
         C = self.C
@@ -151,11 +192,15 @@ class PeerExchange:
             raise RuntimeError("orbd_allgather_frames_peer: %d" % rc)
         return self.all_kps, self.all_desc, self.all_counts
 
-    def close(self):
-        """collective in spirit: call after a barrier that follows the last allgather of every rank"""
+    def close(self, barrier=True):
+        """Collective: every rank unmaps its peers' slabs, all ranks meet, then this rank gives up its own (a peer must not still have a mapping of
+        memory its owner releases).  barrier=False only on an error path where the peers are not known to be in step."""
+        if self._closed:
+            return
+        torch.cuda.synchronize(self.all_kps.device)
         for p in self._opened:
             self.L.orbd_ipc_close(self.C.c_void_p(p))
         self._opened = []
-        self.kps = self.desc = self.counts = None
-        for s in self._slabs:
-            s.free()
+        if barrier and dist.is_initialized():
+            dist.barrier(group=self.group)
+        self._release()

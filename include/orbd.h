@@ -52,6 +52,13 @@ int orbd_ipc_open(const uint8_t handle[64], void** d_ptr_out);
 int orbd_ipc_close(void* d_ptr);
 int orbd_allgather_frames_peer(int world, int rank, int frames_per_rank, int cap, const void* const* peer_kps, const void* const* peer_desc,
                                const void* const* peer_counts, orb_keypoint* d_all_kps, uint8_t* d_all_desc, int32_t* d_all_counts, void* stream);
+/* orbd_peer_enable_access: the same-process form (one host thread per GPU, raw device pointers instead of IPC mappings) needs peer access from the
+ *     calling thread's current device to every other device of `devices`: enabled where missing, ORB_E_HIP if a pair cannot be connected.
+ * orbd_peer_shutdown: drains and releases the calling thread's per-peer copy streams and events (they are per thread, made on first use, and NOT
+ *     released by any destructor: at process exit the HIP runtime may already be gone).  Optional; after it the next all-gather makes them again.
+ * If orbd_allgather_frames_peer fails part-way, the copies it had queued are still joined into `stream`: synchronise `stream` before reuse. */
+int orbd_peer_enable_access(int n_devices, const int* devices);
+int orbd_peer_shutdown(void);
 
 /* Convenience for a single process that drives n_devices GPUs (and for the 1-GPU test): ncclCommInitAll.  comms[i] belongs to devices[i]. */
 int orbd_comm_init_all_local(int n_devices, const int* devices, orbd_comm* comms);

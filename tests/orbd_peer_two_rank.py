@@ -25,19 +25,25 @@ def worker(rank, world, port, q):
     try:
         from orbhip.dist import PeerExchange
         torch.cuda.set_device(0)
-        px = PeerExchange(F, CAP, torch.device("cuda", 0))
-        for rep in range(3):
-            k, d, c = rank_data(rank + 10 * rep)
-            px.kps.copy_(torch.from_numpy(k)); px.desc.copy_(torch.from_numpy(d)); px.counts.copy_(torch.from_numpy(c))
-            torch.cuda.synchronize(); dist.barrier()
-            ak, ad, ac = px.allgather()
-            torch.cuda.synchronize(); dist.barrier()
-            for r in range(world):
-                k2, d2, c2 = rank_data(r + 10 * rep)
-                assert np.array_equal(ak[r * F:(r + 1) * F].cpu().numpy(), k2) and np.array_equal(ad[r * F:(r + 1) * F].cpu().numpy(), d2)
-                assert np.array_equal(ac[r * F:(r + 1) * F].cpu().numpy(), c2)
-        dist.barrier()
-        px.close()
+        with PeerExchange(F, CAP, torch.device("cuda", 0)) as px:
+            for rep in range(3):
+                k, d, c = rank_data(rank + 10 * rep)
+                px.kps.copy_(torch.from_numpy(k)); px.desc.copy_(torch.from_numpy(d)); px.counts.copy_(torch.from_numpy(c))
+                torch.cuda.synchronize(); dist.barrier()
+                ak, ad, ac = px.allgather()
+                torch.cuda.synchronize(); dist.barrier()
+                for r in range(world):
+                    k2, d2, c2 = rank_data(r + 10 * rep)
+                    assert np.array_equal(ak[r * F:(r + 1) * F].cpu().numpy(), k2) and np.array_equal(ad[r * F:(r + 1) * F].cpu().numpy(), d2)
+                    assert np.array_equal(ac[r * F:(r + 1) * F].cpu().numpy(), c2)
+            held = px.kps[1]                       # a view a caller still holds when the exchange is closed (the with-block's exit is the collective close)
+            expect = held.cpu().numpy().copy()
+        assert px.kps is None and px._closed
+        assert np.array_equal(held.cpu().numpy(), expect)      # the slab lives as long as a tensor on it: no dangling device pointer
+        del held
+        import ctypes as C
+        L = C.CDLL(os.path.join(ROOT, "awesome-orb-slam3-3dvisioncraft-version_amd", "liborbd.so"))
+        assert L.orbd_peer_shutdown() == 0         # the calling thread's per-peer copy streams, drained and released
         q.put((rank, "ok"))
     except Exception:   # noqa: BLE001
         import traceback

@@ -185,6 +185,19 @@ def test_emulated_octree_lds_key_cache_path():
             _run_case(lib, case)
 
 
+def test_emulated_octree_1024_threads_per_problem():
+    """The single-frame entry point runs k_octree with 1 024 threads per (frame, level) problem on the GPU (OCT_T_SINGLE; the emulated builds of this
+    tier keep 256, the batch instantiation, because the emulator pays per work-item): the 1 024-thread instantiation on the densest octree input
+    and on a lapping window.  Results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("OCT_T_SINGLE=1024",), tag="octt1024")))
+    for case in CASES:
+        if case[0] in ("noise_tile_overflow", "other_config"):
+            _run_case(lib, case)
+
+
 def test_empty_image_returns_minus_one(emu_lib):
     e = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, lib=emu_lib)
     mono, k, d = e(np.zeros((0, 0), np.uint8))

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "orbd.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(orbd_[a-z0-9_]+)\s*\(", txt)))
     assert {"orbd_allgather_frames", "orbd_allreduce_pose_system", "orbd_allgather_pose_blocks", "orbd_allgather_frames_peer", "orbd_ipc_export",
-            "orbd_ipc_open", "orbd_ipc_close"} <= set(names)
+            "orbd_ipc_open", "orbd_ipc_close", "orbd_peer_enable_access", "orbd_peer_shutdown"} <= set(names)
     if not os.path.exists(SO):
         import __graft_entry__ as ge
         ge.build()
