@@ -1204,6 +1204,11 @@ def main():
                     sq_info["valu_floor_cycles_per_inst_static_mix"] = floor
                     sq_info["valu_issue_frac_of_measured_peak"] = round(floor / sq_info["simd_cycles_per_valu_inst"], 4)
                     sq_info["valu_mix"] = {k: vm["kernels"][inst][k] for k in ("valu", "full_rate", "half_rate", "quarter_rate")}
+                    lw = vm["kernels"][inst].get("loop_weighted")
+                    if lw:   # the same with every instruction weighted by its loop depth (tools/valu_mix.py): prologues no longer count like the hot loops
+                        sq_info["valu_floor_cycles_per_inst_loop_weighted"] = lw["floor_cycles_per_inst"]
+                        sq_info["valu_issue_frac_loop_weighted_floor"] = round(lw["floor_cycles_per_inst"] / sq_info["simd_cycles_per_valu_inst"], 4)
+                        sq_info["valu_mix_loop_weighted"] = {k: lw[k] for k in ("loop_weight", "full_rate_share", "half_rate_share", "quarter_rate_share")}
         except Exception:   # noqa: BLE001
             pass
         traffic_raw = None
