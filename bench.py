@@ -131,13 +131,40 @@ def _synth_one(spec):
 
 
 def synth_many(specs, workers=1):
-    """[(kind, seed, w, h)] -> list of images.  `workers` > 1 forks a process pool (0.15 s per textured 752x480 scene on one core): only to be used
-    BEFORE this process initialises HIP."""
+    """[(kind, seed, w, h)] -> list of images.  `workers` > 1 forks that many children (0.15 s per textured 752x480 scene on one core): only to be used
+    BEFORE this process initialises HIP.  Plain os.fork + a file per child under /dev/shm + os._exit: no multiprocessing pool — a pool stops its workers
+    with SIGTERM and lets them run their exit handlers, and under rocprofv3 (whose tool library every child inherits) a worker then hangs in the
+    profiler's signal handler and takes the parent's join with it (round 5: a --pmc pass of this script sat there until the box's time limit)."""
     if workers <= 1 or len(specs) < 8:
         return [_synth_one(sp) for sp in specs]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(min(workers, len(specs))) as pool:
-        return pool.map(_synth_one, specs, chunksize=max(1, len(specs) // (4 * workers)))
+    import shutil
+    import tempfile
+    n = min(workers, len(specs))
+    tmp = tempfile.mkdtemp(prefix="orbhip_synth_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    pids = []
+    try:
+        for k in range(n):
+            pid = os.fork()
+            if pid == 0:
+                code = 1
+                try:
+                    part = [_synth_one(sp) for sp in specs[k::n]]
+                    np.save(os.path.join(tmp, "part%d.npy" % k), np.stack(part))
+                    code = 0
+                finally:
+                    os._exit(code)          # no exit handlers, no inherited profiler finalisation
+            pids.append(pid)
+        failed = [pid for pid in pids if os.waitpid(pid, 0)[1] != 0]
+        if failed:
+            return [_synth_one(sp) for sp in specs]      # a child died (memory, a signal): do it here
+        out = [None] * len(specs)
+        for k in range(n):
+            part = np.load(os.path.join(tmp, "part%d.npy" % k))
+            for j, img in enumerate(part):
+                out[k + j * n] = img
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _pair_up(base, B, rng):

@@ -9,10 +9,10 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --streams 1 --no-parity-check --repeats 1"   # one stream: kernels run back to back, clean per-kernel durations
-date +%T; rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $CMD > $OUT/stats.log 2>&1
-date +%T; rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- $CMD > $OUT/fetch.log 2>&1
-date +%T; rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o pmc -- $CMD > $OUT/write.log 2>&1
-date +%T; rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq1 -o pmc -- $CMD > $OUT/sq1.log 2>&1
-date +%T; rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY -d $OUT/sq2 -o pmc -- $CMD > $OUT/sq2.log 2>&1
+date +%T; timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $CMD > $OUT/stats.log 2>&1
+date +%T; timeout -k 5 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o pmc -- $CMD > $OUT/fetch.log 2>&1
+date +%T; timeout -k 5 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o pmc -- $CMD > $OUT/write.log 2>&1
+date +%T; timeout -k 5 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/sq1 -o pmc -- $CMD > $OUT/sq1.log 2>&1
+date +%T; timeout -k 5 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY -d $OUT/sq2 -o pmc -- $CMD > $OUT/sq2.log 2>&1
 date +%T; tail -2 $OUT/*.log | cut -c1-300
 ls -la $OUT/*/
