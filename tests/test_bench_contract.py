@@ -78,6 +78,30 @@ def test_round4_fields_of_the_line():
     assert 0.3 < oi["valu_issue_frac_of_measured_peak"] <= 1.0 and 2.0 < oi["valu_floor_cycles_per_inst_static_mix"] < 4.3
 
 
+def test_round5_fields_of_the_line():
+    """Round-4 verdict items 1, 3, 4, 6: the rank bookkeeping of a run (n_gpus = ranks that ran), the headline on rotating input sets of distinct scenes with
+    the round-4 input next to it, the mixed batch with every frame checked, SURVEY's bytes in every per-kernel fraction, the single-window LM time."""
+    d, path = _latest()
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and len(d["per_rank"]["frames_per_s"]) == d["n_gpus"], path
+    assert abs(d["per_rank"]["min"] - d["value"]) / d["value"] < 0.02
+    c = d["config"]
+    assert c["input_sets"] >= 2 and c["distinct_scenes_per_set"] == c["frames_per_gpu_per_step"] // 2
+    sd = d["extra"]["scene_diversity"]
+    assert sd["headline_distinct_scenes"] == c["input_sets"] * c["distinct_scenes_per_set"] and 0.9 < sd["ratio_headline_over_r04_input"] < 1.1
+    assert sd["r04_input_parity"]["mismatches"] == 0
+    mb = d["extra"]["mixed_batch"]
+    assert mb["parity"]["checked_frames"] == c["frames_per_gpu_per_step"] and mb["parity"]["mismatches"] == 0 and mb["frames_per_s"] > 0
+    assert set(mb["frames_by_kind"]) == {"textured", "sparse", "low_contrast", "flat", "noise"} and mb["mean_keypoints_by_kind"]["flat"] == 0.0
+    assert mb["frames_by_kind"]["textured"] > mb["frames_by_kind"]["sparse"] > mb["frames_by_kind"]["low_contrast"] > mb["frames_by_kind"]["noise"] > 0
+    r = d["roofline"]
+    assert r["traffic_ratio"] is not None and abs(r["traffic_ratio"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3
+    B = c["frames_per_gpu_per_step"]
+    want = 1000 * (961 + 512 + 60) * B / (d["kernel_ms"]["describe"] * 1e-3) / 1e9 / r["peak"]        # SURVEY 8(d): N (961 + 512 + 60), not the staged 43 x 43
+    assert abs(r["per_kernel_frac"]["k_describe2"] - want) < 2e-3 and r["describe_patch_bytes_per_frame"] == 1000 * (43 * 43 + 60)
+    lm = d["extra"]["lba"]
+    assert lm["lm_single_window_ms_per_optimize5"] <= 3.0 and lm["lm_trials_per_window"] == 5.0      # round-4 verdict item 4 (was 4.72)
+
+
 def test_valu_rates_table_is_committed():
     import csv
     rows = [r for r in csv.reader(open(os.path.join(ROOT, "profiles", "valu_rates.csv"))) if r and not r[0].startswith("#")]
