@@ -618,22 +618,26 @@ static __global__ __launch_bounds__(256) void k_lm_errors(LmArgs A) {
     if (threadIdx.x == 0) A.part[(size_t)b * A.nPart + blockIdx.x] = red[0];
 }
 
+// grid (MAXDIAG_G, batch): the diagonal scan of a window spread over MAXDIAG_G workgroups (one workgroup walked 60 000 entries of a C5 window in
+// 70 us — 3 % of a lone window's optimize(5)); the maximum of non-negative doubles is the maximum of their bit patterns, so the slices meet in one
+// integer atomicMax on st.maxDiag (k_lm_init zeroes it): exact and order-independent
+#define MAXDIAG_G 16
 static __global__ __launch_bounds__(256) void k_lm_maxdiag(LmArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* red = (double*)orb_smem;
     const lba_problem& P = A.P;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, t0 = (int)blockIdx.x * 256 + tid;
     const int np = min(P.n_poses[b], P.cap_p), nl = min(P.n_points[b], P.cap_l);
     double m = 0;
-    for (int i = tid; i < np * 6; i += 256) m = fmax(m, fabs(A.S.Hpp[((size_t)b * P.cap_p + i / 6) * 36 + (i % 6) * 7]));   // fixed blocks are zero
-    for (int i = tid; i < nl * 3; i += 256) m = fmax(m, fabs(A.S.Hll[((size_t)b * P.cap_l + i / 3) * 9 + (i % 3) * 4]));
+    for (int i = t0; i < np * 6; i += 256 * MAXDIAG_G) m = fmax(m, fabs(A.S.Hpp[((size_t)b * P.cap_p + i / 6) * 36 + (i % 6) * 7]));   // fixed blocks are zero
+    for (int i = t0; i < nl * 3; i += 256 * MAXDIAG_G) m = fmax(m, fabs(A.S.Hll[((size_t)b * P.cap_l + i / 3) * 9 + (i % 3) * 4]));
     red[tid] = m;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
         __syncthreads();
     }
-    if (tid == 0) A.st[b].maxDiag = red[0];
+    if (tid == 0 && red[0] > 0) atomicMax((unsigned long long*)&A.st[b].maxDiag, (unsigned long long)__double_as_longlong(red[0]));
 }
 
 static __global__ void k_lm_begin(LmArgs A, int batch) {
@@ -1553,7 +1557,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 18 * 8, st, L);
             LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(POSES_NT), (POSES_NT / 64) * 27 * 8, st, L);
         }
-        if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(batch), dim3(256), 256 * 8, st, A);
+        if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(MAXDIAG_G, batch), dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
         for (int trial = 0; trial < 100; trial++) {
             if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;

@@ -1117,7 +1117,11 @@ def main():
         barrier()
         dtx = (time.perf_counter() - tx) / 3
         blk = out[0].shape[1] * 60 + 8
-        extra["exchange"] = {"allgather_frame_blocks_ms": round(dtx * 1e3, 3), "bytes_per_rank": int(B * blk),
+        # what every rank holds of ITSELF in the gathered slabs must be its own local slabs, bit for bit (class_id = -1 reads as NaN: compare bit patterns)
+        own = bool(torch.equal(ak[rank * B:(rank + 1) * B].view(torch.int32), out[0].view(torch.int32)) and torch.equal(ad[rank * B:(rank + 1) * B], out[1])
+                   and torch.equal(ac[rank * B:(rank + 1) * B], out[2]))
+        own_all = rank_max([0.0 if own else 1.0])[0] == 0.0
+        extra["exchange"] = {"allgather_frame_blocks_ms": round(dtx * 1e3, 3), "bytes_per_rank": int(B * blk), "own_block_equals_local_slabs_on_every_rank": own_all,
                              "GBps_into_each_rank": round((world - 1) * B * blk / dtx / 1e9, 2),
                              "frames_visible_to_each_rank": int(ak.shape[0]), "what": "one all_gather_into_tensor of per-frame blocks [desc|kps|count]",
                              "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "world": world, "backend": dist.get_backend()}
@@ -1136,6 +1140,7 @@ def main():
                     barrier()
                 dtp = (time.perf_counter() - tp) / 3
                 same = bool(torch.equal(pk.view(torch.int32), ak.view(torch.int32)) and torch.equal(pd, ad) and torch.equal(pc, ac))   # (bit patterns: class_id = -1 reads as NaN)
+                same = rank_max([0.0 if same else 1.0])[0] == 0.0                       # ... on every rank
                 extra["exchange"]["peer"] = {"allgather_frame_blocks_ms": round(dtp * 1e3, 3), "GBps_into_each_rank": round((world - 1) * B * blk / dtp / 1e9, 2),
                                              "equal_to_rccl_result": same, "what": "orbd_allgather_frames_peer: hipMemcpyAsync pull per peer and slab over IPC handles, "
                                                                                    "one stream per peer (timed with a barrier per call)"}

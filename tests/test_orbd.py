@@ -34,3 +34,11 @@ def test_two_rank_peer_allgather_on_one_gpu():
     """the RCCL-free all-gather (IPC handles + one pull per peer): two processes sharing GPU 0"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "orbd_peer_two_rank.py")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "peer exchange OK" in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_all_local_devices_exchange():
+    """one process, a host thread per visible GPU (ncclCommInitAll over orb_device_count() devices): RCCL and peer-copy all-gathers, all-reduce, pose
+    all-gather with every block checked on every rank — the one-rank case on a one-GPU box, the first multi-rank RCCL run wherever there are more"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "orbd_all_local.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all-local exchange OK" in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
