@@ -140,7 +140,9 @@ def synth_many(specs, workers=1):
     import shutil
     import tempfile
     n = min(workers, len(specs))
-    tmp = tempfile.mkdtemp(prefix="orbhip_synth_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    need = sum(sp[2] * sp[3] for sp in specs) + (1 << 20)
+    shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need      # (a container's /dev/shm can be 64 MB: then the default temp dir)
+    tmp = tempfile.mkdtemp(prefix="orbhip_synth_", dir="/dev/shm" if shm_ok else None)
     pids = []
     try:
         for k in range(n):
