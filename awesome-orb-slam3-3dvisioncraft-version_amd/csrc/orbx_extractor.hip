@@ -197,6 +197,75 @@ static __global__ __launch_bounds__(256) void k_resize(ResizeParams P) {
 // estimate of the first / last coefficient widened by one on each side (the exact indices come from the double-precision tables and can differ
 // by one).  Workgroup-uniform float arithmetic — 30 VALU instructions that every lane of every tile repeated (there is no scalar float unit) —
 // so it is evaluated once per level at orbx_create and read back through the scalar cache.
+// ---- the whole pyramid of ONE frame in ONE launch (the single-frame entry point) -----------------------------------------------------------------
+// Seven dependent k_resize2 launches cost a single frame 7 x 4.8 us of launch-to-launch latency for 0.7 ... 3 us of work each.  Here a workgroup takes a
+// tile of the TOP level and computes, level by level from the image up, every pixel its tile depends on — region C_l of level l, two LDS buffers
+// swapped per level — plus its own share of every level (the levels are partitioned among the tiles: a pixel no higher level reads must still
+// exist, FAST and rBRIEF read it).  Regions of neighbouring workgroups overlap by their footprint halos; the overlap is computed twice from the
+// same inputs with the same integer arithmetic and stored twice with the same bytes.  Arithmetic per pixel = k_resize's (cv::resize INTER_LINEAR
+// 8UC1 fixed point), coefficients from the same per-level tables.  Regions (host, orbx_create):
+// C_top = own tile; C_l = bounding box of (own share of level l) and (footprint of C_{l+1} in level l); region 0 = footprint of C_1 in the image.
+#define PYC_T 1024
+struct PyrChainParams {
+    const uint8_t* img; size_t imgFrame; int imgStride;
+    uint8_t* pyr; size_t pyrFrame;
+    size_t planeOff[ORBX_MAX_LEVELS]; int stride[ORBX_MAX_LEVELS]; int w[ORBX_MAX_LEVELS]; int h[ORBX_MAX_LEVELS];
+    const int* coef; int coefOff[ORBX_MAX_LEVELS];   // xs[dw] | xw[dw] | ys[dh] | yw[dh] of level l >= 1 at coef + coefOff[l]
+    const int4* regions;                             // [tiles][nlevels] {x0, y0, w, h}
+    int nlevels, bufBytes;                           // bufBytes: one LDS pixel buffer (largest region of any tile and level, 16-byte multiple)
+};
+static __global__ __launch_bounds__(PYC_T) void k_pyramid_chain(PyrChainParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    const int tid = threadIdx.x, tile = blockIdx.x, frame = blockIdx.y;
+    uint8_t* buf[2] = {orb_smem, orb_smem + P.bufBytes};
+    int* ctab = (int*)(orb_smem + 2 * P.bufBytes);   // per level l >= 1: xs | xw of the region's columns, ys | yw of its rows
+    const int4* R = P.regions + (size_t)tile * P.nlevels;
+    {   // region 0 of the image -> buf[0]; every level's coefficient slices -> LDS (one memory round trip for all of it)
+        const int4 r0 = R[0];
+        const uint8_t* src = P.img + (size_t)frame * P.imgFrame + (size_t)r0.y * P.imgStride + r0.x;
+        for (int y = tid >> 6; y < r0.w; y += PYC_T / 64)
+            for (int x = tid & 63; x < r0.z; x += 64) buf[0][y * r0.z + x] = src[(size_t)y * P.imgStride + x];
+        int off = 0;
+        for (int l = 1; l < P.nlevels; l++) {
+            const int4 r = R[l];
+            const int* xs = P.coef + P.coefOff[l]; const int* xw = xs + P.w[l]; const int* ys = xw + P.w[l]; const int* yw = ys + P.h[l];
+            for (int i = tid; i < r.z; i += PYC_T) { ctab[off + i] = xs[r.x + i]; ctab[off + r.z + i] = xw[r.x + i]; }
+            for (int i = tid; i < r.w; i += PYC_T) { ctab[off + 2 * r.z + i] = ys[r.y + i]; ctab[off + 2 * r.z + r.w + i] = yw[r.y + i]; }
+            off += 2 * (r.z + r.w);
+        }
+    }
+    __syncthreads();
+    int off = 0;
+    for (int l = 1; l < P.nlevels; l++) {
+        const int4 rs = R[l - 1], rd = R[l];
+        const uint8_t* S = buf[(l - 1) & 1];
+        uint8_t* Dl = buf[l & 1];
+        uint8_t* G = P.pyr + P.planeOff[l] + (size_t)frame * P.pyrFrame + (size_t)rd.y * P.stride[l] + rd.x;
+        const int* cxs = ctab + off; const int* cxw = cxs + rd.z; const int* cys = cxw + rd.z; const int* cyw = cys + rd.w;
+        const int sw = P.w[l - 1], sh = P.h[l - 1];
+        for (int y = tid >> 6; y < rd.w; y += PYC_T / 64) {
+            int sy0 = cys[y];
+            const int bw = cyw[y], b0 = (int)(short)(bw & 0xFFFF), b1 = bw >> 16;
+            int sy1 = sy0 + 1;
+            sy0 = sy0 < 0 ? 0 : (sy0 < sh ? sy0 : sh - 1);       // rows are clipped after the weights are fixed (resize.cpp)
+            sy1 = sy1 < 0 ? 0 : (sy1 < sh ? sy1 : sh - 1);
+            const int o0 = (sy0 - rs.y) * rs.z - rs.x, o1 = (sy1 - rs.y) * rs.z - rs.x;   // (indices, not pointers: an LDS pointer must not leave its buffer)
+            for (int x = tid & 63; x < rd.z; x += 64) {
+                const int sx = cxs[x], aw = cxw[x];
+                const int a0 = (int)(short)(aw & 0xFFFF), a1 = aw >> 16;
+                const int x1 = sx + 1 < sw ? sx + 1 : sw - 1;    // weight is 0 there (fx forced to 0)
+                const int t0 = S[o0 + sx] * a0 + S[o0 + x1] * a1;
+                const int t1 = S[o1 + sx] * a0 + S[o1 + x1] * a1;
+                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                Dl[y * rd.z + x] = (uint8_t)v;
+                G[(size_t)y * P.stride[l] + x] = (uint8_t)v;
+            }
+        }
+        off += 2 * (rd.z + rd.w);
+        __syncthreads();
+    }
+}
+
 static inline void resize2_footprint(int t0, int tlen, int dlen, int slen, double scale, bool alignX, int& lo, int& ext) {
     const float fs = (float)scale;
     const int a = std::max((int)floorf(((float)t0 + 0.5f) * fs - 0.5f) - 1, 0);
@@ -2504,6 +2573,7 @@ struct orbx_extractor {
     int nTiles = 0, nTiles1 = 0, fastImgBytes = 0, octKeyOff = 0, octMerge = 0; size_t fastSmem = 0, octSmem = 0;
     hipStream_t stream = nullptr;
     int32_t* d_rowStart = nullptr; int32_t* d_rowIdx = nullptr; int rowCapAlloc = 0;   // ComputeStereoMatches row buckets (lazy)
+    int4* d_chain = nullptr; int chainTiles = 0, chainBuf = 0; size_t chainSmem = 0;   // k_pyramid_chain's regions ([tiles][nlevels]); chainTiles = 0: not usable for this geometry
     int* d_coef = nullptr; size_t coefOff[ORBX_MAX_LEVELS] = {0};   // k_resize2 tables of every level >= 1
     size_t tileTabOff[ORBX_MAX_LEVELS] = {0};                        // k_resize2 staging footprints of every level >= 1 (inside d_coef)
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
@@ -2552,7 +2622,7 @@ static int orbx_fail(orbx_extractor* h, int code, const std::string& msg) {
 static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* bufs[] = {h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
+    void* bufs[] = {h->d_chain, h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
                     h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (h->h_img) (void)hipHostFree(h->h_img);
@@ -2714,6 +2784,45 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
         }
         CK(hipMalloc((void**)&h->d_coef, std::max<size_t>(tab.size() * 4, 256)));
         if (!tab.empty()) CK(hipMemcpy(h->d_coef, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        // k_pyramid_chain's regions (see the kernel): tiles of ~16 x 16 pixels of the top level; every level is partitioned among the tiles
+        // (share t of a length n = [t n / T, (t + 1) n / T)), a tile's region of level l = bounding box of its share and of the footprint of its
+        // region of level l + 1.  Not usable (chainTiles = 0: the launches fall back to the per-level kernels) if a region or the whole set
+        // exceeds the LDS budget, or with a single level.
+        if (nl >= 2) {
+            const int top = nl - 1;
+            const int TX = std::max(1, h->lv[top].w / 16), TY = std::max(1, h->lv[top].h / 16);
+            std::vector<int4> reg((size_t)TX * TY * nl);
+            int maxArea = 0, maxCoef = 0;
+            for (int ty = 0; ty < TY; ty++)
+                for (int tx = 0; tx < TX; tx++) {
+                    int4* R = reg.data() + ((size_t)ty * TX + tx) * nl;
+                    int cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0, ncoef = 0;    // region of the level above, [cx0, cx1) x [cy0, cy1)
+                    for (int l = top; l >= 0; l--) {
+                        const int w = h->lv[l].w, hh = h->lv[l].h;
+                        int x0 = (int)((long long)tx * w / TX), x1 = (int)((long long)(tx + 1) * w / TX);
+                        int y0 = (int)((long long)ty * hh / TY), y1 = (int)((long long)(ty + 1) * hh / TY);
+                        if (l == 0) { x0 = w; x1 = 0; y0 = hh; y1 = 0; }              // the image itself is not produced: footprint only
+                        if (l < top) {
+                            const int* xs = tab.data() + h->coefOff[l + 1]; const int* ys = xs + 2 * h->lv[l + 1].w;
+                            const int fx0 = xs[cx0], fx1 = std::min(xs[cx1 - 1] + 1, w - 1) + 1;
+                            const int fy0 = std::min(std::max(ys[cy0], 0), hh - 1), fy1 = std::min(std::max(ys[cy1 - 1] + 1, 0), hh - 1) + 1;
+                            x0 = std::min(x0, fx0); x1 = std::max(x1, fx1); y0 = std::min(y0, fy0); y1 = std::max(y1, fy1);
+                        }
+                        R[l] = make_int4(x0, y0, x1 - x0, y1 - y0);
+                        maxArea = std::max(maxArea, (x1 - x0) * (y1 - y0));
+                        if (l >= 1) ncoef += 2 * ((x1 - x0) + (y1 - y0));
+                        cx0 = x0; cx1 = x1; cy0 = y0; cy1 = y1;
+                    }
+                    maxCoef = std::max(maxCoef, ncoef);
+                }
+            h->chainBuf = (maxArea + 15) & ~15;
+            h->chainSmem = (size_t)2 * h->chainBuf + (size_t)maxCoef * 4;
+            if (h->chainSmem <= 64 * 1024) {
+                h->chainTiles = TX * TY;
+                CK(hipMalloc((void**)&h->d_chain, reg.size() * sizeof(int4)));
+                CK(hipMemcpy(h->d_chain, reg.data(), reg.size() * sizeof(int4), hipMemcpyHostToDevice));
+            }
+        }
     }
     CK(hipMalloc((void**)&h->d_cand, B * h->candFrame * 4));
     CK(hipMalloc((void**)&h->d_keyNode, B * h->candFrame * 2));
@@ -2810,7 +2919,19 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #ifndef ORBX_EXP_DUP
 #define ORBX_EXP_DUP 0   // experiment only (tools/build_variants.sh): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
 #endif                   // three-stream step (every one of them is idempotent) next to its standalone time
-    for (int rep = 0; rep < ((ORBX_EXP_DUP & 1) ? 2 : 1); rep++)
+#ifndef PYR_CHAIN_MAX_BATCH
+#define PYR_CHAIN_MAX_BATCH 1   // calls of up to this many frames build the pyramid in ONE launch (k_pyramid_chain): the single-frame entry point
+#endif
+    const bool chain = h->chainTiles > 0 && batch <= PYR_CHAIN_MAX_BATCH;
+    if (chain) {
+        PyrChainParams C;
+        memset(&C, 0, sizeof(C));
+        level_view(h, 0, C.img, C.imgFrame, C.imgStride);
+        C.pyr = h->d_pyr; C.pyrFrame = h->pyrFrame; C.coef = h->d_coef; C.regions = h->d_chain; C.nlevels = nl; C.bufBytes = h->chainBuf;
+        for (int l = 0; l < nl; l++) { C.planeOff[l] = h->lv[l].planeOff; C.stride[l] = h->lv[l].stride; C.w[l] = h->lv[l].w; C.h[l] = h->lv[l].h; C.coefOff[l] = (int)h->coefOff[l]; }
+        hipLaunchKernelGGL(k_pyramid_chain, dim3(h->chainTiles, batch), dim3(PYC_T), h->chainSmem, st, C);
+    }
+    for (int rep = 0; !chain && rep < ((ORBX_EXP_DUP & 1) ? 2 : 1); rep++)
     for (int l = 1; l < nl; l++) {
         ResizeParams R;
         level_view(h, l - 1, R.src, R.sFrame, R.sStride);
