@@ -39,7 +39,7 @@ def test_threads_on_emulated_library_under_tsan(tmp_path):
     lib = build_emu.build(tag="tsan", flags=("-fsanitize=thread", "-O1"))
     exe = _build(lib, "tsan", tmp_path, flags=("-fsanitize=thread",))
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1 history_size=4")
-    out = _run(exe, (240, 232, 100, 1), 3000, env=env)
+    out = _run(exe, (240, 232, 100, 1, 1, 0), 3000, env=env)      # one LM iteration, no PoseOptimizer: the sanitised emulator pays seconds per launch
     assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-6000:]
 
 
