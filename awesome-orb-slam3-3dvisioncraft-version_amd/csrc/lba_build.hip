@@ -914,9 +914,10 @@ static __global__ __launch_bounds__(256) void k_lm_schur_combine(LmArgs A, const
 
 #include "dense_chol.inc"
 #ifndef LM_CHOL_SPLIT_MAX_BATCH
-#define LM_CHOL_SPLIT_MAX_BATCH 64    // windows per call up to which one launch per panel (k_lm_chol_step) beats one workgroup per window (MI355X, ms per
+#define LM_CHOL_SPLIT_MAX_BATCH 48    // windows per call up to which one launch per panel (k_lm_chol_step) beats one workgroup per window (MI355X, ms per
                                       // optimize(5) of 100-key-frame windows, per panel / per window: 1 window 2.2 / 6.8, 8: 4.0 / 7.5, 32: 10.6 / 12.7, 64: 18.8 / 19.1,
-                                      // 128: 35.6 / 31.7, 256: 67.7 / 55.8; 40-key-frame windows: 8: 1.68 / 2.17, 64: 5.4 / 5.7, 256: 16.8 / 16.4)
+                                      // 128: 35.6 / 31.7, 256: 67.7 / 55.8; 40-key-frame windows: 8: 1.68 / 2.17, 64: 5.4 / 5.7, 256: 16.8 / 16.4 — a tie at 64, where
+                                      // stereo / fisheye windows came out 2-4 % behind: the switch sits below it)
 #endif
 #ifndef LM_CHOL_NT
 #define LM_CHOL_NT 512    // 8 waves per window: the factorisation is one workgroup per window, its trailing update a global-memory latency problem

@@ -305,7 +305,7 @@ def test_emu_lba_optimize_split_schur_rows():
 
 
 def test_emu_lba_optimize_one_workgroup_per_window():
-    """LM_CHOL_SPLIT_MAX_BATCH=0: the factorisation as ONE workgroup per window with 16-column panels (k_lm_chol<16>, what a batch of more than 64
+    """LM_CHOL_SPLIT_MAX_BATCH=0: the factorisation as ONE workgroup per window with 16-column panels (k_lm_chol<16>, what a batch of more than 48
     small windows takes).  The default build's few-window calls — every other LM test of this tier — take one launch per panel (k_lm_chol_step +
     k_lm_chol_back_x: inverse of the diagonal block, panel rows and trailing tiles on the fp64 matrix core)."""
     import ctypes
@@ -317,7 +317,7 @@ def test_emu_lba_optimize_one_workgroup_per_window():
 
 def test_emu_lba_optimize_wide_panel_one_workgroup():
     """WG_CHOL_NB32_MIN_LD=0 + LM_CHOL_SPLIT_MAX_BATCH=0: the 32-column panel inside ONE workgroup per window (k_lm_chol<32>, what a batch of more
-    than 64 windows of 54 ... 88 free key frames takes) on the small test windows."""
+    than 48 windows of 54 ... 88 free key frames takes) on the small test windows."""
     import ctypes
     import build_emu
     from orbhip import _lib
