@@ -934,8 +934,8 @@ static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const i
 }
 
 #define LM_CHOLS_NB 32
-// One launch per 32-column panel (round 5; replaces the panel + update pair above for few windows per call): a WAVE per 16 x 16 tile of the trailing
-// triangle does everything its tile needs by itself, so that nothing of a panel step waits on another launch:
+// Few windows per call: the factorisation as one launch per 32-column panel (round 5; round 4 ran a panel launch and an update launch per panel).
+// A WAVE per 16 x 16 tile of the trailing triangle does everything its tile needs by itself, so that nothing of a panel step waits on another launch:
 //   1. the 32 x 32 diagonal block A11 = L11 L11^T in registers (lane r < 32 = row r) and, in the SAME instruction stream on lanes 32..63, the
 //      inverse X = L11^-1 by forward substitution of the identity (lane 32 + j = column j): step c scales entry c by 1 / L(c, c) and takes
 //      L(c2, c) * entry c off every later entry c2 — for a row of A that is the right-looking Cholesky update, for a column of X the substitution.
@@ -944,9 +944,10 @@ static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const i
 //      steps per row of a triangular solve are gone), re-laid out through LDS;
 //   3. the tile's rank-32 update C -= L21_i L21_j^T (8 more matrix instructions).
 // Every wave factors the same block (identical values).  L and y = L^-1 b go to cholL / cholY, not back into Hs / xp: other waves of the launch
-// still read the unfactored panel.  Waves of tile column 0 write their rows of L21 and take those rows' share of the forward substitution; wave 0
-// writes L11 and the block's y.  The explicit inverse costs accuracy cond(L11) * eps on the panel rows instead of eps (a 32 x 32 block of a
-// damped reduced camera system: measured against the one-workgroup kernel in test_hip_cholesky_per_phase_launches_agree_with_one_workgroup).
+// still read the unfactored panel.  Waves of tile column 0 write their rows of L21 (row-major: what k_lm_chol_back_x reads) and take those rows'
+// share of the forward substitution; wave 0 writes X and the block's y (L11 itself is not stored: the backward substitution uses X).  The explicit
+// inverse costs accuracy cond(L11) * eps on the panel rows instead of eps — a 32 x 32 block of a damped reduced camera system; measured against the
+// one-workgroup kernel in test_hip_cholesky_per_phase_launches_agree_with_one_workgroup and over 1 200 random windows by tools/fuzz_lm.py.
 #define LM_CHOLF_SMEM ((LM_CHOLS_NB * (LM_CHOLS_NB + 1) + 2 * 16 * (LM_CHOLS_NB + 1) + 2 * LM_CHOLS_NB + 2 * LM_CHOLS_NB) * 8)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
 #define LM_KEEP_LOADED(x) asm volatile("" : "+v"(x))     // the value exists in a (vector) register HERE: its load cannot be sunk below this point
