@@ -38,6 +38,18 @@ int main() {
     CHECK(ex.mvImagePyramid[7].cols == w7 && ex.mvImagePyramid[7].rows == h7 && std::memcmp(ex.mvImagePyramid[7].data, l7.data(), l7.size()) == 0);
     cv::Mat empty;
     CHECK(ex(empty, cv::Mat(), kps, desc, lap) == -1);   // ORBextractor.cc:1078-1079
+    // a failing call must not throw (Frame::ExtractORB runs on bare std::threads): an image too small for eight levels makes orbx_create fail inside
+    // operator() — reported through GlueGuard, -1 and empty outputs returned, and the object keeps working afterwards
+    {
+        const unsigned long f0 = orbslam3_hip::glue_failures();
+        cv::Mat tiny(30, 40, CV_8UC1);
+        CHECK(ex(tiny, cv::Mat(), kps, desc, lap) == -1 && kps.empty() && desc.empty());
+        CHECK(orbslam3_hip::glue_failures() == f0 + 1);
+        const orbslam3_hip::GlueLastError le = orbslam3_hip::glue_last_error();
+        CHECK(std::strcmp(le.function, "ORBextractor::operator()") == 0 && std::strstr(le.what, "orbx_create") != nullptr);
+        CHECK(ex(img, cv::Mat(), kps, desc, lap) == mono && kps.size() == k2.size());
+        CHECK(std::memcmp(d2.data(), desc.data, d2.size()) == 0);
+    }
     std::printf("extractor_cv_test OK: %zu keypoints through operator()(cv::InputArray, ...)\n", k2.size());
     return 0;
 }
