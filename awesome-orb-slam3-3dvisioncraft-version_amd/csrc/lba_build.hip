@@ -536,7 +536,7 @@ extern "C" int lba_compute_errors(const lba_problem* prob, int batch, const lba_
 //   k_lm_chol        dense in-place Cholesky + two triangular solves, one workgroup per window   (linear_solver_eigen.h:94-123)
 //   k_lm_backsub     x_l = Dinv (b_l - Hpl^T x_p), X += x_l, scale partials            block_solver.hpp:461-481, levenberg.cpp:188-195
 //   k_lm_update_pose T <- exp(x_p) * T                       types_six_dof_expmap.h:73-76, se3quat.h:223-256
-//   k_lm_decide      rho test, lambda update, push/pop       optimization_algorithm_levenberg.cpp:126-149
+//   k_lm_sum_decide  chi2 sum + rho test, lambda update, push/pop   optimization_algorithm_levenberg.cpp:126-149
 //   k_lm_restore     pop (restore the backup state of rejected windows)
 //   k_lm_end         "Raul" stop rule                        :151-165
 // ============================================================================================================
@@ -665,6 +665,9 @@ static __device__ __forceinline__ bool inv3_sym(const double* D, double* o) {   
 static __global__ __launch_bounds__(256) void k_lm_dinv(LmArgs A) {
     const lba_problem& P = A.P;
     const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+    // the "another trial is needed" word of this trial (k_lm_sum_decide adds to it, the host reads it after k_lm_restore): cleared by the trial's first
+    // kernel instead of a memset launch of its own — a lone window's trial is ~30 launches of a few microseconds, every one of them counts
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *A.flag = 0;
     if (!A.st[b].needTrial) return;
     const int nl = min(P.n_points[b], P.cap_l);
     if (l >= nl) return;
@@ -1322,7 +1325,9 @@ static __device__ __forceinline__ Quat quat_from_R(const double m[9]) {   // Eig
 }
 
 // pose update + the pose part of computeScale (one thread per pose; the partial goes to slot nPart-1 via a block of its own)
-static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A) {
+// (+ the scale sum of the rho test — the back-substitution's per-block partials and this kernel's own pose part — in k_lm_sum_partials' order: lanes of
+// wave 0 stride over the nBack partials, lane 0 adds the pose part, fixed butterfly; one launch fewer per lambda trial)
+static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A, int nBack) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     double* red = (double*)orb_smem;
     const lba_problem& P = A.P;
@@ -1364,12 +1369,25 @@ static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A) {
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
     if (tid == 0) A.part[(size_t)b * A.nPart + A.nPart - 1] = red[0];
+    if (tid < 64) {
+        double s = 0;
+        for (int i = tid; i < nBack; i += 64) s += A.part[(size_t)b * A.nPart + i];
+        if (tid == 0) s += red[0];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (tid == 0) A.st[b].scale = s;
+    }
 }
 
-static __global__ void k_lm_decide(LmArgs A, int batch) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+// computeActiveErrors' sum (k_lm_sum_partials with what = 0: the same lane-strided partial sums and butterfly) and the rho test of the trial in one launch:
+// one wave per window, lane 0 decides
+static __global__ __launch_bounds__(64) void k_lm_sum_decide(LmArgs A, int n) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double sum = 0;
+    for (int i = lane; i < n; i += 64) sum += A.part[(size_t)b * A.nPart + i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane != 0) return;
     LmState& s = A.st[b];
+    s.tempChi = sum;
     if (!s.needTrial) return;
     double tempChi = s.tempChi;
     if (!s.ok) tempChi = 1.7976931348623157e308;
@@ -1562,7 +1580,6 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(MAXDIAG_G, batch), dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
         for (int trial = 0; trial < 100; trial++) {
-            if (hipMemsetAsync(A.flag, 0, 4, st) != hipSuccess) return ORB_E_HIP;
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
             hipLaunchKernelGGL(k_lm_dinv, gL, dim3(256), 0, st, A);
             {
@@ -1581,11 +1598,9 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             } else if (nb32) hipLaunchKernelGGL(k_lm_chol<32>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             else hipLaunchKernelGGL(k_lm_chol<CH_NB>, dim3(batch), dim3(LM_CHOL_NT), cholSmem, st, A, (const int32_t*)nfree);
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
-            hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gLB.x, 1, nPart - 1);
+            hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A, (int)gLB.x);       // (+ the scale sum)
             LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
-            hipLaunchKernelGGL(k_lm_decide, dim3(gB), dim3(64), 0, st, A, batch);
+            hipLaunchKernelGGL(k_lm_sum_decide, dim3(batch), dim3(64), 0, st, A, (int)gE.x);               // chi2 sum + rho test
             hipLaunchKernelGGL(k_lm_restore, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);       // pop
             int more = 0;
             if (hipMemcpyAsync(&more, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
