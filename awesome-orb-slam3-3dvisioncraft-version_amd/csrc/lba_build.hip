@@ -954,7 +954,11 @@ static __global__ __launch_bounds__(LM_CHOL_NT) void k_lm_chol(LmArgs A, const i
 #define LM_CHOLF_SMEM ((LM_CHOLS_NB * (LM_CHOLS_NB + 1) + 2 * 16 * (LM_CHOLS_NB + 1) + 2 * LM_CHOLS_NB + 2 * LM_CHOLS_NB) * 8)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HIP_EMULATED)
 #define LM_KEEP_LOADED(x) asm volatile("" : "+v"(x))     // the value exists in a (vector) register HERE: its load cannot be sunk below this point
+#ifdef CHOL_PROF
+#define LM_KEEP_LOADED_S(x) do {} while (0)              // (the timers' clock reads move the window state into vector registers: nothing to pin)
+#else
 #define LM_KEEP_LOADED_S(x) asm volatile("" : "+s"(x))   // the same for a wave-uniform value (scalar register)
+#endif
 #else
 #define LM_KEEP_LOADED(x) do {} while (0)
 #define LM_KEEP_LOADED_S(x) do {} while (0)
@@ -1034,25 +1038,32 @@ static __global__ __launch_bounds__(64) void k_lm_chol_step(LmArgs A, const int3
 #pragma unroll
     for (int c = 0; c < NB; c++) v[c] = isA ? ((lane < nb && c <= lane) ? sv[c] : (c == lane ? 1.0 : 0.0)) : (c == j32 ? 1.0 : 0.0);
     CHP_MARK(0);
+    // The pivot of step c + 1 is taken from lane c + 1's OWN registers before step c's column has made its round trip through LDS: for that lane the
+    // update v[c + 1] -= L(c + 1, c) * v[c] has both factors in its own v[c], so the value is bit for bit what the update below leaves there — and the
+    // next pivot's rsqrt (a chain of eight dependent fp64 operations) runs while the column is written, read back and taken off the other entries.
     bool ok = true;
+    double dkk = wg_chol_bcast(v[0], 0);
+#ifdef HIP_EMULATED
+#define LM_RSQRT(x) (1.0 / sqrt(x))
+#else
+#define LM_RSQRT(x) rsqrt(x)
+#endif
+    double ri = LM_RSQRT(dkk);
 #pragma unroll
     for (int c = 0; c < NB; c++) {
-        const double dkk = wg_chol_bcast(v[c], c);
         ok = ok && (dkk > 0) && (dkk < 1.7e308);
-#ifdef HIP_EMULATED
-        const double ri = 1.0 / sqrt(dkk);
-#else
-        const double ri = rsqrt(dkk);
-#endif
         v[c] *= ri;                                   // lane c: sqrt(dkk); row r > c: L(r, c); column j of X: X(c, j)
         if (c + 1 < NB) {
             double* cb = col + (c & 1) * NB;
             if (isA) cb[lane] = v[c];
+            dkk = wg_chol_bcast(__builtin_fma(-v[c], v[c], v[c + 1]), c + 1);
+            ri = LM_RSQRT(dkk);
             LM_WAVE_SYNC();
 #pragma unroll
             for (int c2 = c + 1; c2 < NB; c2++) v[c2] = __builtin_fma(-cb[c2], v[c], v[c2]);   // (entries above the diagonal of A carry unused values)
         }
     }
+#undef LM_RSQRT
     CHP_MARK(1);
     if (!ok) { if (t == 0 && lane == 0) A.st[b].ok = 0; return; }   // uniform over the window's waves: the same values everywhere
     if (!isA) {
