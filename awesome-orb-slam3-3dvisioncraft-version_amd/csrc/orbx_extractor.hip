@@ -409,6 +409,33 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     }
 }
 
+// mvImagePyramid in the reference's own layout (ORBextractor.cc:1164-1179): every level inside a 19-px BORDER_REFLECT_101 frame
+// (copyMakeBorder), all levels of ONE frame in one slab — the host-pyramid option of the single-frame entry point brings that slab down in one
+// copy.  One workgroup per bordered row of any level (blockIdx.x walks the rows of level 0, then level 1, ...); a thread writes dwords.
+struct BorderParams {
+    const uint8_t* src[ORBX_MAX_LEVELS]; int sStride[ORBX_MAX_LEVELS]; int w[ORBX_MAX_LEVELS]; int h[ORBX_MAX_LEVELS];
+    uint8_t* dst; size_t dOff[ORBX_MAX_LEVELS]; int dPitch[ORBX_MAX_LEVELS];   // dPitch: multiple of 4, >= w + 2 * ORBX_EDGE
+    int rowStart[ORBX_MAX_LEVELS + 1];                                         // first bordered row of each level in the grid
+    int nlevels;
+};
+static __device__ __forceinline__ int reflect101(int p, int len) {   // BORDER_REFLECT_101 for |overhang| < len
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+static __global__ __launch_bounds__(256) void k_border_pyramid(BorderParams P) {
+    int l = 0;
+    while (l + 1 < P.nlevels && (int)blockIdx.x >= P.rowStart[l + 1]) l++;
+    const int y = (int)blockIdx.x - P.rowStart[l], w = P.w[l], ow = w + 2 * ORBX_EDGE;
+    const uint8_t* S = P.src[l] + (size_t)reflect101(y - ORBX_EDGE, P.h[l]) * P.sStride[l];
+    uint8_t* D = P.dst + P.dOff[l] + (size_t)y * P.dPitch[l];
+    for (int x4 = threadIdx.x * 4; x4 < ow; x4 += 1024) {
+        uint32_t v = 0;
+        for (int j = 0; j < 4; j++) v |= (uint32_t)S[reflect101(min(x4 + j, ow - 1) - ORBX_EDGE, w)] << (8 * j);
+        *(uint32_t*)(D + x4) = v;   // (the dwords past ow lie inside the pitch)
+    }
+}
+
 // ============================================================================================================
 // E2  FAST-9/16 + per-cell NMS + per-cell minThFAST retry
 // ============================================================================================================
@@ -1617,12 +1644,6 @@ struct DescParams {
     int unitStart[ORBX_MAX_LEVELS + 1];   // workgroup u of a frame serves level l with unitStart[l] <= u < unitStart[l+1] (ceil(selCap_l / 4) each)
 };
 
-static __device__ __forceinline__ int reflect101(int p, int len) {
-    if (p < 0) p = -p;
-    if (p >= len) p = 2 * (len - 1) - p;
-    return p;
-}
-
 // cv::fastAtan2 (degrees), restated; float ops must not be contracted
 static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float s = (float)(180 / 3.1415926535897932384626433832795);
@@ -2595,6 +2616,16 @@ struct orbx_extractor {
     // a frame is ~11 kernels + 2 memsets of a few tens of microseconds each, i.e. launch bound
     hipGraphExec_t graphExec = nullptr; int graphLap0 = 0, graphLap1 = 0; int graphState = 0;   // 0 = not tried, 1 = usable, -1 = capture unsupported
     bool capturing = false;
+    // Host-pyramid option of the single-frame entry point (orbx_set_host_pyramid; mvImagePyramid consumers): all levels in the reference's bordered
+    // layout in one device slab (k_border_pyramid) and its pinned twin, filled on a second stream that forks behind the pyramid launch and joins at
+    // the end of the call — the copy runs under FAST / octree / describe.  Allocated by the first orbx_set_host_pyramid(h, 1).
+    int hostPyr = 0, graphHostPyr = 0; bool hostCall = false, hostPyrValid = false;
+    uint8_t* d_bpyr = nullptr; uint8_t* h_bpyr = nullptr; size_t bpyrBytes = 0, bOff[ORBX_MAX_LEVELS] = {0};
+    int bPitch[ORBX_MAX_LEVELS] = {0}, bRowStart[ORBX_MAX_LEVELS + 1] = {0};
+    hipStream_t stream2 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t lastStream = nullptr;   // the stream of the last batch call (orbx_copy_level and the debug taps wait for it, not for the device)
+    bool lastSingle = false;            // the last call was orbx_extract: d_kps1 / d_desc1 / d_counts1 hold its outputs (orbx_stereo_matches_last)
+    float* d_stereo1 = nullptr; float* h_stereo1 = nullptr;   // [u_right | depth | work] x maxKp of orbx_stereo_matches_last, device and pinned
     std::string err;
 };
 
@@ -2623,8 +2654,13 @@ static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* bufs[] = {h->d_chain, h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
-                    h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1};
+                    h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1, h->d_bpyr, h->d_stereo1};
     for (void* p : bufs) if (p) (void)hipFree(p);
+    if (h->h_bpyr) (void)hipHostFree(h->h_bpyr);
+    if (h->h_stereo1) (void)hipHostFree(h->h_stereo1);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_retry) (void)hipHostFree(h->h_retry);
     if (h->h_out) (void)hipHostFree(h->h_out);
@@ -2913,6 +2949,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     HIPCHK(h, hipSetDevice(h->device));
     const int nl = h->cfg.nlevels;
     h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
+    h->lastStream = st; h->lastSingle = h->hostCall; h->hostPyrValid = false;
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[0], st));
     HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     // E1 pyramid
@@ -2955,6 +2992,23 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (h->hostCall && h->hostPyr && h->d_bpyr) {
+        // mvImagePyramid for the host: fork behind the pyramid, border frame + ONE copy of the slab on the second stream; orbx_extract joins
+        BorderParams Bp;
+        memset(&Bp, 0, sizeof(Bp));
+        for (int l = 0; l < nl; l++) {
+            size_t fs;
+            level_view(h, l, Bp.src[l], fs, Bp.sStride[l]);
+            Bp.w[l] = h->lv[l].w; Bp.h[l] = h->lv[l].h; Bp.dOff[l] = h->bOff[l]; Bp.dPitch[l] = h->bPitch[l]; Bp.rowStart[l] = h->bRowStart[l];
+        }
+        Bp.rowStart[nl] = h->bRowStart[nl]; Bp.dst = h->d_bpyr; Bp.nlevels = nl;
+        HIPCHK(h, hipEventRecord(h->evFork, st));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->evFork, 0));
+        hipLaunchKernelGGL(k_border_pyramid, dim3(h->bRowStart[nl]), dim3(256), 0, h->stream2, Bp);
+        HIPCHK(h, hipMemcpyAsync(h->h_bpyr, h->d_bpyr, h->bpyrBytes, hipMemcpyDeviceToHost, h->stream2));
+        HIPCHK(h, hipEventRecord(h->evJoin, h->stream2));
+        h->hostPyrValid = true;
+    }
     // E2 FAST
     {
         FastParams F;
@@ -3057,15 +3111,51 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     }
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
     if (!h->capturing) h->timed = true;
+    if (h->hostPyrValid) HIPCHK(h, hipStreamWaitEvent(st, h->evJoin, 0));   // the host-pyramid branch joins (inside a capture: the graph's second leaf)
     HIPCHK(h, hipGetLastError());
     return ORB_OK;
 }
 
-extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
-                            orb_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_index) {
+extern "C" int orbx_set_host_pyramid(orbx_handle h, int keep) {
+    if (!h) return ORB_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (keep && !h->d_bpyr) {
+        const int nl = h->cfg.nlevels;
+        size_t off = 0; int rows = 0;
+        for (int l = 0; l < nl; l++) {
+            h->bPitch[l] = (h->lv[l].w + 2 * ORBX_EDGE + 63) & ~63;
+            h->bOff[l] = off; h->bRowStart[l] = rows;
+            off += (size_t)h->bPitch[l] * (h->lv[l].h + 2 * ORBX_EDGE); rows += h->lv[l].h + 2 * ORBX_EDGE;
+            if (h->lv[l].w <= ORBX_EDGE || h->lv[l].h <= ORBX_EDGE) return orbx_fail(h, ORB_E_INVALID, "pyramid level smaller than its border");
+        }
+        h->bRowStart[nl] = rows; h->bpyrBytes = off;
+        HIPCHK(h, hipMalloc((void**)&h->d_bpyr, off));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_bpyr, off, hipHostMallocDefault));
+        if (!h->stream2) HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        if (!h->evFork) HIPCHK(h, hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+        if (!h->evJoin) HIPCHK(h, hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming));
+    }
+    h->hostPyr = keep ? 1 : 0;
+    return ORB_OK;
+}
+
+extern "C" int orbx_host_pyramid_level(orbx_handle h, int level, const uint8_t** ptr, int* w, int* hgt, int* stride) {
+    if (!h || level < 0 || level >= h->cfg.nlevels) return ORB_E_INVALID;
+    if (!h->hostPyrValid || !h->lastSingle) return orbx_fail(h, ORB_E_INVALID, "no host pyramid: orbx_set_host_pyramid(h, 1) before orbx_extract");
+    if (ptr) *ptr = h->h_bpyr + h->bOff[level] + (size_t)ORBX_EDGE * h->bPitch[level] + ORBX_EDGE;
+    if (w) *w = h->lv[level].w;
+    if (hgt) *hgt = h->lv[level].h;
+    if (stride) *stride = h->bPitch[level];
+    return ORB_OK;
+}
+
+extern "C" int orbx_extract_view(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                                 const orb_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_index) {
     if (!h) return ORB_E_INVALID;
     if (n_out) *n_out = 0;
     if (mono_index) *mono_index = 0;
+    if (kps) *kps = nullptr;
+    if (desc) *desc = nullptr;
     if (!image || width <= 0 || height <= 0) return orbx_fail(h, ORB_E_EMPTY_IMAGE, "empty image");
     if (width != h->W || height != h->H || stride < width) return orbx_fail(h, ORB_E_INVALID, "image size differs from the handle's");
     HIPCHK(h, hipSetDevice(h->device));
@@ -3074,7 +3164,8 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
     else for (int y = 0; y < height; y++) memcpy(h->h_img + (size_t)y * h->imgStride, image + (size_t)y * stride, (size_t)width);
     const size_t imgBytes = (size_t)h->imgStride * height;
     int rc = ORB_OK;
-    if (h->graphState >= 0 && (!h->graphExec || h->graphLap0 != lap0 || h->graphLap1 != lap1)) {
+    h->hostCall = true;
+    if (h->graphState >= 0 && (!h->graphExec || h->graphLap0 != lap0 || h->graphLap1 != lap1 || h->graphHostPyr != h->hostPyr)) {
         if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; }
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             h->capturing = true;
@@ -3085,7 +3176,7 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
             hipGraph_t g = nullptr;
             const hipError_t ec = hipStreamEndCapture(h->stream, &g);
             if (rc == ORB_OK && em == hipSuccess && ec == hipSuccess && g && hipGraphInstantiate(&h->graphExec, g, nullptr, nullptr, 0) == hipSuccess) {
-                h->graphLap0 = lap0; h->graphLap1 = lap1; h->graphState = 1;
+                h->graphLap0 = lap0; h->graphLap1 = lap1; h->graphHostPyr = h->hostPyr; h->graphState = 1;
             } else { h->graphExec = nullptr; h->graphState = -1; }
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
@@ -3094,23 +3185,41 @@ extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int 
     }
     if (h->graphExec) {
         h->timed = false;   // per-kernel events are not part of the graph
-        HIPCHK(h, hipGraphLaunch(h->graphExec, h->stream));
+        const hipError_t e = hipGraphLaunch(h->graphExec, h->stream);
+        h->hostPyrValid = h->hostPyr != 0; h->lastStream = h->stream; h->lastSingle = true;   // (what the captured call set, for the replay)
+        if (e != hipSuccess) { h->hostCall = false; HIPCHK(h, e); }
     } else {
-        HIPCHK(h, hipMemcpyAsync(h->d_img, h->h_img, imgBytes, hipMemcpyHostToDevice, h->stream));
-        rc = orbx_extract_batch_dev(h, h->d_img, 1, imgBytes, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp, h->d_counts1, h->stream);
-        if (rc != ORB_OK) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->h_out, h->d_out1, h->out1Bytes, hipMemcpyDeviceToHost, h->stream));
+        hipError_t e = hipMemcpyAsync(h->d_img, h->h_img, imgBytes, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            rc = orbx_extract_batch_dev(h, h->d_img, 1, imgBytes, h->imgStride, lap0, lap1, h->d_kps1, h->d_desc1, h->maxKp, h->d_counts1, h->stream);
+            if (rc != ORB_OK) { h->hostCall = false; return rc; }
+            e = hipMemcpyAsync(h->h_out, h->d_out1, h->out1Bytes, hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e != hipSuccess) { h->hostCall = false; HIPCHK(h, e); }
     }
+    h->hostCall = false;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int32_t counts[2];
     memcpy(counts, h->h_out, sizeof(counts));
     if (n_out) *n_out = counts[0];
     if (mono_index) *mono_index = counts[1];
-    if (counts[0] > cap) return orbx_fail(h, ORB_E_CAPACITY, "output capacity too small");
-    if (counts[0] > 0) {
+    if (kps) *kps = (const orb_keypoint*)(h->h_out + h->kps1Off);
+    if (desc) *desc = h->h_out + h->desc1Off;
+    return ORB_OK;
+}
+
+extern "C" int orbx_extract(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                            orb_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_index) {
+    const orb_keypoint* k = nullptr; const uint8_t* d = nullptr;
+    int n = 0;
+    const int rc = orbx_extract_view(h, image, width, height, stride, lap0, lap1, &k, &d, &n, mono_index);
+    if (n_out) *n_out = n;
+    if (rc != ORB_OK) return rc;
+    if (n > cap) return orbx_fail(h, ORB_E_CAPACITY, "output capacity too small");
+    if (n > 0) {
         if (!kps || !desc) return orbx_fail(h, ORB_E_INVALID, "null output");
-        memcpy(kps, h->h_out + h->kps1Off, (size_t)counts[0] * sizeof(orb_keypoint));
-        memcpy(desc, h->h_out + h->desc1Off, (size_t)counts[0] * 32);
+        memcpy(kps, k, (size_t)n * sizeof(orb_keypoint));
+        memcpy(desc, d, (size_t)n * 32);
     }
     return ORB_OK;
 }
@@ -3172,24 +3281,63 @@ extern "C" int orbx_copy_level(orbx_handle h, int frame, int level, int border, 
     const uint8_t* p; int w, hh, rs;
     int rc = orbx_pyramid_level(h, frame, level, &p, &w, &hh, &rs);
     if (rc != ORB_OK || !out || border < 0 || border >= w || border >= hh) return ORB_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
-    std::vector<uint8_t> plane((size_t)w * hh);
-    HIPCHK(h, hipMemcpy2DAsync(plane.data(), w, p, rs, w, hh, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (border == 0) { memcpy(out, plane.data(), plane.size()); return ORB_OK; }
-    // copyMakeBorder(BORDER_REFLECT_101), ORBextractor.cc:1173-1179
     const int ow = w + 2 * border, oh = hh + 2 * border;
+    if (h->hostPyrValid && h->lastSingle && frame == 0 && border <= ORBX_EDGE) {   // the bordered slab of the last orbx_extract is on the host already
+        const uint8_t* src = h->h_bpyr + h->bOff[level] + (size_t)(ORBX_EDGE - border) * h->bPitch[level] + (ORBX_EDGE - border);
+        for (int y = 0; y < oh; y++) memcpy(out + (size_t)y * ow, src + (size_t)y * h->bPitch[level], (size_t)ow);
+        return ORB_OK;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->lastStream));   // the stream of the call that built the pyramid — not the device: other handles keep running
+    uint8_t* in = out + (size_t)border * ow + border;
+    HIPCHK(h, hipMemcpy2DAsync(in, ow, p, rs, w, hh, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (border == 0) return ORB_OK;
+    // copyMakeBorder(BORDER_REFLECT_101), ORBextractor.cc:1173-1179: the side columns of every image row, then whole rows above and below
     auto refl = [](int p_, int len) { if (p_ < 0) p_ = -p_; if (p_ >= len) p_ = 2 * (len - 1) - p_; return p_; };
+    for (int y = 0; y < hh; y++) {
+        uint8_t* row = in + (size_t)y * ow;
+        for (int x = 1; x <= border; x++) { row[-x] = row[refl(-x, w)]; row[w - 1 + x] = row[refl(w - 1 + x, w)]; }
+    }
     for (int y = 0; y < oh; y++)
-        for (int x = 0; x < ow; x++) out[(size_t)y * ow + x] = plane[(size_t)refl(y - border, hh) * w + refl(x - border, w)];
+        if (y < border || y >= border + hh) memcpy(out + (size_t)y * ow, out + (size_t)(border + refl(y - border, hh)) * ow, (size_t)ow);
+    return ORB_OK;
+}
+
+extern "C" int orbx_stereo_matches_last(orbx_handle left, orbx_handle right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left) {
+    if (!left || !right) return ORB_E_INVALID;
+    orbx_extractor* h = left;
+    if (n_left) *n_left = 0;
+    if (!left->lastSingle || !right->lastSingle || left->maxKp != right->maxKp || left->device != right->device)
+        return orbx_fail(h, ORB_E_INVALID, "orbx_stereo_matches_last: both handles (same configuration) must have run orbx_extract last");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t K = (size_t)h->maxKp;
+    if (!h->d_stereo1) {
+        HIPCHK(h, hipMalloc((void**)&h->d_stereo1, 3 * K * 4));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_stereo1, 2 * K * 4, hipHostMallocDefault));
+    }
+    int32_t cnt[2];
+    memcpy(cnt, h->h_out, sizeof(cnt));   // the pinned output block still holds the last call's counts
+    const int n = cnt[0];
+    if (n_left) *n_left = n;
+    if (n > cap) return orbx_fail(h, ORB_E_CAPACITY, "output capacity too small");
+    if (n <= 0) return ORB_OK;
+    if (!u_right || !depth) return orbx_fail(h, ORB_E_INVALID, "null output");
+    // (both orbx_extract calls synchronised their streams before returning: the right handle's slabs are complete)
+    const int rc = orbx_stereo_matches(left, right, left->d_kps1, left->d_desc1, left->d_counts1, right->d_kps1, right->d_desc1, right->d_counts1,
+                                       h->maxKp, 1, mb, mbf, h->d_stereo1, h->d_stereo1 + K, (int32_t*)(h->d_stereo1 + 2 * K), h->stream);
+    if (rc != ORB_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_stereo1, h->d_stereo1, 2 * K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(u_right, h->h_stereo1, (size_t)n * 4);
+    memcpy(depth, h->h_stereo1 + K, (size_t)n * 4);
     return ORB_OK;
 }
 
 extern "C" int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipStreamSynchronize(h->lastStream));
     int n = 0;
     HIPCHK(h, hipMemcpy(&n, h->d_candCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
     *n_out = n;
@@ -3205,7 +3353,7 @@ extern "C" int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_
 extern "C" int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out) {
     if (!h || level < 0 || level >= h->cfg.nlevels || frame < 0 || frame >= h->lastBatch || !n_out) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipStreamSynchronize(h->lastStream));
     int n = 0;
     HIPCHK(h, hipMemcpy(&n, h->d_selCount + (size_t)frame * h->cfg.nlevels + level, 4, hipMemcpyDeviceToHost));
     *n_out = n;

@@ -716,6 +716,29 @@ def main():
         extra["host_api"] = {"frames_per_s": round(nh / (time.perf_counter() - th), 1),
                              "what": "orbx_extract: one %dx%d host image per call, H2D + 4 kernels + D2H, synchronous (never `value`)" % (W, H)}
 
+    def leg_host_api_cv():
+        # the call the reference actually makes: ORBextractor::operator()(cv::InputArray, ..., cv::OutputArray, vector<int>&) through the header-only
+        # adapter, incl. mvImagePyramid on the host (19-px bordered levels, one pinned slab) — a C++ program (tools/extractor_cv_latency.cpp, built
+        # by tools/build_lib.sh against the mock cv:: of tests/cpp/mock_orbslam3), run on two of this run's own frames
+        import subprocess
+        import tempfile
+        exe = os.path.join(ROOT, "tools", "bin", "extractor_cv_latency")
+        if not os.path.exists(exe):
+            raise RuntimeError("tools/bin/extractor_cv_latency is not built (tools/build_lib.sh)")
+        with tempfile.TemporaryDirectory() as td:
+            fl, fr = os.path.join(td, "left.raw"), os.path.join(td, "right.raw")
+            frames[0].tofile(fl)
+            frames[1 % B].tofile(fr)
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+            out_ = subprocess.run([exe, fl, str(W), str(H), str(NFEAT), fr], capture_output=True, text=True, timeout=300, env=env)
+        if out_.returncode != 0:
+            raise RuntimeError("extractor_cv_latency rc %d: %s %s" % (out_.returncode, out_.stdout[-300:], out_.stderr[-300:]))
+        r_ = json.loads(out_.stdout.strip().splitlines()[-1])
+        r_["what"] = ("orbslam3_hip::ORBextractor::operator() (reference signature, Frame.cc:488-495) per %dx%d host image, synchronous, PCIe inclusive: with "
+                      "mvImagePyramid brought to the host in the reference's bordered layout / without (integration/Frame_hip.cc linked); "
+                      "Frame::ComputeStereoMatches through the adapter on the two calls' device-resident outputs / through the upload path" % (W, H))
+        extra["host_api_cv"] = r_
+
     def leg_lba():
         # ---- extra leg 2: LocalBundleAdjustment linearisations (C5-size windows: 100 KF / 20k landmarks)
         from orbhip.lba import LbaWindows, synth_window
@@ -1179,7 +1202,7 @@ def main():
                                         "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
 
     if not args.headline_only:
-        legs = (("host_api", leg_host_api), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
+        legs = (("host_api", leg_host_api), ("host_api_cv", leg_host_api_cv), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
                 ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
                 ("scene_diversity", leg_scene_diversity), ("mixed_batch", leg_mixed_batch), ("batch_sweep", leg_batch_sweep))
         # N>1: the legs the multi-GPU line is read for (the metric's LBA component, north_star's second frame size); the per-GPU side figures are the

@@ -67,6 +67,20 @@ int orbx_max_keypoints(orbx_handle h);
 int orbx_extract(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
                  orb_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* mono_index);
 
+/* The same call without the two output copies: *kps / *desc point into the handle's pinned output block ([n] records, [n][32] bytes), valid until
+ * the next call on the handle.  The adapters copy from there straight into the caller's final containers (std::vector<cv::KeyPoint>, cv::Mat). */
+int orbx_extract_view(orbx_handle h, const uint8_t* image, int width, int height, int stride, int lap0, int lap1,
+                      const orb_keypoint** kps, const uint8_t** desc, int* n_out, int* mono_index);
+
+/* mvImagePyramid for host consumers (public member ORBextractor.h:83; the only reader in the reference is Frame::ComputeStereoMatches,
+ * Frame.cc:962,1052,1071).  keep = 1: every orbx_extract / orbx_extract_view also brings the pyramid of its image to the host in the reference's
+ * layout (ORBextractor.cc:1164-1179: each level inside a 19-px BORDER_REFLECT_101 frame) — frame built on the device, ONE copy of the whole slab
+ * into pinned memory on a second stream that runs under FAST / octree / describe.  keep = 0 (default): nothing is copied.
+ * orbx_host_pyramid_level: pixel (0, 0) of `level` inside that slab (rows `stride` bytes apart, the 19 border pixels lie around it); the
+ * storage is the handle's and is overwritten by the next call — cv::Mat headers over it need no per-call allocation. */
+int orbx_set_host_pyramid(orbx_handle h, int keep);
+int orbx_host_pyramid_level(orbx_handle h, int level, const uint8_t** ptr, int* w, int* hgt, int* stride);
+
 /* Batched, device-resident form of the same call (MI355X addition; frames are independent units).
  * d_images: batch frames, frame b at d_images + b*frame_stride, rows row_stride bytes apart (4-byte aligned).
  * d_kps / d_desc: per-frame slabs of cap_per_frame entries; d_counts[2*b] = n, d_counts[2*b+1] = monoIndex
@@ -79,7 +93,8 @@ int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, int batch, si
 /* mvImagePyramid (public member, ORBextractor.h:83): device view of level `level` of frame `frame` of the last
  * call (un-bordered plane; the reference's 19-px BORDER_REFLECT_101 frame is produced by orbx_copy_level). */
 int orbx_pyramid_level(orbx_handle h, int frame, int level, const uint8_t** d_ptr, int* w, int* hgt, int* stride);
-/* Copies level to host; border = 0 (plane) or 19 (reference layout incl. reflected frame), out is tightly packed. */
+/* Copies level to host; border = 0 (plane) or up to 19 (reference layout incl. reflected frame), out is tightly packed.  Waits for the stream of
+ * the call that built the pyramid (never for the whole device); served from the host slab when orbx_set_host_pyramid is on. */
 int orbx_copy_level(orbx_handle h, int frame, int level, int border, uint8_t* out);
 
 /* Frame::ComputeStereoMatches (Frame.cc:955-1133) for `batch` rectified stereo pairs whose left / right images were just
@@ -90,6 +105,11 @@ int orbx_stereo_matches(orbx_handle left, orbx_handle right, const orb_keypoint*
                         const int32_t* d_counts_l, const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_counts_r,
                         int cap_per_frame, int batch, float mb, float mbf, float* d_u_right, float* d_depth, int32_t* d_work,
                         void* stream);
+
+/* Frame::ComputeStereoMatches for the pair whose images `left` and `right` each just took through orbx_extract (Frame.cc:110-114 then :132):
+ * key points, descriptors and pyramids are read where those two calls left them on the device — nothing is uploaded; u_right / depth (host,
+ * cap entries) receive mvuRight / mvDepth of the *n_left left key points.  Both handles: same device and configuration, last call = orbx_extract. */
+int orbx_stereo_matches_last(orbx_handle left, orbx_handle right, float mb, float mbf, float* u_right, float* depth, int cap, int* n_left);
 
 /* Stage-level taps for parity tests (valid after an extract call; host outputs):
  * FAST candidates of (frame, level) = vToDistributeKeys (ORBextractor.cc:776,845-850) as (x,y,score) int triples

@@ -39,22 +39,22 @@ public:
     // POD form of operator() (ORBextractor.cc:1074-1156): returns monoIndex, or -1 for an empty image.
     int extract(const uint8_t* image, int width, int height, int stride, std::vector<orb_keypoint>& keypoints,
                 std::vector<uint8_t>& descriptors, const std::vector<int>& vLappingArea) {
-        keypoints.clear();
-        descriptors.clear();
-        if (!image || width <= 0 || height <= 0) return -1;  // ORBextractor.cc:1078-1079
-        ensure(width, height);
-        const int cap = orbx_max_keypoints(h_);
-        keypoints.resize(cap);
-        descriptors.resize((size_t)cap * 32);
-        int n = 0, mono = 0;
-        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
-        const int rc = orbx_extract(h_, image, width, height, stride, lap0, lap1, keypoints.data(), descriptors.data(), cap, &n, &mono);
-        if (rc == ORB_E_EMPTY_IMAGE) { keypoints.clear(); descriptors.clear(); return -1; }
-        if (rc != ORB_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
-        keypoints.resize(n);
-        descriptors.resize((size_t)n * 32);
+        const orb_keypoint* k = nullptr; const uint8_t* d = nullptr;
+        int n = 0;
+        const int mono = extractView(image, width, height, stride, vLappingArea, k, d, n);
+        keypoints.assign(k, k + n);   // (n == 0: both empty)
+        descriptors.assign(d, d + (size_t)n * 32);
         return mono;
     }
+
+    // mvImagePyramid on the host.  The reference fills it on every call (ORBextractor.cc:1158-1183) and exactly one function outside the extractor
+    // reads it: Frame::ComputeStereoMatches (Frame.cc:962,1052,1071).  With integration/Frame_hip.cc linked that function runs on the device and
+    // nobody reads the host copy, so Frame_hip.cc switches the default off (hostPyramidDefault()); otherwise it is on, as in the reference.  When on,
+    // the 19-px bordered pyramid comes down as one pinned slab under the call's own kernels (orbx_set_host_pyramid) and mvImagePyramid[l] are cv::Mat
+    // HEADERS over that slab: no allocation per call, contents replaced by the next call (the reference's are replaced by the next call too).
+    static bool& hostPyramidDefault() { static bool v = true; return v; }
+    void setKeepHostPyramid(bool keep) { keepHostPyr_ = keep; if (h_) applyHostPyramid(); }
+    bool keepHostPyramid() const { return keepHostPyr_; }
 
 #ifdef ORBHIP_WITH_OPENCV
     // ORBextractor.h:57-59 — identical signature; `_mask` is ignored exactly as in the reference.
@@ -76,31 +76,36 @@ public:
         if (_image.empty()) return -1;
         cv::Mat image = _image.getMat();
         CV_Assert(image.type() == CV_8UC1);  // ORBextractor.cc:1082
-        std::vector<orb_keypoint> k;
-        std::vector<uint8_t> d;
-        const int mono = extract(image.data, image.cols, image.rows, (int)image.step, k, d, vLappingArea);
         static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint layout");
-        _keypoints.resize(k.size());
-        if (!k.empty()) std::memcpy((void*)_keypoints.data(), k.data(), k.size() * sizeof(orb_keypoint));
-        if (k.empty()) _descriptors.release();
+        const orb_keypoint* k = nullptr; const uint8_t* d = nullptr;
+        int n = 0;
+        // one copy each, from the handle's pinned output block straight into the caller's containers
+        const int mono = extractView(image.data, image.cols, image.rows, (int)image.step, vLappingArea, k, d, n);
+        _keypoints.resize((size_t)n);
+        if (n) std::memcpy((void*)_keypoints.data(), k, (size_t)n * sizeof(orb_keypoint));
+        if (n == 0) _descriptors.release();
         else {
-            _descriptors.create((int)k.size(), 32, CV_8U);
-            if (_descriptors.getMat().isContinuous()) std::memcpy(_descriptors.getMat().data, d.data(), d.size());
+            _descriptors.create(n, 32, CV_8U);
+            if (_descriptors.getMat().isContinuous()) std::memcpy(_descriptors.getMat().data, d, (size_t)n * 32);
             else {   // (an ROI header of a wider Mat handed in as the output: row by row through its step)
                 cv::Mat dm = _descriptors.getMat();
-                for (int r = 0; r < dm.rows; r++) std::memcpy(dm.ptr(r), d.data() + (size_t)r * 32, 32);
+                for (int r = 0; r < dm.rows; r++) std::memcpy(dm.ptr(r), d + (size_t)r * 32, 32);
             }
         }
-        // mvImagePyramid is a public member read by Frame::ComputeStereoMatches (Frame.cc:1052,1071): keep it populated,
-        // each level as the ROI of a bordered parent exactly like ORBextractor.cc:1164-1179
-        mvImagePyramid.resize(cfg_.nlevels);
-        for (int l = 0; l < cfg_.nlevels; l++) {
-            int w = 0, hgt = 0;
-            orbx_pyramid_level(h_, 0, l, nullptr, &w, &hgt, nullptr);
-            cv::Mat temp(hgt + 38, w + 38, CV_8UC1);
-            orbx_copy_level(h_, 0, l, 19, temp.data);
-            mvImagePyramid[l] = temp(cv::Rect(19, 19, w, hgt));
-        }
+        if (keepHostPyr_) {
+            // headers over the handle's slab, each level the interior of its bordered parent exactly like ORBextractor.cc:1164-1179; rebuilt only when
+            // the handle (image size) changed or somebody resized the member
+            const uint8_t* p0 = nullptr;
+            if (orbx_host_pyramid_level(h_, 0, &p0, nullptr, nullptr, nullptr) != ORB_OK) throw std::runtime_error(std::string("orbx_host_pyramid_level: ") + orbx_last_error(h_));
+            if ((int)mvImagePyramid.size() != cfg_.nlevels || mvImagePyramid[0].data != p0) {
+                mvImagePyramid.resize(cfg_.nlevels);
+                for (int l = 0; l < cfg_.nlevels; l++) {
+                    const uint8_t* p = nullptr; int w = 0, hgt = 0, st = 0;
+                    orbx_host_pyramid_level(h_, l, &p, &w, &hgt, &st);
+                    mvImagePyramid[l] = cv::Mat(hgt, w, CV_8UC1, (void*)p, (size_t)st);
+                }
+            }
+        } else if (!mvImagePyramid.empty()) mvImagePyramid.clear();   // never a stale pyramid of an earlier image
         return mono;
     }
     std::vector<cv::Mat> mvImagePyramid;  // ORBextractor.h:83
@@ -109,11 +114,20 @@ public:
     // Frame::ComputeStereoMatches (reference src/Frame.cc:955-1134) for the rectified pair THIS extractor (left image) and `right` just extracted:
     // the SAD refinement reads both extractors' pyramids where the last extract() left them on the device (the reference reads mvImagePyramid of
     // both, Frame.cc:1052,1071).  kps / desc: what the two extract() calls returned.  mvuRight / mvDepth come back sized N with -1 = no match.
+    // The Frame constructor's own sequence (ExtractORB x 2, then this, Frame.cc:110-132) finds key points and descriptors still on the device where
+    // the two calls wrote them: nothing is uploaded (orbx_stereo_matches_last).  Other inputs (edited key points, a subset) take the upload path.
     void ComputeStereoMatches(ORBextractor& right, const orb_keypoint* kpsL, const uint8_t* descL, int nL, const orb_keypoint* kpsR, const uint8_t* descR, int nR,
                               float mb, float mbf, std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
         mvuRight.assign(nL, -1.0f); mvDepth.assign(nL, -1.0f);
         if (nL == 0 || nR == 0) return;
         if (!h_ || !right.h_) throw std::runtime_error("ComputeStereoMatches: both extractors must have extracted their image first");
+        if (nL == lastN_ && nR == right.lastN_ && sameAsLast(kpsL, descL, nL) && right.sameAsLast(kpsR, descR, nR)) {
+            int n = 0;
+            const int rc = orbx_stereo_matches_last(h_, right.h_, mb, mbf, mvuRight.data(), mvDepth.data(), nL, &n);
+            if (rc == ORB_OK && n == nL) return;
+            if (rc != ORB_E_INVALID) throw std::runtime_error(std::string("orbx_stereo_matches_last: ") + orbx_last_error(h_));
+            mvuRight.assign(nL, -1.0f); mvDepth.assign(nL, -1.0f);   // (handles of different configurations: the general path below)
+        }
         const int cap = nL > nR ? nL : nR;
         // one device block: [kps L | kps R | desc L | desc R | counts L, R (2 x int32 each) | u_right | depth | work], every section on a 256-byte
         // boundary (the kernels read descriptors with 16-byte vector loads; 28-byte key point records would leave them 8-byte aligned at best)
@@ -172,10 +186,33 @@ private:
     void ensure(int w, int h) {
         if (h_ && w == w_ && h == hgt_) return;
         if (h_) { orbx_destroy(h_); h_ = nullptr; }
+        lastN_ = -1; lastK_ = nullptr; lastD_ = nullptr;
         const int rc = orbx_create(&cfg_, w, h, 1, device_, &h_);
         if (rc != ORB_OK) throw std::runtime_error(std::string("orbx_create: ") + orbx_last_error(nullptr));
         w_ = w; hgt_ = h;
         loadTables(h_);
+        applyHostPyramid();
+    }
+    void applyHostPyramid() {
+        if (orbx_set_host_pyramid(h_, keepHostPyr_ ? 1 : 0) != ORB_OK) throw std::runtime_error(std::string("orbx_set_host_pyramid: ") + orbx_last_error(h_));
+    }
+    // one call of the extractor; k / d point into the handle's pinned output block (valid until the next call)
+    int extractView(const uint8_t* image, int width, int height, int stride, const std::vector<int>& vLappingArea, const orb_keypoint*& k, const uint8_t*& d, int& n) {
+        k = nullptr; d = nullptr; n = 0;
+        if (!image || width <= 0 || height <= 0) return -1;  // ORBextractor.cc:1078-1079
+        ensure(width, height);
+        int mono = 0;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        lastN_ = -1;
+        const int rc = orbx_extract_view(h_, image, width, height, stride, lap0, lap1, &k, &d, &n, &mono);
+        if (rc == ORB_E_EMPTY_IMAGE) { n = 0; return -1; }
+        if (rc != ORB_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error(h_));
+        lastN_ = n; lastK_ = k; lastD_ = d;
+        return mono;
+    }
+    // are these the key points / descriptors the last call returned (then the device still holds them)?  The pinned block keeps that call's outputs.
+    bool sameAsLast(const orb_keypoint* k, const uint8_t* d, int n) const {
+        return n == lastN_ && lastK_ && std::memcmp(k, lastK_, (size_t)n * sizeof(orb_keypoint)) == 0 && std::memcmp(d, lastD_, (size_t)n * 32) == 0;
     }
     orbx_config cfg_;
     int device_;
@@ -183,6 +220,8 @@ private:
     int w_ = 0, hgt_ = 0;
     void* stereoBuf_ = nullptr;
     size_t stereoBytes_ = 0;
+    bool keepHostPyr_ = hostPyramidDefault();
+    int lastN_ = -1; const orb_keypoint* lastK_ = nullptr; const uint8_t* lastD_ = nullptr;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 

@@ -25,6 +25,11 @@ namespace ORB_SLAM3 {
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint is read as orb_keypoint (pt.x, pt.y, size, angle, response, octave, class_id)");
 
+// With this file linked, Frame::ComputeStereoMatches — the only reader of ORBextractor::mvImagePyramid outside the extractor (src/Frame.cc:962,1052,
+// 1071) — runs on the device: extractors constructed from here on do not bring the pyramid to the host (setKeepHostPyramid(true) turns it back on
+// for a consumer of the member that is not in the reference).  Runs before main(); Tracking builds its extractors long after.
+static const bool kHostPyramidOff = (orbslam3_hip::ORBextractor::hostPyramidDefault() = false);
+
 void Frame::ComputeStereoMatches() try {
     // mvuRight / mvDepth sized N, -1 = no match (:957-958); everything between :960 and :1133 runs on the device
     const int nR = (int)mvKeysRight.size();

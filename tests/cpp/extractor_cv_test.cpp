@@ -1,6 +1,7 @@
 // Boundary check (GPU tier; CPU tier on the emulated library): orbslam3_hip::ORBextractor compiled WITH its -DORBHIP_WITH_OPENCV branch — the
 // reference's own operator() signature (include/ORBextractor.h:57-59) — against the mock cv:: declarations of tests/cpp/mock_orbslam3, and run:
 // keypoints / descriptors through operator() must be the bytes the POD form extract() returns, mvImagePyramid must hold every level.
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -31,11 +32,46 @@ int main() {
     CHECK(mono2 == mono && k2.size() == kps.size());
     CHECK(std::memcmp(k2.data(), kps.data(), k2.size() * sizeof(orb_keypoint)) == 0);
     CHECK(std::memcmp(d2.data(), desc.data, d2.size()) == 0);
+    // mvImagePyramid (on by default without integration/Frame_hip.cc): headers over the handle's pinned slab, every level inside its 19-px
+    // BORDER_REFLECT_101 frame (ORBextractor.cc:1164-1179)
+    CHECK(ex.keepHostPyramid());
     CHECK((int)ex.mvImagePyramid.size() == 8 && ex.mvImagePyramid[0].cols == W && ex.mvImagePyramid[0].rows == H);
-    CHECK(std::memcmp(ex.mvImagePyramid[0].data, img.data, (size_t)W * H) == 0);   // level 0 is the image itself
-    int w7 = 0, h7 = 0;
-    const std::vector<uint8_t> l7 = ex.pyramidLevel(7, 0, w7, h7);
-    CHECK(ex.mvImagePyramid[7].cols == w7 && ex.mvImagePyramid[7].rows == h7 && std::memcmp(ex.mvImagePyramid[7].data, l7.data(), l7.size()) == 0);
+    for (int y = 0; y < H; y++) CHECK(std::memcmp(ex.mvImagePyramid[0].ptr(y), img.data + (size_t)y * W, (size_t)W) == 0);   // level 0 is the image itself
+    {
+        auto refl = [](int p, int len) { if (p < 0) p = -p; if (p >= len) p = 2 * (len - 1) - p; return p; };
+        const cv::Mat& L0 = ex.mvImagePyramid[0];
+        for (int y = -19; y < H + 19; y++)
+            for (int x = -19; x < W + 19; x++)
+                CHECK(L0.data[(ptrdiff_t)y * (ptrdiff_t)L0.step + x] == img.data[(size_t)refl(y, H) * W + refl(x, W)]);
+    }
+    const unsigned char* slab0 = ex.mvImagePyramid[0].data;
+    // the same levels without the host option: the device plane + the host-side reflect of orbx_copy_level must give the slab's bytes
+    std::vector<std::vector<uint8_t>> slabLevels(8);
+    std::vector<size_t> slabStep(8);
+    for (int l = 0; l < 8; l++) {
+        const cv::Mat& M = ex.mvImagePyramid[l];
+        slabStep[l] = M.step;
+        slabLevels[l].assign(M.data - 19 * (ptrdiff_t)M.step - 19, M.data - 19 * (ptrdiff_t)M.step - 19 + (size_t)(M.rows + 38) * M.step);
+    }
+    ex.setKeepHostPyramid(false);
+    CHECK(ex(img, cv::Mat(), kps, desc, lap) == mono && ex.mvImagePyramid.empty());   // nothing stale is left behind
+    for (int l = 0; l < 8; l++) {
+        int w = 0, h = 0;
+        const std::vector<uint8_t> bl = ex.pyramidLevel(l, 19, w, h);
+        for (int y = 0; y < h + 38; y++) CHECK(std::memcmp(bl.data() + (size_t)y * (w + 38), slabLevels[l].data() + (size_t)y * slabStep[l], (size_t)(w + 38)) == 0);
+        const std::vector<uint8_t> pl = ex.pyramidLevel(l, 0, w, h);
+        for (int y = 0; y < h; y++) CHECK(std::memcmp(pl.data() + (size_t)y * w, slabLevels[l].data() + (size_t)(y + 19) * slabStep[l] + 19, (size_t)w) == 0);
+    }
+    ex.setKeepHostPyramid(true);
+    CHECK(ex(img, cv::Mat(), kps, desc, lap) == mono && (int)ex.mvImagePyramid.size() == 8);
+    CHECK(ex.mvImagePyramid[0].data == slab0);   // persistent storage: no allocation per call
+    {
+        int w = 0, h = 0;
+        const std::vector<uint8_t> b3 = ex.pyramidLevel(3, 19, w, h);   // (served from the slab now)
+        const cv::Mat& M = ex.mvImagePyramid[3];
+        CHECK(M.cols == w && M.rows == h);
+        for (int y = 0; y < h + 38; y++) CHECK(std::memcmp(b3.data() + (size_t)y * (w + 38), M.data + ((ptrdiff_t)y - 19) * (ptrdiff_t)M.step - 19, (size_t)(w + 38)) == 0);
+    }
     cv::Mat empty;
     CHECK(ex(empty, cv::Mat(), kps, desc, lap) == -1);   // ORBextractor.cc:1078-1079
     // a failing call must not throw (Frame::ExtractORB runs on bare std::threads): an image too small for eight levels makes orbx_create fail inside

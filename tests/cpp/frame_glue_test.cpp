@@ -64,7 +64,8 @@ int main() {
         F.mpORBextractorLeft = &exL; F.mpORBextractorRight = &exR;
         F.mbf = bf; F.mb = bf / fx;
         CHECK(F.N > 300 && F.mvKeysRight.size() > 300);
-        F.ComputeStereoMatches();
+        CHECK(exL.mvImagePyramid.empty() && !exL.keepHostPyramid());   // Frame_hip.cc is linked: no host pyramid is produced (its only reader runs on the device)
+        F.ComputeStereoMatches();                                       // key points / descriptors / pyramids where the two calls left them on the device
         // the oracle on its own extraction of the same two images (extractor parity is bit-exact, so its key points are the frame's)
         void *oL = oro_create(600, 1.2f, 8, 20, 7), *oR = oro_create(600, 1.2f, 8, 20, 7);
         std::vector<cv::KeyPoint> kl(4 * 600), kr(4 * 600);
@@ -87,6 +88,14 @@ int main() {
                 nband += std::fabs(F.mvKeys[i].pt.x - F.mvuRight[i] - (band == 0 ? 7.f : (band == 1 ? 19.f : 33.f))) < 1.5f;
             }
         CHECK(nm > 100 && nband > nm * 8 / 10);   // the planted disparities are recovered
+        // the general path (inputs that are not the last call's outputs — here one untouched-by-stereo field differs — are uploaded): same floats
+        {
+            Frame U = F;
+            U.mvKeysRight[0].class_id = 7;
+            U.mvuRight.clear(); U.mvDepth.clear();
+            U.ComputeStereoMatches();
+            CHECK(std::memcmp(U.mvuRight.data(), our.data(), (size_t)nl * 4) == 0 && std::memcmp(U.mvDepth.data(), odp.data(), (size_t)nl * 4) == 0);
+        }
         // no right key points: every entry stays -1
         Frame G = F;
         G.mvKeysRight.clear(); G.mDescriptorsRight = cv::Mat();

@@ -25,13 +25,15 @@ public:
     unsigned char* data = nullptr;
     Mat() {}
     Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_((size_t)r * c * esz(), 0) { data = buf_.data(); step = (size_t)c * esz(); }
-    Mat(const Mat& o) : rows(o.rows), cols(o.cols), step(o.step), type_(o.type_), buf_(o.buf_) { data = buf_.empty() ? nullptr : buf_.data(); }
-    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; step = o.step; type_ = o.type_; buf_ = o.buf_; data = buf_.empty() ? nullptr : buf_.data(); return *this; }
+    // cv::Mat(rows, cols, type, void* data, size_t step): a header over memory somebody else owns (no allocation, no copy; copies of the header share it)
+    Mat(int r, int c, int type, void* ext, size_t step_) : rows(r), cols(c), step(step_), data((unsigned char*)ext), type_(type), ext_(true) {}
+    Mat(const Mat& o) : rows(o.rows), cols(o.cols), step(o.step), type_(o.type_), buf_(o.buf_), ext_(o.ext_) { data = ext_ ? o.data : (buf_.empty() ? nullptr : buf_.data()); }
+    Mat& operator=(const Mat& o) { rows = o.rows; cols = o.cols; step = o.step; type_ = o.type_; buf_ = o.buf_; ext_ = o.ext_; data = ext_ ? o.data : (buf_.empty() ? nullptr : buf_.data()); return *this; }
     Mat operator()(const Rect& r) const { return block(r.y, r.y + r.height, r.x, r.x + r.width); }   // a COPY of the region (value semantics here)
     void create(int r, int c, int type) { *this = Mat(r, c, type); }
     void release() { *this = Mat(); }
     static Mat eye(int r, int c, int type) { Mat m(r, c, type); for (int i = 0; i < r && i < c; i++) m.at<float>(i, i) = 1.f; return m; }
-    bool empty() const { return buf_.empty(); }
+    bool empty() const { return data == nullptr || rows * cols == 0; }
     int type() const { return type_; }
     Mat clone() const { return *this; }
     template <class T> T& at(int r, int c) { return ((T*)data)[(size_t)r * cols + c]; }
@@ -89,10 +91,11 @@ public:
 private:
     int type_ = CV_32F;
     std::vector<unsigned char> buf_;
+    bool ext_ = false;
     size_t esz() const { return type_ == CV_32F ? 4 : 1; }
     Mat block(int r0, int r1, int c0, int c1) const {
         Mat m(r1 - r0, c1 - c0, type_);
-        for (int r = r0; r < r1; r++) memcpy(m.data + (size_t)(r - r0) * m.cols * esz(), data + ((size_t)r * cols + c0) * esz(), (size_t)(c1 - c0) * esz());
+        for (int r = r0; r < r1; r++) memcpy(m.data + (size_t)(r - r0) * m.cols * esz(), data + (size_t)r * step + (size_t)c0 * esz(), (size_t)(c1 - c0) * esz());
         return m;
     }
 };

@@ -409,6 +409,8 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hip_emu"; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_t{0}; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event_t{0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
