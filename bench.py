@@ -358,6 +358,99 @@ class StepPipeline:
                 S["evB"][k].record(S["sB"])
                 S["evB_set"][k] = True
 
+    # ---- host-fed form of the same step (Tracking::GrabImageMonocular receives host images, src/Tracking.cc:507-560): the input sets live in pinned
+    # host memory, the resident device sets become staging buffers, every result of a step goes back to pinned host memory
+    def start_host_fed(self):
+        torch = self.torch
+        S = self._stream_state
+        assert S is not None and self.streams >= 3 and all(s_["frames_host"] is not None for s_ in self.sets)
+        ns = len(self.sets)
+        self._hf = dict(sH=torch.cuda.Stream(self.dev), sD=torch.cuda.Stream(self.dev), pin=[torch.from_numpy(s_["frames_host"]).pin_memory() for s_ in self.sets],
+                        evH=[torch.cuda.Event() for _ in range(ns)], evX=[torch.cuda.Event() for _ in range(ns)], evX_set=[False] * ns,
+                        evD=[torch.cuda.Event() for _ in range(S["nbuf"])], evD_set=[False] * S["nbuf"], host_out=[None] * S["nbuf"], last=None, prev_k=None)
+        torch.cuda.synchronize()
+
+    def host_fed_step(self):
+        """H2D of this step's B images (copy stream) -> extraction (its handle's stream) -> undistort + grid + SearchByProjection (match stream) -> D2H of
+        every result (second copy stream); events order the four, nothing waits on the host: the H2D of step i+1 runs under the kernels of step i."""
+        torch = self.torch
+        S, F = self._stream_state, self._hf
+        j, k = S["step_no"] % len(self.sets), S["step_no"] % S["nbuf"]
+        self._use_set(j)
+        S["step_no"] += 1
+        with torch.cuda.stream(F["sH"]):
+            if F["evX_set"][j]:
+                F["sH"].wait_event(F["evX"][j])                      # the extraction that last read this staging buffer has finished
+            self.d_frames.copy_(F["pin"][j], non_blocking=True)
+            F["evH"][j].record(F["sH"])
+        with torch.cuda.stream(S["sX"][k]):
+            S["sX"][k].wait_event(F["evH"][j])
+            if S["evB_set"][k]:
+                S["sX"][k].wait_event(S["evB"][k])
+            if F["evD_set"][k]:
+                S["sX"][k].wait_event(F["evD"][k])                   # this buffer set's previous results are on the host
+            if not F.get("skip_kernels"):                            # (experiment knob, tools/exp_host_fed.py)
+                S["outs"][k] = S["exs"][k].extract_batch(self.d_frames, self.LAP, out=S["outs"][k])
+            self.out = S["outs"][k]
+            S["evA"][k].record(S["sX"][k])
+            F["evX"][j].record(S["sX"][k]); F["evX_set"][j] = True
+        with torch.cuda.stream(S["sB"]):
+            S["sB"].wait_event(S["evA"][k])
+            if F["prev_k"] is not None:
+                S["sB"].wait_event(F["evD"][F["prev_k"]])            # (the match outputs are single-buffered: the previous step's are on the host)
+            if not F.get("skip_kernels"):
+                self._match(self.out)
+            S["evB"][k].record(S["sB"]); S["evB_set"][k] = True
+        dev_res = (self.out[0], self.out[1], self.out[2], self.un, self.res[0], self.res[1], self.res[2])
+        if F["host_out"][k] is None:
+            F["host_out"][k] = [torch.empty(t_.shape, dtype=t_.dtype).pin_memory() for t_ in dev_res]
+        with torch.cuda.stream(F["sD"]):
+            F["sD"].wait_event(S["evB"][k])
+            for h_, d_ in zip(F["host_out"][k], dev_res if not F.get("skip_d2h") else ()):
+                h_.copy_(d_, non_blocking=True)
+            F["evD"][k].record(F["sD"]); F["evD_set"][k] = True
+        F["last"], F["prev_k"] = (k, j), k
+
+    def host_fed_bytes(self):
+        """(H2D bytes, D2H bytes) of one host-fed step."""
+        F = self._hf
+        ho = next(h_ for h_ in F["host_out"] if h_ is not None)
+        return int(F["pin"][0].numel()), int(sum(t_.numel() * t_.element_size() for t_ in ho))
+
+    def host_fed_copy_only(self, steps, direction):
+        """The step's copies alone (no kernels): `steps` x H2D of an input set, or D2H of a result set — the PCIe side of the overlap figure."""
+        torch = self.torch
+        F = self._hf
+        ho = next(h_ for h_ in F["host_out"] if h_ is not None)
+        dev_res = (self.out[0], self.out[1], self.out[2], self.un, self.res[0], self.res[1], self.res[2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if direction == "h2d":
+                with torch.cuda.stream(F["sH"]):
+                    self.sets[i % len(self.sets)]["d_frames"].copy_(F["pin"][i % len(self.sets)], non_blocking=True)
+            else:
+                with torch.cuda.stream(F["sD"]):
+                    for h_, d_ in zip(ho, dev_res):
+                        h_.copy_(d_, non_blocking=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def check_host_fed_against_oracle(self, sel=None, nthreads=None):
+        """The last completed host-fed step, read from the PINNED HOST result buffers, against the oracle."""
+        import bench_check
+        self.torch.cuda.synchronize()
+        F = self._hf
+        k, j = F["last"]
+        sel = np.arange(self.B) if sel is None else np.asarray(sel)
+        ho = [t_.numpy()[sel] for t_ in F["host_out"][k]]
+        snap = dict(kps=ho[0], desc=ho[1], counts=ho[2], un=ho[3], q_match=ho[4], kp_match=ho[5], nm=ho[6])
+        st = self.sets[j]
+        cam9 = np.array(list(self.cam[:4]) + list(self.cam[4]) + [0.0], np.float32)
+        qd = st["d_qdesc"][self.torch.as_tensor(sel, device=self.dev, dtype=self.torch.long)].cpu().numpy()
+        return bench_check.compare_step(st["frames_host"][sel], snap, st["q"][sel].copy(), qd, st["nq"][sel].copy(), cam9, np.array(self.grid, np.float32), self.nfeat,
+                                        lap=self.LAP, nthreads=nthreads)
+
     def extract_only_step(self):
         if len(self.sets) > 1:
             self._use_set((self.cur + 1) % len(self.sets))
@@ -559,6 +652,10 @@ def main():
     global W, H, NFEAT
     W, H = [int(v) for v in args.size.lower().split("x")]
     NFEAT = args.nfeatures
+    # HIP multiplexes its streams onto 4 hardware queues by default.  The step uses more (two extraction streams, the match stream, the two copy streams
+    # of the host-fed leg, the handles' own): with 4, the H2D stream of the host-fed leg shared a queue with an extraction stream and every second copy
+    # waited for a whole extraction (3.4 -> 4.1 ms per step, profiles/r06_host_fed_queues.txt).  Read by the runtime when it initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     ndev = None
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1 and not args.launch_check:
@@ -715,6 +812,31 @@ def main():
             ex1(frames[i % B], None, (0, 1000))
         extra["host_api"] = {"frames_per_s": round(nh / (time.perf_counter() - th), 1),
                              "what": "orbx_extract: one %dx%d host image per call, H2D + 4 kernels + D2H, synchronous (never `value`)" % (W, H)}
+
+    def leg_host_fed():
+        # the same step fed from host memory: B frames per step pinned on the host -> H2D on a copy stream under the previous step's kernels -> the
+        # step -> every result back to pinned host memory on a second copy stream.  PCIe-bound by construction (B x W x H bytes in per step)
+        P.start_host_fed()
+        for _ in range(max(10, args.warmup)):      # (the first steps also fault in the pinned result buffers)
+            P.host_fed_step()
+        dth = float(np.median(rank_max(timed(P.host_fed_step, args.steps, max(1, min(args.repeats, 3))))))
+        h2d_b, d2h_b = P.host_fed_bytes()
+        n_chk, bad, tot = P.check_host_fed_against_oracle(np.arange(B) if world == 1 else np.unique(np.linspace(0, B - 1, min(B, 64)).astype(np.int64)))
+        t_h2d = P.host_fed_copy_only(args.steps, "h2d") / args.steps
+        t_d2h = P.host_fed_copy_only(args.steps, "d2h") / args.steps
+        fps = B * args.steps / dth
+        pcie_fps, comp_fps = B / max(t_h2d, t_d2h), B * args.steps / dt
+        extra["host_fed"] = {"frames_per_s": round(fps * world, 1), "ms_per_step": round(dth / args.steps * 1e3, 4),
+                             "h2d_GBps": round(h2d_b * args.steps / dth / 1e9, 2), "d2h_GBps": round(d2h_b * args.steps / dth / 1e9, 2),
+                             "h2d_bytes_per_step": h2d_b, "d2h_bytes_per_step": d2h_b,
+                             "copies_alone": {"h2d_ms_per_step": round(t_h2d * 1e3, 4), "h2d_GBps": round(h2d_b / t_h2d / 1e9, 2),
+                                              "d2h_ms_per_step": round(t_d2h * 1e3, 4), "d2h_GBps": round(d2h_b / t_d2h / 1e9, 2)},
+                             "kernels_alone_frames_per_s": round(comp_fps, 1), "pcie_alone_frames_per_s": round(pcie_fps, 1),
+                             "overlap_efficiency": round(fps / min(pcie_fps, comp_fps), 4),
+                             "parity": {"checked_frames": int(n_chk), "mismatches": len(bad), "first_mismatches": bad[:4], "source": "pinned host result buffers of the last step"},
+                             "what": "the headline's step with its %d frames per step read from PINNED HOST memory and every result (key points, descriptors, counts, "
+                                     "undistorted key points, matches) written back to pinned host memory: H2D (copy stream) / kernels (3 streams) / D2H (second copy "
+                                     "stream) ordered by events only; overlap_efficiency = frames/s over min(copies alone, kernels alone).  Never `value`." % B}
 
     def leg_host_api_cv():
         # the call the reference actually makes: ORBextractor::operator()(cv::InputArray, ..., cv::OutputArray, vector<int>&) through the header-only
@@ -1202,7 +1324,7 @@ def main():
                                         "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
 
     if not args.headline_only:
-        legs = (("host_api", leg_host_api), ("host_api_cv", leg_host_api_cv), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
+        legs = (("host_fed", leg_host_fed), ("host_api", leg_host_api), ("host_api_cv", leg_host_api_cv), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),
                 ("pose_inertial", leg_pose_inertial), ("bow", leg_bow), ("stereo", leg_stereo), ("fisheye_stereo", leg_fisheye_stereo), ("size_1280x720", leg_size_1280x720),
                 ("scene_diversity", leg_scene_diversity), ("mixed_batch", leg_mixed_batch), ("batch_sweep", leg_batch_sweep))
         # N>1: the legs the multi-GPU line is read for (the metric's LBA component, north_star's second frame size); the per-GPU side figures are the

@@ -98,6 +98,30 @@ def test_hip_bench_step_752x480_B64_streams(hip_lib, streams):
 
 
 @pytest.mark.gpu
+def test_hip_bench_host_fed_step_B48_three_sets(hip_lib):
+    """The host-fed form of the step (extra.host_fed; Tracking::GrabImageMonocular receives host images, src/Tracking.cc:507-560): three input sets in
+    pinned host memory, H2D / kernels / D2H ordered by events only.  The device staging sets are overwritten with garbage first, so a result can only
+    be right if the step's own H2D delivered the images; seven steps walk every (input set, buffer set) pairing, each one's PINNED HOST results are
+    compared with the oracle, all frames."""
+    import torch
+    hosts = [bench.make_batch(48, seed0=900 + 50 * i, unique=24, w=752, h=480) for i in range(3)]
+    d_sets = [torch.from_numpy(f_).to("cuda:0") for f_ in hosts]
+    P = bench.StepPipeline(d_sets, 752, 480, 1000, 0, streams=3, frames_host=hosts)
+    P.start_streams()
+    P.start_host_fed()
+    for d_ in d_sets:
+        d_.fill_(0x5A)
+    torch.cuda.synchronize()
+    for i in range(7):
+        P.host_fed_step()
+        n, bad, tot = P.check_host_fed_against_oracle()
+        assert n == 48 and bad == [], (i, bad)
+        assert tot["keypoints"] > 48 * 950 and tot["matches"] > 48 * 250
+    h2d, d2h = P.host_fed_bytes()
+    assert h2d == 48 * 752 * 480 and d2h > 48 * 1000 * 60
+
+
+@pytest.mark.gpu
 def test_hip_bench_step_1280x720_1500kp_B256_every_frame(hip_lib):
     """north_star's second frame size at its feature count (TUM_512.yaml:62), one-pass policy territory (sparser frames)."""
     frames, P = _pipeline(256, 1280, 720, 1500, seed0=5000, unique=8)
