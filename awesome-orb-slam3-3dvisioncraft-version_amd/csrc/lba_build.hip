@@ -556,6 +556,9 @@ struct LmArgs {
     double* cholX;                          // [ceil(np6 / 32)][32][32] per window: the inverses of L's diagonal blocks (row-major), for its backward substitution
     double* part;                           // [batch][nPart] partial sums (chi2 / scale)
     LmState* st; int* flag; int nPart, np6;
+    int shard;                              // lba_optimize_sharded: 0 = the whole window is here; 1 = this rank holds a landmark shard and OWNS the pose-side terms
+                                            // (Hpp + lambda I, b_p, the pose part of computeScale enter the all-reduced sums once); 2 = a shard, not the owner
+    double* red;                            // [batch][4] packed per-window scalars for the cross-rank reductions of the sharded form
     int4* rowMeta;                          // [batch][cap_e] per entry of the pose-major edge lists: (edge, landmark, first / end edge of the landmark's run)
     int32_t* edgeH;                         // [batch][cap_e + 8] Hessian index of each edge's pose (-1: fixed), landmark-major like the edges
 };
@@ -862,7 +865,7 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
             double v = Sall[q * SCH_LD + k];
 #pragma unroll
             for (int w = 1; w < NW; w++) v += Sall[(size_t)w * rowCap * SCH_LD + q * SCH_LD + k];   // the waves' copies in wave order
-            if (d == 0) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
+            if (d == 0 && A.shard != 2) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
             const int c = k / 6, r = k - c * 6;                   // entry (r, c) of block (h1, h2)
             if (h2 <= h1) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;     // lower triangle: row block h1, column block h2
             else Hs[(size_t)(h1 * 6 + r) * np6 + h2 * 6 + c] = v;              // transposed into block (h2, h1)
@@ -881,7 +884,7 @@ static __global__ __launch_bounds__(64 * NW) void k_lm_schur_rows(LmArgs A, int 
         double c = 0;
         for (int w = 0; w < SCH_NT / 64; w++) c += coefw[w * 6 + tid];
         if (G > 1) A.schurPart[(((size_t)b * (np6 / 6) + h1) * G + g) * ((size_t)(np6 / 12 + 1) * 36 + 6) + (size_t)(np6 / 12 + 1) * 36 + tid] = c;
-        else A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - c;
+        else A.xp[(size_t)b * np6 + h1 * 6 + tid] = (A.shard != 2 ? A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] : 0.0) - c;
     }
 }
 
@@ -903,7 +906,7 @@ static __global__ __launch_bounds__(256) void k_lm_schur_combine(LmArgs A, const
         const int h2 = h1 - d + (h1 < d ? n : 0);
         double v = part[t];
         for (int gg = 1; gg < G; gg++) v += part[(size_t)gg * rowD + t];
-        if (d == 0) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
+        if (d == 0 && A.shard != 2) v += A.S.Hpp[((size_t)b * P.cap_p + h1) * 36 + k] + ((k % 7 == 0) ? A.st[b].lambda : 0.0);
         const int c = k / 6, r = k - c * 6;
         if (h2 <= h1) Hs[(size_t)(h2 * 6 + c) * np6 + h1 * 6 + r] = v;
         else Hs[(size_t)(h1 * 6 + r) * np6 + h2 * 6 + c] = v;
@@ -911,7 +914,7 @@ static __global__ __launch_bounds__(256) void k_lm_schur_combine(LmArgs A, const
     if (tid < 6) {
         double c = 0;
         for (int gg = 0; gg < G; gg++) c += part[(size_t)gg * rowD + (size_t)(np6 / 12 + 1) * 36 + tid];
-        A.xp[(size_t)b * np6 + h1 * 6 + tid] = A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] - c;
+        A.xp[(size_t)b * np6 + h1 * 6 + tid] = (A.shard != 2 ? A.S.bp[((size_t)b * P.cap_p + h1) * 6 + tid] : 0.0) - c;
     }
 }
 
@@ -1383,7 +1386,7 @@ static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A, int nBa
     if (tid < 64) {
         double s = 0;
         for (int i = tid; i < nBack; i += 64) s += A.part[(size_t)b * A.nPart + i];
-        if (tid == 0) s += red[0];
+        if (tid == 0 && A.shard != 2) s += red[0];   // (every rank of the sharded form computes the same pose part: it enters the all-reduced sum once)
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         if (tid == 0) A.st[b].scale = s;
     }
@@ -1391,14 +1394,7 @@ static __global__ __launch_bounds__(256) void k_lm_update_pose(LmArgs A, int nBa
 
 // computeActiveErrors' sum (k_lm_sum_partials with what = 0: the same lane-strided partial sums and butterfly) and the rho test of the trial in one launch:
 // one wave per window, lane 0 decides
-static __global__ __launch_bounds__(64) void k_lm_sum_decide(LmArgs A, int n) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    double sum = 0;
-    for (int i = lane; i < n; i += 64) sum += A.part[(size_t)b * A.nPart + i];
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    if (lane != 0) return;
-    LmState& s = A.st[b];
-    s.tempChi = sum;
+static __device__ __forceinline__ void lm_decide(LmState& s, int* flag) {
     if (!s.needTrial) return;
     double tempChi = s.tempChi;
     if (!s.ok) tempChi = 1.7976931348623157e308;
@@ -1417,7 +1413,36 @@ static __global__ __launch_bounds__(64) void k_lm_sum_decide(LmArgs A, int n) {
     }
     s.rho = rho; s.qmax++; s.trials++; s.ok = 1;
     s.needTrial = (rho < 0 && s.qmax < 100) ? 1 : 0;
-    if (s.needTrial) atomicAdd(A.flag, 1);
+    if (s.needTrial) atomicAdd(flag, 1);
+}
+static __global__ __launch_bounds__(64) void k_lm_sum_decide(LmArgs A, int n) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double sum = 0;
+    for (int i = lane; i < n; i += 64) sum += A.part[(size_t)b * A.nPart + i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane != 0) return;
+    LmState& s = A.st[b];
+    s.tempChi = sum;
+    lm_decide(s, A.flag);
+}
+// the sharded form (lba_optimize_sharded): the per-window scalars a rank can only know for ITS landmarks go through one all-reduce between the
+// kernels that produce them and the ones that read them.  what 0: tempChi (sum); 1: tempChi, scale, failures (sums) of a lambda trial; 2: maxDiag (max)
+static __global__ void k_lm_pack(LmArgs A, int batch, int what) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const LmState& s = A.st[b];
+    double* r = A.red + (size_t)b * 4;
+    if (what == 2) { r[0] = s.maxDiag; r[1] = r[2] = r[3] = 0; return; }
+    r[0] = s.tempChi; r[1] = what == 1 ? s.scale : 0.0; r[2] = (what == 1 && !s.ok) ? 1.0 : 0.0; r[3] = 0;
+}
+static __global__ void k_lm_unpack(LmArgs A, int batch, int what) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    LmState& s = A.st[b];
+    const double* r = A.red + (size_t)b * 4;
+    if (what == 2) { s.maxDiag = r[0]; return; }
+    s.tempChi = r[0];
+    if (what == 1) { s.scale = r[1]; s.ok = r[2] == 0.0 ? 1 : 0; lm_decide(s, A.flag); }
 }
 
 // pop: windows whose last trial was rejected get their state back (also those that will retry)
@@ -1448,9 +1473,20 @@ static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
 #define LM_SCHUR_SPLIT_MIN_EDGES 256   // edges of a row per slice, at least (tests build with a tiny value to cover the split on their small windows)
 #endif
 static size_t lm_schur_part_doubles(size_t rows6) { return (rows6 / 12 + 1) * 36 + 6; }     // per (row, slice) of a system of rows6 unknowns
+// compute units of the calling thread's current device (256 on MI355X), asked once per device
+static int lm_device_cus() {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cached[dev]) cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return cached[dev];
+}
 static int lm_schur_groups(int batch, int rows, int cap_e, size_t np6alloc) {
     if (rows < 1 || batch < 1) return 1;
-    int G = std::min(LM_SCHUR_SPLIT_MAX, 256 / std::max(1, batch * rows));
+    if (rows / 2 + 1 > LM_SCHUR_ROWCAP) return 1;   // a split row leaves its slice in ONE chunk of schurPart: rows longer than the LDS chunk are never split
+    int G = std::min(LM_SCHUR_SPLIT_MAX, lm_device_cus() / std::max(1, batch * rows));
     G = std::min(G, std::max(1, cap_e / rows / LM_SCHUR_SPLIT_MIN_EDGES));
     const size_t perG = (size_t)batch * (np6alloc / 6) * lm_schur_part_doubles(np6alloc) * 8;
     G = (int)std::min<size_t>((size_t)G, ((size_t)64 << 20) / std::max<size_t>(perG, 1));
@@ -1472,6 +1508,7 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     s += lm_align(B * p->cap_l * 9 * 8) + lm_align(B * p->cap_l * 3 * 8);            // Dinv, db
     s += lm_align(B * np6 * np6 * 8) + lm_align(B * np6 * 8) + lm_align(B * p->cap_l * 3 * 8);   // Hs, xp, xl
     s += lm_align(B * nPart * 8) + lm_align(B * sizeof(LmState)) + lm_align(B * 4) + 256;
+    s += lm_align(B * 4 * 8);                                                         // packed scalars of the sharded form
     s += lm_align(B * p->cap_e * 16) + lm_align(B * ((size_t)p->cap_e + 8) * 4);     // Schur row metadata
     {   // partial Schur rows (few windows per call): sized for the most slices any free-pose count of this shape could take
         int gmax = 1;
@@ -1483,8 +1520,10 @@ extern "C" size_t lba_lm_workspace_bytes(const lba_problem* p, int batch) {
     return s;
 }
 
+// shard / reduce / user: lba_optimize_sharded (0 / nullptr: the whole window lives here)
 static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
-                             const volatile int* abort_flag, const volatile unsigned char* abort_byte, void* stream) {
+                             const volatile int* abort_flag, const volatile unsigned char* abort_byte, void* stream,
+                             int shard = 0, lba_allreduce_fn reduce = nullptr, void* user = nullptr) {
     lba_system dummy;
     memset(&dummy, 0, sizeof(dummy));
     int rc = lba_check(prob, batch, &dummy);
@@ -1523,6 +1562,14 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
     int32_t* nfree = (int32_t*)take(B * 4);
     A.flag = (int*)take(4);
     A.rowMeta = (int4*)take(B * P.cap_e * 16); A.edgeH = (int32_t*)take(B * ((size_t)P.cap_e + 8) * 4);
+    A.red = (double*)take(B * 4 * 8);
+    A.shard = shard;
+    // the cross-rank sums of the sharded form: `what` as in k_lm_pack / k_lm_unpack
+#define LM_REDUCE(ptr, n, op) do { if (shard && reduce(user, (ptr), (n), (op), stream) != 0) return ORB_E_HIP; } while (0)
+#define LM_REDUCE_STATE(what) do { if (shard) {                                                            \
+        hipLaunchKernelGGL(k_lm_pack, dim3((batch + 63) / 64), dim3(64), 0, st, A, batch, (what));             \
+        LM_REDUCE(A.red, B * 4, (what) == 2 ? 1 : 0);                                                        \
+        hipLaunchKernelGGL(k_lm_unpack, dim3((batch + 63) / 64), dim3(64), 0, st, A, batch, (what)); } } while (0)
     A.schurG = lm_schur_groups(batch, maxFree, P.cap_e, np6cap);
     if (A.schurG > 1) A.schurPart = (double*)take(B * (np6cap / 6) * A.schurG * lm_schur_part_doubles(np6cap) * 8);   // (used with the strides of np6)
     if (lm_chol_step_possible(batch, np6cap)) {       // used with ld = np6
@@ -1579,6 +1626,7 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         if (it == 0) {
             LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
             hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+            LM_REDUCE_STATE(0);
         }
         {
             LbaArgs L;
@@ -1587,8 +1635,12 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             if (hipMemsetAsync(A.S.bp, 0, B * P.cap_p * 6 * 8, st) != hipSuccess) return ORB_E_HIP;
             LM_LAUNCH_MP(k_lba_landmarks, dim3((P.cap_l + LBA_LB - 1) / LBA_LB, batch), dim3(LBA_CT), LBA_CT * 18 * 8, st, L);
             LM_LAUNCH_MP(k_lba_poses, dim3(P.cap_p, batch), dim3(POSES_NT), (POSES_NT / 64) * 27 * 8, st, L);
+            // sharded: every rank linearised the edges of ITS landmarks — the pose-side blocks are sums over all of them (the all-reduce of
+            // SURVEY 8(e)); H_ll / b_l / H_pl stay local
+            LM_REDUCE(A.S.Hpp, B * P.cap_p * 36, 0);
+            LM_REDUCE(A.S.bp, B * P.cap_p * 6, 0);
         }
-        if (it == 0) hipLaunchKernelGGL(k_lm_maxdiag, dim3(MAXDIAG_G, batch), dim3(256), 256 * 8, st, A);
+        if (it == 0) { hipLaunchKernelGGL(k_lm_maxdiag, dim3(MAXDIAG_G, batch), dim3(256), 256 * 8, st, A); LM_REDUCE_STATE(2); }
         hipLaunchKernelGGL(k_lm_begin, dim3(gB), dim3(64), 0, st, A, batch);
         for (int trial = 0; trial < 100; trial++) {
             hipLaunchKernelGGL(k_lm_backup, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);   // push
@@ -1599,6 +1651,10 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
                 else if (schurNW == 2) hipLaunchKernelGGL(k_lm_schur_rows<2>, gS, dim3(128), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
                 else hipLaunchKernelGGL(k_lm_schur_rows<1>, gS, dim3(64), schurSmem, st, A, rowCap, batch, (const int32_t*)nfree);
                 if (A.schurG > 1) hipLaunchKernelGGL(k_lm_schur_combine, dim3(maxFree, batch), dim3(256), 0, st, A, (const int32_t*)nfree);
+                // sharded: the reduced camera system is the sum of the ranks' Schur terms (+ H_pp + lambda I and b_p, which the owner rank added):
+                // one all-reduce of [np6 x np6 | np6] per window (block_solver.hpp:381-432 builds it in one piece); every rank then factorises it
+                LM_REDUCE(A.Hs, B * np6 * np6, 0);
+                LM_REDUCE(A.xp, B * np6, 0);
             }
             if (cholStep) {
                 for (int kb = 0; kb < (int)np6; kb += LM_CHOLS_NB) {
@@ -1611,7 +1667,11 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
             hipLaunchKernelGGL(k_lm_backsub, gLB, dim3(BS_CT), (BS_CT * 21 + BS_LB) * 8, st, A);
             hipLaunchKernelGGL(k_lm_update_pose, dim3(batch), dim3(256), 256 * 8, st, A, (int)gLB.x);       // (+ the scale sum)
             LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
-            hipLaunchKernelGGL(k_lm_sum_decide, dim3(batch), dim3(64), 0, st, A, (int)gE.x);               // chi2 sum + rho test
+            if (!shard) hipLaunchKernelGGL(k_lm_sum_decide, dim3(batch), dim3(64), 0, st, A, (int)gE.x);               // chi2 sum + rho test
+            else {   // chi2 / computeScale / failures summed over the ranks first, then the same rho test on every rank (k_lm_unpack)
+                hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+                LM_REDUCE_STATE(1);
+            }
             hipLaunchKernelGGL(k_lm_restore, dim3(gCopy), dim3(256), 0, st, A, nPose, nPoint, P.cap_p * 7, P.cap_l * 3);       // pop
             int more = 0;
             if (hipMemcpyAsync(&more, A.flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
@@ -1632,6 +1692,9 @@ static int lba_optimize_impl(const lba_problem* prob, int batch, int iterations,
         if (hipMemcpyAsync(A.st, on.data(), B * sizeof(LmState), hipMemcpyHostToDevice, st) != hipSuccess) return ORB_E_HIP;
         LM_LAUNCH_MP(k_lm_errors, gE, dim3(256), 256 * 8, st, A);
         hipLaunchKernelGGL(k_lm_sum_partials, dim3(batch), dim3(64), 0, st, A, batch, (int)gE.x, 0, -1);
+        LM_REDUCE_STATE(0);
+#undef LM_REDUCE_STATE
+#undef LM_REDUCE
         std::vector<LmState> fin(B);
 #undef LM_LAUNCH_MP
         if (hipMemcpyAsync(fin.data(), A.st, B * sizeof(LmState), hipMemcpyDeviceToHost, st) != hipSuccess) return ORB_E_HIP;
@@ -1652,6 +1715,17 @@ extern "C" int lba_optimize(const lba_problem* prob, int batch, int iterations, 
 extern "C" int lba_optimize_stopflag(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
                                      const volatile unsigned char* pb_stop_flag, void* stream) {
     return lba_optimize_impl(prob, batch, iterations, d_workspace, h_stats, nullptr, pb_stop_flag, stream);
+}
+
+// One window (per batch entry) sharded by LANDMARK over several processes (BASELINE configs[4]): every rank passes the whole pose set and
+// the edges / points of ITS landmarks; the pose-side sums (H_pp, b_p), the reduced camera system, chi2, computeScale and the lambda start value go
+// through `reduce` (an all-reduce over the ranks: RCCL on MI355X, gloo in the CPU tests), after which every rank takes the same decisions, solves the
+// same system and updates all poses; landmarks are back-substituted where they live.  owner: non-zero on EXACTLY ONE rank.  No stop flag: the ranks
+// must take the same number of trials.
+extern "C" int lba_optimize_sharded(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats, int owner,
+                                    lba_allreduce_fn reduce, void* user, void* stream) {
+    if (!reduce) return ORB_E_INVALID;
+    return lba_optimize_impl(prob, batch, iterations, d_workspace, h_stats, nullptr, nullptr, stream, owner ? 1 : 2, reduce, user);
 }
 
 // ============================================================================================================

@@ -47,6 +47,37 @@ def allgather_frame_blocks(kps, desc, counts, group=None):
     return unpack_frame_blocks(out, cap)
 
 
+def _contig(a):
+    return a.contiguous() if hasattr(a, "contiguous") else __import__("numpy").ascontiguousarray(a)
+
+
+def cross_rank_match(kps, desc, counts, all_kps, all_desc, all_counts, matcher, vocab=None, rank=None, world=None, levelsup=4):
+    """The consumer of the descriptor all-gather (north_star: "RCCL all-gather of descriptors ... for cross-frame matching"): frame i of THIS rank
+    against frame i of rank (rank + 1) % world, read out of the gathered slabs —
+      * cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) as Frame::ComputeStereoFishEyeMatches uses it (reference src/Frame.cc:1300; orbm_knn2), and
+      * with a vocabulary, ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:984-1124; LoopClosing / relocalisation match a
+        key frame against candidates other ranks extracted).  Both sides are ComputeBoW'd here (Frame.cc:865-872): the vocabulary is replicated on every
+        rank as in any ORB-SLAM3 process, only descriptors travel.
+    Inputs: this rank's extractor outputs [F, cap, ...] and the gathered ones [world * F, cap, ...] (torch tensors, or numpy with the emulated build).
+    -> dict(knn_idx [F,cap,2], knn_dist [F,cap,2][, bow_m12 [F,cap], bow_nmatches [F]])"""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    F = kps.shape[0]
+    peer = (rank + 1) % world
+    t_kps, t_desc, t_cnt = (_contig(a[peer * F:(peer + 1) * F]) for a in (all_kps, all_desc, all_counts))
+    nq, nt = _contig(counts[:, 0]), _contig(t_cnt[:, 0])
+    idx, dst = matcher.knnMatch2(_contig(desc), nq, t_desc, nt)
+    res = dict(knn_idx=idx, knn_dist=dst)
+    if vocab is not None:
+        ra, rb = vocab.transform(_contig(desc), nq, levelsup), vocab.transform(t_desc, nt, levelsup)
+        side = lambda r, d_, k_: dict(desc=_contig(d_), angle=_contig(k_[..., 3]), node_id=r["fv_node_id"], node_start=r["fv_node_start"],
+                                      feat_idx=r["fv_feat_idx"], n_nodes=r["fv_n_nodes"])
+        ones = lambda d_: (d_[..., 0] * 0 + 1) if hasattr(d_, "contiguous") else __import__("numpy").ones(d_.shape[:2], "u1")
+        m12, nm = matcher.SearchByBoWKF(side(ra, desc, kps), _contig(ones(desc)), side(rb, t_desc, t_kps), _contig(ones(t_desc)))
+        res.update(bow_m12=m12, bow_nmatches=nm)
+    return res
+
+
 def allgather_pose_blocks(poses, group=None):
     """LBA sharded by landmark: after a solve the updated pose blocks (n_p x 7 f64 = 5.6 kB at 100 KFs) of the
     poses each rank updated are all-gathered — the collective BASELINE.json configs[4] names.  poses: [n_local, 7] f64."""
@@ -54,6 +85,16 @@ def allgather_pose_blocks(poses, group=None):
     out = torch.empty((world * poses.shape[0], poses.shape[1]), dtype=poses.dtype, device=poses.device)
     dist.all_gather_into_tensor(out, poses.contiguous(), group=group)
     return out
+
+
+def shard_window_by_landmark(w, llo, lhi):
+    """The part of a flattened LocalBundleAdjustment window (orbhip.lba: dict(poses, pose_hidx, points, edges)) a rank holds when the window is
+    sharded by landmark: ALL poses, the points [llo, lhi) re-indexed from 0 and their edges (landmark-major order is kept).  For
+    LbaWindows.optimize_sharded / the landmark-sharded linearisation."""
+    e = w["edges"]
+    el = e[(e["point"] >= llo) & (e["point"] < lhi)].copy()
+    el["point"] -= llo
+    return dict(w, points=w["points"][llo:lhi].copy(), edges=el)
 
 
 def allreduce_pose_system(Hpp, bp, group=None):
@@ -146,17 +187,30 @@ class PeerExchange:
             if bad:
                 raise RuntimeError("rank %d: %s" % bad[0])
             self._peer = [(C.c_void_p * W)() for _ in range(3)]
+            open_err = None
             for r in range(W):
                 for k in range(3):
                     if r == self.rank:
                         self._peer[k][r] = self._slabs[k].ptr
-                    else:
+                    elif open_err is None:
                         p = C.c_void_p()
                         hb = (C.c_uint8 * 64).from_buffer_copy(allh[r][0][k])
                         if self.L.orbd_ipc_open(hb, C.byref(p)) != 0:
-                            raise RuntimeError("orbd_ipc_open failed for rank %d" % r)
-                        self._opened.append(p.value)
-                        self._peer[k][r] = p.value
+                            open_err = "orbd_ipc_open failed for the slabs of rank %d" % r
+                        else:
+                            self._opened.append(p.value)
+                            self._peer[k][r] = p.value
+            # the opens are agreed on collectively as well: a rank whose open failed would otherwise drop its own slabs while the peers that did map
+            # them carry on and read freed memory.  Every rank raises (and releases) together, after all of them have closed what they had opened.
+            oks = [None] * W
+            dist.all_gather_object(oks, open_err, group=group)
+            bad = [(r, e) for r, e in enumerate(oks) if e]
+            if bad:
+                for p_ in self._opened:
+                    self.L.orbd_ipc_close(C.c_void_p(p_))
+                self._opened = []
+                dist.barrier(group=group)                 # nobody still maps a peer's slab when the owners let go below
+                raise RuntimeError("rank %d: %s" % bad[0])
         except Exception:
             self._release()           # what this rank had allocated / opened so far (no barrier: the peers are not known to be in step)
             raise
@@ -180,9 +234,12 @@ class PeerExchange:
         self._opened = []
         self.kps = self.desc = self.counts = None
         self._slabs = []              # each slab frees itself when the last tensor on it is gone (_DevSlab.__del__)
+        self._peer = None             # (closed mappings and freed slabs: nothing may hand these to the native call again)
         self._closed = True
 
     def allgather(self, stream=None):
+        if self._closed:
+            raise RuntimeError("PeerExchange is closed")
         C = self.C
         st = stream if stream is not None else torch.cuda.current_stream(self.kps.device).cuda_stream
         rc = self.L.orbd_allgather_frames_peer(self.world, self.rank, self.F, self.cap, self._peer[0], self._peer[1], self._peer[2],

@@ -32,6 +32,9 @@ class LbaSystem(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2", "rho", "depth", "robust_chi2_sum")]
 
 
+LBA_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)   # lba_allreduce_fn (include/orbhip.h)
+
+
 def bind(lib):
     for name in ("lba_build_system", "lba_compute_errors"):
         fn = getattr(lib, name)
@@ -43,6 +46,8 @@ def bind(lib):
     lib.lba_lm_workspace_bytes.argtypes = [C.POINTER(LbaProblem), C.c_int]
     lib.lba_optimize.restype = C.c_int
     lib.lba_optimize.argtypes = [C.POINTER(LbaProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lba_optimize_sharded.restype = C.c_int
+    lib.lba_optimize_sharded.argtypes = [C.POINTER(LbaProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, LBA_ALLREDUCE_FN, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -126,6 +131,44 @@ class LbaWindows:
                                   _stream(self.d["poses"]))
         if rc != 0:
             raise OrbHipError(rc, "lba_optimize failed")
+        return stats
+
+    def optimize_sharded(self, iterations, group=None, owner=None):
+        """optimize() for windows sharded by LANDMARK over the ranks of `group` (orbhip.dist.shard_window_by_landmark; include/orbhip.h
+        lba_optimize_sharded): every rank holds all poses and the points / edges of its landmarks.  The library's reductions (pose-side blocks per
+        linearisation; reduced camera system + three scalars per lambda trial) run as torch.distributed all-reduces on views of the workspace —
+        RCCL on MI355X, gloo in the CPU tests.  -> stats as optimize(), identical on every rank; self.d["poses"] holds ALL updated poses,
+        self.d["points"] this rank's landmarks.  self.reduce_stats: calls / doubles moved by the last call."""
+        import torch
+        import torch.distributed as dist
+        P, _ = self._structs(())
+        if getattr(self, "_lm_ws", None) is None:
+            n = self._L.lba_lm_workspace_bytes(C.byref(P), self.B)
+            self._lm_ws = _like(self.d["poses"], (n,), np.uint8)
+        ws = self._lm_ws
+        is_np = isinstance(ws, np.ndarray)
+        base = ws.ctypes.data if is_np else ws.data_ptr()
+        owner = (dist.get_rank(group) == 0) if owner is None else bool(owner)
+        self.reduce_stats = dict(calls=0, doubles=0, error=None)
+
+        def _reduce(user, buf, n, op, stream):
+            try:
+                off = int(buf) - base
+                assert 0 <= off and off + 8 * n <= ws.shape[0] and off % 8 == 0
+                t = torch.from_numpy(ws[off:off + 8 * n].view(np.float64)) if is_np else ws[off:off + 8 * n].view(torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)   # (stream-ordered on RCCL: the kernels run on torch's current stream)
+                self.reduce_stats["calls"] += 1
+                self.reduce_stats["doubles"] += int(n)
+                return 0
+            except Exception as err:   # noqa: BLE001  (no exception may cross the C ABI)
+                self.reduce_stats["error"] = "%s: %s" % (type(err).__name__, err)
+                return 1
+        cb = LBA_ALLREDUCE_FN(_reduce)
+        stats = np.zeros((self.B, 4), np.float64)
+        rc = self._L.lba_optimize_sharded(C.byref(P), self.B, int(iterations), _ptr(ws), stats.ctypes.data_as(C.c_void_p), 1 if owner else 0, cb, None,
+                                          _stream(self.d["poses"]))
+        if rc != 0:
+            raise OrbHipError(rc, "lba_optimize_sharded failed" + (": " + self.reduce_stats["error"] if self.reduce_stats["error"] else ""))
         return stats
 
     def compute_errors(self, outputs=("err", "chi2", "rho", "depth", "robust_chi2_sum")):

@@ -306,6 +306,32 @@ class StepPipeline:
         self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
         self._match(self.out)
 
+    def capture_graph(self):
+        """The sequential step (extraction + match on ONE stream) captured once as a HIP graph and replayed: what a caller with few frames per call does
+        about launch overhead (a step is ~20 launches; at B <= 16 they cost more than the kernels).  The captured call keeps its FAST pass form
+        (include/orbhip.h, orbx_last_fast_passes).  -> False when the capture is refused."""
+        torch = self.torch
+        assert len(self.sets) == 1
+        self.sequential_step()                       # every buffer of the step exists before the capture
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    self.sequential_step()
+            torch.cuda.synchronize()
+            self._graph = g
+            return True
+        except Exception as err:   # noqa: BLE001
+            self._graph, self._graph_error = None, "%s: %s" % (type(err).__name__, err)
+            torch.cuda.synchronize()
+            return False
+
+    def graph_step(self):
+        self._graph.replay()
+
     def kernel_times(self, warm=4):
         """Per-kernel device times (HIP events recorded on the launch stream inside the C ABI) from one untimed, sequential step — call before
         the extra streams exist."""
@@ -1175,10 +1201,10 @@ def main():
         del P2
 
     def leg_batch_sweep():
-        # ---- B in {64, 512, 4096} per GPU.  The 512 input frames (185 MB) fit the 256 MiB Infinity Cache and are re-read every step;
+        # ---- B in {64, 512, 4096} per GPU, plus the sizes a camera rig delivers per call (2, 8, 16).  The 512 input frames (185 MB) fit the 256 MiB Infinity Cache and are re-read every step;
         #      4096 frames (1.48 GB of input, 4.6 GB of pyramid per handle) cannot — the rate must not depend on that residency.
         sweep = {}
-        for SB in (64, 4096):
+        for SB in (2, 8, 16, 64, 4096):
             dfs = grow_batch_on_device(torch.cat(d_sets) if SB > B else d_frames, SB)      # 4096 = the resident sets' distinct frames, then rolled copies
             Ps = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=args.streams)
             Ps.kernel_times(warm=1)
@@ -1191,9 +1217,23 @@ def main():
                    "frames_per_s_min": round(world * SB * st / max(ds), 1), "frames_per_s_max": round(world * SB * st / min(ds), 1),
                    "input_bytes": int(SB) * W * H, "fast_passes": Ps.ex.last_fast_passes()}
             if not args.no_parity_check:
-                sels = np.unique(np.linspace(0, SB - 1, 32).astype(np.int64))
+                sels = np.unique(np.linspace(0, SB - 1, min(SB, 32)).astype(np.int64))
                 ns, bads, _ = Ps.check_against_oracle(sels)
                 ent["parity"] = {"checked_frames": int(ns), "mismatches": len(bads), "first_mismatches": bads[:2]}
+            if SB <= 64:
+                # the sizes a rig delivers per call (2-16 images): the same step as ONE graph launch (one stream), next to the eager three-stream figure
+                Pg = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=1)
+                if Pg.capture_graph():
+                    for _ in range(3):
+                        Pg.graph_step()
+                    dg = rank_max(timed(Pg.graph_step, st, 3))
+                    ent["graph_replay"] = {"frames_per_s": round(world * SB * st / float(np.median(dg)), 1), "ms_per_step": round(float(np.median(dg)) / st * 1e3, 4)}
+                    if not args.no_parity_check:
+                        ng, badg, _ = Pg.check_against_oracle(sels)
+                        ent["graph_replay"]["parity"] = {"checked_frames": int(ng), "mismatches": len(badg), "first_mismatches": badg[:2]}
+                else:
+                    ent["graph_replay"] = {"error": Pg._graph_error}
+                del Pg
             sweep[str(SB)] = ent
             del Ps, dfs
             torch.cuda.empty_cache()
@@ -1295,10 +1335,50 @@ def main():
                 px.close()
             except Exception as err:   # noqa: BLE001
                 extra["exchange"]["peer_error"] = "%s: %s" % (type(err).__name__, err)
+        # ---- the consumer of the all-gather: every rank matches frames of ITS OWN against the same-numbered frames of rank (rank + 1) % world, read out of
+        #      the gathered slabs — knnMatch(k = 2) (Frame.cc:1300) and SearchByBoW(KF, KF) (ORBmatcher.cc:984-1124).  Checked against ONE process: this
+        #      rank regenerates the peer's first frames from their seeds, extracts them itself and matches against those
+        from orbhip.bow import ORBVocabulary, synth_vocabulary_fast
+        P._use_set(0)
+        ox = P.ex.extract_batch(P.d_frames, P.LAP)
+        barrier()
+        gk, gd, gc = D.allgather_frame_blocks(ox[0], ox[1], ox[2])
+        S = min(B, 64)
+        capx = ox[0].shape[1]
+        first = lambda t: t.reshape((world, B) + tuple(t.shape[1:]))[:, :S].reshape((world * S,) + tuple(t.shape[1:])).contiguous()
+        sample = ox[1][0, :900].contiguous()
+        dist.broadcast(sample, 0)                                  # one vocabulary for all ranks (replicated, like ORBvoc in every ORB-SLAM3 process)
+        V = ORBVocabulary(synth_vocabulary_fast(5, 10, 4, sample_desc=sample.cpu().numpy()), device=local_rank)
+        mm = orbhip.ORBmatcher(0.75, True)
+        mine = (ox[0][:S].contiguous(), ox[1][:S].contiguous(), ox[2][:S].contiguous())
+        gath = (first(gk), first(gd), first(gc))
+        got = D.cross_rank_match(*mine, *gath, mm, V, rank=rank, world=world)
+        barrier()
+        tm = time.perf_counter()
+        for _ in range(3):
+            got = D.cross_rank_match(*mine, *gath, mm, V, rank=rank, world=world)
+        barrier()
+        dtm = (time.perf_counter() - tm) / 3
+        peer, R = (rank + 1) % world, min(8, S)
+        ref_frames = make_batch(R, seed0=1000 * peer, unique=max(1, R // 2))          # == the peer's frames 0..R-1 of input set 0 (make_batch is prefix-stable)
+        exr = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=R)
+        rk, rd, rc_ = exr.extract_batch(torch.from_numpy(ref_frames).to(dev), P.LAP)
+        pad = lambda t: torch.cat([t, t.new_zeros((R, capx - t.shape[1]) + tuple(t.shape[2:]))], 1) if t.shape[1] < capx else t
+        loc = [torch.cat([a[:R], pad(b_)]) for a, b_ in zip(mine, (rk, rd, rc_))][:2] + [torch.cat([mine[2][:R], rc_])]
+        ref = D.cross_rank_match(mine[0][:R], mine[1][:R], mine[2][:R], loc[0], loc[1], loc[2], mm, V, rank=0, world=2)
+        same = all(bool(torch.equal(got[k_][:R], ref[k_])) for k_ in ("knn_idx", "knn_dist", "bow_m12", "bow_nmatches"))
+        same = rank_max([0.0 if same else 1.0])[0] == 0.0
+        nn = got["knn_dist"][..., 0]
+        extra["cross_rank_match"] = {"frame_pairs_per_rank": int(S), "ms": round(dtm * 1e3, 3), "frame_pairs_per_s": round(world * S / dtm, 1),
+                                     "mean_bow_matches": float(got["bow_nmatches"].float().mean().item()),
+                                     "mean_nearest_distance": float(nn[nn < 256].float().mean().item()),
+                                     "equal_to_single_process_on_every_rank": same, "single_process_pairs_checked": int(R),
+                                     "what": "frame i of this rank against frame i of rank (rank + 1) %% world out of the all-gathered slabs: orbm_knn2 + "
+                                             "ComputeBoW (k = 10, L = 4 vocabulary) of both sides + SearchByBoW(KF, KF); the first %d pairs also against the peer's frames "
+                                             "regenerated and extracted in THIS process" % R}
         w, cams = synth_window(77, 100, 20, 20000, 8, "mono")   # the same window on every rank, landmarks sharded
         llo, lhi = D.shard(len(w["points"]), rank, world)
-        e = w["edges"]
-        wl = dict(w, edges=e[(e["point"] >= llo) & (e["point"] < lhi)].copy())
+        wl = D.shard_window_by_landmark(w, llo, lhi)
         Ls = LbaWindows([wl], cams, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
         nfree = int((w["pose_hidx"] >= 0).sum())
         plo, phi = D.shard(nfree, rank, world)
@@ -1322,6 +1402,39 @@ def main():
                                 "edges_this_rank": int(len(wl["edges"])), "landmarks_this_rank": int(lhi - llo),
                                 "what": "ONE 100-KF / 20k-landmark window, landmarks sharded over %d ranks: local build + all-reduce of H_pp/b_p "
                                         "(%d doubles) + all-gather of the pose blocks" % (world, nfree * 42)}
+        # ---- the sharded LM step (lba_optimize_sharded): the same window, optimize(5) with the reduced camera system all-reduced per lambda trial,
+        #      next to the whole window optimised on this rank alone — time reported as it is (one window does not scale: the collectives are latency)
+        to_d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        one = LbaWindows([w], cams, to_d)
+        p0 = one.d["poses"].clone(); x0 = one.d["points"].clone()
+        one.optimize(5)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            one.d["poses"].copy_(p0); one.d["points"].copy_(x0)
+            st1 = one.optimize(5)
+        barrier()
+        dt1 = (time.perf_counter() - t1) / 2
+        sh = LbaWindows([wl], cams, to_d)
+        ps0 = sh.d["poses"].clone(); xs0 = sh.d["points"].clone()
+        sh.optimize_sharded(5)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            sh.d["poses"].copy_(ps0); sh.d["points"].copy_(xs0)
+            st2 = sh.optimize_sharded(5)
+        barrier()
+        dt2 = (time.perf_counter() - t2) / 2
+        dpose = float((one.d["poses"][0] - sh.d["poses"][0]).abs().max().item())
+        dpts = float((one.d["points"][0, llo:lhi] - sh.d["points"][0, :lhi - llo]).abs().max().item())
+        dmax = rank_max([dpose, dpts])
+        extra["lm_sharded"] = {"ms_per_optimize5_sharded": round(dt2 * 1e3, 3), "ms_per_optimize5_one_rank": round(dt1 * 1e3, 3),
+                               "iterations": [float(st1[0, 0]), float(st2[0, 0])], "lambda_trials": [float(st1[0, 3]), float(st2[0, 3])],
+                               "chi2": [float(st1[0, 1]), float(st2[0, 1])], "max_abs_pose_difference": dmax[0], "max_abs_point_difference": dmax[1],
+                               "allreduce_calls": sh.reduce_stats["calls"], "allreduce_doubles": sh.reduce_stats["doubles"],
+                               "what": "ONE 100-KF / 20k-landmark window, optimize(5): landmarks sharded over %d ranks, per lambda trial one all-reduce of the reduced "
+                                       "camera system (%d doubles) + 3 scalars, per linearisation one of H_pp | b_p; every rank factorises — vs the whole window on one "
+                                       "rank" % (world, (nfree * 6) ** 2 + nfree * 6)}
 
     if not args.headline_only:
         legs = (("host_fed", leg_host_fed), ("host_api", leg_host_api), ("host_api_cv", leg_host_api_cv), ("lba", leg_lba), ("pose_optimization", leg_pose_optimization), ("inertial_ba", leg_inertial_ba),

@@ -511,6 +511,19 @@ int lba_optimize(const lba_problem* prob, int batch, int iterations, void* d_wor
  * another thread) and passes it to g2o's setForceStopFlag (Optimizer.cc:1975-1976); pb_stop_flag may be NULL. */
 int lba_optimize_stopflag(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats,
                           const volatile unsigned char* pb_stop_flag, void* stream);
+
+/* lba_optimize for windows SHARDED BY LANDMARK over several processes, one per GPU (BASELINE configs[4]; the reference solves one
+ * window in one process: BlockSolver::buildSystem / solve, block_solver.hpp:381-432,502-560).  Every rank passes the whole pose set of each window and the
+ * points / edges of ITS landmarks only (re-indexed from 0).  Per linearisation the pose-side blocks H_pp | b_p are summed over the ranks, per lambda
+ * trial the reduced camera system [np6 x np6 | np6] and three scalars per window (chi2, computeScale, failures), once the lambda start value (max):
+ * all through `reduce(user, d_buf, n, op, stream)`, which must leave d_buf[0..n) = the sum (op 0) or maximum (op 1) over all ranks of their d_buf,
+ * bit-identical on every rank, ordered after the work already queued on `stream` and complete (or stream-ordered) when it returns; non-zero = failure.
+ * Every rank then takes the same decisions, factorises the same system and updates ALL poses; its own landmarks are back-substituted locally.
+ * owner: non-zero on exactly one rank (the terms that exist once — H_pp + lambda I, b_p, the pose part of computeScale — enter the sums there).
+ * h_stats as lba_optimize, identical on every rank (chi2 of the WHOLE window).  There is no stop flag: the ranks must run the same trials. */
+typedef int (*lba_allreduce_fn)(void* user, double* d_buf, size_t n, int op, void* stream);
+int lba_optimize_sharded(const lba_problem* prob, int batch, int iterations, void* d_workspace, double* h_stats, int owner,
+                         lba_allreduce_fn reduce, void* user, void* stream);
 /* lba_optimize returns ORB_E_CAPACITY when the reduced camera system (6 unknowns per FREE key frame; fixed key frames do not count) no
  * longer fits the solver's LDS budget (> ~3 300 free key frames): nothing was changed, the window stays as it was.  A host that must optimise such a map
  * keeps its own CPU solver for it (integration/Optimizer_hip.cc REPLACES the g2o body and therefore leaves the map untouched instead — GlueGuard.h). */

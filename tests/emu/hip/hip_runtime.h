@@ -369,6 +369,8 @@ using std::min;
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }   // the host-side work split is sized as on an MI355X
 inline hipError_t hipMalloc(void** p, size_t n) {
     n = (n + 255) & ~(size_t)255;
     *p = aligned_alloc(256, n ? n : 256);

@@ -304,6 +304,16 @@ def test_emu_lba_optimize_split_schur_rows():
     check_optimize(lib, "emu", ("mono", "stereo"), 5)
 
 
+def test_emu_lba_optimize_split_and_chunked_schur_rows():
+    """Both knobs at once (round-5 advisor finding): a row that is split over workgroups leaves its slice in ONE column chunk of schurPart, so rows
+    longer than the LDS chunk (n / 2 + 1 > LM_SCHUR_ROWCAP) must not be split — lm_schur_groups returns 1 for them; results must not change."""
+    import ctypes
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(ctypes.CDLL(build_emu.build(defines=("LM_SCHUR_ROWCAP=3", "LM_SCHUR_SPLIT_MIN_EDGES=4"), tag="schurchunksplit")))
+    check_optimize(lib, "emu", ("mono", "stereo"), 5)
+
+
 def test_emu_lba_optimize_one_workgroup_per_window():
     """LM_CHOL_SPLIT_MAX_BATCH=0: the factorisation as ONE workgroup per window with 16-column panels (k_lm_chol<16>, what a batch of more than 48
     small windows takes).  The default build's few-window calls — every other LM test of this tier — take one launch per panel (k_lm_chol_step +
