@@ -1364,7 +1364,7 @@ def main():
         exr = orbhip.ORBextractor(NFEAT, 1.2, 8, 20, 7, device=local_rank, max_batch=R)
         rk, rd, rc_ = exr.extract_batch(torch.from_numpy(ref_frames).to(dev), P.LAP)
         pad = lambda t: torch.cat([t, t.new_zeros((R, capx - t.shape[1]) + tuple(t.shape[2:]))], 1) if t.shape[1] < capx else t
-        loc = [torch.cat([a[:R], pad(b_)]) for a, b_ in zip(mine, (rk, rd, rc_))][:2] + [torch.cat([mine[2][:R], rc_])]
+        loc = [torch.cat([a[:R], pad(b_)]) for a, b_ in zip(mine[:2], (rk, rd))] + [torch.cat([mine[2][:R], rc_])]
         ref = D.cross_rank_match(mine[0][:R], mine[1][:R], mine[2][:R], loc[0], loc[1], loc[2], mm, V, rank=0, world=2)
         same = all(bool(torch.equal(got[k_][:R], ref[k_])) for k_ in ("knn_idx", "knn_dist", "bow_m12", "bow_nmatches"))
         same = rank_max([0.0 if same else 1.0])[0] == 0.0
