@@ -1094,7 +1094,7 @@ static __device__ __forceinline__ void sbpf_walk(const SbpfFrame& F, const orbm_
     }
 }
 #ifndef SBPF_EXP
-#define SBPF_EXP 0      // timing experiments only (tools/build_variants.sh): 1 no reading on behind the kept keys, 2 one round, 4 no sorted insertion, 8 no window walk
+#define SBPF_EXP 0      // timing experiments only (tools/exp.py build): 1 no reading on behind the kept keys, 2 one round, 4 no sorted insertion, 8 no window walk
 #endif
 #define SBPF_T 1024
 #ifndef SBPF_WPE

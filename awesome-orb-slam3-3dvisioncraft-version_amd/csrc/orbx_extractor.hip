@@ -2954,7 +2954,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     // E1 pyramid
 #ifndef ORBX_EXP_DUP
-#define ORBX_EXP_DUP 0   // experiment only (tools/build_variants.sh): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
+#define ORBX_EXP_DUP 0   // experiment only (tools/exp.py build): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
 #endif                   // three-stream step (every one of them is idempotent) next to its standalone time
 #ifndef PYR_CHAIN_MAX_BATCH
 #define PYR_CHAIN_MAX_BATCH 1   // calls of up to this many frames build the pyramid in ONE launch (k_pyramid_chain): the single-frame entry point

@@ -415,7 +415,7 @@ class StepPipeline:
                 S["sX"][k].wait_event(S["evB"][k])
             if F["evD_set"][k]:
                 S["sX"][k].wait_event(F["evD"][k])                   # this buffer set's previous results are on the host
-            if not F.get("skip_kernels"):                            # (experiment knob, tools/exp_host_fed.py)
+            if not F.get("skip_kernels"):                            # (experiment knob, tools/exp.py host_fed)
                 S["outs"][k] = S["exs"][k].extract_batch(self.d_frames, self.LAP, out=S["outs"][k])
             self.out = S["outs"][k]
             S["evA"][k].record(S["sX"][k])
@@ -667,7 +667,7 @@ def main():
                          "handles (orbd_allgather_frames_peer: one pull per peer and slab, a stream per peer), or both; the peer form has never run "
                          "on more than one GPU (DESIGN section 5), so the driver's default stays RCCL and a failing peer leg is reported, not fatal")
     ap.add_argument("--headline-only", action="store_true", help="skip the extract+match and LBA legs")
-    ap.add_argument("--lba-windows", type=int, default=256, help="LBA windows per GPU per step (linearisations/s against windows per launch on MI355X: 4 -> 67 k, 16 -> 78 k, 64 -> 83 k, 256 -> 91 k; tools/exp_lba_windows.py)")
+    ap.add_argument("--lba-windows", type=int, default=256, help="LBA windows per GPU per step (linearisations/s against windows per launch on MI355X: 4 -> 67 k, 16 -> 78 k, 64 -> 83 k, 256 -> 91 k)")
     ap.add_argument("--lm-windows", type=int, default=256, help="LBA windows per GPU per step in the full-LM leg")
     ap.add_argument("--input-sets", type=int, default=3, help="resident input sets the steps rotate over (step i reads set i mod N; every set = --batch frames "
                                                                "from --batch/2 distinct seeded scenes with its own projection records): consecutive steps never see the same images")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel means of the PMC passes tools/exp_lm_pmc.sh left under gpurun_out/lmpmc/ (LM leg)."""
+"""Per-kernel means of the passes tools/pmc_passes.sh TAG left under gpurun_out/pmc_TAG/:  python tools/pmc_summary.py TAG [kernel name prefixes]"""
 import collections
 import csv
 import glob
@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-base = os.path.join(ROOT, "gpurun_out", "lmpmc")
+base = os.path.join(ROOT, "gpurun_out", "pmc_" + (sys.argv[1] if len(sys.argv) > 1 else "lm"))
 dur = {}
 for f in glob.glob(os.path.join(base, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(base, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-want = sys.argv[1:] or [k for k in dur if k.startswith(("k_lm", "k_lba", "void k_lm"))]
+want = [k for k in dur if not sys.argv[2:] or k.replace("void ", "").startswith(tuple(sys.argv[2:]))]
 for k in want:
     if k not in acc:
         continue
