@@ -436,6 +436,39 @@ static __global__ __launch_bounds__(256) void k_border_pyramid(BorderParams P) {
     }
 }
 
+// Longest work first.  k_fast and k_octree run one workgroup per (frame, tile) / (frame, level) and the hardware hands workgroups out in grid order:
+// a frame that costs ten times the others (every pixel a corner; a realistic mix has such frames next to flat ones) and sits at the END of the batch
+// leaves its long workgroups running alone after everything else has finished — on the mixed batch of bench.py that tail was a third of k_fast's
+// time and two thirds of k_octree's.  The handle's previous call left its FAST candidate counts per (frame, level) in candCount: frames are served
+// in descending order of that count (rank sort in LDS, ties by index: a permutation whatever the counts hold — stale or uninitialised counts only
+// cost the ordering its benefit).  A camera slot of a rig or a video stream keeps its character from call to call, which is all this relies on; the
+// key points never depend on it.  The same workgroup then clears the counters for the call that follows (it replaces that call's memset launch).
+#define ORDER_T 1024
+#define ORDER_MAX_BATCH 4096
+static __global__ __launch_bounds__(ORDER_T) void k_frame_order(int* candCount, int nlevels, int batch, int* order, uint32_t* hostMax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    uint32_t* keys = (uint32_t*)orb_smem;   // [batch], then one word: the largest count of any (frame, level)
+    const int tid = threadIdx.x;
+    if (tid == 0) keys[batch] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int b = tid; b < batch; b += ORDER_T) {
+        uint32_t s = 0;
+        for (int l = 0; l < nlevels; l++) { const uint32_t c = (uint32_t)candCount[(size_t)b * nlevels + l]; s += c; mx = max(mx, c); }
+        keys[b] = s;
+    }
+    if (mx) atomicMax(&keys[batch], mx);
+    __syncthreads();
+    if (tid == 0) *hostMax = keys[batch];   // pinned host word: the NEXT call's launch plan reads it (is a 1 024-thread octree pass worth launching?)
+    for (int b = tid; b < batch; b += ORDER_T) {
+        const uint32_t k = keys[b];
+        int r = 0;
+        for (int j = 0; j < batch; j++) { const uint32_t kj = keys[j]; r += (kj > k || (kj == k && j < b)) ? 1 : 0; }
+        order[r] = b;
+    }
+    for (int i = tid; i < batch * nlevels; i += ORDER_T) candCount[i] = 0;   // (every key was formed before the barrier above)
+}
+
 // ============================================================================================================
 // E2  FAST-9/16 + per-cell NMS + per-cell minThFAST retry
 // ============================================================================================================
@@ -456,6 +489,7 @@ struct FastParams {
     int imgBytes;                       // LDS bytes reserved for the image tile (== score-map bytes)
     int nTiles, batch;                  // tiles per frame, frames: the XCD-aware 1-D grid
     uint32_t* retry;                    // [0] tiles listed, then {tile | frame << 16, mask of its cells to detect again: bit 16 * cell row + cell}
+    const int* order;                   // frame of grid row y (k_frame_order: heaviest frames of the handle's previous call first), or nullptr = y
 };
 
 #define RING16(F)                                                                                         \
@@ -716,7 +750,7 @@ static __device__ __forceinline__ void fast_tile(const FastParams& P, const int 
     // tiles have one) lists itself with their mask; a tile whose corner list overflows lists all of its cells and emits nothing.  Pass 1 (the same grid,
     // launched behind pass 0) takes a listed tile at min(ini, min) exactly as the one-pass form (pass 2) does — as a one-cell tile if one cell is
     // asked for — and reports the listed cells only.
-    int tileIdx = blockIdx.x, frame = blockIdx.y;
+    int tileIdx = blockIdx.x, frame = P.order ? P.order[blockIdx.y] : (int)blockIdx.y;
     FastTile T;
     uint32_t emitMask = 0xFFFFFFFFu;   // cells (bit 16 * cell row + cell) this workgroup reports
     if (PASS == 1) {
@@ -1142,6 +1176,9 @@ struct OctParams {
     int merge;                         // 1: second child-count buffer present (key move counts the next round's children)
     int keyCap, keyOff;                // LDS key cache: capacity (keys) and byte offset inside the dynamic LDS block
     int lap0, lap1;
+    const int* order;                  // as FastParams::order
+    int gridLevels;                    // levels this launch's grid covers (0 .. gridLevels - 1; nlevels, or the levels that can hold a heavy problem)
+    int heavyMode, heavyMin;           // 0: every problem; 2: problems of fewer than heavyMin candidates (a second launch, mode 1, takes the others with OCT_T_HEAVY threads)
 };
 
 // In-place exclusive scan of a[0..n) (LDS) by the whole OCT_T-thread block; returns the total.  Thread-serial chunks, one
@@ -1152,6 +1189,12 @@ struct OctParams {
 #ifndef OCT_T_BATCH
 #define OCT_T_BATCH 256
 #endif
+#ifndef OCT_HEAVY_MIN
+#define OCT_HEAVY_MIN 8192   // candidates of one (frame, level) from which a batch's problem goes to the OCT_T_HEAVY-thread launch (tests build with a small value)
+#endif
+#ifndef OCT_HEAVY_PASS
+#define OCT_HEAVY_PASS 1
+#endif
 #ifndef OCT_T_SINGLE
 #ifdef HIP_EMULATED
 #define OCT_T_SINGLE 256    // (the CPU tier's emulator pays per work-item and barrier: one variant test builds the 1 024-thread instantiation)
@@ -1159,6 +1202,7 @@ struct OctParams {
 #define OCT_T_SINGLE 1024
 #endif
 #endif
+#define OCT_T_HEAVY OCT_T_SINGLE   // threads of the heavy-problem launch of a batch: the single-frame shape
 template <int OCT_T>
 static __device__ int block_scan_excl(int* a, int n, int* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1601,15 +1645,17 @@ static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
     // and 8 levels would give every XCD ONE level (XCD 0 all the level-0 problems, 4x the work of level 7); the alternative build rotates the
     // level by the frame index for an even mix.
 #if OCT_LEVEL_MAJOR
-    const int nframes = gridDim.x / P.nlevels;
-    const int level = blockIdx.x / nframes, frame = blockIdx.x - level * nframes;
+    const int nframes = gridDim.x / P.gridLevels;
+    const int level = blockIdx.x / nframes, slot = blockIdx.x - level * nframes;
 #else
-    const int frame = blockIdx.x / P.nlevels;
-    const int level = (blockIdx.x - frame * P.nlevels + frame) % P.nlevels;
+    const int slot = blockIdx.x / P.gridLevels;
+    const int level = (blockIdx.x - slot * P.gridLevels + slot) % P.gridLevels;
 #endif
+    const int frame = P.order ? P.order[slot] : slot;
     const OctLevel& L = P.lv[level];
     int nk = P.candCount[(size_t)frame * P.nlevels + level];
     nk = min(nk, L.candCap);
+    if (P.heavyMode == 1 ? nk < P.heavyMin : (P.heavyMode == 2 && nk >= P.heavyMin)) return;   // the other launch's problem
     const uint32_t* gkeys = P.cand + (size_t)frame * P.candFrame + L.candOff;
     if (nk == 0) {
         if (tid == 0) { P.selCount[(size_t)frame * P.nlevels + level] = 0; P.lapCount[(size_t)frame * P.nlevels + level] = 0; }
@@ -2599,9 +2645,10 @@ struct orbx_extractor {
     size_t tileTabOff[ORBX_MAX_LEVELS] = {0};                        // k_resize2 staging footprints of every level >= 1 (inside d_coef)
     uint8_t* d_pyr = nullptr; uint32_t* d_cand = nullptr; int* d_candCount = nullptr; uint16_t* d_keyNode = nullptr;
     uint32_t *d_sel = nullptr, *d_selAux = nullptr; int *d_selCount = nullptr, *d_lapCount = nullptr;
-    FastTile* d_tiles = nullptr; uint32_t* d_retry = nullptr;
-    uint32_t* h_retry = nullptr;   // pinned: [0] tiles the last two-pass FAST call listed for its second pass (copied back asynchronously), [1] tiles of that call
-    uint32_t fastCalls = 0; int fastLastTwoPass = 0;
+    FastTile* d_tiles = nullptr; uint32_t* d_retry = nullptr; int* d_order = nullptr;
+    uint32_t* h_retry = nullptr;   // pinned: [0] tiles the last two-pass FAST call listed for its second pass (copied back asynchronously), [1] tiles of that call,
+                                   // [2] the largest FAST candidate count of any (frame, level) of the call before last (k_frame_order writes it)
+    uint32_t fastCalls = 0; int fastLastTwoPass = 0, lastOrdered = 0, lastHeavy = 0;
     // single-image staging
     uint8_t* d_img = nullptr; int imgStride = 0; orb_keypoint* d_kps1 = nullptr; uint8_t* d_desc1 = nullptr; int32_t* d_counts1 = nullptr;
     // single-frame host call: the three outputs share ONE device block ([counts | keypoints | descriptors]; the pointers above point into it) so that
@@ -2654,7 +2701,7 @@ static void orbx_free(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* bufs[] = {h->d_chain, h->d_rowStart, h->d_rowIdx, h->d_coef, h->d_pyr, h->d_cand, h->d_candCount, h->d_keyNode, h->d_sel, h->d_selAux, h->d_selCount,
-                    h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1, h->d_bpyr, h->d_stereo1};
+                    h->d_lapCount, h->d_tiles, h->d_retry, h->d_img, h->d_out1, h->d_bpyr, h->d_stereo1, h->d_order};
     for (void* p : bufs) if (p) (void)hipFree(p);
     if (h->h_bpyr) (void)hipHostFree(h->h_bpyr);
     if (h->h_stereo1) (void)hipHostFree(h->h_stereo1);
@@ -2863,6 +2910,8 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_cand, B * h->candFrame * 4));
     CK(hipMalloc((void**)&h->d_keyNode, B * h->candFrame * 2));
     CK(hipMalloc((void**)&h->d_candCount, B * nl * 4));
+    CK(hipMemset(h->d_candCount, 0, B * nl * 4));
+    CK(hipMalloc((void**)&h->d_order, B * 4));
     CK(hipMalloc((void**)&h->d_retry, ((size_t)B * tiles.size() * 2 + 2) * 4));   // k_fast's retry list: count, then two words per (frame, two-row tile) at most
     CK(hipMalloc((void**)&h->d_sel, B * h->selFrame * 4));
     CK(hipMalloc((void**)&h->d_selAux, B * h->selFrame * 4));
@@ -2882,8 +2931,8 @@ extern "C" int orbx_create(const orbx_config* cfg, int width, int height, int ma
     CK(hipMalloc((void**)&h->d_out1, h->out1Bytes));
     h->d_counts1 = (int32_t*)h->d_out1; h->d_kps1 = (orb_keypoint*)(h->d_out1 + h->kps1Off); h->d_desc1 = h->d_out1 + h->desc1Off;
     CK(hipHostMalloc((void**)&h->h_img, (size_t)h->imgStride * height, hipHostMallocDefault));
-    CK(hipHostMalloc((void**)&h->h_retry, 8, hipHostMallocDefault));
-    h->h_retry[0] = 0; h->h_retry[1] = 1;
+    CK(hipHostMalloc((void**)&h->h_retry, 16, hipHostMallocDefault));
+    h->h_retry[0] = 0; h->h_retry[1] = 1; h->h_retry[2] = 0; h->h_retry[3] = 0;
     CK(hipHostMalloc((void**)&h->h_out, h->out1Bytes, hipHostMallocDefault));
     {
         // c_umax / c_patternf / c_icmask do not depend on the configuration (HALF_PATCH_SIZE = 15, the 256 test pairs): uploaded by the FIRST handle of a
@@ -2951,7 +3000,13 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
     h->lastStream = st; h->lastSingle = h->hostCall; h->hostPyrValid = false;
     if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[0], st));
-    HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
+#ifndef ORBX_FRAME_ORDER
+#define ORBX_FRAME_ORDER 1   // 0: frames in batch order (experiments)
+#endif
+    // frames in descending order of the previous call's candidate counts (k_frame_order; it also clears the counters) — batches only
+    const bool ordered = ORBX_FRAME_ORDER && batch >= 2 && batch <= ORDER_MAX_BATCH && !h->capturing;
+    if (ordered) hipLaunchKernelGGL(k_frame_order, dim3(1), dim3(ORDER_T), (size_t)batch * 4 + 4, st, h->d_candCount, nl, batch, h->d_order, h->h_retry + 2);
+    else HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     // E1 pyramid
 #ifndef ORBX_EXP_DUP
 #define ORBX_EXP_DUP 0   // experiment only (tools/exp.py build): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
@@ -3025,7 +3080,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         F.tiles = tall ? h->d_tiles : h->d_tiles + h->nTiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
         F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
         F.imgBytes = h->fastImgBytes;
-        F.nTiles = nTiles; F.batch = batch; F.retry = h->d_retry;
+        F.nTiles = nTiles; F.batch = batch; F.retry = h->d_retry; F.order = ordered ? h->d_order : nullptr;
 #if FAST_XCD
         hipLaunchKernelGGL((k_fast<2>), dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
@@ -3082,6 +3137,21 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         O.sel = h->d_sel; O.selAux = h->d_selAux; O.selFrame = h->selFrame; O.selCount = h->d_selCount; O.lapCount = h->d_lapCount;
         const bool cache = batch <= OCT_CACHE_MAX_BATCH && h->octSmem > (size_t)h->octKeyOff;
         O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
+        O.order = ordered ? h->d_order : nullptr;
+        O.gridLevels = nl; O.heavyMode = 0; O.heavyMin = OCT_HEAVY_MIN;
+        // A problem of tens of thousands of candidates (every pixel a corner) runs ~3x longer than the whole launch of ordinary ones on 256 threads
+        // and no ordering shortens ONE workgroup: when the call before last had such a problem (k_frame_order's word; a stale word only picks the
+        // other of two correct plans) they get a launch of their own with OCT_T_HEAVY threads, over the levels that can hold one.
+        int heavyLevels = 0;
+        while (heavyLevels < nl && h->lv[heavyLevels].candCap >= OCT_HEAVY_MIN) heavyLevels++;
+        const bool heavy = OCT_HEAVY_PASS && ordered && heavyLevels > 0 && ((const volatile uint32_t*)h->h_retry)[2] >= (uint32_t)OCT_HEAVY_MIN;
+        h->lastOrdered = ordered ? 1 : 0; h->lastHeavy = heavy ? 1 : 0;
+        if (heavy) {
+            OctParams Oh = O;
+            Oh.heavyMode = 1; Oh.gridLevels = heavyLevels;
+            hipLaunchKernelGGL(k_octree<OCT_T_HEAVY>, dim3(heavyLevels * batch), dim3(OCT_T_HEAVY), (size_t)h->octKeyOff, st, Oh);   // (first: the long ones)
+            O.heavyMode = 2;
+        }
         for (int rep = 0; rep < ((ORBX_EXP_DUP & 2) ? 2 : 1); rep++)
             if (batch == 1) hipLaunchKernelGGL(k_octree<OCT_T_SINGLE>, dim3(nl * batch), dim3(OCT_T_SINGLE), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
             else hipLaunchKernelGGL(k_octree<OCT_T_BATCH>, dim3(nl * batch), dim3(OCT_T_BATCH), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
@@ -3383,6 +3453,13 @@ extern "C" int orbx_last_fast_passes(orbx_handle h, int* two_pass, uint32_t* lis
     if (two_pass) *two_pass = h->fastLastTwoPass;
     if (listed) *listed = hr[0];
     if (tiles) *tiles = hr[1];
+    return ORB_OK;
+}
+
+extern "C" int orbx_last_schedule(orbx_handle h, int* frames_ordered, int* heavy_octree_pass) {
+    if (!h) return ORB_E_INVALID;
+    if (frames_ordered) *frames_ordered = h->lastOrdered;
+    if (heavy_octree_pass) *heavy_octree_pass = h->lastHeavy;
     return ORB_OK;
 }
 

@@ -391,7 +391,12 @@ class StepPipeline:
         S = self._stream_state
         assert S is not None and self.streams >= 3 and all(s_["frames_host"] is not None for s_ in self.sets)
         ns = len(self.sets)
-        self._hf = dict(sH=torch.cuda.Stream(self.dev), sD=torch.cuda.Stream(self.dev), pin=[torch.from_numpy(s_["frames_host"]).pin_memory() for s_ in self.sets],
+        # The copy streams are HIGH-PRIORITY streams: HIP multiplexes its streams onto a few hardware queues (4 per priority by default) and hands them
+        # out round robin — as plain streams the H2D stream landed on the queue of an extraction stream and every second copy waited for a whole
+        # extraction (4.1 instead of 3.4 ms per step, profiles/r06_host_fed_queues.txt); raising GPU_MAX_HW_QUEUES instead un-shares the two extraction
+        # streams as well, which costs the resident step 12 % (1.51 -> 1.72 ms).  Queues of another priority are never shared with the kernels' streams.
+        prio = int(os.environ.get("ORBHIP_COPY_STREAM_PRIORITY", "-1"))
+        self._hf = dict(sH=torch.cuda.Stream(self.dev, priority=prio), sD=torch.cuda.Stream(self.dev, priority=prio), pin=[torch.from_numpy(s_["frames_host"]).pin_memory() for s_ in self.sets],
                         evH=[torch.cuda.Event() for _ in range(ns)], evX=[torch.cuda.Event() for _ in range(ns)], evX_set=[False] * ns,
                         evD=[torch.cuda.Event() for _ in range(S["nbuf"])], evD_set=[False] * S["nbuf"], host_out=[None] * S["nbuf"], last=None, prev_k=None)
         torch.cuda.synchronize()
@@ -678,10 +683,6 @@ def main():
     global W, H, NFEAT
     W, H = [int(v) for v in args.size.lower().split("x")]
     NFEAT = args.nfeatures
-    # HIP multiplexes its streams onto 4 hardware queues by default.  The step uses more (two extraction streams, the match stream, the two copy streams
-    # of the host-fed leg, the handles' own): with 4, the H2D stream of the host-fed leg shared a queue with an extraction stream and every second copy
-    # waited for a whole extraction (3.4 -> 4.1 ms per step, profiles/r06_host_fed_queues.txt).  Read by the runtime when it initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     ndev = None
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1 and not args.launch_check:

@@ -130,6 +130,12 @@ int orbx_last_timing(orbx_handle h, float* ms5);
  * A HIP graph captured from a batch call keeps the pass form it was captured with (the copy-back is not part of a capture).  Any pointer may be NULL. */
 int orbx_last_fast_passes(orbx_handle h, int* two_pass, uint32_t* listed, uint32_t* tiles);
 
+/* Two more scheduling decisions of the last batch call (never the result): frames_ordered = the (frame, tile) / (frame, level) workgroups were handed
+ * out heaviest frame first, by the FAST candidate counts the handle's previous call left (a frame that costs ten times the others no longer ends the
+ * launch alone); heavy_octree_pass = (frame, level) problems of 8 192 candidates or more were taken by a second k_octree launch with four times the
+ * threads (chosen when the call before last had such a problem).  Any pointer may be NULL. */
+int orbx_last_schedule(orbx_handle h, int* frames_ordered, int* heavy_octree_pass);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Stage 2 — ORBmatcher  (reference include/ORBmatcher.h:39-94, src/ORBmatcher.cc) + the Frame grid helpers it
  * depends on (src/Frame.cc:444-478, 755-862).  The reference functions walk pointer graphs (Frame&, KeyFrame*,

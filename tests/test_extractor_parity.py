@@ -309,3 +309,42 @@ def test_hip_full_size_batch_properties(hip_lib):
     for b in (0, 17, 63):
         mono, k, d = o.extract(imgs[b], 0, 0)
         assert np.array_equal(kps[b, :len(k)].view(np.uint8).reshape(-1), k.view(np.uint8).reshape(-1)) and np.array_equal(desc[b, :len(k)], d)
+
+
+def test_emulated_batch_frame_order_and_heavy_octree_pass():
+    """Batches hand their workgroups out heaviest frame first (k_frame_order: the previous call's FAST candidate counts; it also clears the
+    counters) and give (frame, level) problems above OCT_HEAVY_MIN candidates to a second k_octree launch.  OCT_HEAVY_MIN=300 makes ordinary
+    levels "heavy" on small images.  Four frames of very different density (noise, flat, textured, sparse), three calls on one handle: the first
+    runs on cleared counters (identity order), the second ordered, the third also with the heavy launch — every frame of every call equals the
+    oracle's single-frame result, and a different batch afterwards (stale order and counts) does too."""
+    import ctypes as C
+    import build_emu
+    from orbhip import _lib
+    lib = _lib.bind(C.CDLL(build_emu.build(defines=("OCT_HEAVY_MIN=300",), tag="octheavy300")))
+    lib.orbx_last_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    W, H, nf = 240, 200, 300
+    rng = np.random.default_rng(9)
+    frames = np.stack([rng.integers(0, 256, (H, W), dtype=np.uint8), flat_image(W, H, 90), synth_image(61, W, H, n_rect=60, n_disc=30),
+                       synth_image(62, W, H, n_rect=6, n_disc=3)])
+    e = orbhip.ORBextractor(nf, 1.2, 5, 20, 7, lib=lib)
+    h = e._handle(W, H, max_batch=4)
+    cap = lib.orbx_max_keypoints(h)
+    o = O.OrbOracle(nf, 1.2, 5, 20, 7)
+
+    def run(fr):
+        B = len(fr)
+        kps = np.zeros((B, cap), O.KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); cnt = np.zeros((B, 2), np.int32)
+        rc = lib.orbx_extract_batch_dev(h, _lib.ptr(fr), B, W * H, W, 0, 1000, _lib.ptr(kps), _lib.ptr(desc), cap, _lib.ptr(cnt), None)
+        assert rc == 0
+        for b in range(B):
+            mono, k, d = o.extract(fr[b], 0, 1000)
+            n = cnt[b, 0]
+            assert n == len(k) and cnt[b, 1] == mono, (b, n, len(k))
+            assert np.array_equal(kps[b, :n].view(np.uint8), k.view(np.uint8)) and np.array_equal(desc[b, :n], d), b
+        a, b_ = C.c_int(-1), C.c_int(-1)
+        assert lib.orbx_last_schedule(h, C.byref(a), C.byref(b_)) == 0
+        return a.value, b_.value
+    plans = [run(frames) for _ in range(3)]
+    assert plans[0] == (1, 0) and plans[1][0] == 1 and plans[2] == (1, 1), plans
+    assert run(np.ascontiguousarray(frames[::-1][:3])) [0] == 1          # another batch size and content on stale counts
+    assert run(frames)[0] == 1                                           # (whether the heavy launch runs here depends on when the host read the word)

@@ -162,6 +162,30 @@ def cmd_mixed(argv):
     print("OK" if bad == 0 else "FAIL")
 
 
+def cmd_kinds(argv):
+    """Per-kernel times of a batch made of ONE scene kind each (what a frame of that kind costs), and of the mixed batch."""
+    import numpy as np
+    import torch
+    import bench
+    import orbhip
+    B = int(argv[0]) if argv else 256
+    sets = {}
+    for kind in ("textured", "sparse", "low_contrast", "flat", "noise"):
+        base = bench.synth_many([(kind, 900 + i, 752, 480) for i in range(16)], 16)
+        sets[kind] = bench._pair_up(base, B, np.random.default_rng(5))
+    sets["mixed"] = bench.make_mixed_batch(B, seed0=7000, workers=16)[0]
+    ex = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_batch=B)
+    for kind, fr in sets.items():
+        d = torch.from_numpy(fr).cuda()
+        out = None
+        for _ in range(3):
+            out = ex.extract_batch(d, (0, 1000), out=out)
+        torch.cuda.synchronize()
+        t = ex.last_timing()
+        print("%-13s %s  passes %s  mean kp %.0f" % (kind, {k: round(v * 1e3 / B, 3) for k, v in t.items()}, ex.last_fast_passes(), float(out[2][:, 0].float().mean())), flush=True)
+    print("(us per frame)")
+
+
 def cmd_phases(argv):
     import ctypes as C
     import numpy as np
