@@ -844,7 +844,7 @@ def main():
         # the same step fed from host memory: B frames per step pinned on the host -> H2D on a copy stream under the previous step's kernels -> the
         # step -> every result back to pinned host memory on a second copy stream.  PCIe-bound by construction (B x W x H bytes in per step)
         P.start_host_fed()
-        for _ in range(max(10, args.warmup)):      # (the first steps also fault in the pinned result buffers)
+        for _ in range(max(40, args.warmup)):      # (the first ~30 steps run at half speed: pinned result buffers are faulted in, the copy queues warm up)
             P.host_fed_step()
         dth = float(np.median(rank_max(timed(P.host_fed_step, args.steps, max(1, min(args.repeats, 3))))))
         h2d_b, d2h_b = P.host_fed_bytes()

@@ -128,7 +128,7 @@ def cmd_host_fed(argv):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         print("%-28s %.3f ms per step  %.0f frames/s" % (label, dt * 1e3, B / dt), flush=True)
-    run("full"); run("no d2h", skip_d2h=True); run("no kernels", skip_kernels=True); run("no kernels, no d2h", skip_kernels=True, skip_d2h=True); run("full again")
+    run("full", steps=10); run("full", steps=10); run("full", steps=20); run("full"); run("no d2h", skip_d2h=True); run("no kernels", skip_kernels=True); run("no kernels, no d2h", skip_kernels=True, skip_d2h=True); run("full again")
     print("h2d alone %.3f ms, d2h alone %.3f ms" % (P.host_fed_copy_only(20, "h2d") / 20 * 1e3, P.host_fed_copy_only(20, "d2h") / 20 * 1e3))
     for _ in range(20):
         P.step()
