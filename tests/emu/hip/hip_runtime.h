@@ -46,6 +46,7 @@ struct uchar4 { unsigned char x, y, z, w; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
+static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
