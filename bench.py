@@ -1207,15 +1207,29 @@ def main():
         sweep = {}
         for SB in (2, 8, 16, 64, 4096):
             dfs = grow_batch_on_device(torch.cat(d_sets) if SB > B else d_frames, SB)      # 4096 = the resident sets' distinct frames, then rolled copies
-            Ps = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=args.streams)
-            Ps.kernel_times(warm=1)
-            Ps.start_streams()
             st = max(3, args.steps // 4) if SB > B else args.steps
-            for _ in range(2):
-                Ps.step()
-            ds = rank_max(timed(Ps.step, st, 3))
+            # A call of few frames leaves most of the machine idle between its ~14 dependent launches: calls of up to 128 frames are pipelined over
+            # more extractor handles / streams (the step is the same; 3 is the headline's count) — every count tried is reported, the best one is the entry
+            by_streams, best = {}, None
+            for nst in ((args.streams,) if SB > 128 else tuple(sorted({args.streams, 4, 5, 6}))):
+                Pt = StepPipeline(dfs, W, H, NFEAT, local_rank, streams=nst)
+                Pt.kernel_times(warm=1)
+                Pt.start_streams()
+                for _ in range(4):
+                    Pt.step()
+                dt_ = rank_max(timed(Pt.step, st, 3))
+                by_streams[str(nst)] = round(world * SB * st / float(np.median(dt_)), 1)
+                if best is None or float(np.median(dt_)) < float(np.median(best[1])):
+                    if best is not None:
+                        del best
+                    best = (Pt, dt_, nst)
+                else:
+                    del Pt
+                torch.cuda.empty_cache()
+            Ps, ds, nst_best = best
             ent = {"frames_per_s": round(world * SB * st / float(np.median(ds)), 1), "ms_per_step": round(float(np.median(ds)) / st * 1e3, 4), "steps": st,
                    "frames_per_s_min": round(world * SB * st / max(ds), 1), "frames_per_s_max": round(world * SB * st / min(ds), 1),
+                   "hip_streams": nst_best, "frames_per_s_by_hip_streams": by_streams,
                    "input_bytes": int(SB) * W * H, "fast_passes": Ps.ex.last_fast_passes()}
             if not args.no_parity_check:
                 sels = np.unique(np.linspace(0, SB - 1, min(SB, 32)).astype(np.int64))
@@ -1236,7 +1250,7 @@ def main():
                     ent["graph_replay"] = {"error": Pg._graph_error}
                 del Pg
             sweep[str(SB)] = ent
-            del Ps, dfs
+            del Ps, dfs, best
             torch.cuda.empty_cache()
         sweep[str(B)] = {"frames_per_s": round(world * B * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps,
                          "input_bytes": int(B) * W * H, "note": "the headline"}
