@@ -63,8 +63,8 @@ static __constant__ uint32_t c_icmask[16][12];   // [|v|][dword k of the patch r
 // its own L2: up to 8x the fill traffic, and these kernels' load phases run at several TB/s.  Instead the grid is 1-D and XCD x takes the
 // frames f with f % 8 == x, walking a frame's units in order: a frame's pyramid is fetched once and stays L2-resident while it is worked on.
 // grid = units_per_frame * 8 * ceil(batch / 8); returns false for the padding workgroups of a batch that is not a multiple of 8.
-static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, const int batch, int* frame, int* unit) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, const int batch, int* frame, int* unit, const int lead = 0) {   // lead: workgroups in front of the mapped ones, a multiple of 8
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x - lead) >> 3;
     const int fr = (slot / unitsPerFrame) * 8 + xcd;
     *frame = fr;
     *unit = slot - (slot / unitsPerFrame) * unitsPerFrame;
@@ -78,6 +78,8 @@ struct ResizeParams {
     const int* coef;           // k_resize2: per-level tables xs[dw] | xw[dw] | ys[dh] | yw[dh] (resize_coef of every column / row)
     const int* tileTab;        // k_resize2: per-level staging footprints {xal, ndw} x tilesX | {ylo, nrows} x tilesY (resize2_footprint, built at orbx_create)
     int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
+    // the call's bookkeeping, carried by ONE extra workgroup at the front of the level-1 launch (frame_order_body; null: none)
+    int* ordCand; int* ordOut; uint32_t* ordHostMax; uint32_t* ordRetry; int ordLevels; uint32_t ordTiles;
 };
 
 // cv::resize coefficient of one destination coordinate, computed in-kernel with the same IEEE
@@ -273,6 +275,8 @@ static inline void resize2_footprint(int t0, int tlen, int dlen, int slen, doubl
     if (alignX) { lo = a & ~3; ext = ((e - lo) >> 2) + 1; }   // dwords
     else { lo = a; ext = e - a + 1; }                          // rows
 }
+static __device__ __forceinline__ void frame_order_body(unsigned char* smem, int* candCount, const int nlevels, const int batch, int* order, uint32_t* hostMax,
+                                                        uint32_t* retry, const uint32_t retryTiles);   // (below, with k_frame_order)
 #ifndef R2_PAIR
 #define R2_PAIR 2         // vertically adjacent destination tiles per workgroup (2: the second tile's staging loads are in flight during the first tile's H pass)
 #endif
@@ -288,8 +292,14 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     constexpr int NP = R2_PAIR;
     const int unitsY = (P.tilesY + NP - 1) / NP;
 #if R2_XCD
+    // the launch's FIRST workgroup (it runs ~50 us on 256 threads: dispatched last it was the launch's tail): frame order + counters of the call, no
+    // tile of its own; seven idle ones behind it keep every tile on the XCD its frame number names
+    if (P.ordCand && blockIdx.x < 8) {
+        if (blockIdx.x == 0) frame_order_body(orb_smem, P.ordCand, P.ordLevels, P.batch, P.ordOut, P.ordHostMax, P.ordRetry, P.ordTiles);
+        return;
+    }
     int frameZ, tileI;
-    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI)) return;
+    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI, P.ordCand ? 8 : 0)) return;
     const int uyI = tileI / P.tilesX, txI = tileI - uyI * P.tilesX;
 #else
     const int frameZ = blockIdx.z;
@@ -445,14 +455,15 @@ static __global__ __launch_bounds__(256) void k_border_pyramid(BorderParams P) {
 // key points never depend on it.  The same workgroup then clears the counters for the call that follows (it replaces that call's memset launch).
 #define ORDER_T 1024
 #define ORDER_MAX_BATCH 4096
-static __global__ __launch_bounds__(ORDER_T) void k_frame_order(int* candCount, int nlevels, int batch, int* order, uint32_t* hostMax) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
-    uint32_t* keys = (uint32_t*)orb_smem;   // [batch], then one word: the largest count of any (frame, level)
-    const int tid = threadIdx.x;
-    if (tid == 0) keys[batch] = 0;
+// (any workgroup size; LDS: batch + 1 words.)  retry != null: the FAST second-pass list of the call that follows starts empty — [0] = 0, [1] = its tile count
+static __device__ __forceinline__ void frame_order_body(unsigned char* smem, int* candCount, const int nlevels, const int batch, int* order, uint32_t* hostMax,
+                                                        uint32_t* retry, const uint32_t retryTiles) {
+    uint32_t* keys = (uint32_t*)smem;   // [batch], then one word: the largest count of any (frame, level)
+    const int tid = threadIdx.x, NT = blockDim.x;
+    if (tid == 0) { keys[batch] = 0; if (retry) { retry[0] = 0; retry[1] = retryTiles; } }
     __syncthreads();
     uint32_t mx = 0;
-    for (int b = tid; b < batch; b += ORDER_T) {
+    for (int b = tid; b < batch; b += NT) {
         uint32_t s = 0;
         for (int l = 0; l < nlevels; l++) { const uint32_t c = (uint32_t)candCount[(size_t)b * nlevels + l]; s += c; mx = max(mx, c); }
         keys[b] = s;
@@ -460,13 +471,19 @@ static __global__ __launch_bounds__(ORDER_T) void k_frame_order(int* candCount, 
     if (mx) atomicMax(&keys[batch], mx);
     __syncthreads();
     if (tid == 0) *hostMax = keys[batch];   // pinned host word: the NEXT call's launch plan reads it (is a 1 024-thread octree pass worth launching?)
-    for (int b = tid; b < batch; b += ORDER_T) {
+    for (int b = tid; b < batch; b += NT) {
         const uint32_t k = keys[b];
         int r = 0;
         for (int j = 0; j < batch; j++) { const uint32_t kj = keys[j]; r += (kj > k || (kj == k && j < b)) ? 1 : 0; }
         order[r] = b;
     }
-    for (int i = tid; i < batch * nlevels; i += ORDER_T) candCount[i] = 0;   // (every key was formed before the barrier above)
+    for (int i = tid; i < batch * nlevels; i += NT) candCount[i] = 0;   // (every key was formed before the barrier above)
+}
+// A launch of its own only where the pyramid's first level does not take the separable kernel (scale factors above 1.3): otherwise the job rides as one
+// extra workgroup of the level-1 k_resize2 launch — a dependent 19-us launch, two memset launches and (k_octree) an 8-byte copy launch less per call
+static __global__ __launch_bounds__(ORDER_T) void k_frame_order(int* candCount, int nlevels, int batch, int* order, uint32_t* hostMax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
+    frame_order_body(orb_smem, candCount, nlevels, batch, order, hostMax, nullptr, 0u);
 }
 
 // ============================================================================================================
@@ -1179,6 +1196,7 @@ struct OctParams {
     const int* order;                  // as FastParams::order
     int gridLevels;                    // levels this launch's grid covers (0 .. gridLevels - 1; nlevels, or the levels that can hold a heavy problem)
     int heavyMode, heavyMin;           // 0: every problem; 2: problems of fewer than heavyMin candidates (a second launch, mode 1, takes the others with OCT_T_HEAVY threads)
+    const uint32_t* retry; uint32_t* retryHost;   // non-null: the FAST second-pass list's {count, tiles} of this call -> the pinned host words (in place of a copy launch)
 };
 
 // In-place exclusive scan of a[0..n) (LDS) by the whole OCT_T-thread block; returns the total.  Thread-serial chunks, one
@@ -1651,6 +1669,7 @@ static __global__ __launch_bounds__(OCT_T) void k_octree(OctParams P) {
     const int slot = blockIdx.x / P.gridLevels;
     const int level = (blockIdx.x - slot * P.gridLevels + slot) % P.gridLevels;
 #endif
+    if (P.retryHost && blockIdx.x == 0 && tid == 0) *(unsigned long long*)P.retryHost = *(const unsigned long long*)P.retry;   // (both words in one store: a pair of one call)
     const int frame = P.order ? P.order[slot] : slot;
     const OctLevel& L = P.lv[level];
     int nk = P.candCount[(size_t)frame * P.nlevels + level];
@@ -3003,18 +3022,45 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #ifndef ORBX_FRAME_ORDER
 #define ORBX_FRAME_ORDER 1   // 0: frames in batch order (experiments)
 #endif
-    // frames in descending order of the previous call's candidate counts (k_frame_order; it also clears the counters) — batches only
-    const bool ordered = ORBX_FRAME_ORDER && batch >= 2 && batch <= ORDER_MAX_BATCH && !h->capturing;
-    if (ordered) hipLaunchKernelGGL(k_frame_order, dim3(1), dim3(ORDER_T), (size_t)batch * 4 + 4, st, h->d_candCount, nl, batch, h->d_order, h->h_retry + 2);
-    else HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
-    // E1 pyramid
-#ifndef ORBX_EXP_DUP
-#define ORBX_EXP_DUP 0   // experiment only (tools/exp.py build): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
-#endif                   // three-stream step (every one of them is idempotent) next to its standalone time
 #ifndef PYR_CHAIN_MAX_BATCH
 #define PYR_CHAIN_MAX_BATCH 1   // calls of up to this many frames build the pyramid in ONE launch (k_pyramid_chain): the single-frame entry point
 #endif
+#ifndef ORBX_EXP_DUP
+#define ORBX_EXP_DUP 0   // experiment only (tools/exp.py build): launch a stage twice — 1 pyramid, 2 octree, 4 describe — to read its MARGINAL cost in the
+#endif                   // three-stream step (every one of them is idempotent) next to its standalone time
+    // frames in descending order of the previous call's candidate counts (k_frame_order; it also clears the counters) — batches only
+    const bool ordered = ORBX_FRAME_ORDER && batch >= 2 && batch <= ORDER_MAX_BATCH && !h->capturing;
+    // the FAST plan of this call (the pyramid's first launch carries its bookkeeping, see below)
+    const bool tall = batch >= FAST_TALL_MIN_BATCH;
+    const int nTiles = tall ? h->nTiles : h->nTiles1;
+    const int iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255), minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
+    // Two passes for batches of FAST_TWO_PASS_MIN_BATCH frames or more (two dependent launches cost a small batch more than the first pass saves:
+    // k_fast 0.036 vs 0.030 ms at 8 frames, 0.046 vs 0.042 at 16, 0.065 vs 0.063 at 32, 0.102 vs 0.105 at 64, 0.171 vs 0.184 at 128) — while they pay.  Both forms give the same key points; which is faster depends on the frames: the first pass saves the corners between the two
+    // thresholds, every listed tile pays staging and pre-test a second time.  On the benchmark's frames 13 % of the tiles are listed (k_fast
+    // 0.70 -> 0.63 ms per 512 frames), on sparsely textured ones (the same synthetic scene at 1280x720) most are (0.78 -> 0.90 ms).  The listed
+    // share of the handle's previous two-pass call (written back by that call's k_octree, read here without waiting: a stale figure only delays the
+    // switch) decides; in one-pass mode every FAST_PROBE_EVERY-th call takes the two passes to measure again.
+    bool two = !FAST_XCD && FAST_TWO_PASS && tall && batch >= FAST_TWO_PASS_MIN_BATCH && iniTh > minTh && nTiles <= 65535 && batch <= 65535;
+    if (two) {
+        const volatile uint32_t* hr = h->h_retry;
+        const bool pays = (double)hr[0] <= FAST_TWO_PASS_MAX_LISTED * (double)hr[1];
+        two = pays || (h->fastCalls % FAST_PROBE_EVERY) == 0;
+        h->fastCalls++;
+    }
+    h->fastLastTwoPass = two;
+    // frame order + cleared counters + the empty second-pass list: one extra workgroup of the level-1 k_resize2 launch when there is one
+    // (scale factors <= 1.3 and more than one level), else launches of their own
+    const bool sep1 = nl > 1 && 1. / ((double)h->lv[1].w / h->lv[0].w) <= 1.3 && 1. / ((double)h->lv[1].h / h->lv[0].h) <= 1.3;
     const bool chain = h->chainTiles > 0 && batch <= PYR_CHAIN_MAX_BATCH;
+#ifndef ORBX_FOLD_ORDER
+#define ORBX_FOLD_ORDER 1   // 0: k_frame_order and the list's two memsets as launches of their own (experiments)
+#endif
+    const bool folded = ORBX_FOLD_ORDER && ordered && sep1 && !chain && R2_XCD && !(ORBX_EXP_DUP & 1);
+    if (!folded) {
+        if (ordered) hipLaunchKernelGGL(k_frame_order, dim3(1), dim3(ORDER_T), (size_t)batch * 4 + 4, st, h->d_candCount, nl, batch, h->d_order, h->h_retry + 2);
+        else HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
+    }
+    // E1 pyramid
     if (chain) {
         PyrChainParams C;
         memset(&C, 0, sizeof(C));
@@ -3036,7 +3082,11 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
 #if R2_XCD
-            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8)), dim3(256), R2_SMEM, st, R);
+            const bool carry = folded && l == 1;           // + the bookkeeping workgroup (LDS: batch + 1 words <= R2_SMEM for ORDER_MAX_BATCH frames)
+            static_assert((size_t)ORDER_MAX_BATCH * 4 + 4 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
+            R.ordCand = carry ? h->d_candCount : nullptr; R.ordOut = h->d_order; R.ordHostMax = h->h_retry + 2; R.ordLevels = nl;
+            R.ordRetry = carry && two ? h->d_retry : nullptr; R.ordTiles = (uint32_t)nTiles * (uint32_t)batch;
+            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8) + (carry ? 8 : 0)), dim3(256), R2_SMEM, st, R);
 #else
             dim3 grid(R.tilesX, (R.tilesY + R2_PAIR - 1) / R2_PAIR, batch);
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
@@ -3075,34 +3125,20 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             fl.wCellMagic = (65536 + L.wCell - 1) / L.wCell;   // wCell = ceil(fw / floor(fw / 30)) < 60
             fl.candOff = L.candOff; fl.candCap = L.candCap;
         }
-        const bool tall = batch >= FAST_TALL_MIN_BATCH;
-        const int nTiles = tall ? h->nTiles : h->nTiles1;
         F.tiles = tall ? h->d_tiles : h->d_tiles + h->nTiles; F.cand = h->d_cand; F.candFrame = h->candFrame; F.candCount = h->d_candCount; F.nlevels = nl;
-        F.iniTh = std::min(std::max(h->cfg.ini_th_fast, 0), 255); F.minTh = std::min(std::max(h->cfg.min_th_fast, 0), 255);
+        F.iniTh = iniTh; F.minTh = minTh;
         F.imgBytes = h->fastImgBytes;
         F.nTiles = nTiles; F.batch = batch; F.retry = h->d_retry; F.order = ordered ? h->d_order : nullptr;
 #if FAST_XCD
         hipLaunchKernelGGL((k_fast<2>), dim3(nTiles * 8 * ((batch + 7) / 8)), dim3(256), h->fastSmem, st, F);
 #else
-        // Two passes for batches of FAST_TWO_PASS_MIN_BATCH frames or more (two dependent launches cost a small batch more than the first pass saves:
-        // k_fast 0.036 vs 0.030 ms at 8 frames, 0.046 vs 0.042 at 16, 0.065 vs 0.063 at 32, 0.102 vs 0.105 at 64, 0.171 vs 0.184 at 128) — while they pay.  Both forms give the same key points; which is faster depends on the frames: the first pass saves the corners between the two
-        // thresholds, every listed tile pays staging and pre-test a second time.  On the benchmark's frames 13 % of the tiles are listed (k_fast
-        // 0.70 -> 0.63 ms per 512 frames), on sparsely textured ones (the same synthetic scene at 1280x720) most are (0.78 -> 0.90 ms).  The listed
-        // share of the handle's previous two-pass call (copied back asynchronously, read here without waiting: a stale figure only delays the
-        // switch) decides; in one-pass mode every FAST_PROBE_EVERY-th call takes the two passes to measure again.
-        bool two = FAST_TWO_PASS && tall && batch >= FAST_TWO_PASS_MIN_BATCH && F.iniTh > F.minTh && nTiles <= 65535 && batch <= 65535;
-        if (two) {
-            const volatile uint32_t* hr = h->h_retry;
-            const bool pays = (double)hr[0] <= FAST_TWO_PASS_MAX_LISTED * (double)hr[1];
-            two = pays || (h->fastCalls % FAST_PROBE_EVERY) == 0;
-            h->fastCalls++;
-        }
-        h->fastLastTwoPass = two;
         if (two) {
             // [0] the list's count, [1] the tiles of THIS call: both words travel back in one copy, so the pair the next call's policy (and
             // orbx_last_fast_passes) reads always belongs to one call, whatever batch sizes alternate on the handle
-            HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
-            HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_retry + 1), (int)((uint32_t)nTiles * (uint32_t)batch), 1, st));
+            if (!folded) {   // (else the pyramid's bookkeeping workgroup has written both)
+                HIPCHK(h, hipMemsetAsync(h->d_retry, 0, 4, st));
+                HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)(h->d_retry + 1), (int)((uint32_t)nTiles * (uint32_t)batch), 1, st));
+            }
             hipLaunchKernelGGL((k_fast<0>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
             {
                 // the second pass's grid: the previous two-pass call's list length (+ 25 % + 1 024) if that call had the same tile count, else every tile
@@ -3115,7 +3151,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #endif
                 hipLaunchKernelGGL((k_fast<1>), dim3(g1), dim3(256), h->fastSmem, st, F);
             }
-            if (!h->capturing) HIPCHK(h, hipMemcpyAsync(h->h_retry, h->d_retry, 8, hipMemcpyDeviceToHost, st));
+            // (the pair travels back to h_retry in k_octree's first workgroup — no copy launch)
         } else {
             hipLaunchKernelGGL((k_fast<2>), dim3(nTiles, batch), dim3(256), h->fastSmem, st, F);
         }
@@ -3139,6 +3175,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         O.nodeCap = h->nodeCap; O.merge = h->octMerge; O.lap0 = lap0; O.lap1 = lap1; O.keyCap = cache ? OCT_KEYCAP : 0; O.keyOff = h->octKeyOff;
         O.order = ordered ? h->d_order : nullptr;
         O.gridLevels = nl; O.heavyMode = 0; O.heavyMin = OCT_HEAVY_MIN;
+        O.retry = h->d_retry; O.retryHost = two && !h->capturing ? h->h_retry : nullptr;
         // A problem of tens of thousands of candidates (every pixel a corner) runs ~3x longer than the whole launch of ordinary ones on 256 threads
         // and no ordering shortens ONE workgroup: when the call before last had such a problem (k_frame_order's word; a stale word only picks the
         // other of two correct plans) they get a launch of their own with OCT_T_HEAVY threads, over the levels that can hold one.
