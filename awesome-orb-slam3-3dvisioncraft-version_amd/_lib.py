@@ -42,6 +42,7 @@ def bind(lib):
         "orbx_copy_level": (i32, [vp, i32, i32, i32, vp]),
         "orbx_debug_candidates": (i32, [vp, i32, i32, vp, i32, C.POINTER(i32)]),
         "orbx_debug_selected": (i32, [vp, i32, i32, vp, i32, C.POINTER(i32)]),
+        "orbx_enable_timing": (i32, [vp, i32]),
         "orbx_last_timing": (i32, [vp, vp]),
         "orbx_last_fast_passes": (i32, [vp, vp, vp, vp]),
         "orbx_stereo_matches": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp]),

@@ -40,6 +40,7 @@ __device__ unsigned long long g_prof[2][8][256];   // [kernel][phase][shard]: sh
 #define PROF_MARK(k, slot) do {} while (0)
 #define PROF_FLUSH(k) do {} while (0)
 #endif
+#define ORBX_EVENTS_ON(h) ((h)->timing && !(h)->capturing)   // the five stage events of a batch call (orbx_enable_timing / orbx_last_timing)
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:72
 #define ORBX_MINB 16          // EDGE_THRESHOLD-3, ORBextractor.cc:769
 #define FAST_QCAP 2048        // sizes k_fast's queues: a wave's pre-test queue holds FAST_QCAP / 4 + 64 entries, the staged emit list FAST_QCAP / 2
@@ -2677,7 +2678,7 @@ struct orbx_extractor {
     uint8_t* d_out1 = nullptr; uint8_t* h_img = nullptr; uint8_t* h_out = nullptr; size_t out1Bytes = 0, kps1Off = 0, desc1Off = 0;
     // last call (debug taps / pyramid views)
     const uint8_t* lastImages = nullptr; size_t lastFrameStride = 0; int lastRowStride = 0, lastBatch = 0;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool timed = false, timing = false;
     // single-frame entry point: the launch sequence of one call is captured once into a HIP graph (per lapping window) and replayed —
     // a frame is ~11 kernels + 2 memsets of a few tens of microseconds each, i.e. launch bound
     hipGraphExec_t graphExec = nullptr; int graphLap0 = 0, graphLap1 = 0; int graphState = 0;   // 0 = not tried, 1 = usable, -1 = capture unsupported
@@ -3018,7 +3019,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
     const int nl = h->cfg.nlevels;
     h->lastImages = d_images; h->lastFrameStride = frame_stride; h->lastRowStride = row_stride; h->lastBatch = batch;
     h->lastStream = st; h->lastSingle = h->hostCall; h->hostPyrValid = false;
-    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[0], st));
+    if (ORBX_EVENTS_ON(h)) HIPCHK(h, hipEventRecord(h->ev[0], st));
 #ifndef ORBX_FRAME_ORDER
 #define ORBX_FRAME_ORDER 1   // 0: frames in batch order (experiments)
 #endif
@@ -3096,7 +3097,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             hipLaunchKernelGGL(k_resize, grid, dim3(256), RS_PITCH * RS_ROWS + (2 * RS_TW + 2 * RS_TH) * 4, st, R);
         }
     }
-    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (ORBX_EVENTS_ON(h)) HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (h->hostCall && h->hostPyr && h->d_bpyr) {
         // mvImagePyramid for the host: fork behind the pyramid, border frame + ONE copy of the slab on the second stream; orbx_extract joins
         BorderParams Bp;
@@ -3157,7 +3158,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         }
 #endif
     }
-    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[2], st));
+    if (ORBX_EVENTS_ON(h)) HIPCHK(h, hipEventRecord(h->ev[2], st));
     // E3 octree
     {
         OctParams O;
@@ -3193,7 +3194,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             if (batch == 1) hipLaunchKernelGGL(k_octree<OCT_T_SINGLE>, dim3(nl * batch), dim3(OCT_T_SINGLE), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
             else hipLaunchKernelGGL(k_octree<OCT_T_BATCH>, dim3(nl * batch), dim3(OCT_T_BATCH), cache ? h->octSmem : (size_t)h->octKeyOff, st, O);
     }
-    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (ORBX_EVENTS_ON(h)) HIPCHK(h, hipEventRecord(h->ev[3], st));
     // E5-E8 orientation + blur + descriptors + assembly
     {
         DescParams D;
@@ -3216,8 +3217,8 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         hipLaunchKernelGGL(k_describe, dim3(D.groups * (4 / DESC_WPB) * 8 * ((batch + 7) / 8)), dim3(64 * DESC_WPB), DESC_WPB * DESC_WAVE_STRIDE + 96, st, D);
 #endif
     }
-    if (!h->capturing) HIPCHK(h, hipEventRecord(h->ev[4], st));
-    if (!h->capturing) h->timed = true;
+    if (ORBX_EVENTS_ON(h)) HIPCHK(h, hipEventRecord(h->ev[4], st));
+    if (ORBX_EVENTS_ON(h)) h->timed = true;
     if (h->hostPyrValid) HIPCHK(h, hipStreamWaitEvent(st, h->evJoin, 0));   // the host-pyramid branch joins (inside a capture: the graph's second leaf)
     HIPCHK(h, hipGetLastError());
     return ORB_OK;
@@ -3500,6 +3501,12 @@ extern "C" int orbx_last_schedule(orbx_handle h, int* frames_ordered, int* heavy
     return ORB_OK;
 }
 
+extern "C" int orbx_enable_timing(orbx_handle h, int on) {
+    if (!h) return ORB_E_INVALID;
+    h->timing = on != 0;
+    if (!on) h->timed = false;
+    return ORB_OK;
+}
 extern "C" int orbx_last_timing(orbx_handle h, float* ms5) {
     if (!h || !ms5 || !h->timed) return ORB_E_INVALID;
     HIPCHK(h, hipSetDevice(h->device));

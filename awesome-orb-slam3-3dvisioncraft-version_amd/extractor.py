@@ -89,6 +89,10 @@ class ORBextractor:
         self._check(rc)
         return out
 
+    def enable_timing(self, on=True):
+        """Stage events of the batch calls that follow (orbhip.h: orbx_enable_timing; off by default), for last_timing()."""
+        self._check(self._L.orbx_enable_timing(self._h, 1 if on else 0))
+
     def last_timing(self):
         ms = np.zeros(5, np.float32)
         self._check(self._L.orbx_last_timing(self._h, ptr(ms)))

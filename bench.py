@@ -341,11 +341,13 @@ class StepPipeline:
         torch.cuda.synchronize()
         kern = {}
         self.m.enable_timing(True)
+        self.ex.enable_timing(True)
         self.out = self.ex.extract_batch(self.d_frames, self.LAP, out=self.out)
         self._match(self.out)
         torch.cuda.synchronize()
         for k, v in self.ex.last_timing().items():
             kern[k if k != "total" else "extract_total"] = v
+        self.ex.enable_timing(False)
         mt = self.m.last_timing()      # (grid_build, sbp_candidates, sbp_resolve) = the three event intervals of the matcher's launches
         kern["undistort_grid"], kern["sbp_frame"], kern["sbp_fallback"] = mt["grid_build"], mt["sbp_candidates"], mt["sbp_resolve"]
         self.m.enable_timing(False)

@@ -119,8 +119,10 @@ int orbx_debug_candidates(orbx_handle h, int frame, int level, int32_t* xys, int
  * (x,y,score) int triples, coordinates relative to minBorder like the reference at that point. */
 int orbx_debug_selected(orbx_handle h, int frame, int level, int32_t* xys, int cap, int* n_out);
 
-/* Device time of the last batch call's kernels, measured with HIP events on the launch stream:
- * ms[0]=pyramid ms[1]=FAST ms[2]=octree ms[3]=orient+blur+rBRIEF ms[4]=total.  Synchronises the stream. */
+/* Measurement facility (bench.py's per-kernel figures).  While enabled, a batch call records five HIP events on its launch stream (they cost the
+ * three-stream step 0.5 %: off by default); orbx_last_timing then gives the device time of the last batch call's kernels:
+ * ms[0]=pyramid ms[1]=FAST ms[2]=octree ms[3]=orient+blur+rBRIEF ms[4]=total (synchronises the stream; ORB_E_INVALID if no call was timed). */
+int orbx_enable_timing(orbx_handle h, int on);
 int orbx_last_timing(orbx_handle h, float* ms5);
 
 /* How the last batch call ran FAST (a scheduling decision only: the key points do not depend on it).  two_pass: 1 = detection at iniThFAST followed by a

@@ -175,6 +175,7 @@ def cmd_kinds(argv):
         sets[kind] = bench._pair_up(base, B, np.random.default_rng(5))
     sets["mixed"] = bench.make_mixed_batch(B, seed0=7000, workers=16)[0]
     ex = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_batch=B)
+    ex.enable_timing(True)
     for kind, fr in sets.items():
         d = torch.from_numpy(fr).cuda()
         out = None
@@ -196,6 +197,7 @@ def cmd_phases(argv):
     L = _lib.load()
     d = torch.from_numpy(bench.make_batch(512)).cuda()
     ex = orbhip.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_batch=512)
+    ex.enable_timing(True)
     out = ex.extract_batch(d, (0, 1000))
     buf = (C.c_ulonglong * 32)()
     L.orbx_debug_prof(buf, 1)
