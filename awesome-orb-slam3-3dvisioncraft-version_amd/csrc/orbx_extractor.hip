@@ -281,6 +281,8 @@ static __device__ __forceinline__ void frame_order_body(unsigned char* smem, int
 #ifndef R2_PAIR
 #define R2_PAIR 2         // vertically adjacent destination tiles per workgroup (2: the second tile's staging loads are in flight during the first tile's H pass)
 #endif
+template <bool CARRY>   // CARRY: the level-1 launch of a batch call, with the call's bookkeeping workgroup in front (a template parameter, not a field test: the
+                        // plain instantiation must not wait for a kernel argument before it asks for its tile)
 static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     typedef unsigned short u16x2 __attribute__((vector_size(4)));
@@ -295,12 +297,12 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
 #if R2_XCD
     // the launch's FIRST workgroup (it runs ~50 us on 256 threads: dispatched last it was the launch's tail): frame order + counters of the call, no
     // tile of its own; seven idle ones behind it keep every tile on the XCD its frame number names
-    if (P.ordCand && blockIdx.x < 8) {
+    if (CARRY && blockIdx.x < 8) {
         if (blockIdx.x == 0) frame_order_body(orb_smem, P.ordCand, P.ordLevels, P.batch, P.ordOut, P.ordHostMax, P.ordRetry, P.ordTiles);
         return;
     }
     int frameZ, tileI;
-    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI, P.ordCand ? 8 : 0)) return;
+    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI, CARRY ? 8 : 0)) return;
     const int uyI = tileI / P.tilesX, txI = tileI - uyI * P.tilesX;
 #else
     const int frameZ = blockIdx.z;
@@ -3087,10 +3089,12 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             static_assert((size_t)ORDER_MAX_BATCH * 4 + 4 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
             R.ordCand = carry ? h->d_candCount : nullptr; R.ordOut = h->d_order; R.ordHostMax = h->h_retry + 2; R.ordLevels = nl;
             R.ordRetry = carry && two ? h->d_retry : nullptr; R.ordTiles = (uint32_t)nTiles * (uint32_t)batch;
-            hipLaunchKernelGGL(k_resize2, dim3(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8) + (carry ? 8 : 0)), dim3(256), R2_SMEM, st, R);
+            const dim3 g2(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8) + (carry ? 8 : 0));
+            if (carry) hipLaunchKernelGGL(k_resize2<true>, g2, dim3(256), R2_SMEM, st, R);
+            else hipLaunchKernelGGL(k_resize2<false>, g2, dim3(256), R2_SMEM, st, R);
 #else
             dim3 grid(R.tilesX, (R.tilesY + R2_PAIR - 1) / R2_PAIR, batch);
-            hipLaunchKernelGGL(k_resize2, grid, dim3(256), R2_SMEM, st, R);
+            hipLaunchKernelGGL(k_resize2<false>, grid, dim3(256), R2_SMEM, st, R);
 #endif
         } else {
             dim3 grid((R.dw + RS_TW - 1) / RS_TW, (R.dh + RS_TH - 1) / RS_TH, batch);
