@@ -71,6 +71,23 @@ static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, c
     *unit = slot - (slot / unitsPerFrame) * unitsPerFrame;
     return fr < batch;
 }
+// The same with the division as a multiplication by magic = floor(2^32 / unitsPerFrame) + 1 (host: xcd_units_magic): exact while slot * unitsPerFrame < 2^32
+// (the host passes 0 for larger grids).
+// The compiler's own 32-bit division is ~30 instructions around a v_rcp_f32 and a v_readfirstlane — at the head of every workgroup, in front of its first load.
+static __device__ __forceinline__ bool xcd_frame_unit_m(const int unitsPerFrame, const uint32_t magic, const int batch, int* frame, int* unit, const int lead = 0) {
+    const int xcd = blockIdx.x & 7;
+    const uint32_t slot = (uint32_t)(blockIdx.x - lead) >> 3;
+    const uint32_t q = magic ? (uint32_t)(((unsigned long long)slot * magic) >> 32) : slot / (uint32_t)unitsPerFrame;   // (0: a grid too large for the magic to be exact)
+    const int fr = (int)q * 8 + xcd;
+    *frame = fr;
+    *unit = (int)(slot - q * (uint32_t)unitsPerFrame);
+    return fr < batch;
+}
+static inline uint32_t xcd_units_magic(int unitsPerFrame, int batch) {
+    const unsigned long long u = (unsigned long long)std::max(unitsPerFrame, 1), slots = u * (unsigned long long)((batch + 7) / 8);   // slot < slots
+    if (u < 2 || slots * u >= 0x100000000ull) return 0u;   // (u == 1: the magic itself would not fit 32 bits)
+    return (uint32_t)(0x100000000ull / u + 1ull);
+}
 
 struct ResizeParams {
     const uint8_t* src; size_t sFrame; int sStride, sw, sh;
@@ -79,6 +96,7 @@ struct ResizeParams {
     const int* coef;           // k_resize2: per-level tables xs[dw] | xw[dw] | ys[dh] | yw[dh] (resize_coef of every column / row)
     const int* tileTab;        // k_resize2: per-level staging footprints {xal, ndw} x tilesX | {ylo, nrows} x tilesY (resize2_footprint, built at orbx_create)
     int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
+    uint32_t unitsMagic;       // xcd_units_magic(tilesX * ceil(tilesY / R2_PAIR))
     // the call's bookkeeping, carried by ONE extra workgroup at the front of the level-1 launch (frame_order_body; null: none)
     int* ordCand; int* ordOut; uint32_t* ordHostMax; uint32_t* ordRetry; int ordLevels; uint32_t ordTiles;
 };
@@ -302,7 +320,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
         return;
     }
     int frameZ, tileI;
-    if (!xcd_frame_unit(P.tilesX * unitsY, P.batch, &frameZ, &tileI, CARRY ? 8 : 0)) return;
+    if (!xcd_frame_unit_m(P.tilesX * unitsY, P.unitsMagic, P.batch, &frameZ, &tileI, CARRY ? 8 : 0)) return;
     const int uyI = tileI / P.tilesX, txI = tileI - uyI * P.tilesX;
 #else
     const int frameZ = blockIdx.z;
@@ -1709,6 +1727,7 @@ struct DescParams {
     const int* selCount; const int* lapCount; int nlevels;
     orb_keypoint* kps; uint8_t* desc; int cap; int32_t* counts;
     int groups, batch;   // workgroups (4 keypoints each) per frame, frames: the XCD-aware 1-D grid
+    uint32_t groupsMagic; // xcd_units_magic(groups * 2): k_describe2's units per frame
     int unitStart[ORBX_MAX_LEVELS + 1];   // workgroup u of a frame serves level l with unitStart[l] <= u < unitStart[l+1] (ceil(selCap_l / 4) each)
 };
 
@@ -2130,7 +2149,7 @@ static __global__ __launch_bounds__(64, DESC_WAVES) void k_describe2(DescParams 
     extern __shared__ __attribute__((aligned(16))) unsigned char orb_smem[];
     const int lane = threadIdx.x & 63;
     int frame, grp;
-    if (!xcd_frame_unit(P.groups * 2, P.batch, &frame, &grp)) return;
+    if (!xcd_frame_unit_m(P.groups * 2, P.groupsMagic, P.batch, &frame, &grp)) return;
     const int kpair = grp & 1;
     grp >>= 1;
     uint8_t* patch = orb_smem;
@@ -3084,6 +3103,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         R.tileTab = h->d_coef + h->tileTabOff[l];
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
+            R.unitsMagic = xcd_units_magic(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR), batch);
 #if R2_XCD
             const bool carry = folded && l == 1;           // + the bookkeeping workgroup (LDS: batch + 1 words <= R2_SMEM for ORDER_MAX_BATCH frames)
             static_assert((size_t)ORDER_MAX_BATCH * 4 + 4 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
@@ -3213,7 +3233,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         D.unitStart[0] = 0;
         for (int l = 0; l < nl; l++) D.unitStart[l + 1] = D.unitStart[l] + (h->lv[l].selCap + 3) / 4;
         for (int l = nl + 1; l <= ORBX_MAX_LEVELS; l++) D.unitStart[l] = INT_MAX;
-        D.groups = D.unitStart[nl]; D.batch = batch;
+        D.groups = D.unitStart[nl]; D.batch = batch; D.groupsMagic = xcd_units_magic(D.groups * 2, batch);
 #if DESC_KPW == 2
         for (int rep = 0; rep < ((ORBX_EXP_DUP & 4) ? 2 : 1); rep++)
             hipLaunchKernelGGL(k_describe2, dim3(D.groups * 2 * 8 * ((batch + 7) / 8)), dim3(64), DESC2_WAVE_BYTES + 48, st, D);
