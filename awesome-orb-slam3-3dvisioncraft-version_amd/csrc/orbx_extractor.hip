@@ -97,6 +97,7 @@ struct ResizeParams {
     const int* tileTab;        // k_resize2: per-level staging footprints {xal, ndw} x tilesX | {ylo, nrows} x tilesY (resize2_footprint, built at orbx_create)
     int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
     uint32_t unitsMagic;       // xcd_units_magic(tilesX * ceil(tilesY / R2_PAIR))
+    uint32_t tilesXMagic;      // floor(2^32 / tilesX) + 1 (tilesX >= 2), or 0 + the plain path for one tile column
     // the call's bookkeeping, carried by ONE extra workgroup at the front of the level-1 launch (frame_order_body; null: none)
     int* ordCand; int* ordOut; uint32_t* ordHostMax; uint32_t* ordRetry; int ordLevels; uint32_t ordTiles;
 };
@@ -321,7 +322,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
     }
     int frameZ, tileI;
     if (!xcd_frame_unit_m(P.tilesX * unitsY, P.unitsMagic, P.batch, &frameZ, &tileI, CARRY ? 8 : 0)) return;
-    const int uyI = tileI / P.tilesX, txI = tileI - uyI * P.tilesX;
+    const int uyI = P.tilesXMagic ? (int)(((unsigned long long)(uint32_t)tileI * P.tilesXMagic) >> 32) : tileI, txI = tileI - uyI * P.tilesX;   // tileI / tilesX (magic: exact for tileI * tilesX < 2^32)
 #else
     const int frameZ = blockIdx.z;
     const int txI = blockIdx.x, uyI = blockIdx.y;
@@ -3104,6 +3105,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
             R.unitsMagic = xcd_units_magic(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR), batch);
+            R.tilesXMagic = R.tilesX >= 2 ? (uint32_t)(0x100000000ull / (unsigned long long)R.tilesX + 1ull) : 0u;
 #if R2_XCD
             const bool carry = folded && l == 1;           // + the bookkeeping workgroup (LDS: batch + 1 words <= R2_SMEM for ORDER_MAX_BATCH frames)
             static_assert((size_t)ORDER_MAX_BATCH * 4 + 4 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
