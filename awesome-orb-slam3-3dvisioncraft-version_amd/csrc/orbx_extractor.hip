@@ -477,26 +477,33 @@ static __global__ __launch_bounds__(256) void k_border_pyramid(BorderParams P) {
 // key points never depend on it.  The same workgroup then clears the counters for the call that follows (it replaces that call's memset launch).
 #define ORDER_T 1024
 #define ORDER_MAX_BATCH 4096
-// (any workgroup size; LDS: batch + 1 words.)  retry != null: the FAST second-pass list of the call that follows starts empty — [0] = 0, [1] = its tile count
+// (any workgroup size; LDS: batch + 4 words.)  retry != null: the FAST second-pass list of the call that follows starts empty — [0] = 0, [1] = its tile count
 static __device__ __forceinline__ void frame_order_body(unsigned char* smem, int* candCount, const int nlevels, const int batch, int* order, uint32_t* hostMax,
                                                         uint32_t* retry, const uint32_t retryTiles) {
-    uint32_t* keys = (uint32_t*)smem;   // [batch], then one word: the largest count of any (frame, level)
-    const int tid = threadIdx.x, NT = blockDim.x;
-    if (tid == 0) { keys[batch] = 0; if (retry) { retry[0] = 0; retry[1] = retryTiles; } }
+    // keys[b] = count << 12 | (4095 - b): descending order of the packed word = descending count, ties by ascending frame (batch <= ORDER_MAX_BATCH = 4096;
+    // counts above 2^20 - 1 saturate — a 752 x 480 frame holds < 500 000 candidates — which can only cost such frames their mutual order)
+    uint32_t* keys = (uint32_t*)smem;   // [batch rounded up to 4 (padded with 0: below every real key)], then one word: the largest count of any (frame, level)
+    const int tid = threadIdx.x, NT = blockDim.x, b4 = (batch + 3) & ~3;
+    if (tid == 0) { keys[b4] = 0; if (retry) { retry[0] = 0; retry[1] = retryTiles; } }
+    for (int i = batch + tid; i < b4; i += NT) keys[i] = 0;
     __syncthreads();
     uint32_t mx = 0;
     for (int b = tid; b < batch; b += NT) {
         uint32_t s = 0;
         for (int l = 0; l < nlevels; l++) { const uint32_t c = (uint32_t)candCount[(size_t)b * nlevels + l]; s += c; mx = max(mx, c); }
-        keys[b] = s;
+        keys[b] = (min(s, 0xFFFFFu) << 12) | (uint32_t)(4095 - b);
     }
-    if (mx) atomicMax(&keys[batch], mx);
+    if (mx) atomicMax(&keys[b4], mx);
     __syncthreads();
-    if (tid == 0) *hostMax = keys[batch];   // pinned host word: the NEXT call's launch plan reads it (is a 1 024-thread octree pass worth launching?)
+    if (tid == 0) *hostMax = keys[b4];   // pinned host word: the NEXT call's launch plan reads it (is a 1 024-thread octree pass worth launching?)
+    // rank = keys above mine; the workgroup rides a launch whose other workgroups share its compute unit, so the loop is kept short: four keys per LDS read
     for (int b = tid; b < batch; b += NT) {
         const uint32_t k = keys[b];
         int r = 0;
-        for (int j = 0; j < batch; j++) { const uint32_t kj = keys[j]; r += (kj > k || (kj == k && j < b)) ? 1 : 0; }
+        for (int j = 0; j < b4; j += 4) {
+            const uint4 q = *(const uint4*)(keys + j);
+            r += (q.x > k ? 1 : 0) + (q.y > k ? 1 : 0) + (q.z > k ? 1 : 0) + (q.w > k ? 1 : 0);
+        }
         order[r] = b;
     }
     for (int i = tid; i < batch * nlevels; i += NT) candCount[i] = 0;   // (every key was formed before the barrier above)
@@ -3080,7 +3087,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
 #endif
     const bool folded = ORBX_FOLD_ORDER && ordered && sep1 && !chain && R2_XCD && !(ORBX_EXP_DUP & 1);
     if (!folded) {
-        if (ordered) hipLaunchKernelGGL(k_frame_order, dim3(1), dim3(ORDER_T), (size_t)batch * 4 + 4, st, h->d_candCount, nl, batch, h->d_order, h->h_retry + 2);
+        if (ordered) hipLaunchKernelGGL(k_frame_order, dim3(1), dim3(ORDER_T), (size_t)batch * 4 + 16, st, h->d_candCount, nl, batch, h->d_order, h->h_retry + 2);
         else HIPCHK(h, hipMemsetAsync(h->d_candCount, 0, (size_t)batch * nl * 4, st));
     }
     // E1 pyramid
@@ -3108,7 +3115,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
             R.tilesXMagic = R.tilesX >= 2 ? (uint32_t)(0x100000000ull / (unsigned long long)R.tilesX + 1ull) : 0u;
 #if R2_XCD
             const bool carry = folded && l == 1;           // + the bookkeeping workgroup (LDS: batch + 1 words <= R2_SMEM for ORDER_MAX_BATCH frames)
-            static_assert((size_t)ORDER_MAX_BATCH * 4 + 4 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
+            static_assert((size_t)ORDER_MAX_BATCH * 4 + 16 <= R2_SMEM, "frame_order_body's keys fit k_resize2's LDS block");
             R.ordCand = carry ? h->d_candCount : nullptr; R.ordOut = h->d_order; R.ordHostMax = h->h_retry + 2; R.ordLevels = nl;
             R.ordRetry = carry && two ? h->d_retry : nullptr; R.ordTiles = (uint32_t)nTiles * (uint32_t)batch;
             const dim3 g2(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR) * 8 * ((batch + 7) / 8) + (carry ? 8 : 0));
