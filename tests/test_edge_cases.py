@@ -8,6 +8,7 @@ from orbhip.bow import ORBVocabulary, synth_vocabulary
 from orbhip.lba import POSE_EDGE_DTYPE, pose_optimization, synth_pose_frames
 from orbhip.matcher import MODE_BEST_ONLY, MODE_INIT, MODE_LOCAL_MAP, Q_VALID, QUERY_DTYPE, TRI_PAIR_DTYPE
 from test_matcher_parity import to_dev, to_host
+from orbhip._lib import OrbHipError as _OrbHipError
 
 GRID = (0.0, 0.0, 64 / 640.0, 48 / 480.0)
 
@@ -129,3 +130,30 @@ def test_emu_resize_staging_footprints_cover_their_tiles(emu_lib):
         else:
             assert "footprint" not in (emu_lib.orbx_last_error(None) or b"").decode(), (W, H, sf)
     assert created > 1500
+
+
+@pytest.mark.gpu
+def test_hip_stage_events_are_opt_in(hip_lib):
+    """orbx_enable_timing (round 6): a batch call records its five stage events only while timing is on — orbx_last_timing refuses (ORB_E_INVALID) before
+    any timed call and again after timing is switched off; with it on the four stage intervals are positive and add up to the total.  The key points do
+    not depend on it."""
+    import torch
+    from orbhip.synth import synth_image
+    frames = torch.from_numpy(np.stack([synth_image(70 + i, 320, 240) for i in range(4)])).cuda()
+    e = orbhip.ORBextractor(300, 1.2, 5, 20, 7, device=0, max_batch=4, lib=hip_lib)
+    out0 = [t.clone() for t in e.extract_batch(frames, (0, 1000))]
+    torch.cuda.synchronize()
+    with pytest.raises(_OrbHipError):
+        e.last_timing()
+    e.enable_timing(True)
+    out1 = e.extract_batch(frames, (0, 1000))
+    t = e.last_timing()
+    assert all(t[k] > 0 for k in ("pyramid", "fast", "octree", "describe")) and abs(t["total"] - (t["pyramid"] + t["fast"] + t["octree"] + t["describe"])) < 0.05 * t["total"] + 0.02
+    assert torch.equal(out0[2], out1[2])
+    for b in range(4):                                   # (the slots past a frame's count are never written)
+        n = int(out0[2][b, 0])
+        assert n > 50 and torch.equal(out0[0][b, :n].contiguous().view(torch.uint8), out1[0][b, :n].contiguous().view(torch.uint8)) and torch.equal(out0[1][b, :n], out1[1][b, :n])   # (bytes: class_id = -1 reads as NaN)
+    e.enable_timing(False)
+    e.extract_batch(frames, (0, 1000))
+    with pytest.raises(_OrbHipError):
+        e.last_timing()
