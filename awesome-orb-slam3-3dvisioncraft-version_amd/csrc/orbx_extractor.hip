@@ -74,13 +74,14 @@ static __device__ __forceinline__ bool xcd_frame_unit(const int unitsPerFrame, c
 // The same with the division as a multiplication by magic = floor(2^32 / unitsPerFrame) + 1 (host: xcd_units_magic): exact while slot * unitsPerFrame < 2^32
 // (the host passes 0 for larger grids).
 // The compiler's own 32-bit division is ~30 instructions around a v_rcp_f32 and a v_readfirstlane — at the head of every workgroup, in front of its first load.
-static __device__ __forceinline__ bool xcd_frame_unit_m(const int unitsPerFrame, const uint32_t magic, const int batch, int* frame, int* unit, const int lead = 0) {
+static __device__ __forceinline__ bool xcd_frame_unit_m(const int unitsPerFrame, const uint32_t magic, const int batch, int* frame, int* unit, const int lead = 0, const bool reverse = false) {
     const int xcd = blockIdx.x & 7;
     const uint32_t slot = (uint32_t)(blockIdx.x - lead) >> 3;
-    const uint32_t q = magic ? (uint32_t)(((unsigned long long)slot * magic) >> 32) : slot / (uint32_t)unitsPerFrame;   // (0: a grid too large for the magic to be exact)
+    const uint32_t q0 = magic ? (uint32_t)(((unsigned long long)slot * magic) >> 32) : slot / (uint32_t)unitsPerFrame;   // (0: a grid too large for the magic to be exact)
+    const uint32_t q = reverse ? (uint32_t)((batch + 7) >> 3) - 1u - q0 : q0;   // the XCD's frames last to first: what the launch before this one wrote last is still in this XCD's L2
     const int fr = (int)q * 8 + xcd;
     *frame = fr;
-    *unit = (int)(slot - q * (uint32_t)unitsPerFrame);
+    *unit = (int)(slot - q0 * (uint32_t)unitsPerFrame);
     return fr < batch;
 }
 static inline uint32_t xcd_units_magic(int unitsPerFrame, int batch) {
@@ -98,6 +99,7 @@ struct ResizeParams {
     int tilesX, tilesY, batch; // k_resize2 with R2_XCD: the frame-per-XCD 1-D grid
     uint32_t unitsMagic;       // xcd_units_magic(tilesX * ceil(tilesY / R2_PAIR))
     uint32_t tilesXMagic;      // floor(2^32 / tilesX) + 1 (tilesX >= 2), or 0 + the plain path for one tile column
+    int reverse;               // 1: the frames of an XCD in descending order (alternate levels: see xcd_frame_unit_m)
     // the call's bookkeeping, carried by ONE extra workgroup at the front of the level-1 launch (frame_order_body; null: none)
     int* ordCand; int* ordOut; uint32_t* ordHostMax; uint32_t* ordRetry; int ordLevels; uint32_t ordTiles;
 };
@@ -297,6 +299,9 @@ static inline void resize2_footprint(int t0, int tlen, int dlen, int slen, doubl
 }
 static __device__ __forceinline__ void frame_order_body(unsigned char* smem, int* candCount, const int nlevels, const int batch, int* order, uint32_t* hostMax,
                                                         uint32_t* retry, const uint32_t retryTiles);   // (below, with k_frame_order)
+#ifndef R2_REVERSE
+#define R2_REVERSE 1   // even levels walk an XCD's frames backwards (experiment switch)
+#endif
 #ifndef R2_PAIR
 #define R2_PAIR 2         // vertically adjacent destination tiles per workgroup (2: the second tile's staging loads are in flight during the first tile's H pass)
 #endif
@@ -321,7 +326,7 @@ static __global__ __launch_bounds__(256) void k_resize2(ResizeParams P) {
         return;
     }
     int frameZ, tileI;
-    if (!xcd_frame_unit_m(P.tilesX * unitsY, P.unitsMagic, P.batch, &frameZ, &tileI, CARRY ? 8 : 0)) return;
+    if (!xcd_frame_unit_m(P.tilesX * unitsY, P.unitsMagic, P.batch, &frameZ, &tileI, CARRY ? 8 : 0, R2_REVERSE && P.reverse)) return;
     const int uyI = P.tilesXMagic ? (int)(((unsigned long long)(uint32_t)tileI * P.tilesXMagic) >> 32) : tileI, txI = tileI - uyI * P.tilesX;   // tileI / tilesX (magic: exact for tileI * tilesX < 2^32)
 #else
     const int frameZ = blockIdx.z;
@@ -3112,6 +3117,7 @@ extern "C" int orbx_extract_batch_dev(orbx_handle h, const uint8_t* d_images, in
         if (R.scale_x <= 1.3 && R.scale_y <= 1.3) {   // separable tile kernel (its LDS footprint is sized for scale <= 1.3)
             R.tilesX = (R.dw + RS_TW - 1) / RS_TW; R.tilesY = (R.dh + R2_TH - 1) / R2_TH; R.batch = batch;
             R.unitsMagic = xcd_units_magic(R.tilesX * ((R.tilesY + R2_PAIR - 1) / R2_PAIR), batch);
+            R.reverse = (l & 1) == 0;
             R.tilesXMagic = R.tilesX >= 2 ? (uint32_t)(0x100000000ull / (unsigned long long)R.tilesX + 1ull) : 0u;
 #if R2_XCD
             const bool carry = folded && l == 1;           // + the bookkeeping workgroup (LDS: batch + 1 words <= R2_SMEM for ORDER_MAX_BATCH frames)
