@@ -1248,6 +1248,29 @@ def main():
                     if not args.no_parity_check:
                         ng, badg, _ = Pg.check_against_oracle(sels)
                         ent["graph_replay"]["parity"] = {"checked_frames": int(ng), "mismatches": len(badg), "first_mismatches": badg[:2]}
+                    # ... and K such graphs (K handles, K streams, the same frames) replayed round robin: one launch per call on the host AND calls that
+                    # overlap on the device — what a rig's cameras, each with its own extractor, give the machine
+                    KG = 4
+                    Pk = [Pg] + [StepPipeline(dfs, W, H, NFEAT, local_rank, streams=1) for _ in range(KG - 1)]
+                    if all(p_.capture_graph() for p_ in Pk[1:]):
+                        sk = [torch.cuda.Stream(dfs.device) for _ in range(KG)]
+
+                        def round_robin():
+                            for p_, s_ in zip(Pk, sk):
+                                with torch.cuda.stream(s_):
+                                    p_.graph_step()
+                        for _ in range(3):
+                            round_robin()
+                        torch.cuda.synchronize()
+                        dk = rank_max(timed(round_robin, max(1, st // KG), 3))
+                        nst = max(1, st // KG) * KG
+                        ent["graph_replay"]["x%d_streams" % KG] = {"frames_per_s": round(world * SB * nst / float(np.median(dk)), 1),
+                                                                   "ms_per_call": round(float(np.median(dk)) / nst * 1e3, 4)}
+                        if not args.no_parity_check:
+                            torch.cuda.synchronize()
+                            nk, badk, _ = Pk[-1].check_against_oracle(sels)
+                            ent["graph_replay"]["x%d_streams" % KG]["parity"] = {"checked_frames": int(nk), "mismatches": len(badk), "first_mismatches": badk[:2]}
+                    del Pk
                 else:
                     ent["graph_replay"] = {"error": Pg._graph_error}
                 del Pg
